@@ -1,0 +1,187 @@
+"""ctypes binding of oracle/liboracle.so (TEST INFRASTRUCTURE ONLY; never imported by speaksense_amd/)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MODE_F32, MODE_GGML_F16, MODE_BF16 = 0, 1, 2
+
+
+class OrcOpts(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("gelu_erf", C.c_int32), ("n_threads", C.c_int32)]
+
+
+class FullParams(C.Structure):
+    # mirrors `struct FullParams` in whisper_oracle.cpp (the whisper_full_params fields whisper.rs:131-173 sets)
+    _fields_ = [
+        ("best_of", C.c_int32), ("temperature", C.c_float), ("temperature_inc", C.c_float), ("entropy_thold", C.c_float),
+        ("logprob_thold", C.c_float), ("max_initial_ts", C.c_float), ("length_penalty", C.c_float),
+        ("no_context", C.c_int32), ("single_segment", C.c_int32), ("no_timestamps", C.c_int32), ("suppress_blank", C.c_int32),
+        ("tdrz_enable", C.c_int32), ("print_special", C.c_int32), ("max_tokens", C.c_int32), ("n_max_text_ctx", C.c_int32),
+        ("audio_ctx", C.c_int32), ("translate", C.c_int32), ("fixed_steps", C.c_int32), ("language", C.c_char * 8),
+    ]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "whisper_oracle.cpp")
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        L.orc_load.restype = C.c_void_p
+        L.orc_load.argtypes = [C.c_char_p]
+        L.orc_free.argtypes = [C.c_void_p]
+        L.orc_hparams.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_special_tokens.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_token_str.restype = C.c_char_p
+        L.orc_token_str.argtypes = [C.c_void_p, C.c_int]
+        L.orc_log_mel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(OrcOpts), C.c_void_p]
+        L.orc_state_new.restype = C.c_void_p
+        L.orc_state_new.argtypes = [C.c_void_p, C.POINTER(OrcOpts)]
+        L.orc_state_free.argtypes = [C.c_void_p]
+        L.orc_state_set_encoder.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_state_cross_kv.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_process_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(FullParams), C.c_void_p, C.c_void_p]
+        L.orc_full_default_params.argtypes = [C.POINTER(FullParams)]
+        L.orc_full.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FullParams)]
+        L.orc_n_segments.argtypes = [C.c_void_p]
+        L.orc_segment_text.restype = C.c_char_p
+        L.orc_segment_text.argtypes = [C.c_void_p, C.c_int]
+        L.orc_segment_t0.restype = C.c_int64
+        L.orc_segment_t0.argtypes = [C.c_void_p, C.c_int]
+        L.orc_segment_t1.restype = C.c_int64
+        L.orc_segment_t1.argtypes = [C.c_void_p, C.c_int]
+        L.orc_segment_speaker_turn_next.argtypes = [C.c_void_p, C.c_int]
+        L.orc_n_tokens.argtypes = [C.c_void_p]
+        L.orc_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_mel_of_state.argtypes = [C.c_void_p, C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleModel:
+    def __init__(self, path: str):
+        self.L = lib()
+        self.h = self.L.orc_load(path.encode())
+        if not self.h:
+            raise RuntimeError(f"oracle: cannot load {path}")
+        hp = np.zeros(11, np.int32)
+        self.L.orc_hparams(self.h, _p(hp))
+        (self.n_vocab, self.n_audio_ctx, self.n_audio_state, self.n_audio_head, self.n_audio_layer, self.n_text_ctx,
+         self.n_text_state, self.n_text_head, self.n_text_layer, self.n_mels, self.ftype) = [int(x) for x in hp]
+        st = np.zeros(9, np.int32)
+        self.L.orc_special_tokens(self.h, _p(st))
+        (self.eot, self.sot, self.translate, self.transcribe, self.solm, self.prev, self.nosp, self.not_, self.beg) = [int(x) for x in st]
+
+    def close(self):
+        if self.h:
+            self.L.orc_free(self.h)
+            self.h = None
+
+    def token_str(self, i: int) -> bytes:
+        return self.L.orc_token_str(self.h, i)
+
+    def log_mel(self, pcm: np.ndarray) -> np.ndarray:
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        n_len = self.L.orc_mel_n_len(len(pcm))
+        out = np.empty((self.n_mels, n_len), np.float32)
+        self.L.orc_log_mel(self.h, _p(pcm), len(pcm), _p(out), n_len)
+        return out
+
+    def encode(self, mel: np.ndarray, seek: int = 0, mode: int = MODE_F32, gelu_erf: int = 0) -> np.ndarray:
+        mel = np.ascontiguousarray(mel, np.float32)
+        out = np.empty((self.n_audio_ctx, self.n_audio_state), np.float32)
+        o = OrcOpts(mode, gelu_erf, 0)
+        self.L.orc_encode(self.h, _p(mel), mel.shape[1], seek, C.byref(o), _p(out))
+        return out
+
+    def new_state(self, mode: int = MODE_F32, gelu_erf: int = 0) -> "OracleState":
+        return OracleState(self, mode, gelu_erf)
+
+
+def default_params(**kw) -> FullParams:
+    """whisper_full_default_params(GREEDY) + the reference's build_params (whisper.rs:131-173) + stream-mode
+    overrides (whisper.rs:65-69): greedy best_of 5, temperature 0 (+0.2 ladder), no_context, max_initial_ts 1.0."""
+    p = FullParams()
+    lib().orc_full_default_params(C.byref(p))
+    p.no_context = 1
+    for k, v in kw.items():
+        if k == "language":
+            v = v.encode() if isinstance(v, str) else v
+        setattr(p, k, v)
+    return p
+
+
+class OracleState:
+    def __init__(self, model: OracleModel, mode: int, gelu_erf: int):
+        self.m = model
+        self.L = model.L
+        o = OrcOpts(mode, gelu_erf, 0)
+        self.h = self.L.orc_state_new(model.h, C.byref(o))
+
+    def close(self):
+        if self.h:
+            self.L.orc_state_free(self.h)
+            self.h = None
+
+    def set_encoder(self, enc: np.ndarray):
+        enc = np.ascontiguousarray(enc, np.float32)
+        self.L.orc_state_set_encoder(self.h, _p(enc))
+
+    def cross_kv(self, il: int):
+        k = np.empty((self.m.n_audio_ctx, self.m.n_text_state), np.float32)
+        v = np.empty_like(k)
+        self.L.orc_state_cross_kv(self.h, il, _p(k), _p(v))
+        return k, v
+
+    def decode(self, tokens, n_past: int) -> np.ndarray:
+        t = np.ascontiguousarray(tokens, np.int32)
+        out = np.empty(self.m.n_vocab, np.float32)
+        self.L.orc_decode(self.h, _p(t), len(t), n_past, _p(out))
+        return out
+
+    def process_logits(self, raw: np.ndarray, hist, has_ts: bool, seek_delta: int, params: FullParams):
+        raw = np.ascontiguousarray(raw, np.float32)
+        h = np.ascontiguousarray(hist, np.int32)
+        lp = np.empty(self.m.n_vocab, np.float32)
+        o5 = np.zeros(5, np.float32)
+        tid = self.L.orc_process_logits(self.h, _p(raw), _p(h), len(h), int(has_ts), seek_delta, C.byref(params), _p(lp), _p(o5))
+        return tid, lp, o5
+
+    def full(self, pcm: np.ndarray, params: FullParams | None = None):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        params = params or default_params()
+        rc = self.L.orc_full(self.h, _p(pcm), len(pcm), C.byref(params))
+        if rc != 0:
+            raise RuntimeError(f"orc_full -> {rc}")
+        segs = []
+        for i in range(self.L.orc_n_segments(self.h)):
+            segs.append(dict(text=self.L.orc_segment_text(self.h, i), t0=self.L.orc_segment_t0(self.h, i),
+                             t1=self.L.orc_segment_t1(self.h, i), speaker_turn_next=bool(self.L.orc_segment_speaker_turn_next(self.h, i))))
+        n = self.L.orc_n_tokens(self.h)
+        ids = np.zeros(n, np.int32)
+        plog = np.zeros(n, np.float32)
+        if n:
+            self.L.orc_tokens(self.h, _p(ids), _p(plog))
+        c = np.zeros(3, np.int32)
+        self.L.orc_counters(self.h, _p(c))
+        return dict(segments=segs, tokens=ids, plog=plog, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]))

@@ -1,0 +1,855 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.  Nothing under speaksense_amd/ may include, link or call this file.
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and only as the checker.
+//
+// PARITY UNPINNED: the arithmetic of the hot path lives in whisper.cpp (crate whisper-rs 0.11.1 ->
+// whisper-rs-sys 0.9.0, /root/reference/Cargo.lock:3888-3907), which is NOT in /root/reference and not in
+// this container; the reference's own tests hold no golden vectors for this path.
+// This file restates whisper.cpp v1.5.x's published algorithm from the call the reference makes at
+// /root/reference/src/asr/whisper.rs:75 (`state.full(params, &audio)`), with the parameters the reference
+// sets at whisper.rs:131-173 and the stream-mode overrides at whisper.rs:60-71.  Each function names the
+// whisper.cpp routine it restates (marked "wcpp:"; unverifiable offline).  The network arithmetic is
+// cross-checked against HF transformers' Whisper on seeded random weights (tests/golden/make_golden.py).
+//
+// Numerics modes (orc_opts.mode):
+//   0  F32      : f32 everywhere, exact tanh-GELU / expf (clean mathematical restatement)
+//   1  GGML_F16 : what ggml's CPU backend does with f16 weights: activations rounded to f16 at every
+//                 mat-mul input, K/V caches f16, GELU and softmax-exp through f16 tables
+//                 (wcpp: ggml_vec_gelu_f32 / ggml_compute_forward_soft_max_f32 with ggml_table_*_f16)
+//   2  BF16     : as mode 1 but rounding activations / caches to bf16 (what a bf16 MFMA pipeline does)
+//   gelu_erf=1 switches GELU to the exact erf form (HF cross-check only; whisper.cpp uses tanh).
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <random>
+#include <string>
+#include <vector>
+#include <immintrin.h>
+#include <omp.h>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// scalar conversions
+// ---------------------------------------------------------------------------------------------
+inline float f16_round(float x) { return _cvtsh_ss(_cvtss_sh(x, _MM_FROUND_TO_NEAREST_INT)); }
+inline float f16_bits_to_f32(uint16_t h) { return _cvtsh_ss(h); }
+inline float bf16_round(float x) {
+    uint32_t u; memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return x;
+    u += 0x7fffu + ((u >> 16) & 1u); u &= 0xffff0000u;
+    float y; memcpy(&y, &u, 4); return y;
+}
+
+struct Opts { int mode = 0; int gelu_erf = 0; int n_threads = 0; };
+inline float act_round(float x, int mode) { return mode == 1 ? f16_round(x) : mode == 2 ? bf16_round(x) : x; }
+
+inline float gelu_tanh(float x) {
+    const float GELU_COEF_A = 0.044715f, SQRT_2_OVER_PI = 0.79788456080286535587989211986876f;
+    return 0.5f * x * (1.0f + tanhf(SQRT_2_OVER_PI * x * (1.0f + GELU_COEF_A * x * x)));
+}
+// wcpp: ggml_vec_gelu_f32 (GGML_GELU_FP16): y = table[f16(x)], table[i] = f16(gelu(f32(i)))
+inline float gelu_op(float x, const Opts& o) {
+    if (o.gelu_erf) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    if (o.mode == 1) return f16_round(gelu_tanh(f16_round(x)));
+    if (o.mode == 2) return bf16_round(gelu_tanh(x));
+    return gelu_tanh(x);
+}
+// wcpp: soft_max CPU: val = table_exp_f16[f16(x - max)]
+inline float exp_op(float x, const Opts& o) {
+    if (o.mode == 1) return f16_round(expf(f16_round(x)));
+    return expf(x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------
+struct HParams {
+    int32_t n_vocab, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int32_t n_text_ctx, n_text_state, n_text_head, n_text_layer, n_mels, ftype;
+};
+struct Tensor { std::vector<int> ne; std::vector<float> data; };  // data in file order, f32
+struct Vocab {
+    int n_vocab = 51864;
+    std::vector<std::string> id_to_token;
+    std::map<std::string, int> token_to_id;
+    int token_eot = 50256, token_sot = 50257, token_translate = 50357, token_transcribe = 50358;
+    int token_solm = 50359, token_prev = 50360, token_nosp = 50361, token_not = 50362, token_beg = 50363;
+    bool is_multilingual() const { return n_vocab >= 51865; }
+    int num_languages() const { return n_vocab - 51765 - (is_multilingual() ? 1 : 0); }
+};
+
+// wcpp: g_lang (id order).  Only the id is needed on this path.
+const char* const k_lang[] = {"en","zh","de","es","ru","ko","fr","ja","pt","tr","pl","ca","nl","ar","sv","it","id","hi","fi","vi",
+    "he","uk","el","ms","cs","ro","da","hu","ta","no","th","ur","hr","bg","lt","la","mi","ml","cy","sk","te","fa","lv","bn","sr","az",
+    "sl","kn","et","mk","br","eu","is","hy","ne","mn","bs","kk","sq","sw","gl","mr","pa","si","km","sn","yo","so","af","oc","ka","be",
+    "tg","sd","gu","am","yi","lo","uz","fo","ht","ps","tk","nn","mt","sa","lb","my","bo","tl","mg","as","tt","haw","ln","ha","ba","jw","su","yue"};
+const int k_n_lang = 100;
+int lang_id(const char* s) { for (int i = 0; i < k_n_lang; i++) if (!strcmp(s, k_lang[i])) return i; return -1; }
+
+struct Model {
+    HParams hp;
+    int filt_n_mel = 0, filt_n_fft = 0;
+    std::vector<float> filters;
+    Vocab vocab;
+    std::map<std::string, Tensor> t;
+    const std::vector<float>& w(const std::string& n) const {
+        auto it = t.find(n);
+        if (it == t.end()) { fprintf(stderr, "oracle: missing tensor %s\n", n.c_str()); abort(); }
+        return it->second.data;
+    }
+};
+
+// wcpp: whisper_model_load -- magic, hparams, mel filters, vocab (+ synthesised specials), tensors
+bool load_model(const char* path, Model& m) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    auto rd = [&](void* p, size_t n) { return fread(p, 1, n, f) == n; };
+    uint32_t magic;
+    if (!rd(&magic, 4) || magic != 0x67676d6c) { fclose(f); return false; }
+    if (!rd(&m.hp, sizeof(HParams))) { fclose(f); return false; }
+    int32_t nm, nf; rd(&nm, 4); rd(&nf, 4);
+    m.filt_n_mel = nm; m.filt_n_fft = nf; m.filters.resize((size_t)nm * nf);
+    rd(m.filters.data(), m.filters.size() * 4);
+    int32_t nv; rd(&nv, 4);
+    Vocab& v = m.vocab;
+    v.id_to_token.resize(nv);
+    for (int i = 0; i < nv; i++) {
+        uint32_t len; rd(&len, 4);
+        std::string s(len, 0);
+        if (len) rd(&s[0], len);
+        v.id_to_token[i] = s; v.token_to_id[s] = i;
+    }
+    v.n_vocab = m.hp.n_vocab;
+    if (v.is_multilingual()) {
+        v.token_eot++; v.token_sot++;
+        const int dt = v.num_languages() - 98;
+        v.token_translate += dt; v.token_transcribe += dt; v.token_solm += dt; v.token_prev += dt;
+        v.token_nosp += dt; v.token_not += dt; v.token_beg += dt;
+    }
+    if (nv < m.hp.n_vocab) {
+        v.id_to_token.resize(m.hp.n_vocab);
+        for (int i = nv; i < m.hp.n_vocab; i++) {
+            std::string w;
+            if (i > v.token_beg) w = "[_TT_" + std::to_string(i - v.token_beg) + "]";
+            else if (i == v.token_eot) w = "[_EOT_]";
+            else if (i == v.token_sot) w = "[_SOT_]";
+            else if (i == v.token_translate) w = "[_TRANSLATE_]";
+            else if (i == v.token_transcribe) w = "[_TRANSCRIBE_]";
+            else if (i == v.token_solm) w = "[_SOLM_]";
+            else if (i == v.token_prev) w = "[_PREV_]";
+            else if (i == v.token_nosp) w = "[_NOSP_]";
+            else if (i == v.token_not) w = "[_NOT_]";
+            else if (i == v.token_beg) w = "[_BEG_]";
+            else if (i > v.token_sot && i <= v.token_sot + v.num_languages()) w = "[_LANG_" + std::string(k_lang[i - v.token_sot - 1]) + "]";
+            else w = "[_extra_token_" + std::to_string(i) + "]";
+            v.id_to_token[i] = w; v.token_to_id[w] = i;
+        }
+    }
+    while (true) {
+        int32_t nd, nl, tt;
+        if (!rd(&nd, 4)) break;
+        rd(&nl, 4); rd(&tt, 4);
+        Tensor T; T.ne.resize(nd);
+        size_t n = 1;
+        for (int i = 0; i < nd; i++) { int32_t e; rd(&e, 4); T.ne[i] = e; n *= e; }
+        std::string name(nl, 0); rd(&name[0], nl);
+        T.data.resize(n);
+        if (tt == 0) { if (!rd(T.data.data(), n * 4)) { fclose(f); return false; } }
+        else if (tt == 1) {
+            std::vector<uint16_t> h(n);
+            if (!rd(h.data(), n * 2)) { fclose(f); return false; }
+            for (size_t i = 0; i < n; i++) T.data[i] = f16_bits_to_f32(h[i]);
+        } else { fprintf(stderr, "oracle: unsupported tensor type %d\n", tt); fclose(f); return false; }
+        m.t[name] = std::move(T);
+    }
+    fclose(f);
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// log-mel   (wcpp: fill_sin_cos_table, hann_window, dft, fft, log_mel_spectrogram[_worker_thread])
+// ---------------------------------------------------------------------------------------------
+constexpr int SAMPLE_RATE = 16000, N_FFT = 400, HOP = 160, CHUNK = 30, SIN_COS_N = 400;
+struct MelTables {
+    float sin_vals[SIN_COS_N], cos_vals[SIN_COS_N], hann[N_FFT];
+    MelTables() {
+        for (int i = 0; i < SIN_COS_N; i++) {
+            double theta = (2 * M_PI * i) / SIN_COS_N;
+            sin_vals[i] = sinf(theta); cos_vals[i] = cosf(theta);
+        }
+        for (int i = 0; i < N_FFT; i++) hann[i] = 0.5 * (1.0 - cosf((2.0 * M_PI * i) / (N_FFT)));  // periodic
+    }
+};
+const MelTables g_mt;
+
+void dft(const float* in, int N, float* out) {
+    const int step = SIN_COS_N / N;
+    for (int k = 0; k < N; k++) {
+        float re = 0, im = 0;
+        for (int n = 0; n < N; n++) {
+            int idx = (k * n * step) % SIN_COS_N;
+            re += in[n] * g_mt.cos_vals[idx];
+            im -= in[n] * g_mt.sin_vals[idx];
+        }
+        out[k * 2 + 0] = re; out[k * 2 + 1] = im;
+    }
+}
+void fft(const float* in, int N, float* out) {  // out: 2N floats
+    if (N == 1) { out[0] = in[0]; out[1] = 0; return; }
+    if (N % 2 == 1) { dft(in, N, out); return; }
+    std::vector<float> even(N / 2), odd(N / 2), ef(N), of(N);
+    for (int i = 0; i < N; i++) { if (i % 2 == 0) even[i / 2] = in[i]; else odd[i / 2] = in[i]; }
+    fft(even.data(), N / 2, ef.data());
+    fft(odd.data(), N / 2, of.data());
+    const int step = SIN_COS_N / N;
+    for (int k = 0; k < N / 2; k++) {
+        int idx = k * step;
+        float re = g_mt.cos_vals[idx], im = -g_mt.sin_vals[idx];
+        float re_odd = of[2 * k], im_odd = of[2 * k + 1];
+        out[2 * k + 0] = ef[2 * k + 0] + re * re_odd - im * im_odd;
+        out[2 * k + 1] = ef[2 * k + 1] + re * im_odd + im * re_odd;
+        out[2 * (k + N / 2) + 0] = ef[2 * k + 0] - re * re_odd + im * im_odd;
+        out[2 * (k + N / 2) + 1] = ef[2 * k + 1] - re * im_odd - im * re_odd;
+    }
+}
+
+int mel_n_len(int n_samples) { return (n_samples + SAMPLE_RATE * CHUNK + 2 * (N_FFT / 2) - N_FFT) / HOP; }
+int mel_n_len_org(int n_samples) { return 1 + (n_samples + N_FFT / 2 - N_FFT) / HOP; }
+
+// out: [n_mel][n_len] f32
+void log_mel(const Model& m, const float* samples, int n_samples, float* out, int n_len) {
+    const int n_mel = m.filt_n_mel, n_fft = 1 + N_FFT / 2;
+    const int pad1 = SAMPLE_RATE * CHUNK, pad2 = N_FFT / 2;
+    std::vector<float> sp((size_t)n_samples + pad1 + 2 * pad2, 0.0f);
+    std::copy(samples, samples + n_samples, sp.begin() + pad2);
+    if (n_samples > pad2) std::reverse_copy(samples + 1, samples + 1 + pad2, sp.begin());  // reflect pad at the start
+    const int n_sp = (int)sp.size();
+    const int n_frames = std::min(n_sp / HOP + 1, n_len);
+#pragma omp parallel
+    {
+        std::vector<float> fin(N_FFT), fout(2 * N_FFT);
+#pragma omp for schedule(static)
+        for (int i = 0; i < n_len; i++) {
+            if (i >= n_frames) { for (int j = 0; j < n_mel; j++) out[(size_t)j * n_len + i] = (float)log10(1e-10); continue; }
+            const int offset = i * HOP;
+            const int nv = std::min(N_FFT, n_sp - offset);
+            for (int j = 0; j < nv; j++) fin[j] = g_mt.hann[j] * sp[offset + j];
+            for (int j = std::max(nv, 0); j < N_FFT; j++) fin[j] = 0.0f;
+            fft(fin.data(), N_FFT, fout.data());
+            for (int j = 0; j < N_FFT; j++) fout[j] = fout[2 * j] * fout[2 * j] + fout[2 * j + 1] * fout[2 * j + 1];
+            for (int j = 0; j < n_mel; j++) {
+                double sum = 0.0;
+                const float* fl = &m.filters[(size_t)j * n_fft];
+                int k = 0;
+                for (k = 0; k < n_fft - 3; k += 4)
+                    sum += fout[k + 0] * fl[k + 0] + fout[k + 1] * fl[k + 1] + fout[k + 2] * fl[k + 2] + fout[k + 3] * fl[k + 3];
+                for (; k < n_fft; k++) sum += fout[k] * fl[k];
+                sum = log10(std::max(sum, 1e-10));
+                out[(size_t)j * n_len + i] = (float)sum;
+            }
+        }
+    }
+    double mmax = -1e20;
+    for (size_t i = 0; i < (size_t)n_mel * n_len; i++) if (out[i] > mmax) mmax = out[i];
+    mmax -= 8.0;
+    for (size_t i = 0; i < (size_t)n_mel * n_len; i++) {
+        if (out[i] < mmax) out[i] = (float)mmax;
+        out[i] = (float)((out[i] + 4.0) / 4.0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// dense helpers (row-major activations [rows][cols]; weights [N][K] as stored by PyTorch / ggml)
+// ---------------------------------------------------------------------------------------------
+typedef __m256 v8;
+inline float hsum(v8 v) { float t[8]; _mm256_storeu_ps(t, v); float s = 0; for (int i = 0; i < 8; i++) s += t[i]; return s; }
+
+// C[M][N] = A[M][K](lda) * W[N][K]^T + bias[N]; A rounded per `mode` first (ggml converts src1 to the weight type).
+void matmul(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int mode) {
+    std::vector<float> Ar;
+    const float* Ap = A; int la = lda;
+    if (mode != 0) {
+        Ar.resize((size_t)M * K);
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < M; i++) for (int k = 0; k < K; k++) Ar[(size_t)i * K + k] = act_round(A[(size_t)i * lda + k], mode);
+        Ap = Ar.data(); la = K;
+    }
+    const int K8 = K & ~7;
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+    for (int i0 = 0; i0 < M; i0 += 4) {
+        for (int j0 = 0; j0 < N; j0 += 64) {
+            const int im = std::min(4, M - i0), jm = std::min(64, N - j0);
+            for (int jj = 0; jj < jm; jj += 4) {
+                const int jn = std::min(4, jm - jj);
+                v8 acc[4][4];
+                for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) acc[r][c] = _mm256_setzero_ps();
+                float tail[4][4] = {};
+                const float* a[4]; const float* w[4];
+                for (int r = 0; r < 4; r++) a[r] = Ap + (size_t)(i0 + std::min(r, im - 1)) * la;
+                for (int c = 0; c < 4; c++) w[c] = W + (size_t)(j0 + jj + std::min(c, jn - 1)) * K;
+                for (int k = 0; k < K8; k += 8) {
+                    v8 av[4], wv[4];
+                    for (int r = 0; r < 4; r++) av[r] = _mm256_loadu_ps(a[r] + k);
+                    for (int c = 0; c < 4; c++) wv[c] = _mm256_loadu_ps(w[c] + k);
+                    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) acc[r][c] = _mm256_fmadd_ps(av[r], wv[c], acc[r][c]);
+                }
+                for (int k = K8; k < K; k++) for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) tail[r][c] += a[r][k] * w[c][k];
+                for (int r = 0; r < im; r++) for (int c = 0; c < jn; c++) {
+                    float s = hsum(acc[r][c]) + tail[r][c];
+                    if (bias) s += bias[j0 + jj + c];
+                    C[(size_t)(i0 + r) * ldc + j0 + jj + c] = s;
+                }
+            }
+        }
+    }
+}
+
+// wcpp: ggml_compute_forward_norm_f32 (double sums) followed by mul(w) + add(b)
+void layer_norm(const float* x, const float* w, const float* b, float* y, int rows, int d, float eps = 1e-5f) {
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < rows; r++) {
+        const float* xr = x + (size_t)r * d; float* yr = y + (size_t)r * d;
+        double sum = 0.0; for (int i = 0; i < d; i++) sum += (double)xr[i];
+        float mean = sum / d;
+        double sum2 = 0.0;
+        for (int i = 0; i < d; i++) { float v = xr[i] - mean; yr[i] = v; sum2 += (double)(v * v); }
+        float variance = sum2 / d;
+        const float scale = 1.0f / sqrtf(variance + eps);
+        for (int i = 0; i < d; i++) yr[i] = yr[i] * scale * w[i] + b[i];
+    }
+}
+
+// softmax(q.k) v for one (query row, head). K: [n_kv][ldk] (head slice at +hoff), V likewise. scores scaled by `scale`.
+void attend_row(const float* q, const float* Kc, const float* Vc, int ldkv, int n_kv, int dh, float scale, float* out,
+                const Opts& o, std::vector<float>& sc) {
+    sc.resize(n_kv);
+    float qr[256];
+    for (int i = 0; i < dh; i++) qr[i] = act_round(q[i], o.mode);
+    float mx = -INFINITY;
+    for (int t = 0; t < n_kv; t++) {
+        const float* k = Kc + (size_t)t * ldkv;
+        float s = 0; for (int i = 0; i < dh; i++) s += qr[i] * k[i];
+        s *= scale; sc[t] = s; mx = std::max(mx, s);
+    }
+    double sum = 0.0;
+    for (int t = 0; t < n_kv; t++) { float v = exp_op(sc[t] - mx, o); sc[t] = v; sum += (double)v; }
+    const float inv = (float)(1.0 / sum);
+    for (int i = 0; i < dh; i++) out[i] = 0.0f;
+    for (int t = 0; t < n_kv; t++) {
+        const float p = act_round(sc[t] * inv, o.mode);
+        const float* v = Vc + (size_t)t * ldkv;
+        for (int i = 0; i < dh; i++) out[i] += p * v[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// encoder   (wcpp: whisper_build_graph_conv / _encoder / _cross)
+// ---------------------------------------------------------------------------------------------
+// mel: [n_mel][n_len]; window [seek, seek+2*n_ctx) zero-padded past n_len. enc_out: [n_ctx][d]
+void encode(const Model& m, const float* mel, int n_len, int seek, const Opts& o, float* enc_out) {
+    const HParams& hp = m.hp;
+    const int n_ctx = hp.n_audio_ctx, d = hp.n_audio_state, H = hp.n_audio_head, dh = d / H, n_mel = hp.n_mels;
+    const int T2 = 2 * n_ctx;
+    // time-major padded input [T2+2][n_mel]
+    std::vector<float> x0((size_t)(T2 + 2) * n_mel, 0.0f);
+    for (int t = 0; t < T2; t++) {
+        if (seek + t >= n_len) break;
+        for (int c = 0; c < n_mel; c++) x0[(size_t)(t + 1) * n_mel + c] = mel[(size_t)c * n_len + seek + t];
+    }
+    // conv1: W[d][n_mel][3] -> Wr[d][3][n_mel] so that im2col rows are contiguous slices of the time-major input
+    auto reorder = [](const std::vector<float>& w, int co, int ci) {
+        std::vector<float> r((size_t)co * 3 * ci);
+        for (int a = 0; a < co; a++) for (int c = 0; c < ci; c++) for (int k = 0; k < 3; k++)
+            r[((size_t)a * 3 + k) * ci + c] = w[((size_t)a * ci + c) * 3 + k];
+        return r;
+    };
+    std::vector<float> w1 = reorder(m.w("encoder.conv1.weight"), d, n_mel);
+    std::vector<float> h1((size_t)(T2 + 2) * d, 0.0f);
+    matmul(x0.data(), n_mel, w1.data(), m.w("encoder.conv1.bias").data(), h1.data() + d, d, T2, d, 3 * n_mel, o.mode);
+    for (size_t i = d; i < (size_t)(T2 + 1) * d; i++) h1[i] = gelu_op(h1[i], o);
+    std::vector<float> w2 = reorder(m.w("encoder.conv2.weight"), d, d);
+    std::vector<float> x((size_t)n_ctx * d);
+    matmul(h1.data(), 2 * d, w2.data(), m.w("encoder.conv2.bias").data(), x.data(), d, n_ctx, d, 3 * d, o.mode);
+    const std::vector<float>& pe = m.w("encoder.positional_embedding");
+    for (size_t i = 0; i < x.size(); i++) x[i] = gelu_op(x[i], o) + pe[i];
+
+    std::vector<float> ln((size_t)n_ctx * d), q((size_t)n_ctx * d), k((size_t)n_ctx * d), v((size_t)n_ctx * d),
+        att((size_t)n_ctx * d), tmp((size_t)n_ctx * d), ff((size_t)n_ctx * 4 * d);
+    const float scale = 1.0f / sqrtf((float)dh);
+    for (int il = 0; il < hp.n_audio_layer; il++) {
+        const std::string p = "encoder.blocks." + std::to_string(il) + ".";
+        layer_norm(x.data(), m.w(p + "attn_ln.weight").data(), m.w(p + "attn_ln.bias").data(), ln.data(), n_ctx, d);
+        matmul(ln.data(), d, m.w(p + "attn.query.weight").data(), m.w(p + "attn.query.bias").data(), q.data(), d, n_ctx, d, d, o.mode);
+        matmul(ln.data(), d, m.w(p + "attn.key.weight").data(), nullptr, k.data(), d, n_ctx, d, d, o.mode);
+        matmul(ln.data(), d, m.w(p + "attn.value.weight").data(), m.w(p + "attn.value.bias").data(), v.data(), d, n_ctx, d, d, o.mode);
+        if (o.mode) for (size_t i = 0; i < k.size(); i++) { k[i] = act_round(k[i], o.mode); v[i] = act_round(v[i], o.mode); }  // K,V stored as itype
+#pragma omp parallel
+        {
+            std::vector<float> sc;
+#pragma omp for collapse(2) schedule(static)
+            for (int h = 0; h < H; h++) for (int t = 0; t < n_ctx; t++)
+                attend_row(q.data() + (size_t)t * d + h * dh, k.data() + h * dh, v.data() + h * dh, d, n_ctx, dh, scale,
+                           att.data() + (size_t)t * d + h * dh, o, sc);
+        }
+        matmul(att.data(), d, m.w(p + "attn.out.weight").data(), m.w(p + "attn.out.bias").data(), tmp.data(), d, n_ctx, d, d, o.mode);
+        for (size_t i = 0; i < x.size(); i++) x[i] += tmp[i];
+        layer_norm(x.data(), m.w(p + "mlp_ln.weight").data(), m.w(p + "mlp_ln.bias").data(), ln.data(), n_ctx, d);
+        matmul(ln.data(), d, m.w(p + "mlp.0.weight").data(), m.w(p + "mlp.0.bias").data(), ff.data(), 4 * d, n_ctx, 4 * d, d, o.mode);
+        for (size_t i = 0; i < ff.size(); i++) ff[i] = gelu_op(ff[i], o);
+        matmul(ff.data(), 4 * d, m.w(p + "mlp.2.weight").data(), m.w(p + "mlp.2.bias").data(), tmp.data(), d, n_ctx, d, 4 * d, o.mode);
+        for (size_t i = 0; i < x.size(); i++) x[i] += tmp[i];
+    }
+    layer_norm(x.data(), m.w("encoder.ln_post.weight").data(), m.w("encoder.ln_post.bias").data(), enc_out, n_ctx, d);
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoder state (wcpp: whisper_state kv_cross / kv_self per decoder, whisper_build_graph_decoder)
+// ---------------------------------------------------------------------------------------------
+struct TokenData { int id = 0, tid = 0; float p = 0, plog = 0, pt = 0, ptsum = 0; };
+struct Sequence {
+    std::vector<TokenData> tokens;
+    int result_len = 0;
+    double sum_logprobs_all = 0, sum_logprobs = -INFINITY, avg_logprobs = -INFINITY, entropy = 0, score = -INFINITY;
+};
+struct Decoder {
+    std::vector<float> k, v;  // self KV: [L][n_text_ctx][d]
+    Sequence sequence;
+    int seek_delta = 0; bool failed = false, completed = false, has_ts = false;
+    std::vector<float> probs, logits, logprobs;
+};
+struct Segment { int64_t t0, t1; std::string text; std::vector<TokenData> tokens; bool speaker_turn_next; };
+
+struct FullParams {  // wcpp: whisper_full_params (fields the reference sets, whisper.rs:131-173)
+    int32_t best_of = 5;
+    float temperature = 0.0f, temperature_inc = 0.2f, entropy_thold = 2.4f, logprob_thold = -1.0f, max_initial_ts = 1.0f;
+    float length_penalty = -1.0f;
+    int32_t no_context = 0, single_segment = 0, no_timestamps = 0, suppress_blank = 1, tdrz_enable = 0, print_special = 0;
+    int32_t max_tokens = 0, n_max_text_ctx = 16384, audio_ctx = 0, translate = 0;
+    int32_t fixed_steps = 0;   // bench "Mode F" (SURVEY.md §8d): >0 => exactly this many greedy steps, EOT suppressed, no fallback
+    char language[8] = "en";
+};
+
+struct State {
+    const Model* m; Opts o;
+    std::vector<float> mel; int n_len = 0, n_len_org = 0;
+    std::vector<float> enc;               // [n_ctx][d]
+    std::vector<float> ck, cv;            // cross KV [L][n_ctx][d]
+    std::vector<Decoder> decoders;
+    std::vector<int> prompt_past;
+    std::vector<Segment> result_all;
+    std::vector<TokenData> all_tokens;    // concatenated accepted tokens over windows (test hook)
+    std::vector<float> logits;            // last decode: [n_tokens_out][n_vocab]
+    std::mt19937 rng{0};
+    int n_fail = 0, n_encode = 0, n_decode = 0;
+};
+
+void cross_kv(State& s) {
+    const Model& m = *s.m; const HParams& hp = m.hp;
+    const int n_ctx = hp.n_audio_ctx, d = hp.n_text_state, L = hp.n_text_layer, dh = d / hp.n_text_head;
+    const float kscale = powf((float)dh, -0.25f);
+    s.ck.resize((size_t)L * n_ctx * d); s.cv.resize((size_t)L * n_ctx * d);
+    for (int il = 0; il < L; il++) {
+        const std::string p = "decoder.blocks." + std::to_string(il) + ".cross_attn.";
+        float* K = &s.ck[(size_t)il * n_ctx * d]; float* V = &s.cv[(size_t)il * n_ctx * d];
+        matmul(s.enc.data(), hp.n_audio_state, m.w(p + "key.weight").data(), nullptr, K, d, n_ctx, d, hp.n_audio_state, s.o.mode);
+        matmul(s.enc.data(), hp.n_audio_state, m.w(p + "value.weight").data(), m.w(p + "value.bias").data(), V, d, n_ctx, d, hp.n_audio_state, s.o.mode);
+        for (size_t i = 0; i < (size_t)n_ctx * d; i++) { K[i] = act_round(K[i] * kscale, s.o.mode); V[i] = act_round(V[i], s.o.mode); }
+    }
+}
+
+// Decode n tokens for one decoder at positions [n_past, n_past+n); logits_out (n_vocab) for the LAST token.
+void decode(State& s, Decoder& dec, const int* tokens, int n, int n_past, float* logits_out) {
+    const Model& m = *s.m; const HParams& hp = m.hp; const Opts& o = s.o;
+    const int d = hp.n_text_state, H = hp.n_text_head, dh = d / H, L = hp.n_text_layer, n_ctx = hp.n_text_ctx, n_actx = hp.n_audio_ctx;
+    const float qs = powf((float)dh, -0.25f);
+    if (dec.k.empty()) { dec.k.assign((size_t)L * n_ctx * d, 0.f); dec.v.assign((size_t)L * n_ctx * d, 0.f); }
+    std::vector<float> x((size_t)n * d), ln((size_t)n * d), q((size_t)n * d), kk((size_t)n * d), vv((size_t)n * d), att((size_t)n * d),
+        tmp((size_t)n * d), ff((size_t)n * 4 * d);
+    const std::vector<float>& te = m.w("decoder.token_embedding.weight"); const std::vector<float>& pe = m.w("decoder.positional_embedding");
+    for (int i = 0; i < n; i++) for (int c = 0; c < d; c++) x[(size_t)i * d + c] = te[(size_t)tokens[i] * d + c] + pe[(size_t)(n_past + i) * d + c];
+    std::vector<float> sc;
+    for (int il = 0; il < L; il++) {
+        const std::string p = "decoder.blocks." + std::to_string(il) + ".";
+        layer_norm(x.data(), m.w(p + "attn_ln.weight").data(), m.w(p + "attn_ln.bias").data(), ln.data(), n, d);
+        matmul(ln.data(), d, m.w(p + "attn.query.weight").data(), m.w(p + "attn.query.bias").data(), q.data(), d, n, d, d, o.mode);
+        matmul(ln.data(), d, m.w(p + "attn.key.weight").data(), nullptr, kk.data(), d, n, d, d, o.mode);
+        matmul(ln.data(), d, m.w(p + "attn.value.weight").data(), m.w(p + "attn.value.bias").data(), vv.data(), d, n, d, d, o.mode);
+        float* Kc = &dec.k[(size_t)il * n_ctx * d]; float* Vc = &dec.v[(size_t)il * n_ctx * d];
+        for (int i = 0; i < n; i++) for (int c = 0; c < d; c++) {
+            q[(size_t)i * d + c] *= qs;
+            Kc[(size_t)(n_past + i) * d + c] = act_round(kk[(size_t)i * d + c] * qs, o.mode);
+            Vc[(size_t)(n_past + i) * d + c] = act_round(vv[(size_t)i * d + c], o.mode);
+        }
+        for (int i = 0; i < n; i++) for (int h = 0; h < H; h++)
+            attend_row(q.data() + (size_t)i * d + h * dh, Kc + h * dh, Vc + h * dh, d, n_past + i + 1, dh, 1.0f, att.data() + (size_t)i * d + h * dh, o, sc);
+        matmul(att.data(), d, m.w(p + "attn.out.weight").data(), m.w(p + "attn.out.bias").data(), tmp.data(), d, n, d, d, o.mode);
+        for (size_t i = 0; i < x.size(); i++) x[i] += tmp[i];
+        // cross attention
+        layer_norm(x.data(), m.w(p + "cross_attn_ln.weight").data(), m.w(p + "cross_attn_ln.bias").data(), ln.data(), n, d);
+        matmul(ln.data(), d, m.w(p + "cross_attn.query.weight").data(), m.w(p + "cross_attn.query.bias").data(), q.data(), d, n, d, d, o.mode);
+        for (size_t i = 0; i < q.size(); i++) q[i] *= qs;
+        const float* CK = &s.ck[(size_t)il * n_actx * d]; const float* CV = &s.cv[(size_t)il * n_actx * d];
+#pragma omp parallel
+        {
+            std::vector<float> sc2;
+#pragma omp for collapse(2) schedule(static)
+            for (int i = 0; i < n; i++) for (int h = 0; h < H; h++)
+                attend_row(q.data() + (size_t)i * d + h * dh, CK + h * dh, CV + h * dh, d, n_actx, dh, 1.0f, att.data() + (size_t)i * d + h * dh, o, sc2);
+        }
+        matmul(att.data(), d, m.w(p + "cross_attn.out.weight").data(), m.w(p + "cross_attn.out.bias").data(), tmp.data(), d, n, d, d, o.mode);
+        for (size_t i = 0; i < x.size(); i++) x[i] += tmp[i];
+        // mlp
+        layer_norm(x.data(), m.w(p + "mlp_ln.weight").data(), m.w(p + "mlp_ln.bias").data(), ln.data(), n, d);
+        matmul(ln.data(), d, m.w(p + "mlp.0.weight").data(), m.w(p + "mlp.0.bias").data(), ff.data(), 4 * d, n, 4 * d, d, o.mode);
+        for (size_t i = 0; i < ff.size(); i++) ff[i] = gelu_op(ff[i], o);
+        matmul(ff.data(), 4 * d, m.w(p + "mlp.2.weight").data(), m.w(p + "mlp.2.bias").data(), tmp.data(), d, n, d, 4 * d, o.mode);
+        for (size_t i = 0; i < x.size(); i++) x[i] += tmp[i];
+    }
+    layer_norm(x.data() + (size_t)(n - 1) * d, m.w("decoder.ln.weight").data(), m.w("decoder.ln.bias").data(), ln.data(), 1, d);
+    matmul(ln.data(), d, te.data(), nullptr, logits_out, hp.n_vocab, 1, hp.n_vocab, d, o.mode);
+    s.n_decode++;
+}
+
+// ---------------------------------------------------------------------------------------------
+// logits rules + sampling  (wcpp: whisper_process_logits, whisper_sample_token, whisper_sequence_score)
+// ---------------------------------------------------------------------------------------------
+void process_logits(const State& s, Decoder& dec, const FullParams& P, const float* raw, float temperature) {
+    const Vocab& vocab = s.m->vocab;
+    const auto& tokens_cur = dec.sequence.tokens;
+    const bool is_initial = tokens_cur.empty();
+    const int n_logits = vocab.n_vocab;
+    auto& probs = dec.probs; auto& logits = dec.logits; auto& logprobs = dec.logprobs;
+    logits.assign(raw, raw + n_logits); probs.resize(n_logits); logprobs.resize(n_logits);
+    if (temperature > 0.0f) for (int i = 0; i < n_logits; i++) logits[i] /= temperature;
+    if (P.suppress_blank && is_initial) {
+        logits[vocab.token_eot] = -INFINITY;
+        auto it = vocab.token_to_id.find(" ");
+        if (it != vocab.token_to_id.end()) logits[it->second] = -INFINITY;
+    }
+    logits[vocab.token_not] = -INFINITY;
+    if (P.no_timestamps) for (int i = vocab.token_beg; i < n_logits; i++) logits[i] = -INFINITY;
+    logits[vocab.token_sot] = -INFINITY;
+    logits[vocab.token_nosp] = -INFINITY;
+    if (!P.tdrz_enable) logits[vocab.token_solm] = -INFINITY;
+    logits[vocab.token_translate] = -INFINITY;
+    logits[vocab.token_transcribe] = -INFINITY;
+    logits[vocab.token_prev] = -INFINITY;
+    for (int i = 0; i < vocab.num_languages(); i++) logits[vocab.token_sot + 1 + i] = -INFINITY;
+    if (P.fixed_steps > 0) logits[vocab.token_eot] = -INFINITY;  // Mode F only (not a whisper.cpp rule)
+    {
+        const bool last_was_timestamp = tokens_cur.size() > 0 && tokens_cur.back().id >= vocab.token_beg;
+        const bool penultimate_was_timestamp = tokens_cur.size() < 2 || tokens_cur[tokens_cur.size() - 2].id >= vocab.token_beg;
+        if (last_was_timestamp) {
+            if (penultimate_was_timestamp) for (int i = vocab.token_beg; i < n_logits; i++) logits[i] = -INFINITY;
+            else for (int i = 0; i < vocab.token_eot; i++) logits[i] = -INFINITY;
+        }
+    }
+    if (is_initial && P.max_initial_ts > 0.0f) {
+        const float precision = float(CHUNK) / s.m->hp.n_audio_ctx;
+        const int tid0 = std::round(P.max_initial_ts / precision);
+        for (int i = vocab.token_beg + tid0 + 1; i < n_logits; i++) logits[i] = -INFINITY;
+    }
+    if (dec.has_ts) {
+        const int tid0 = dec.seek_delta / 2;
+        for (int i = vocab.token_beg; i < vocab.token_beg + tid0; i++) logits[i] = -INFINITY;
+    }
+    {
+        const float logit_max = *std::max_element(logits.begin(), logits.end());
+        float logsumexp = 0.0f;
+        for (int i = 0; i < n_logits; i++) if (logits[i] > -INFINITY) logsumexp += expf(logits[i] - logit_max);
+        logsumexp = logf(logsumexp) + logit_max;
+        for (int i = 0; i < n_logits; i++) logprobs[i] = logits[i] > -INFINITY ? logits[i] - logsumexp : -INFINITY;
+    }
+    {
+        float timestamp_logprob = -INFINITY;
+        {
+            float logsumexp = 0.0f;
+            const float logprob_max = *std::max_element(logprobs.begin() + vocab.token_beg, logprobs.end());
+            for (int i = vocab.token_beg; i < n_logits; i++) if (logprobs[i] > -INFINITY) logsumexp += expf(logprobs[i] - logprob_max);
+            if (logsumexp > 0.0f) timestamp_logprob = logf(logsumexp) + logprob_max;
+        }
+        const float max_text_token_logprob = *std::max_element(logprobs.begin(), logprobs.begin() + vocab.token_beg);
+        if (timestamp_logprob > max_text_token_logprob)
+            for (int i = 0; i < vocab.token_beg; i++) { logits[i] = -INFINITY; logprobs[i] = -INFINITY; }
+    }
+    for (int i = 0; i < n_logits; i++) probs[i] = logits[i] == -INFINITY ? 0.0f : expf(logprobs[i]);
+}
+
+TokenData sample_token(State& s, Decoder& dec, bool best) {
+    TokenData r;
+    const Vocab& vocab = s.m->vocab; const auto& probs = dec.probs; const auto& logprobs = dec.logprobs;
+    const int n_logits = vocab.n_vocab;
+    {
+        double sum_ts = 0.0, max_ts = 0.0;
+        for (int i = vocab.token_beg; i < n_logits; i++) {
+            sum_ts += probs[i];
+            if (max_ts < probs[i]) { max_ts = probs[i]; r.tid = i; }
+        }
+        r.pt = max_ts / (sum_ts + 1e-10); r.ptsum = sum_ts;
+    }
+    if (best) {
+        for (int i = 0; i < n_logits; i++) if (r.p < probs[i]) { r.id = i; r.p = probs[i]; r.plog = logprobs[i]; }
+    } else {
+        std::discrete_distribution<> dist(probs.begin(), probs.end());
+        r.id = dist(s.rng); r.p = probs[r.id]; r.plog = logprobs[r.id];
+    }
+    if (r.id >= vocab.token_beg) { r.tid = r.id; r.pt = r.p; }
+    return r;
+}
+
+void sequence_score(const FullParams& P, Sequence& q) {
+    if (q.result_len == 0) return;
+    double result = 0.0;
+    for (int i = 0; i < q.result_len; i++) result += q.tokens[i].plog;
+    q.sum_logprobs = result; q.avg_logprobs = result / q.result_len;
+    double penalty = q.result_len;
+    if (P.length_penalty > 0.0f) penalty = pow((5.0 + penalty) / 6.0, P.length_penalty);
+    q.score = result / penalty;
+    const int n = 32; int cnt = 0; double entropy = 0.0;
+    std::map<int, int> tc;
+    for (int i = std::max(0, q.result_len - n); i < q.result_len; i++) { tc[q.tokens[i].id]++; cnt++; }
+    for (auto& kv : tc) { const double p = kv.second / (double)cnt; entropy -= p * log(p); }
+    q.entropy = entropy;
+}
+
+// ---------------------------------------------------------------------------------------------
+// whisper_full_with_state
+// ---------------------------------------------------------------------------------------------
+int full(State& s, const float* samples, int n_samples, const FullParams& P) {
+    const Model& m = *s.m; const Vocab& vocab = m.vocab; const HParams& hp = m.hp;
+    s.result_all.clear(); s.all_tokens.clear();
+    if (n_samples > 0) {
+        s.n_len = mel_n_len(n_samples); s.n_len_org = mel_n_len_org(n_samples);
+        s.mel.resize((size_t)m.filt_n_mel * s.n_len);
+        log_mel(m, samples, n_samples, s.mel.data(), s.n_len);
+    }
+    const int seek_start = 0, seek_end = s.n_len_org;
+    if (seek_end < seek_start + 100) return 0;
+    std::vector<float> temperatures;
+    if (P.fixed_steps > 0) temperatures.push_back(0.0f);
+    else if (P.temperature_inc > 0.0f) for (float t = P.temperature; t < 1.0f + 1e-6f; t += P.temperature_inc) temperatures.push_back(t);
+    else temperatures.push_back(P.temperature);
+    const int n_decoders = std::max(1, (int)P.best_of);
+    s.decoders.resize(n_decoders);
+    if (P.no_context) s.prompt_past.clear();
+    if (P.audio_ctx > hp.n_audio_ctx) return -5;
+    std::vector<int> prompt_init = {vocab.token_sot};
+    if (vocab.is_multilingual()) {
+        const int lid = lang_id(P.language);
+        if (lid < 0) return -3;
+        prompt_init.push_back(vocab.token_sot + 1 + lid);
+        prompt_init.push_back(P.translate ? vocab.token_translate : vocab.token_transcribe);
+    }
+    if (P.no_timestamps) prompt_init.push_back(vocab.token_not);
+    int seek = seek_start;
+    std::vector<int> prompt;
+    std::vector<float> lg(hp.n_vocab);
+    s.enc.resize((size_t)hp.n_audio_ctx * hp.n_audio_state);
+    while (true) {
+        if (seek + 100 >= seek_end) break;
+        encode(m, s.mel.data(), s.n_len, seek, s.o, s.enc.data());
+        cross_kv(s); s.n_encode++;
+        if (seek > seek_start && seek + 500 >= seek_end) s.prompt_past.clear();
+        int best_decoder_id = 0;
+        for (int it = 0; it < (int)temperatures.size(); it++) {
+            const float t_cur = temperatures[it];
+            int n_cur = 1;
+            if (t_cur > 0.0f) n_cur = P.best_of;
+            n_cur = std::max(1, n_cur);
+            for (int j = 0; j < n_cur; j++) {
+                Decoder& d = s.decoders[j];
+                d.sequence = Sequence();
+                d.seek_delta = 100 * CHUNK; d.failed = d.completed = d.has_ts = false;
+            }
+            prompt.clear();
+            if (!s.prompt_past.empty() && t_cur < 0.5f && P.n_max_text_ctx > 0) {
+                int n_take = std::min(std::min((int)P.n_max_text_ctx, hp.n_text_ctx / 2), (int)s.prompt_past.size());
+                prompt = {vocab.token_prev};
+                prompt.insert(prompt.begin() + 1, s.prompt_past.end() - n_take, s.prompt_past.end());
+            }
+            prompt.insert(prompt.end(), prompt_init.begin(), prompt_init.end());
+            decode(s, s.decoders[0], prompt.data(), (int)prompt.size(), 0, lg.data());
+            process_logits(s, s.decoders[0], P, lg.data(), t_cur);
+            for (int j = 1; j < n_cur; j++) {
+                Decoder& d = s.decoders[j];
+                d.k = s.decoders[0].k; d.v = s.decoders[0].v;
+                d.probs = s.decoders[0].probs; d.logits = s.decoders[0].logits; d.logprobs = s.decoders[0].logprobs;
+            }
+            const int n_max = P.fixed_steps > 0 ? P.fixed_steps : hp.n_text_ctx / 2 - 4;
+            for (int i = 0; i < n_max; i++) {
+                for (int j = 0; j < n_cur; j++) {
+                    Decoder& d = s.decoders[j];
+                    if (d.completed || d.failed) continue;
+                    d.sequence.tokens.push_back(sample_token(s, d, t_cur < 1e-6f));
+                    d.sequence.sum_logprobs_all += d.sequence.tokens.back().plog;
+                }
+                for (int j = 0; j < n_cur; j++) {
+                    Decoder& d = s.decoders[j];
+                    if (d.completed || d.failed) continue;
+                    bool& has_ts = d.has_ts; bool& failed = d.failed; bool& completed = d.completed;
+                    int& seek_delta = d.seek_delta; int& result_len = d.sequence.result_len;
+                    {
+                        const TokenData& token = d.sequence.tokens.back();
+                        if (token.id > vocab.token_beg) {
+                            const int seek_delta_new = 2 * (token.id - vocab.token_beg);
+                            if (has_ts && seek_delta > seek_delta_new && result_len < i) { failed = true; continue; }
+                            seek_delta = seek_delta_new; result_len = i + 1; has_ts = true;
+                        }
+                        if (P.fixed_steps > 0) { if (i == n_max - 1) { result_len = i + 1; completed = true; } continue; }
+                        if (token.id == vocab.token_eot || (P.max_tokens > 0 && i >= P.max_tokens) || (has_ts && seek + seek_delta + 100 >= seek_end)) {
+                            if (result_len == 0) {
+                                if (seek + seek_delta + 100 >= seek_end) result_len = i + 1;
+                                else { failed = true; continue; }
+                            }
+                            if (P.single_segment) { result_len = i + 1; seek_delta = 100 * CHUNK; }
+                            completed = true; continue;
+                        }
+                    }
+                    if (i == n_max - 1 && (result_len == 0 || seek_delta < 100 * CHUNK / 2)) { failed = true; continue; }
+                }
+                {
+                    bool completed_all = true;
+                    for (int j = 0; j < n_cur; j++) { Decoder& d = s.decoders[j]; if (d.completed || d.failed) continue; completed_all = false; }
+                    if (completed_all) break;
+                }
+                {
+                    const int n_past = (int)prompt.size() + i;
+                    for (int j = 0; j < n_cur; j++) {
+                        Decoder& d = s.decoders[j];
+                        if (d.failed || d.completed) continue;
+                        const int tok = d.sequence.tokens.back().id;
+                        decode(s, d, &tok, 1, n_past, lg.data());
+                        process_logits(s, d, P, lg.data(), t_cur);
+                    }
+                }
+            }
+            {
+                double best_score = -INFINITY;
+                for (int j = 0; j < n_cur; j++) {
+                    Decoder& d = s.decoders[j];
+                    if (d.failed) continue;
+                    d.sequence.tokens.resize(d.sequence.result_len);
+                    sequence_score(P, d.sequence);
+                    if (P.fixed_steps == 0 && d.sequence.result_len > 32 && d.sequence.entropy < P.entropy_thold) { d.failed = true; continue; }
+                    if (best_score < d.sequence.score) { best_score = d.sequence.score; best_decoder_id = j; }
+                }
+            }
+            bool success = true;
+            if (it != (int)temperatures.size() - 1) {
+                const Decoder& d = s.decoders[best_decoder_id];
+                if (d.failed || d.sequence.avg_logprobs < P.logprob_thold) { success = false; s.n_fail++; }
+            }
+            if (success) break;
+        }
+        {
+            const Decoder& bd = s.decoders[best_decoder_id];
+            const int seek_delta = bd.seek_delta; const int result_len = bd.sequence.result_len;
+            const auto& tokens_cur = bd.sequence.tokens;
+            s.prompt_past.clear();
+            if (!prompt.empty() && prompt.front() == vocab.token_prev) s.prompt_past.insert(s.prompt_past.end(), prompt.begin() + 1, prompt.end() - prompt_init.size());
+            for (int i = 0; i < result_len && i < (int)tokens_cur.size(); i++) s.prompt_past.push_back(tokens_cur[i].id);
+            for (auto& t : tokens_cur) s.all_tokens.push_back(t);
+            if (!tokens_cur.empty()) {
+                int i0 = 0;
+                int64_t t0 = seek + 2 * (tokens_cur.front().tid - vocab.token_beg);
+                std::string text; bool speaker_turn_next = false;
+                for (int i = 0; i < (int)tokens_cur.size(); i++) {
+                    if (P.print_special || tokens_cur[i].id < vocab.token_eot) text += vocab.id_to_token[tokens_cur[i].id];
+                    if (P.tdrz_enable && tokens_cur[i].id == vocab.token_solm) speaker_turn_next = true;
+                    if (tokens_cur[i].id > vocab.token_beg && !P.single_segment) {
+                        const int64_t t1 = seek + 2 * (tokens_cur[i].tid - vocab.token_beg);
+                        if (!text.empty()) {
+                            s.result_all.push_back({t0, t1, text, {}, speaker_turn_next});
+                            for (int j = i0; j <= i; j++) s.result_all.back().tokens.push_back(tokens_cur[j]);
+                        }
+                        text = "";
+                        while (i < (int)tokens_cur.size() && tokens_cur[i].id > vocab.token_beg) i++;
+                        i--; t0 = t1; i0 = i + 1; speaker_turn_next = false;
+                    }
+                }
+                if (!text.empty()) {
+                    const int64_t t1 = seek + seek_delta;
+                    s.result_all.push_back({t0, t1, text, {}, speaker_turn_next});
+                    for (int j = i0; j < (int)tokens_cur.size(); j++) s.result_all.back().tokens.push_back(tokens_cur[j]);
+                }
+            }
+            seek += seek_delta;
+        }
+    }
+    return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C API for ctypes (tests/, smoke(), bench cpu_baseline)
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+struct orc_opts { int32_t mode, gelu_erf, n_threads; };
+
+void* orc_load(const char* path) { Model* m = new Model(); if (!load_model(path, *m)) { delete m; return nullptr; } return m; }
+void orc_free(void* m) { delete (Model*)m; }
+void orc_hparams(void* m, int32_t* out) { memcpy(out, &((Model*)m)->hp, sizeof(HParams)); }
+void orc_special_tokens(void* mp, int32_t* out) {
+    const Vocab& v = ((Model*)mp)->vocab;
+    int t[9] = {v.token_eot, v.token_sot, v.token_translate, v.token_transcribe, v.token_solm, v.token_prev, v.token_nosp, v.token_not, v.token_beg};
+    memcpy(out, t, sizeof(t));
+}
+const char* orc_token_str(void* mp, int id) { return ((Model*)mp)->vocab.id_to_token[id].c_str(); }
+int orc_mel_n_len(int n_samples) { return mel_n_len(n_samples); }
+int orc_mel_n_len_org(int n_samples) { return mel_n_len_org(n_samples); }
+int orc_log_mel(void* mp, const float* pcm, int n, float* out, int n_len) { log_mel(*(Model*)mp, pcm, n, out, n_len); return 0; }
+int orc_encode(void* mp, const float* mel, int n_len, int seek, const orc_opts* o, float* enc_out) {
+    Opts op; op.mode = o->mode; op.gelu_erf = o->gelu_erf;
+    if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
+    encode(*(Model*)mp, mel, n_len, seek, op, enc_out); return 0;
+}
+void* orc_state_new(void* mp, const orc_opts* o) {
+    State* s = new State(); s->m = (Model*)mp; s->o.mode = o->mode; s->o.gelu_erf = o->gelu_erf;
+    if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
+    s->decoders.resize(1); return s;
+}
+void orc_state_free(void* s) { delete (State*)s; }
+int orc_state_set_encoder(void* sp, const float* enc) {
+    State* s = (State*)sp; const HParams& hp = s->m->hp;
+    s->enc.assign(enc, enc + (size_t)hp.n_audio_ctx * hp.n_audio_state); cross_kv(*s); return 0;
+}
+// cross KV of layer il: k,v [n_ctx][d]
+int orc_state_cross_kv(void* sp, int il, float* k, float* v) {
+    State* s = (State*)sp; const HParams& hp = s->m->hp; size_t n = (size_t)hp.n_audio_ctx * hp.n_text_state;
+    memcpy(k, &s->ck[il * n], n * 4); memcpy(v, &s->cv[il * n], n * 4); return 0;
+}
+int orc_decode(void* sp, const int32_t* tokens, int n, int n_past, float* logits) {
+    State* s = (State*)sp; decode(*s, s->decoders[0], tokens, n, n_past, logits); return 0;
+}
+// apply whisper.cpp's logits rules for decoder 0 given its token history; returns greedy token + fills logprobs if non-null
+int orc_process_logits(void* sp, const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta,
+                       const FullParams* P, float* logprobs_out, float* out5) {
+    State* s = (State*)sp; Decoder& d = s->decoders[0];
+    d.sequence.tokens.clear();
+    for (int i = 0; i < n_hist; i++) { TokenData t; t.id = hist[i]; d.sequence.tokens.push_back(t); }
+    d.has_ts = has_ts; d.seek_delta = seek_delta;
+    process_logits(*s, d, *P, raw, 0.0f);
+    TokenData r = sample_token(*s, d, true);
+    if (logprobs_out) memcpy(logprobs_out, d.logprobs.data(), d.logprobs.size() * 4);
+    if (out5) { out5[0] = r.p; out5[1] = r.plog; out5[2] = (float)r.tid; out5[3] = r.pt; out5[4] = r.ptsum; }
+    return r.id;
+}
+void orc_full_default_params(FullParams* p) { *p = FullParams(); }
+int orc_full(void* sp, const float* pcm, int n, const FullParams* P) { return full(*(State*)sp, pcm, n, *P); }
+int orc_n_segments(void* sp) { return (int)((State*)sp)->result_all.size(); }
+const char* orc_segment_text(void* sp, int i) { return ((State*)sp)->result_all[i].text.c_str(); }
+int64_t orc_segment_t0(void* sp, int i) { return ((State*)sp)->result_all[i].t0; }
+int64_t orc_segment_t1(void* sp, int i) { return ((State*)sp)->result_all[i].t1; }
+int orc_segment_speaker_turn_next(void* sp, int i) { return ((State*)sp)->result_all[i].speaker_turn_next; }
+int orc_n_tokens(void* sp) { return (int)((State*)sp)->all_tokens.size(); }
+void orc_tokens(void* sp, int32_t* ids, float* plog) {
+    State* s = (State*)sp;
+    for (size_t i = 0; i < s->all_tokens.size(); i++) { ids[i] = s->all_tokens[i].id; if (plog) plog[i] = s->all_tokens[i].plog; }
+}
+void orc_counters(void* sp, int32_t* out) { State* s = (State*)sp; out[0] = s->n_encode; out[1] = s->n_decode; out[2] = s->n_fail; }
+int orc_mel_of_state(void* sp, float* out) { State* s = (State*)sp; memcpy(out, s->mel.data(), s->mel.size() * 4); return s->n_len; }
+}

@@ -1,0 +1,275 @@
+"""ggml legacy model-file I/O (the `ggml-*.bin` files SpeakSense points ASR_MODEL_PATH at).
+
+The reference loads these through `WhisperContext::new_with_params` (/root/reference/src/asr/whisper.rs:21-28),
+i.e. whisper.cpp's `whisper_model_load` (third party, not in tree; format restated in SURVEY.md §8 a-2).
+No real weights exist offline, so tests and bench.py synthesise seeded random models in exactly that format:
+the product loader (csrc/model.cpp) and the oracle loader (oracle/whisper_oracle.cpp) both parse the same file.
+
+numpy only -- this module must work on the GPU box (no transformers / no reference there).
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, asdict
+
+import numpy as np
+
+GGML_MAGIC = 0x67676D6C
+GGML_TYPE_F32 = 0
+GGML_TYPE_F16 = 1
+
+
+@dataclass
+class HParams:
+    n_vocab: int = 51864
+    n_audio_ctx: int = 1500
+    n_audio_state: int = 384
+    n_audio_head: int = 6
+    n_audio_layer: int = 4
+    n_text_ctx: int = 448
+    n_text_state: int = 384
+    n_text_head: int = 6
+    n_text_layer: int = 4
+    n_mels: int = 80
+    ftype: int = 1
+
+    def astuple(self):
+        return tuple(asdict(self).values())
+
+
+PRESETS = {
+    # real shapes (SURVEY.md §8 header)
+    "tiny.en": HParams(51864, 1500, 384, 6, 4, 448, 384, 6, 4, 80, 1),
+    "base.en": HParams(51864, 1500, 512, 8, 6, 448, 512, 8, 6, 80, 1),
+    "large-v3": HParams(51866, 1500, 1280, 20, 32, 448, 1280, 20, 32, 128, 1),
+    # toy shapes for fast CPU tests: same context sizes / vocabulary rules, tiny width
+    "toy.en": HParams(51864, 1500, 128, 2, 2, 448, 128, 2, 2, 80, 1),
+    "toy": HParams(51866, 1500, 128, 2, 2, 448, 128, 2, 2, 128, 1),
+}
+
+
+# ----------------------------------------------------------------------------------------------
+# mel filterbank (slaney scale + slaney norm, as shipped inside every ggml whisper file)
+# ----------------------------------------------------------------------------------------------
+def _hz_to_mel(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mels = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    log_t = f >= min_log_hz
+    mels = np.where(log_t, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mels)
+    return mels
+
+
+def _mel_to_hz(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    freqs = f_sp * m
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    log_t = m >= min_log_mel
+    freqs = np.where(log_t, min_log_hz * np.exp(logstep * (m - min_log_mel)), freqs)
+    return freqs
+
+
+def mel_filters(n_mels: int, n_fft: int = 400, sr: int = 16000) -> np.ndarray:
+    """[n_mels, n_fft/2+1] float32, identical to librosa.filters.mel(sr, n_fft, n_mels) (slaney)."""
+    n_bins = n_fft // 2 + 1
+    fftfreqs = np.linspace(0, sr / 2, n_bins)
+    mel_pts = _mel_to_hz(np.linspace(_hz_to_mel(0.0), _hz_to_mel(sr / 2), n_mels + 2))
+    fdiff = np.diff(mel_pts)
+    ramps = mel_pts[:, None] - fftfreqs[None, :]
+    lower = -ramps[:-2] / fdiff[:-1, None]
+    upper = ramps[2:] / fdiff[1:, None]
+    w = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_pts[2 : n_mels + 2] - mel_pts[:n_mels])
+    w *= enorm[:, None]
+    return w.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic vocabulary: the file carries the n_vocab_base "text" tokens; whisper.cpp synthesises
+# names for the specials above them (restated in both loaders)
+# ----------------------------------------------------------------------------------------------
+_SYL = ["ka", "to", "mi", "ra", "ne", "so", "lu", "vi", "pa", "chi", "ng", "er", "an", "th", "ou", "we"]
+
+
+def synth_vocab(n_vocab: int) -> list[bytes]:
+    """Deterministic fake BPE table with the properties the path relies on: a " " token exists
+    (suppress_blank looks it up), ids < eot are printable UTF-8, some CJK tokens exist so the
+    reference's punctuation/promo post-pass (whisper.rs:41-43,175-201) is exercised."""
+    multilingual = n_vocab >= 51865
+    n_base = 50257 if multilingual else 50256  # tokens stored in the file = [0, eot)
+    toks: list[bytes] = []
+    cjk = ["吗", "呢", "什么", "好", "太", "啊", "。", "！", "？", "，", "订阅", "點贊", "真是", "怎么"]
+    for i in range(n_base):
+        if i == 220:
+            toks.append(b" ")
+        elif i < 256:
+            toks.append(bytes([33 + (i % 90)]) + b"%d" % i)
+        elif i % 97 == 0:
+            toks.append(cjk[(i // 97) % len(cjk)].encode("utf-8"))
+        else:
+            a, b, c = i % 16, (i // 16) % 16, (i // 256) % 16
+            word = _SYL[a] + _SYL[b] + (_SYL[c] if i % 3 == 0 else "")
+            toks.append(((" " if i % 2 == 0 else "") + word).encode("utf-8"))
+    return toks
+
+
+# ----------------------------------------------------------------------------------------------
+# tensor inventory (names as in whisper.cpp's loader; shapes in PyTorch order)
+# ----------------------------------------------------------------------------------------------
+def tensor_specs(hp: HParams):
+    """Yield (name, shape, ggml_type). 2-D+ weights are f16 when ftype==1, the rest f32."""
+    wt = GGML_TYPE_F16 if hp.ftype == 1 else GGML_TYPE_F32
+    da, dt = hp.n_audio_state, hp.n_text_state
+    yield "encoder.positional_embedding", (hp.n_audio_ctx, da), GGML_TYPE_F32
+    yield "encoder.conv1.weight", (da, hp.n_mels, 3), wt
+    yield "encoder.conv1.bias", (da, 1), GGML_TYPE_F32
+    yield "encoder.conv2.weight", (da, da, 3), wt
+    yield "encoder.conv2.bias", (da, 1), GGML_TYPE_F32
+    for i in range(hp.n_audio_layer):
+        p = f"encoder.blocks.{i}."
+        yield p + "attn_ln.weight", (da,), GGML_TYPE_F32
+        yield p + "attn_ln.bias", (da,), GGML_TYPE_F32
+        yield p + "attn.query.weight", (da, da), wt
+        yield p + "attn.query.bias", (da,), GGML_TYPE_F32
+        yield p + "attn.key.weight", (da, da), wt
+        yield p + "attn.value.weight", (da, da), wt
+        yield p + "attn.value.bias", (da,), GGML_TYPE_F32
+        yield p + "attn.out.weight", (da, da), wt
+        yield p + "attn.out.bias", (da,), GGML_TYPE_F32
+        yield p + "mlp_ln.weight", (da,), GGML_TYPE_F32
+        yield p + "mlp_ln.bias", (da,), GGML_TYPE_F32
+        yield p + "mlp.0.weight", (4 * da, da), wt
+        yield p + "mlp.0.bias", (4 * da,), GGML_TYPE_F32
+        yield p + "mlp.2.weight", (da, 4 * da), wt
+        yield p + "mlp.2.bias", (da,), GGML_TYPE_F32
+    yield "encoder.ln_post.weight", (da,), GGML_TYPE_F32
+    yield "encoder.ln_post.bias", (da,), GGML_TYPE_F32
+    yield "decoder.positional_embedding", (hp.n_text_ctx, dt), GGML_TYPE_F32
+    yield "decoder.token_embedding.weight", (hp.n_vocab, dt), wt
+    for i in range(hp.n_text_layer):
+        p = f"decoder.blocks.{i}."
+        for a in ("attn", "cross_attn"):
+            yield p + a + "_ln.weight", (dt,), GGML_TYPE_F32
+            yield p + a + "_ln.bias", (dt,), GGML_TYPE_F32
+            yield p + a + ".query.weight", (dt, dt), wt
+            yield p + a + ".query.bias", (dt,), GGML_TYPE_F32
+            yield p + a + ".key.weight", (dt, dt), wt
+            yield p + a + ".value.weight", (dt, dt), wt
+            yield p + a + ".value.bias", (dt,), GGML_TYPE_F32
+            yield p + a + ".out.weight", (dt, dt), wt
+            yield p + a + ".out.bias", (dt,), GGML_TYPE_F32
+        yield p + "mlp_ln.weight", (dt,), GGML_TYPE_F32
+        yield p + "mlp_ln.bias", (dt,), GGML_TYPE_F32
+        yield p + "mlp.0.weight", (4 * dt, dt), wt
+        yield p + "mlp.0.bias", (4 * dt,), GGML_TYPE_F32
+        yield p + "mlp.2.weight", (dt, 4 * dt), wt
+        yield p + "mlp.2.bias", (dt,), GGML_TYPE_F32
+    yield "decoder.ln.weight", (dt,), GGML_TYPE_F32
+    yield "decoder.ln.bias", (dt,), GGML_TYPE_F32
+
+
+def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.ndarray:
+    inc = np.log(max_timescale) / (channels // 2 - 1)
+    inv = np.exp(-inc * np.arange(channels // 2))
+    t = np.arange(length)[:, None] * inv[None, :]
+    return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
+
+
+def synth_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logit_gain: float) -> np.ndarray:
+    """Seeded random weights with sane scales so activations stay O(1) through 32 layers.
+    `logit_gain` scales the (tied) token embedding so greedy argmax has a real margin and the
+    chosen-token probability is high enough not to trip whisper.cpp's logprob fallback."""
+    if name == "encoder.positional_embedding":
+        return sinusoids(shape[0], shape[1])
+    if name.endswith("_ln.weight") or name.endswith("ln_post.weight") or name == "decoder.ln.weight":
+        return (1.0 + 0.1 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+    if name.endswith(".bias"):
+        return (0.02 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+    if name == "decoder.positional_embedding":
+        return (0.1 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+    if name == "decoder.token_embedding.weight":
+        d = shape[1]
+        return (logit_gain / np.sqrt(d) * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+    fan_in = int(np.prod(shape[1:]))
+    return (rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
+
+
+def write_model(path: str, hp: HParams | str, seed: int = 0, logit_gain: float = 8.0, tensors: dict | None = None):
+    """Write a ggml legacy whisper model. `tensors` (name -> ndarray in PyTorch layout) overrides the
+    synthetic draw -- used by the HF cross-check to export a transformers model's weights."""
+    if isinstance(hp, str):
+        hp = PRESETS[hp]
+    rng = np.random.default_rng(seed)
+    vocab = synth_vocab(hp.n_vocab)
+    filt = mel_filters(hp.n_mels)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<I", GGML_MAGIC))
+        f.write(struct.pack("<11i", *hp.astuple()))
+        f.write(struct.pack("<2i", filt.shape[0], filt.shape[1]))
+        f.write(filt.astype("<f4").tobytes())
+        f.write(struct.pack("<i", len(vocab)))
+        for t in vocab:
+            f.write(struct.pack("<I", len(t)))
+            f.write(t)
+        for name, shape, ttype in tensor_specs(hp):
+            if tensors is not None and name in tensors:
+                data = np.asarray(tensors[name], dtype=np.float32).reshape(shape)
+            else:
+                data = synth_tensor(name, shape, hp, rng, logit_gain)
+            nb = name.encode()
+            f.write(struct.pack("<3i", len(shape), len(nb), ttype))
+            for i in range(len(shape)):
+                f.write(struct.pack("<i", shape[len(shape) - 1 - i]))  # ggml order: ne[0] fastest
+            f.write(nb)
+            f.write(data.astype("<f2" if ttype == GGML_TYPE_F16 else "<f4").tobytes())
+    return hp
+
+
+def read_model(path: str):
+    """Parse a ggml legacy whisper file -> (HParams, filters[n_mel,n_fft], vocab list[bytes], {name: float32 ndarray})."""
+    with open(path, "rb") as f:
+        buf = f.read()
+    off = 0
+    (magic,) = struct.unpack_from("<I", buf, off)
+    off += 4
+    if magic != GGML_MAGIC:
+        raise ValueError("bad ggml magic")
+    hp = HParams(*struct.unpack_from("<11i", buf, off))
+    off += 44
+    n_mel, n_fft = struct.unpack_from("<2i", buf, off)
+    off += 8
+    filt = np.frombuffer(buf, "<f4", n_mel * n_fft, off).reshape(n_mel, n_fft).copy()
+    off += 4 * n_mel * n_fft
+    (nv,) = struct.unpack_from("<i", buf, off)
+    off += 4
+    vocab = []
+    for _ in range(nv):
+        (ln,) = struct.unpack_from("<I", buf, off)
+        off += 4
+        vocab.append(bytes(buf[off : off + ln]))
+        off += ln
+    tensors = {}
+    while off < len(buf):
+        n_dims, nlen, ttype = struct.unpack_from("<3i", buf, off)
+        off += 12
+        ne = struct.unpack_from(f"<{n_dims}i", buf, off)
+        off += 4 * n_dims
+        name = bytes(buf[off : off + nlen]).decode()
+        off += nlen
+        n = int(np.prod(ne))
+        if ttype == GGML_TYPE_F16:
+            data = np.frombuffer(buf, "<f2", n, off).astype(np.float32)
+            off += 2 * n
+        elif ttype == GGML_TYPE_F32:
+            data = np.frombuffer(buf, "<f4", n, off).copy()
+            off += 4 * n
+        else:
+            raise ValueError(f"unsupported ggml tensor type {ttype} for {name}")
+        tensors[name] = data.reshape(tuple(reversed(ne)))
+    return hp, filt, vocab, tensors
