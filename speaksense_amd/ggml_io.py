@@ -181,31 +181,80 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> np.
     return np.concatenate([np.sin(t), np.cos(t)], axis=1).astype(np.float32)
 
 
-def synth_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logit_gain: float) -> np.ndarray:
-    """Seeded random weights with sane scales so activations stay O(1) through 32 layers.
-    `logit_gain` scales the (tied) token embedding so greedy argmax has a real margin and the
-    chosen-token probability is high enough not to trip whisper.cpp's logprob fallback."""
+def _special_ids(hp: HParams):
+    multilingual = hp.n_vocab >= 51865
+    eot = 50257 if multilingual else 50256
+    beg = 50363 + ((hp.n_vocab - 51765 - 1 - 98) if multilingual else 0)
+    n_prompt = 3 if multilingual else 1
+    return eot, beg, n_prompt
+
+
+def synth_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logit_gain: float, ctx: dict) -> np.ndarray:
+    """Seeded random weights with sane scales so activations stay O(1) through 32 layers, plus a little
+    hand-built structure so that a random decoder behaves like a transcriber instead of a fixed point:
+
+    * `logit_gain` = target std of the logits over the vocabulary (token embedding per-element std 0.5, final
+      LayerNorm gain chosen to match).  Around 9 the greedy choice has a top-2 margin ~2 and p_top ~0.5, which
+      keeps whisper.cpp's logprob/entropy fallback from firing on every window.
+    * tied embeddings make a random decoder predict its own input; the last block's self-attention is built as
+      an anti-repetition head (-c * mean of the history) and its MLP output is boosted to drown the direct path.
+    * timestamp-token embeddings share a common direction, and the learned positional embedding pushes along it
+      every `ts_period` positions (-> timestamp pairs) and along the EOT embedding late in the sequence
+      (-> natural termination), so segments / seek / EOT logic is exercised.
+    """
+    d = hp.n_text_state
+    eot, beg, n_prompt = _special_ids(hp)
     if name == "encoder.positional_embedding":
         return sinusoids(shape[0], shape[1])
-    if name.endswith("_ln.weight") or name.endswith("ln_post.weight") or name == "decoder.ln.weight":
+    if name == "decoder.ln.weight":
+        g = logit_gain / (0.5 * np.sqrt(shape[0]))
+        return (g * (1.0 + 0.05 * rng.standard_normal(shape, dtype=np.float32))).astype(np.float32)
+    if name.endswith("_ln.weight") or name.endswith("ln_post.weight"):
         return (1.0 + 0.1 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
     if name.endswith(".bias"):
         return (0.02 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
     if name == "decoder.positional_embedding":
-        return (0.1 * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        pe = rng.standard_normal(shape, dtype=np.float32)
+        ctx["u_ts"] = rng.standard_normal(d).astype(np.float32)
+        ctx["u_ts"] /= np.linalg.norm(ctx["u_ts"])
+        ctx["u_eot"] = rng.standard_normal(d).astype(np.float32)
+        ctx["u_eot"] /= np.linalg.norm(ctx["u_eot"])
+        sx = 0.3 * np.sqrt(d)  # ~ per-element std of the final residual stream (boosted MLP)
+        period = ctx["ts_period"]
+        for p in range(shape[0]):
+            k = (p - (n_prompt - 1)) % period
+            if p >= n_prompt - 1 and k in (0, period - 1):
+                pe[p] += 6.0 * sx * ctx["u_ts"]
+            ramp = (p - ctx["eot_start"]) / 10.0
+            if ramp > 0:
+                pe[p] += min(ramp, 3.0) * 6.0 * sx * ctx["u_eot"]
+        return pe.astype(np.float32)
     if name == "decoder.token_embedding.weight":
-        d = shape[1]
-        return (logit_gain / np.sqrt(d) * rng.standard_normal(shape, dtype=np.float32)).astype(np.float32)
+        te = 0.5 * rng.standard_normal(shape, dtype=np.float32)
+        te[beg:] = 0.35 * rng.standard_normal((shape[0] - beg, d), dtype=np.float32) + 0.35 * np.sqrt(d) * ctx["u_ts"]
+        te[eot] = 0.5 * np.sqrt(d) * ctx["u_eot"]
+        return te.astype(np.float32)
     fan_in = int(np.prod(shape[1:]))
+    last = f"decoder.blocks.{hp.n_text_layer - 1}."
+    if name in (last + "attn.value.weight", last + "attn.out.weight"):
+        eye = np.eye(shape[0], dtype=np.float32)
+        return eye if name.endswith("value.weight") else (-4.0 * eye)
+    if name == last + "mlp.2.weight":
+        boost = np.sqrt(hp.n_text_state) / 2
+        return (boost * rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
+    if name.endswith("cross_attn.out.weight") or name.endswith("cross_attn.query.weight"):
+        return (3.0 * rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)  # make the audio matter
     return (rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
 
 
-def write_model(path: str, hp: HParams | str, seed: int = 0, logit_gain: float = 8.0, tensors: dict | None = None):
+def write_model(path: str, hp: HParams | str, seed: int = 0, logit_gain: float = 9.0, tensors: dict | None = None,
+                ts_period: int = 12, eot_start: int = 40):
     """Write a ggml legacy whisper model. `tensors` (name -> ndarray in PyTorch layout) overrides the
     synthetic draw -- used by the HF cross-check to export a transformers model's weights."""
     if isinstance(hp, str):
         hp = PRESETS[hp]
     rng = np.random.default_rng(seed)
+    ctx = {"ts_period": ts_period, "eot_start": eot_start}
     vocab = synth_vocab(hp.n_vocab)
     filt = mel_filters(hp.n_mels)
     with open(path, "wb") as f:
@@ -221,7 +270,7 @@ def write_model(path: str, hp: HParams | str, seed: int = 0, logit_gain: float =
             if tensors is not None and name in tensors:
                 data = np.asarray(tensors[name], dtype=np.float32).reshape(shape)
             else:
-                data = synth_tensor(name, shape, hp, rng, logit_gain)
+                data = synth_tensor(name, shape, hp, rng, logit_gain, ctx)
             nb = name.encode()
             f.write(struct.pack("<3i", len(shape), len(nb), ttype))
             for i in range(len(shape)):
