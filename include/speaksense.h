@@ -1,0 +1,133 @@
+/* speaksense.h -- C ABI of libspeaksense_hip.so: the MI355X-native Whisper transcription path.
+ *
+ * Drop-in boundary.  The reference reaches its inference engine only through
+ *   /root/reference/src/asr/mod.rs:58-73     trait AsrEngine { create_state, transcribe_with_state, transcribe }
+ *   /root/reference/src/asr/whisper.rs:21-28 WhisperAsr::new           -> ss_engine_create
+ *   /root/reference/src/asr/whisper.rs:30-39 WhisperAsr::create_state  -> ss_session_create
+ *   /root/reference/src/asr/whisper.rs:75    state.full(params, &audio)-> ss_transcribe / ss_submit + ss_wait
+ *   /root/reference/src/asr/whisper.rs:77-95 full_n_segments / full_get_segment_{text,t0,t1,speaker_turn_next}
+ *                                                                      -> ss_result_*
+ * Plain pointers and sizes only; 0 = ok, negative = failure; no exceptions cross this boundary.
+ * A whisper.h-compatible subset (what whisper-rs-sys binds) is in whisper_compat.h and is implemented on top
+ * of these entry points.  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Threading: an engine is shared by any number of sessions and threads (the reference shares one
+ * Arc<WhisperContext> between tokio tasks, whisper.rs:17,26).  A session is used by one caller at a time
+ * (the reference guards it with a Mutex, whisper.rs:38,51).  ss_submit never blocks on the GPU: the engine's
+ * batch former groups queued 30 s chunks from different sessions into one device batch.
+ */
+#ifndef SPEAKSENSE_H
+#define SPEAKSENSE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ss_engine ss_engine;
+typedef struct ss_session ss_session;
+typedef struct ss_ticket ss_ticket;
+
+enum { SS_DTYPE_BF16 = 0, SS_DTYPE_F16 = 1 };
+enum {
+    SS_OK = 0,
+    SS_ERR_ARG = -1,       /* null / out-of-range argument */
+    SS_ERR_MODEL = -2,     /* model file missing, bad magic, unsupported tensor type, missing tensor */
+    SS_ERR_LANG = -3,      /* unknown language for a multilingual model */
+    SS_ERR_DEVICE = -4,    /* no HIP device / HIP runtime error (message via ss_last_error) */
+    SS_ERR_AUDIO_CTX = -5, /* audio_ctx larger than the model's (whisper_full returns -5) */
+    SS_ERR_UNSUPPORTED = -9
+};
+
+typedef struct ss_engine_opts {
+    int32_t device;       /* HIP device ordinal (one engine per GPU; one process per GPU under torchrun) */
+    int32_t dtype;        /* SS_DTYPE_BF16 (default) | SS_DTYPE_F16: MFMA operand / KV-cache type, f32 accumulate */
+    int32_t max_batch;    /* windows encoded+decoded together on the device (default 8) */
+    int32_t max_decoders; /* decoders per window at temperature > 0 (reference: Greedy{best_of:5}, whisper.rs:132) */
+    int32_t batch_wait_us;/* how long the batch former waits for more chunks before launching a partial batch */
+    int32_t reserved[3];
+} ss_engine_opts;
+
+/* The whisper_full_params fields the reference sets (whisper.rs:131-173) plus its per-request overrides
+ * (language whisper.rs:60-63, stream mode whisper.rs:65-69, tdrz whisper.rs:136-139).  ss_default_params()
+ * returns exactly what build_params() + stream-mode produce. */
+typedef struct ss_params {
+    int32_t best_of;          /* 5 */
+    float temperature;        /* 0.0 */
+    float temperature_inc;    /* 0.2 (whisper_full_default_params) */
+    float entropy_thold;      /* 2.4 */
+    float logprob_thold;      /* -1.0 */
+    float max_initial_ts;     /* 1.0 */
+    float length_penalty;     /* -1.0 */
+    int32_t no_context;       /* 1 in stream mode (both reference callers); 0 is SS_ERR_UNSUPPORTED for now */
+    int32_t single_segment;   /* 0 */
+    int32_t no_timestamps;    /* 0 */
+    int32_t suppress_blank;   /* 1 */
+    int32_t tdrz_enable;      /* AsrParams.speaker_diarization */
+    int32_t print_special;    /* 0 */
+    int32_t max_tokens;       /* 0 */
+    int32_t audio_ctx;        /* 0 = full (1500) */
+    int32_t translate;        /* 0 */
+    int32_t fixed_steps;      /* bench Mode F: >0 = exactly this many greedy steps, EOT suppressed, no fallback */
+    char language[8];         /* "en" default; AsrParams.language */
+} ss_params;
+
+void ss_default_params(ss_params* p);
+const char* ss_last_error(void); /* thread-local, valid until the next failing call on this thread */
+
+/* ---- engine / session lifetime ---------------------------------------------------------------------- */
+int ss_engine_create(const char* ggml_model_path, const ss_engine_opts* opts, ss_engine** out);
+void ss_engine_free(ss_engine* e);
+int ss_engine_hparams(const ss_engine* e, int32_t out11[11]);       /* n_vocab ... ftype, ggml header order */
+int ss_engine_special_tokens(const ss_engine* e, int32_t out9[9]);  /* eot sot translate transcribe solm prev nosp not beg */
+const char* ss_engine_token_str(const ss_engine* e, int32_t id);
+
+ss_session* ss_session_create(ss_engine* e);
+void ss_session_free(ss_session* s);
+
+/* ---- transcription ---------------------------------------------------------------------------------- */
+/* Blocking: n chunks (one per session, sessions distinct) processed as one device batch stream.
+ * pcm[i]: n_samples[i] mono f32 samples @16 kHz in [-1,1].  pcm_on_device != 0: pcm[i] are device pointers
+ * on the engine's GPU (bench: inputs resident in HBM).  Returns 0 or the first failing chunk's error. */
+int ss_transcribe_batch(ss_engine* e, ss_session* const* sessions, const float* const* pcm, const int32_t* n_samples,
+                        int32_t n, const ss_params* params, int32_t pcm_on_device);
+/* One chunk on one session (== whisper_full_with_state). */
+int ss_transcribe(ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params);
+/* Non-blocking: copies the samples, returns a ticket; the engine batches across sessions. */
+int ss_submit(ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, ss_ticket** out);
+int ss_wait(ss_ticket* t);      /* blocks; returns the chunk's status; frees the ticket */
+
+/* ---- results of the session's last chunk (valid until its next transcribe/submit) -------------------- */
+int32_t ss_result_n_segments(const ss_session* s);
+const char* ss_result_segment_text(const ss_session* s, int32_t i);   /* bytes from the vocab, NUL-terminated */
+int64_t ss_result_segment_t0(const ss_session* s, int32_t i);         /* centiseconds, as whisper.cpp reports */
+int64_t ss_result_segment_t1(const ss_session* s, int32_t i);
+int32_t ss_result_segment_speaker_turn_next(const ss_session* s, int32_t i);
+int32_t ss_result_n_tokens(const ss_session* s);                      /* accepted tokens over all windows */
+int ss_result_tokens(const ss_session* s, int32_t* ids, float* plog); /* plog may be NULL */
+int ss_result_counters(const ss_session* s, int32_t out4[4]);         /* n_encode, n_decode_steps, n_fail, n_windows */
+
+/* ---- per-stage hooks for parity tests (host f32 in / out; each runs the same device kernels) -------- */
+int32_t ss_mel_n_len(int32_t n_samples);
+int ss_log_mel(ss_engine* e, const float* pcm, int32_t n_samples, float* mel_out /* [n_mel][n_len] */, int32_t n_len);
+int ss_encode(ss_engine* e, const float* mel /* [n_mel][n_len] */, int32_t n_len, int32_t seek,
+              float* enc_out /* [n_audio_ctx][n_audio_state] */);
+/* Decoder hook on a session: set encoder output (computes cross-KV), then decode tokens at n_past with the
+ * session's self-KV; logits_out: [n_vocab] of the LAST token, before any rule. */
+int ss_session_set_encoder(ss_session* s, const float* enc /* [n_audio_ctx][n_audio_state] */);
+int ss_session_decode(ss_session* s, const int32_t* tokens, int32_t n_tokens, int32_t n_past, float* logits_out);
+/* Fused logits rules + log-softmax + greedy pick on the device for one row of raw logits.
+ * hist: tokens sampled so far in this window.  out6: id, p, plog, tid, pt, ptsum. */
+int ss_process_logits(ss_engine* e, const float* raw_logits, const int32_t* hist, int32_t n_hist, int32_t has_ts,
+                      int32_t seek_delta, const ss_params* params, float out6[6]);
+
+/* ---- timing hooks for bench.py (HIP events on the engine's own stream) ------------------------------ */
+/* ms spent in the phases of the last ss_transcribe_batch: [0] mel, [1] encoder+cross-KV, [2] decode, [3] total */
+int ss_engine_last_timing(const ss_engine* e, float out_ms[4]);
+/* average device time (ms) of `reps` launches of the dominant encoder GEMM (FC1: M=batch*1500, N=4d, K=d) on the
+ * engine's stream, and its algorithmic FLOPs per launch: the roofline probe bench.py reports. */
+int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_ms, double* flops_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -70,8 +70,20 @@ def lib():
         L.orc_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_mel_of_state.argtypes = [C.c_void_p, C.c_void_p]
+        # cap OpenMP: the GPU box reports 256 logical CPUs; hundreds of spinning threads on tiny decode-step loops
+        # (or a cgroup quota below the CPU count) make the oracle orders of magnitude slower
+        L.orc_set_threads.argtypes = [C.c_int]
+        L.orc_set_threads(default_threads())
         _LIB = L
     return _LIB
+
+
+def default_threads() -> int:
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
 
 
 def _p(a: np.ndarray):
@@ -110,7 +122,7 @@ class OracleModel:
     def encode(self, mel: np.ndarray, seek: int = 0, mode: int = MODE_F32, gelu_erf: int = 0) -> np.ndarray:
         mel = np.ascontiguousarray(mel, np.float32)
         out = np.empty((self.n_audio_ctx, self.n_audio_state), np.float32)
-        o = OrcOpts(mode, gelu_erf, 0)
+        o = OrcOpts(mode, gelu_erf, default_threads())
         self.L.orc_encode(self.h, _p(mel), mel.shape[1], seek, C.byref(o), _p(out))
         return out
 
@@ -135,7 +147,7 @@ class OracleState:
     def __init__(self, model: OracleModel, mode: int, gelu_erf: int):
         self.m = model
         self.L = model.L
-        o = OrcOpts(mode, gelu_erf, 0)
+        o = OrcOpts(mode, gelu_erf, default_threads())
         self.h = self.L.orc_state_new(model.h, C.byref(o))
 
     def close(self):

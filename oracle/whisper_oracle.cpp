@@ -621,6 +621,7 @@ void sequence_score(const FullParams& P, Sequence& q) {
 int full(State& s, const float* samples, int n_samples, const FullParams& P) {
     const Model& m = *s.m; const Vocab& vocab = m.vocab; const HParams& hp = m.hp;
     s.result_all.clear(); s.all_tokens.clear();
+    s.n_encode = s.n_decode = s.n_fail = 0;
     if (n_samples > 0) {
         s.n_len = mel_n_len(n_samples); s.n_len_org = mel_n_len_org(n_samples);
         s.mel.resize((size_t)m.filt_n_mel * s.n_len);
@@ -698,7 +699,7 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
                             if (has_ts && seek_delta > seek_delta_new && result_len < i) { failed = true; continue; }
                             seek_delta = seek_delta_new; result_len = i + 1; has_ts = true;
                         }
-                        if (P.fixed_steps > 0) { if (i == n_max - 1) { result_len = i + 1; completed = true; } continue; }
+                        if (P.fixed_steps > 0) { if (i == n_max - 1) { result_len = i + 1; seek_delta = 100 * CHUNK; completed = true; } continue; }
                         if (token.id == vocab.token_eot || (P.max_tokens > 0 && i >= P.max_tokens) || (has_ts && seek + seek_delta + 100 >= seek_end)) {
                             if (result_len == 0) {
                                 if (seek + seek_delta + 100 >= seek_end) result_len = i + 1;
@@ -790,6 +791,7 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
 extern "C" {
 struct orc_opts { int32_t mode, gelu_erf, n_threads; };
 
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 void* orc_load(const char* path) { Model* m = new Model(); if (!load_model(path, *m)) { delete m; return nullptr; } return m; }
 void orc_free(void* m) { delete (Model*)m; }
 void orc_hparams(void* m, int32_t* out) { memcpy(out, &((Model*)m)->hp, sizeof(HParams)); }

@@ -1,0 +1,234 @@
+"""ctypes binding of libspeaksense_hip.so (include/speaksense.h).  Product path: raises if the HIP library is
+missing or no GPU is visible -- there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspeaksense_hip.so")
+_LIB = None
+
+DTYPE_BF16, DTYPE_F16 = 0, 1
+
+
+class EngineOpts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("dtype", C.c_int32), ("max_batch", C.c_int32), ("max_decoders", C.c_int32),
+                ("batch_wait_us", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class Params(C.Structure):
+    _fields_ = [("best_of", C.c_int32), ("temperature", C.c_float), ("temperature_inc", C.c_float), ("entropy_thold", C.c_float),
+                ("logprob_thold", C.c_float), ("max_initial_ts", C.c_float), ("length_penalty", C.c_float), ("no_context", C.c_int32),
+                ("single_segment", C.c_int32), ("no_timestamps", C.c_int32), ("suppress_blank", C.c_int32), ("tdrz_enable", C.c_int32),
+                ("print_special", C.c_int32), ("max_tokens", C.c_int32), ("audio_ctx", C.c_int32), ("translate", C.c_int32),
+                ("fixed_steps", C.c_int32), ("language", C.c_char * 8)]
+
+
+class SpeakSenseError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"speaksense error {code}: {msg}")
+        self.code = code
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+        L = C.CDLL(LIB_PATH)
+        vp, i32, f32p = C.c_void_p, C.c_int32, C.c_void_p
+        L.ss_last_error.restype = C.c_char_p
+        L.ss_default_params.argtypes = [C.POINTER(Params)]
+        L.ss_engine_create.argtypes = [C.c_char_p, C.POINTER(EngineOpts), C.POINTER(vp)]
+        L.ss_engine_free.argtypes = [vp]
+        L.ss_engine_hparams.argtypes = [vp, vp]
+        L.ss_engine_special_tokens.argtypes = [vp, vp]
+        L.ss_engine_token_str.restype = C.c_char_p
+        L.ss_engine_token_str.argtypes = [vp, i32]
+        L.ss_session_create.restype = vp
+        L.ss_session_create.argtypes = [vp]
+        L.ss_session_free.argtypes = [vp]
+        L.ss_transcribe_batch.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), i32, C.POINTER(Params), i32]
+        L.ss_transcribe.argtypes = [vp, f32p, i32, C.POINTER(Params)]
+        L.ss_submit.argtypes = [vp, f32p, i32, C.POINTER(Params), C.POINTER(vp)]
+        L.ss_wait.argtypes = [vp]
+        L.ss_result_n_segments.argtypes = [vp]
+        L.ss_result_segment_text.restype = C.c_char_p
+        L.ss_result_segment_text.argtypes = [vp, i32]
+        L.ss_result_segment_t0.restype = C.c_int64
+        L.ss_result_segment_t0.argtypes = [vp, i32]
+        L.ss_result_segment_t1.restype = C.c_int64
+        L.ss_result_segment_t1.argtypes = [vp, i32]
+        L.ss_result_segment_speaker_turn_next.argtypes = [vp, i32]
+        L.ss_result_n_tokens.argtypes = [vp]
+        L.ss_result_tokens.argtypes = [vp, vp, vp]
+        L.ss_result_counters.argtypes = [vp, vp]
+        L.ss_mel_n_len.argtypes = [i32]
+        L.ss_log_mel.argtypes = [vp, f32p, i32, f32p, i32]
+        L.ss_encode.argtypes = [vp, f32p, i32, i32, f32p]
+        L.ss_session_set_encoder.argtypes = [vp, f32p]
+        L.ss_session_decode.argtypes = [vp, vp, i32, i32, f32p]
+        L.ss_process_logits.argtypes = [vp, f32p, vp, i32, i32, i32, C.POINTER(Params), f32p]
+        L.ss_engine_last_timing.argtypes = [vp, f32p]
+        L.ss_engine_probe_gemm.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise SpeakSenseError(rc, lib().ss_last_error().decode(errors="replace"))
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().ss_default_params(C.byref(p))
+    for k, v in kw.items():
+        if k == "language" and isinstance(v, str):
+            v = v.encode()
+        setattr(p, k, v)
+    return p
+
+
+class Engine:
+    def __init__(self, model_path: str, device: int = 0, dtype: int = DTYPE_BF16, max_batch: int = 8, max_decoders: int = 5,
+                 batch_wait_us: int = 2000):
+        self.L = lib()
+        o = EngineOpts(device, dtype, max_batch, max_decoders, batch_wait_us)
+        h = C.c_void_p()
+        _check(self.L.ss_engine_create(model_path.encode(), C.byref(o), C.byref(h)))
+        self.h = h
+        hp = np.zeros(11, np.int32)
+        self.L.ss_engine_hparams(self.h, _p(hp))
+        (self.n_vocab, self.n_audio_ctx, self.n_audio_state, self.n_audio_head, self.n_audio_layer, self.n_text_ctx, self.n_text_state,
+         self.n_text_head, self.n_text_layer, self.n_mels, self.ftype) = [int(x) for x in hp]
+        st = np.zeros(9, np.int32)
+        self.L.ss_engine_special_tokens(self.h, _p(st))
+        (self.eot, self.sot, self.translate, self.transcribe, self.solm, self.prev, self.nosp, self.not_, self.beg) = [int(x) for x in st]
+        self.max_batch = max_batch
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ss_engine_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def token_str(self, i: int) -> bytes:
+        return self.L.ss_engine_token_str(self.h, i)
+
+    def new_session(self) -> "Session":
+        return Session(self)
+
+    # ---- stage hooks ----
+    def log_mel(self, pcm: np.ndarray) -> np.ndarray:
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        n_len = self.L.ss_mel_n_len(len(pcm))
+        out = np.empty((self.n_mels, n_len), np.float32)
+        _check(self.L.ss_log_mel(self.h, _p(pcm), len(pcm), _p(out), n_len))
+        return out
+
+    def encode(self, mel: np.ndarray, seek: int = 0) -> np.ndarray:
+        mel = np.ascontiguousarray(mel, np.float32)
+        out = np.empty((self.n_audio_ctx, self.n_audio_state), np.float32)
+        _check(self.L.ss_encode(self.h, _p(mel), mel.shape[1], seek, _p(out)))
+        return out
+
+    def process_logits(self, raw, hist, has_ts: bool, seek_delta: int, params: Params | None = None):
+        raw = np.ascontiguousarray(raw, np.float32)
+        h = np.ascontiguousarray(hist, np.int32)
+        out = np.zeros(6, np.float32)
+        _check(self.L.ss_process_logits(self.h, _p(raw), _p(h), len(h), int(has_ts), seek_delta,
+                                        C.byref(params) if params is not None else None, _p(out)))
+        return dict(id=int(out[0]), p=float(out[1]), plog=float(out[2]), tid=int(out[3]), pt=float(out[4]), ptsum=float(out[5]))
+
+    def transcribe_batch(self, sessions, pcms, params: Params | None = None, device_ptrs=None):
+        """pcms: list of np.float32 arrays (host), or with device_ptrs=[(ptr, n), ...] device buffers already in HBM."""
+        n = len(sessions)
+        sh = (C.c_void_p * n)(*[s.h for s in sessions])
+        if device_ptrs is not None:
+            pp = (C.c_void_p * n)(*[int(p) for p, _ in device_ptrs])
+            nn = (C.c_int32 * n)(*[int(k) for _, k in device_ptrs])
+            on_dev = 1
+        else:
+            pcms = [np.ascontiguousarray(p, np.float32) for p in pcms]
+            pp = (C.c_void_p * n)(*[p.ctypes.data for p in pcms])
+            nn = (C.c_int32 * n)(*[len(p) for p in pcms])
+            on_dev = 0
+        _check(self.L.ss_transcribe_batch(self.h, sh, pp, nn, n, C.byref(params) if params is not None else None, on_dev))
+        return [s.result() for s in sessions]
+
+    def last_timing(self):
+        t = np.zeros(4, np.float32)
+        self.L.ss_engine_last_timing(self.h, _p(t))
+        return dict(mel_ms=float(t[0]), encode_ms=float(t[1]), decode_ms=float(t[2]), total_ms=float(t[3]))
+
+    def probe_gemm(self, batch: int, reps: int):
+        ms, fl = C.c_float(), C.c_double()
+        _check(self.L.ss_engine_probe_gemm(self.h, batch, reps, C.byref(ms), C.byref(fl)))
+        return ms.value, fl.value
+
+
+class Session:
+    def __init__(self, eng: Engine):
+        self.eng = eng
+        self.L = eng.L
+        self.h = self.L.ss_session_create(eng.h)
+        if not self.h:
+            raise SpeakSenseError(-1, "ss_session_create failed")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ss_session_free(self.h)
+            self.h = None
+
+    def transcribe(self, pcm: np.ndarray, params: Params | None = None):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        _check(self.L.ss_transcribe(self.h, _p(pcm), len(pcm), C.byref(params) if params is not None else None))
+        return self.result()
+
+    def submit(self, pcm: np.ndarray, params: Params | None = None):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        t = C.c_void_p()
+        _check(self.L.ss_submit(self.h, _p(pcm), len(pcm), C.byref(params) if params is not None else None, C.byref(t)))
+        return t
+
+    def wait(self, ticket):
+        _check(self.L.ss_wait(ticket))
+        return self.result()
+
+    def result(self):
+        segs = []
+        for i in range(self.L.ss_result_n_segments(self.h)):
+            segs.append(dict(text=self.L.ss_result_segment_text(self.h, i), t0=self.L.ss_result_segment_t0(self.h, i),
+                             t1=self.L.ss_result_segment_t1(self.h, i),
+                             speaker_turn_next=bool(self.L.ss_result_segment_speaker_turn_next(self.h, i))))
+        n = self.L.ss_result_n_tokens(self.h)
+        ids = np.zeros(n, np.int32)
+        plog = np.zeros(n, np.float32)
+        if n:
+            self.L.ss_result_tokens(self.h, _p(ids), _p(plog))
+        c = np.zeros(4, np.int32)
+        self.L.ss_result_counters(self.h, _p(c))
+        return dict(segments=segs, tokens=ids, plog=plog, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]), n_windows=int(c[3]))
+
+    def set_encoder(self, enc: np.ndarray):
+        enc = np.ascontiguousarray(enc, np.float32)
+        _check(self.L.ss_session_set_encoder(self.h, _p(enc)))
+
+    def decode(self, tokens, n_past: int) -> np.ndarray:
+        t = np.ascontiguousarray(tokens, np.int32)
+        out = np.empty(self.eng.n_vocab, np.float32)
+        _check(self.L.ss_session_decode(self.h, _p(t), len(t), n_past, _p(out)))
+        return out

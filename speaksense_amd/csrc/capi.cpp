@@ -1,0 +1,181 @@
+// extern "C" boundary of libspeaksense_hip.so (include/speaksense.h).  No exceptions cross it.
+#include <cstring>
+
+#include "engine.h"
+
+using namespace ss;
+
+struct ss_engine { EngineBase* e; };
+struct ss_session { Session s; };
+struct ss_ticket { Job job; };
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define SS_TRY try {
+#define SS_CATCH                                                          \
+    } catch (const ss::Error& e) { return fail(e.code, e.what()); }        \
+    catch (const std::exception& e) { return fail(SS_ERR_DEVICE, e.what()); }
+
+extern "C" {
+
+const char* ss_last_error(void) { return g_err.c_str(); }
+
+void ss_default_params(ss_params* p) {
+    // whisper_full_default_params(GREEDY) + build_params (/root/reference/src/asr/whisper.rs:131-173) + stream mode (65-69)
+    memset(p, 0, sizeof(*p));
+    p->best_of = 5; p->temperature = 0.0f; p->temperature_inc = 0.2f; p->entropy_thold = 2.4f; p->logprob_thold = -1.0f;
+    p->max_initial_ts = 1.0f; p->length_penalty = -1.0f; p->no_context = 1; p->single_segment = 0; p->no_timestamps = 0;
+    p->suppress_blank = 1; p->tdrz_enable = 0; p->print_special = 0; p->max_tokens = 0; p->audio_ctx = 0; p->translate = 0;
+    p->fixed_steps = 0;
+    strcpy(p->language, "en");
+}
+
+int ss_engine_create(const char* path, const ss_engine_opts* opts, ss_engine** out) {
+    if (!path || !out) return fail(SS_ERR_ARG, "ss_engine_create: null argument");
+    *out = nullptr;
+    ss_engine_opts o{};
+    if (opts) o = *opts;
+    if (o.max_batch <= 0) o.max_batch = 8;
+    if (o.max_decoders <= 0) o.max_decoders = 5;
+    if (o.max_batch * o.max_decoders > 64 * 8) return fail(SS_ERR_ARG, "ss_engine_create: max_batch*max_decoders too large");
+    SS_TRY
+    EngineBase* e = o.dtype == SS_DTYPE_F16 ? make_engine_f16(path, o) : make_engine_bf16(path, o);
+    *out = new ss_engine{e};
+    return SS_OK;
+    SS_CATCH
+}
+void ss_engine_free(ss_engine* e) {
+    if (!e) return;
+    delete e->e;
+    delete e;
+}
+int ss_engine_hparams(const ss_engine* e, int32_t out11[11]) {
+    if (!e || !out11) return fail(SS_ERR_ARG, "null argument");
+    memcpy(out11, &e->e->hm.hp, sizeof(HParams));
+    return SS_OK;
+}
+int ss_engine_special_tokens(const ss_engine* e, int32_t out9[9]) {
+    if (!e || !out9) return fail(SS_ERR_ARG, "null argument");
+    const Vocab& v = e->e->hm.vocab;
+    const int t[9] = {v.token_eot, v.token_sot, v.token_translate, v.token_transcribe, v.token_solm, v.token_prev, v.token_nosp, v.token_not, v.token_beg};
+    memcpy(out9, t, sizeof(t));
+    return SS_OK;
+}
+const char* ss_engine_token_str(const ss_engine* e, int32_t id) {
+    if (!e || id < 0 || id >= (int)e->e->hm.vocab.id_to_token.size()) return nullptr;
+    return e->e->hm.vocab.id_to_token[id].c_str();
+}
+
+ss_session* ss_session_create(ss_engine* e) {
+    if (!e) return nullptr;
+    ss_session* s = new ss_session();
+    s->s.eng = e->e;
+    return s;
+}
+void ss_session_free(ss_session* s) { delete s; }
+
+int ss_transcribe_batch(ss_engine* e, ss_session* const* sessions, const float* const* pcm, const int32_t* n_samples, int32_t n,
+                        const ss_params* params, int32_t pcm_on_device) {
+    if (!e || !sessions || !pcm || !n_samples || n <= 0) return fail(SS_ERR_ARG, "ss_transcribe_batch: bad argument");
+    ss_params P;
+    if (params) P = *params; else ss_default_params(&P);
+    std::vector<Job> jobs(n);
+    std::vector<Job*> jp(n);
+    for (int i = 0; i < n; i++) {
+        if (!sessions[i] || (n_samples[i] > 0 && !pcm[i]) || n_samples[i] < 0) return fail(SS_ERR_ARG, "ss_transcribe_batch: bad chunk");
+        for (int k = 0; k < i; k++) if (sessions[k] == sessions[i]) return fail(SS_ERR_ARG, "ss_transcribe_batch: sessions must be distinct");
+        jobs[i].sess = &sessions[i]->s; jobs[i].pcm = pcm[i]; jobs[i].n_samples = n_samples[i]; jobs[i].pcm_on_device = pcm_on_device != 0;
+        jobs[i].P = P;
+        jp[i] = &jobs[i];
+    }
+    SS_TRY
+    e->e->run_jobs(jp);
+    for (int i = 0; i < n; i++) if (jobs[i].status != 0) return fail(jobs[i].status, "chunk " + std::to_string(i) + " failed");
+    return SS_OK;
+    SS_CATCH
+}
+int ss_transcribe(ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params) {
+    if (!s) return fail(SS_ERR_ARG, "ss_transcribe: null session");
+    ss_engine tmp{s->s.eng};
+    ss_session* ss1[1] = {s};
+    const float* p1[1] = {pcm};
+    int32_t n1[1] = {n_samples};
+    return ss_transcribe_batch(&tmp, ss1, p1, n1, 1, params, 0);
+}
+int ss_submit(ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, ss_ticket** out) {
+    if (!s || !out || n_samples < 0 || (n_samples > 0 && !pcm)) return fail(SS_ERR_ARG, "ss_submit: bad argument");
+    ss_ticket* t = new ss_ticket();
+    t->job.sess = &s->s;
+    t->job.owned.assign(pcm, pcm + n_samples);
+    t->job.pcm = t->job.owned.data(); t->job.n_samples = n_samples;
+    if (params) t->job.P = *params; else ss_default_params(&t->job.P);
+    s->s.eng->submit(&t->job);
+    *out = t;
+    return SS_OK;
+}
+int ss_wait(ss_ticket* t) {
+    if (!t) return fail(SS_ERR_ARG, "ss_wait: null ticket");
+    t->job.sess->eng->wait(&t->job);
+    const int st = t->job.status;
+    delete t;
+    return st == 0 ? SS_OK : fail(st, "chunk failed");
+}
+
+int32_t ss_result_n_segments(const ss_session* s) { return s ? (int32_t)s->s.segments.size() : 0; }
+const char* ss_result_segment_text(const ss_session* s, int32_t i) {
+    if (!s || i < 0 || i >= (int)s->s.segments.size()) return nullptr;
+    return s->s.segments[i].text.c_str();
+}
+int64_t ss_result_segment_t0(const ss_session* s, int32_t i) { return (!s || i < 0 || i >= (int)s->s.segments.size()) ? 0 : s->s.segments[i].t0; }
+int64_t ss_result_segment_t1(const ss_session* s, int32_t i) { return (!s || i < 0 || i >= (int)s->s.segments.size()) ? 0 : s->s.segments[i].t1; }
+int32_t ss_result_segment_speaker_turn_next(const ss_session* s, int32_t i) {
+    return (!s || i < 0 || i >= (int)s->s.segments.size()) ? 0 : (int32_t)s->s.segments[i].speaker_turn_next;
+}
+int32_t ss_result_n_tokens(const ss_session* s) { return s ? (int32_t)s->s.tokens.size() : 0; }
+int ss_result_tokens(const ss_session* s, int32_t* ids, float* plog) {
+    if (!s || !ids) return fail(SS_ERR_ARG, "null argument");
+    for (size_t i = 0; i < s->s.tokens.size(); i++) { ids[i] = s->s.tokens[i].id; if (plog) plog[i] = s->s.tokens[i].plog; }
+    return SS_OK;
+}
+int ss_result_counters(const ss_session* s, int32_t out4[4]) {
+    if (!s || !out4) return fail(SS_ERR_ARG, "null argument");
+    out4[0] = s->s.n_encode; out4[1] = s->s.n_decode; out4[2] = s->s.n_fail; out4[3] = s->s.n_windows;
+    return SS_OK;
+}
+
+int32_t ss_mel_n_len(int32_t n_samples) { return mel_n_len(n_samples); }
+int ss_log_mel(ss_engine* e, const float* pcm, int32_t n, float* out, int32_t n_len) {
+    if (!e || !pcm || !out || n <= 0) return fail(SS_ERR_ARG, "ss_log_mel: bad argument");
+    SS_TRY e->e->log_mel_host(pcm, n, out, n_len); return SS_OK; SS_CATCH
+}
+int ss_encode(ss_engine* e, const float* mel, int32_t n_len, int32_t seek, float* enc_out) {
+    if (!e || !mel || !enc_out || n_len <= 0 || seek < 0) return fail(SS_ERR_ARG, "ss_encode: bad argument");
+    SS_TRY e->e->encode_host(mel, n_len, seek, enc_out); return SS_OK; SS_CATCH
+}
+int ss_session_set_encoder(ss_session* s, const float* enc) {
+    if (!s || !enc) return fail(SS_ERR_ARG, "ss_session_set_encoder: bad argument");
+    SS_TRY s->s.eng->set_encoder_host(enc); return SS_OK; SS_CATCH
+}
+int ss_session_decode(ss_session* s, const int32_t* tokens, int32_t n, int32_t n_past, float* logits_out) {
+    if (!s || !tokens || !logits_out || n <= 0 || n_past < 0 || n_past + n > s->s.eng->hm.hp.n_text_ctx) return fail(SS_ERR_ARG, "ss_session_decode: bad argument");
+    for (int i = 0; i < n; i++) if (tokens[i] < 0 || tokens[i] >= s->s.eng->hm.hp.n_vocab) return fail(SS_ERR_ARG, "ss_session_decode: token out of range");
+    SS_TRY s->s.eng->decode_host(tokens, n, n_past, logits_out); return SS_OK; SS_CATCH
+}
+int ss_process_logits(ss_engine* e, const float* raw, const int32_t* hist, int32_t n_hist, int32_t has_ts, int32_t seek_delta, const ss_params* params,
+                      float out6[6]) {
+    if (!e || !raw || !out6 || n_hist < 0 || (n_hist > 0 && !hist)) return fail(SS_ERR_ARG, "ss_process_logits: bad argument");
+    ss_params P;
+    if (params) P = *params; else ss_default_params(&P);
+    SS_TRY e->e->process_logits_host(raw, hist, n_hist, has_ts, seek_delta, P, out6); return SS_OK; SS_CATCH
+}
+int ss_engine_last_timing(const ss_engine* e, float out_ms[4]) {
+    if (!e || !out_ms) return fail(SS_ERR_ARG, "null argument");
+    memcpy(out_ms, e->e->last_ms, 16);
+    return SS_OK;
+}
+int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_ms, double* flops) {
+    if (!e || !avg_ms || !flops || reps <= 0) return fail(SS_ERR_ARG, "bad argument");
+    SS_TRY e->e->probe_gemm(batch, reps, avg_ms, flops); return SS_OK; SS_CATCH
+}
+
+}  // extern "C"

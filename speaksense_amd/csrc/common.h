@@ -1,0 +1,67 @@
+// Shared declarations for the MI355X (gfx950) Whisper path.  Product code: never includes anything from oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace ss {
+
+typedef __bf16 bf16;
+typedef _Float16 f16;
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+#define SS_HIP(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            throw ss::Error(-4, std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" + std::to_string(__LINE__)); \
+    } while (0)
+
+// ggml legacy header; field order is the file order
+struct HParams {
+    int32_t n_vocab, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;
+    int32_t n_text_ctx, n_text_state, n_text_head, n_text_layer, n_mels, ftype;
+};
+
+struct Vocab {
+    int n_vocab = 51864;
+    std::vector<std::string> id_to_token;
+    std::map<std::string, int> token_to_id;
+    int token_eot = 50256, token_sot = 50257, token_translate = 50357, token_transcribe = 50358;
+    int token_solm = 50359, token_prev = 50360, token_nosp = 50361, token_not = 50362, token_beg = 50363;
+    bool is_multilingual() const { return n_vocab >= 51865; }
+    int num_languages() const { return n_vocab - 51765 - (is_multilingual() ? 1 : 0); }
+};
+int lang_id(const char* code);  // -1 if unknown
+
+// Host-side tensor as read from the file: f32 copy + the raw f16 payload when the file stored f16
+struct HostTensor {
+    std::vector<int> ne;            // ggml order (ne[0] fastest)
+    int ttype = 0;                  // 0 f32, 1 f16
+    std::vector<float> f32;         // always filled
+    size_t n() const { return f32.size(); }
+};
+
+struct HostModel {
+    HParams hp{};
+    int filt_n_mel = 0, filt_n_fft = 0;
+    std::vector<float> filters;  // [n_mel][n_fft]
+    Vocab vocab;
+    std::map<std::string, HostTensor> t;
+    const HostTensor& get(const std::string& name) const;
+};
+void load_ggml_model(const char* path, HostModel& m);  // throws ss::Error(-2,...)
+
+// audio constants (whisper.cpp: WHISPER_SAMPLE_RATE / N_FFT / HOP_LENGTH / CHUNK_SIZE)
+constexpr int kSampleRate = 16000, kNFft = 400, kHop = 160, kChunkSec = 30, kNBins = 201;
+inline int mel_n_len(int n_samples) { return (n_samples + kSampleRate * kChunkSec + 2 * (kNFft / 2) - kNFft) / kHop; }
+inline int mel_n_len_org(int n_samples) { return 1 + (n_samples + kNFft / 2 - kNFft) / kHop; }
+
+}  // namespace ss

@@ -1,0 +1,880 @@
+// EngineT<T>: device-resident model + batch workspaces + the batched whisper_full_with_state state machine.
+//
+// Host-side mirror of what the reference reaches through `state.full(params, &audio)` (/root/reference/src/asr/whisper.rs:75):
+// whisper.cpp's whisper_full_with_state window loop (seek / temperature fallback / segmenting),
+// re-organised so that many independent 30 s windows (from different sessions) advance in lock-step on one GPU:
+// one encoder pass over W windows (M = W*1500 rows per GEMM), then KV-cached decoding of all their decoders as rows of
+// skinny GEMMs so every decoder weight is read once per step for the whole batch.  Sampling rules run on the device;
+// only {id,p,plog,tid,pt,ptsum} per row return to the host each step.  No CPU fallback: without a HIP device
+// engine creation fails with SS_ERR_DEVICE.
+#include "engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace ss {
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+static inline uint16_t f32_to_bf16_bits(float x) {
+    uint32_t u; memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline uint16_t f32_to_f16_bits(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  // overflow -> inf (after rounding)
+    if (x < 0x33000001u) return (uint16_t)sign;              // underflow -> 0
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    if (e < -14) {  // subnormal half
+        const int shift = -14 - e + 13;
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (r & 1))) r++;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = ((uint32_t)(e + 15) << 10) | ((m >> 13) & 0x3ffu);
+    const uint32_t rem = m & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1))) r++;
+    return (uint16_t)(sign | r);
+}
+template <typename T> static inline uint16_t to_bits(float x);
+template <> inline uint16_t to_bits<bf16>(float x) { return f32_to_bf16_bits(x); }
+template <> inline uint16_t to_bits<f16>(float x) { return f32_to_f16_bits(x); }
+
+struct DBuf {
+    void* p = nullptr; size_t bytes = 0;
+    void alloc(size_t n, bool zero = true) {
+        free();
+        if (n == 0) n = 16;
+        SS_HIP(hipMalloc(&p, n)); bytes = n;
+        if (zero) SS_HIP(hipMemset(p, 0, n));
+    }
+    void ensure(size_t n) { if (n > bytes) alloc(n); }
+    void free() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    ~DBuf() { free(); }
+    template <typename U> U* as() const { return (U*)p; }
+};
+
+constexpr int kNMaxTextCtx = 16384;  // whisper_full_default_params: n_max_text_ctx
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// per-decoder state (whisper_decoder + whisper_sequence)
+struct Dec {
+    std::vector<TokenData> tokens;
+    int result_len = 0;
+    double sum_logprobs_all = 0, sum_logprobs = -INFINITY, avg_logprobs = -INFINITY, entropy = 0, score = -INFINITY;
+    int seek_delta = 0;
+    bool failed = false, completed = false, has_ts = false;
+    int n_fed = 0;   // tokens fed to the device so far (prompt first, then sampled tokens)
+    int i = 0;       // index of the next token to sample
+    bool active = false;
+    int slot = 0;
+};
+struct Window {
+    Job* job = nullptr;
+    int cross = 0;   // cross-KV index in this batch
+    int it = 0;      // temperature ladder position
+    bool pending = true;
+    std::vector<float> temperatures;
+    std::vector<int> prompt;
+    std::vector<Dec> decs;
+    int best = 0;
+};
+struct JobState {
+    Job* job; int slot; int n_len = 0, n_len_org = 0, seek = 0, seek_end = 0; bool alive = false;
+    std::vector<int> prompt_init;
+};
+
+static void sequence_score(const ss_params& P, Dec& q) {  // whisper_sequence_score
+    if (q.result_len == 0) return;
+    double result = 0.0;
+    for (int i = 0; i < q.result_len; i++) result += q.tokens[i].plog;
+    q.sum_logprobs = result;
+    q.avg_logprobs = result / q.result_len;
+    double penalty = q.result_len;
+    if (P.length_penalty > 0.0f) penalty = pow((5.0 + penalty) / 6.0, P.length_penalty);
+    q.score = result / penalty;
+    int cnt = 0;
+    double entropy = 0.0;
+    std::map<int, int> tc;
+    for (int i = std::max(0, q.result_len - 32); i < q.result_len; i++) { tc[q.tokens[i].id]++; cnt++; }
+    for (auto& kv : tc) { const double p = kv.second / (double)cnt; entropy -= p * log(p); }
+    q.entropy = entropy;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct EngineT : EngineBase {
+    hipStream_t st = nullptr;
+    int B = 8, ND = 5, S = 40;  // windows per batch, decoders per window, decoder slots
+    int d, da, H, Ha, L, La, n_mel, n_ctx, n_tctx, n_vocab, n_vocab_pad, K1, Tpad;
+    float qscale;
+    int dtype_is_f16;
+
+    // ---- weights ----
+    DBuf w_all;  // one arena
+    struct EncL { float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2; T *wqkv, *wo, *w1, *w2; };
+    struct DecL { float *ln1w, *ln1b, *bqkv, *bo, *lncw, *lncb, *bcq, *bco, *ln2w, *ln2b, *b1, *b2; T *wqkv, *wo, *wcq, *wco, *w1, *w2; };
+    std::vector<EncL> enc;
+    std::vector<DecL> dec;
+    T *conv1w, *conv2w, *tok_emb, *crosskv_w;
+    float *conv1b, *conv2b, *enc_pos, *lnpostw, *lnpostb, *dec_pos, *crosskv_b, *lnw, *lnb;
+    MelTables mt{};
+
+    // ---- workspaces ----
+    std::vector<DBuf> pcm_d, mel_d, fmax_d;  // per batch slot
+    DBuf x0, h1, x, ln, qk, vT, att, ff, encT, encF, cross, kself, vself;
+    DBuf xd, lnd, qd, attd, ffd, logits, probs, cscratch, ctl_d;
+    RowCtl* ctl_h = nullptr;       // pinned, mapped
+    SampleOut* samp_h = nullptr;   // pinned, mapped
+    float* probs_h = nullptr;      // pinned: [S][n_vocab_pad] for t > 0 sampling
+    hipEvent_t ev[4];
+
+    EngineT(const char* path, const ss_engine_opts& o) {
+        opts = o;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw Error(SS_ERR_DEVICE, "no HIP device visible: the MI355X path has no CPU fallback");
+        if (o.device < 0 || o.device >= ndev) throw Error(SS_ERR_DEVICE, "bad device ordinal");
+        SS_HIP(hipSetDevice(o.device));
+        load_ggml_model(path, hm);
+        const HParams& hp = hm.hp;
+        B = o.max_batch > 0 ? o.max_batch : 8;
+        ND = o.max_decoders > 0 ? o.max_decoders : 5;
+        S = B * ND;
+        d = hp.n_text_state; da = hp.n_audio_state; H = hp.n_text_head; Ha = hp.n_audio_head; L = hp.n_text_layer; La = hp.n_audio_layer;
+        n_mel = hp.n_mels; n_ctx = hp.n_audio_ctx; n_tctx = hp.n_text_ctx; n_vocab = hp.n_vocab; n_vocab_pad = round_up(n_vocab, 64);
+        K1 = round_up(3 * n_mel, 64);
+        Tpad = round_up(n_ctx, 32);
+        qscale = powf(64.0f, -0.25f);
+        dtype_is_f16 = sizeof(T) == 2 && std::is_same<T, f16>::value;
+        if (d % 128 || da % 128) throw Error(SS_ERR_MODEL, "model: state size must be a multiple of 128");
+        if (n_ctx % 4 || n_tctx > 448) throw Error(SS_ERR_MODEL, "model: unsupported context sizes");
+        SS_HIP(hipStreamCreate(&st));
+        for (auto& e : ev) SS_HIP(hipEventCreate(&e));
+        upload_weights();
+        alloc_workspaces();
+        start_worker();
+    }
+    ~EngineT() override {
+        stop_worker();
+        if (ctl_h) (void)hipHostFree(ctl_h);
+        if (samp_h) (void)hipHostFree(samp_h);
+        if (probs_h) (void)hipHostFree(probs_h);
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        if (st) (void)hipStreamDestroy(st);
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // weights: one arena; 2-D weights converted to T ([N][K], K contiguous), the rest f32
+    // ------------------------------------------------------------------------------------------
+    struct Arena { std::vector<uint8_t> host; size_t off = 0;
+        size_t take(size_t bytes) { size_t o = (off + 255) & ~(size_t)255; off = o + bytes; if (host.size() < off) host.resize(off); return o; } };
+    Arena ar;
+    std::vector<std::pair<void**, size_t>> fix;
+    template <typename P> void reg(P*& ptr, size_t off) { fix.push_back({(void**)&ptr, off}); }
+
+    void put_f32(float*& ptr, const std::vector<float>& v) {
+        size_t o = ar.take(v.size() * 4); memcpy(ar.host.data() + o, v.data(), v.size() * 4); reg(ptr, o);
+    }
+    void put_T(T*& ptr, const float* v, size_t n, size_t n_alloc = 0) {
+        if (n_alloc < n) n_alloc = n;
+        size_t o = ar.take(n_alloc * 2);
+        uint16_t* dst = (uint16_t*)(ar.host.data() + o);
+        for (size_t i = 0; i < n; i++) dst[i] = to_bits<T>(v[i]);
+        for (size_t i = n; i < n_alloc; i++) dst[i] = 0;
+        reg(ptr, o);
+    }
+    const std::vector<float>& W(const std::string& n) { return hm.get(n).f32; }
+    void expect(const std::string& n, size_t cnt) { if (hm.get(n).f32.size() != cnt) throw Error(SS_ERR_MODEL, "model: bad shape for " + n); }
+
+    // conv weight [co][ci][3] -> [co][Kpad] with k-major columns: col = k*ci + c
+    std::vector<float> conv_reorder(const std::vector<float>& w, int co, int ci, int Kpad) {
+        std::vector<float> r((size_t)co * Kpad, 0.0f);
+        for (int a = 0; a < co; a++) for (int c = 0; c < ci; c++) for (int k = 0; k < 3; k++)
+            r[(size_t)a * Kpad + k * ci + c] = w[((size_t)a * ci + c) * 3 + k];
+        return r;
+    }
+    std::vector<float> cat(std::initializer_list<const std::vector<float>*> parts) {
+        std::vector<float> r;
+        for (auto p : parts) r.insert(r.end(), p->begin(), p->end());
+        return r;
+    }
+
+    void upload_weights() {
+        const std::vector<float> zeros_d(d, 0.0f), zeros_da(da, 0.0f);
+        expect("encoder.conv1.weight", (size_t)da * n_mel * 3);
+        expect("encoder.conv2.weight", (size_t)da * da * 3);
+        expect("encoder.positional_embedding", (size_t)n_ctx * da);
+        expect("decoder.token_embedding.weight", (size_t)n_vocab * d);
+        expect("decoder.positional_embedding", (size_t)n_tctx * d);
+        auto c1 = conv_reorder(W("encoder.conv1.weight"), da, n_mel, K1);
+        put_T(conv1w, c1.data(), c1.size());
+        put_f32(conv1b, W("encoder.conv1.bias"));
+        auto c2 = conv_reorder(W("encoder.conv2.weight"), da, da, 3 * da);
+        put_T(conv2w, c2.data(), c2.size());
+        put_f32(conv2b, W("encoder.conv2.bias"));
+        put_f32(enc_pos, W("encoder.positional_embedding"));
+        enc.resize(La);
+        for (int i = 0; i < La; i++) {
+            const std::string p = "encoder.blocks." + std::to_string(i) + ".";
+            EncL& e = enc[i];
+            put_f32(e.ln1w, W(p + "attn_ln.weight")); put_f32(e.ln1b, W(p + "attn_ln.bias"));
+            auto wqkv = cat({&W(p + "attn.query.weight"), &W(p + "attn.key.weight"), &W(p + "attn.value.weight")});
+            if (wqkv.size() != (size_t)3 * da * da) throw Error(SS_ERR_MODEL, "model: bad attention weight shape");
+            put_T(e.wqkv, wqkv.data(), wqkv.size());
+            put_f32(e.bqkv, cat({&W(p + "attn.query.bias"), &zeros_da, &W(p + "attn.value.bias")}));
+            put_T(e.wo, W(p + "attn.out.weight").data(), (size_t)da * da); put_f32(e.bo, W(p + "attn.out.bias"));
+            put_f32(e.ln2w, W(p + "mlp_ln.weight")); put_f32(e.ln2b, W(p + "mlp_ln.bias"));
+            put_T(e.w1, W(p + "mlp.0.weight").data(), (size_t)4 * da * da); put_f32(e.b1, W(p + "mlp.0.bias"));
+            put_T(e.w2, W(p + "mlp.2.weight").data(), (size_t)4 * da * da); put_f32(e.b2, W(p + "mlp.2.bias"));
+        }
+        put_f32(lnpostw, W("encoder.ln_post.weight")); put_f32(lnpostb, W("encoder.ln_post.bias"));
+        put_T(tok_emb, W("decoder.token_embedding.weight").data(), (size_t)n_vocab * d, (size_t)n_vocab_pad * d);
+        put_f32(dec_pos, W("decoder.positional_embedding"));
+        dec.resize(L);
+        std::vector<float> ckw, ckb;
+        for (int i = 0; i < L; i++) {
+            const std::string p = "decoder.blocks." + std::to_string(i) + ".";
+            DecL& e = dec[i];
+            put_f32(e.ln1w, W(p + "attn_ln.weight")); put_f32(e.ln1b, W(p + "attn_ln.bias"));
+            auto wqkv = cat({&W(p + "attn.query.weight"), &W(p + "attn.key.weight"), &W(p + "attn.value.weight")});
+            put_T(e.wqkv, wqkv.data(), wqkv.size());
+            put_f32(e.bqkv, cat({&W(p + "attn.query.bias"), &zeros_d, &W(p + "attn.value.bias")}));
+            put_T(e.wo, W(p + "attn.out.weight").data(), (size_t)d * d); put_f32(e.bo, W(p + "attn.out.bias"));
+            put_f32(e.lncw, W(p + "cross_attn_ln.weight")); put_f32(e.lncb, W(p + "cross_attn_ln.bias"));
+            put_T(e.wcq, W(p + "cross_attn.query.weight").data(), (size_t)d * d); put_f32(e.bcq, W(p + "cross_attn.query.bias"));
+            put_T(e.wco, W(p + "cross_attn.out.weight").data(), (size_t)d * d); put_f32(e.bco, W(p + "cross_attn.out.bias"));
+            put_f32(e.ln2w, W(p + "mlp_ln.weight")); put_f32(e.ln2b, W(p + "mlp_ln.bias"));
+            put_T(e.w1, W(p + "mlp.0.weight").data(), (size_t)4 * d * d); put_f32(e.b1, W(p + "mlp.0.bias"));
+            put_T(e.w2, W(p + "mlp.2.weight").data(), (size_t)4 * d * d); put_f32(e.b2, W(p + "mlp.2.bias"));
+            const auto& kw = W(p + "cross_attn.key.weight"); const auto& vw = W(p + "cross_attn.value.weight");
+            ckw.insert(ckw.end(), kw.begin(), kw.end()); ckw.insert(ckw.end(), vw.begin(), vw.end());
+            ckb.insert(ckb.end(), zeros_d.begin(), zeros_d.end());
+            const auto& vb = W(p + "cross_attn.value.bias"); ckb.insert(ckb.end(), vb.begin(), vb.end());
+        }
+        put_T(crosskv_w, ckw.data(), ckw.size()); put_f32(crosskv_b, ckb);
+        put_f32(lnw, W("decoder.ln.weight")); put_f32(lnb, W("decoder.ln.bias"));
+        // mel tables: same libm calls as whisper.cpp's fill_sin_cos_table / hann_window (periodic)
+        std::vector<float> sinv(400), cosv(400), hann(400);
+        for (int i = 0; i < 400; i++) {
+            const double theta = (2 * M_PI * i) / 400;
+            sinv[i] = sinf(theta); cosv[i] = cosf(theta);
+            hann[i] = 0.5 * (1.0 - cosf((2.0 * M_PI * i) / 400));
+        }
+        float *dsin, *dcos, *dhann, *dfilt;
+        put_f32(dsin, sinv); put_f32(dcos, cosv); put_f32(dhann, hann); put_f32(dfilt, hm.filters);
+        w_all.alloc(ar.off + 256, false);
+        SS_HIP(hipMemcpy(w_all.p, ar.host.data(), ar.off, hipMemcpyHostToDevice));
+        for (auto& f : fix) *f.first = (uint8_t*)w_all.p + f.second;
+        mt.sin_t = dsin; mt.cos_t = dcos; mt.hann = dhann; mt.filt = dfilt; mt.n_mel = n_mel;
+        std::vector<uint8_t>().swap(ar.host);
+        for (auto& kv : hm.t) std::vector<float>().swap(kv.second.f32);  // host copies no longer needed
+    }
+
+    void alloc_workspaces() {
+        pcm_d.resize(B); mel_d.resize(B); fmax_d.resize(B);
+        const size_t M = (size_t)B * n_ctx;
+        x0.alloc(((size_t)B * (2 * n_ctx + 2) * n_mel + 256) * 2);
+        h1.alloc(((size_t)B * (2 * n_ctx + 2) * da + 256) * 2);
+        x.alloc(M * da * 4); ln.alloc(M * da * 2); qk.alloc(M * 2 * da * 2);
+        vT.alloc((size_t)B * Ha * 64 * Tpad * 2);
+        att.alloc(M * da * 2); ff.alloc(M * 4 * da * 2); encT.alloc(M * da * 2); encF.alloc(M * da * 4);
+        cross.alloc((size_t)L * B * 2 * H * n_ctx * 64 * 2);
+        kself.alloc((size_t)L * S * n_tctx * d * 2); vself.alloc((size_t)L * S * n_tctx * d * 2);
+        const int R = 64;  // rows per decode launch
+        xd.alloc((size_t)R * d * 4); lnd.alloc((size_t)R * d * 2); qd.alloc((size_t)R * d * 2); attd.alloc((size_t)R * d * 2);
+        ffd.alloc((size_t)R * 4 * d * 2); logits.alloc((size_t)R * n_vocab_pad * 4); probs.alloc((size_t)R * n_vocab_pad * 4);
+        cscratch.alloc((size_t)R * H * 4 * 66 * 4); ctl_d.alloc(2 * R * sizeof(RowCtl));
+        samp_d.alloc(R * sizeof(SampleOut)); rowidx_d.alloc(R * 4);
+        SS_HIP(hipHostMalloc((void**)&ctl_h, 2 * R * sizeof(RowCtl), hipHostMallocDefault));
+        SS_HIP(hipHostMalloc((void**)&samp_h, R * sizeof(SampleOut), hipHostMallocDefault));
+        SS_HIP(hipHostMalloc((void**)&probs_h, (size_t)R * n_vocab_pad * 4, hipHostMallocDefault));
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // device passes
+    // ------------------------------------------------------------------------------------------
+    GemmDesc gd(const void* A, long lda, const void* Wt, int M, int N, int K, int kind, const float* bias, void* out, long ldo) {
+        GemmDesc g{};
+        g.A = A; g.lda = lda; g.a_rows_per_batch = (long)1 << 40; g.a_batch_stride = 0;
+        g.W = Wt; g.M = M; g.N = N; g.K = K; g.kind = kind; g.bias = bias; g.out = out; g.ldo = ldo;
+        g.o_rows_per_batch = (long)1 << 40; g.o_batch_stride = 0; g.scale = 1.0f; g.rows_per_batch = n_ctx; g.d = da; g.Tpad = Tpad;
+        g.n_batch = B; g.gelu_f16_in = dtype_is_f16;
+        return g;
+    }
+
+    // encoder over Wn windows whose time-major inputs are already in x0; leaves ln_post output in encT (and encF if want_f32)
+    void encoder_pass(int Wn, bool want_f32) {
+        const int T2 = 2 * n_ctx, M = Wn * n_ctx;
+        {   // conv1 + GELU: implicit GEMM over overlapping rows of the padded time-major input
+            GemmDesc g = gd(x0.p, n_mel, conv1w, Wn * T2, da, K1, EPI_GELU_T, conv1b, h1.as<T>() + da, da);
+            g.a_rows_per_batch = T2; g.a_batch_stride = (long)(T2 + 2) * n_mel;
+            g.o_rows_per_batch = T2; g.o_batch_stride = (long)(T2 + 2) * da;
+            launch_gemm<T>(g, st);
+        }
+        {   // conv2 (stride 2) + GELU + positional embedding -> f32 residual stream
+            GemmDesc g = gd(h1.p, 2 * da, conv2w, M, da, 3 * da, EPI_GELU_POS_F32, conv2b, x.p, da);
+            g.a_rows_per_batch = n_ctx; g.a_batch_stride = (long)(T2 + 2) * da;
+            g.pos = enc_pos;
+            launch_gemm<T>(g, st);
+        }
+        for (int il = 0; il < La; il++) {
+            const EncL& e = enc[il];
+            launch_layernorm<T>(x.as<float>(), e.ln1w, e.ln1b, ln.as<T>(), M, da, nullptr, st);
+            launch_gemm<T>(gd(ln.p, da, e.wqkv, M, 2 * da, da, EPI_STORE_T, e.bqkv, qk.p, 2 * da), st);
+            {
+                GemmDesc g = gd(ln.p, da, e.wqkv + (size_t)2 * da * da, M, da, da, EPI_VT, e.bqkv + 2 * da, vT.p, 0);
+                launch_gemm<T>(g, st);
+            }
+            launch_enc_attention<T>(qk.as<T>(), qk.as<T>() + da, 2 * da, vT.as<T>(), Tpad, att.as<T>(), da, Wn, Ha, n_ctx, st);
+            {
+                GemmDesc g = gd(att.p, da, e.wo, M, da, da, EPI_RES_F32, e.bo, x.p, da);
+                g.res = x.as<float>();
+                launch_gemm<T>(g, st);
+            }
+            launch_layernorm<T>(x.as<float>(), e.ln2w, e.ln2b, ln.as<T>(), M, da, nullptr, st);
+            launch_gemm<T>(gd(ln.p, da, e.w1, M, 4 * da, da, EPI_GELU_T, e.b1, ff.p, 4 * da), st);
+            {
+                GemmDesc g = gd(ff.p, 4 * da, e.w2, M, da, 4 * da, EPI_RES_F32, e.b2, x.p, da);
+                g.res = x.as<float>();
+                launch_gemm<T>(g, st);
+            }
+        }
+        launch_layernorm<T>(x.as<float>(), lnpostw, lnpostb, encT.as<T>(), M, da, nullptr, st);
+        if (want_f32) launch_layernorm_f32out<T>(x.as<float>(), lnpostw, lnpostb, encF.as<float>(), M, da, st);
+    }
+    // cross K/V of every decoder layer for Wn windows: one GEMM, N = L*2d, written straight into the cache layout
+    void cross_kv_pass(int Wn) {
+        GemmDesc g = gd(encT.p, da, crosskv_w, Wn * n_ctx, L * 2 * d, da, EPI_CROSS_KV, crosskv_b, cross.p, 0);
+        g.scale = qscale; g.d = d; g.rows_per_batch = n_ctx; g.n_batch = B;
+        launch_gemm<T>(g, st);
+    }
+
+    SkinnyDesc sd(const void* X, long ldx, const void* Wt, int M, int N, int K, int kind, const float* bias, void* out, long ldo) {
+        SkinnyDesc g{};
+        g.X = X; g.ldx = ldx; g.W = Wt; g.M = M; g.N = N; g.K = K; g.kind = kind; g.bias = bias; g.out = out; g.ldo = ldo; g.scale = 1.0f;
+        g.gelu_f16_in = dtype_is_f16; g.d = d;
+        return g;
+    }
+    // One decoder launch over M rows described by ctl_h[0..M).  Rows may belong to the same decoder (a multi-token
+    // prompt): K/V of every row are written to the cache before the attention kernels run, and each row attends to
+    // cache positions <= its own, so causality holds without a mask.  The n_samp rows listed in samp_rows (with their
+    // rule state in ctl_h[64..64+n_samp)) get logits + rules; results land in samp_h[0..n_samp).
+    void decoder_step(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
+        const int n_samp = (int)samp_rows.size();
+        SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
+        const RowCtl* ctl = ctl_d.as<RowCtl>();
+        launch_embed<T>(tok_emb, dec_pos, ctl, M, d, xd.as<float>(), st);
+        const long slot_stride = (long)n_tctx * d, layer_stride = (long)S * slot_stride;
+        const long cb_stride = (long)2 * H * n_ctx * 64, cl_stride = (long)B * cb_stride;
+        for (int il = 0; il < L; il++) {
+            const DecL& e = dec[il];
+            launch_layernorm<T>(xd.as<float>(), e.ln1w, e.ln1b, lnd.as<T>(), M, d, nullptr, st);
+            {
+                SkinnyDesc g = sd(lnd.p, d, e.wqkv, M, 3 * d, d, SK_SELF_QKV, e.bqkv, qd.p, d);
+                g.scale = qscale; g.ctl = ctl; g.kcache = kself.as<T>() + il * layer_stride; g.vcache = vself.as<T>() + il * layer_stride;
+                g.slot_stride = slot_stride;
+                launch_skinny<T>(g, st);
+            }
+            launch_dec_self_attention<T>(qd.as<T>(), kself.as<T>() + il * layer_stride, vself.as<T>() + il * layer_stride, slot_stride, d, H, ctl, M,
+                                         attd.as<T>(), st);
+            launch_skinny<T>(sd(attd.p, d, e.wo, M, d, d, SK_RES_F32, e.bo, xd.p, d), st);
+            launch_layernorm<T>(xd.as<float>(), e.lncw, e.lncb, lnd.as<T>(), M, d, nullptr, st);
+            {
+                SkinnyDesc g = sd(lnd.p, d, e.wcq, M, d, d, SK_STORE_T, e.bcq, qd.p, d);
+                g.scale = qscale;
+                launch_skinny<T>(g, st);
+            }
+            const T* kc = cross.as<T>() + il * cl_stride;
+            launch_dec_cross_attention<T>(qd.as<T>(), kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M, cscratch.as<float>(), attd.as<T>(), st);
+            launch_skinny<T>(sd(attd.p, d, e.wco, M, d, d, SK_RES_F32, e.bco, xd.p, d), st);
+            launch_layernorm<T>(xd.as<float>(), e.ln2w, e.ln2b, lnd.as<T>(), M, d, nullptr, st);
+            launch_skinny<T>(sd(lnd.p, d, e.w1, M, 4 * d, d, SK_GELU_T, e.b1, ffd.p, 4 * d), st);
+            launch_skinny<T>(sd(ffd.p, 4 * d, e.w2, M, d, 4 * d, SK_RES_F32, e.b2, xd.p, d), st);
+        }
+        if (n_samp == 0) return;
+        // gather the sampling rows: final LayerNorm reads x[samp_rows[i]] and writes compact row i
+        SS_HIP(hipMemcpyAsync(rowidx_d.p, samp_rows.data(), (size_t)n_samp * 4, hipMemcpyHostToDevice, st));
+        launch_layernorm<T>(xd.as<float>(), lnw, lnb, lnd.as<T>(), n_samp, d, rowidx_d.as<int>(), st);
+        {
+            SkinnyDesc g = sd(lnd.p, d, tok_emb, n_samp, n_vocab_pad, d, SK_LOGITS_F32, nullptr, logits.p, n_vocab_pad);
+            g.n_valid = n_vocab;
+            launch_skinny<T>(g, st);
+        }
+        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, st);
+        SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
+        if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
+    }
+    DBuf samp_d, rowidx_d;
+
+    RuleConsts rule_consts(const ss_params& P) {
+        const Vocab& v = hm.vocab;
+        RuleConsts rc{};
+        rc.n_vocab = n_vocab; rc.eot = v.token_eot; rc.sot = v.token_sot; rc.translate = v.token_translate; rc.transcribe = v.token_transcribe;
+        rc.solm = v.token_solm; rc.prev = v.token_prev; rc.nosp = v.token_nosp; rc.not_ = v.token_not; rc.beg = v.token_beg;
+        auto it = v.token_to_id.find(" ");
+        rc.blank = it == v.token_to_id.end() ? -1 : it->second;
+        rc.n_lang = v.num_languages();
+        rc.suppress_blank = P.suppress_blank; rc.no_timestamps = P.no_timestamps; rc.tdrz_enable = P.tdrz_enable;
+        rc.max_initial_tid = -1;
+        if (P.max_initial_ts > 0.0f) {
+            const float precision = float(kChunkSec) / hm.hp.n_audio_ctx;
+            rc.max_initial_tid = (int)std::round(P.max_initial_ts / precision);
+        }
+        rc.suppress_eot = P.fixed_steps > 0;
+        return rc;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // the batched whisper_full_with_state
+    // ------------------------------------------------------------------------------------------
+    void run_jobs(std::vector<Job*>& jobs) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        for (size_t i = 0; i < jobs.size(); i += B) {
+            std::vector<Job*> grp(jobs.begin() + i, jobs.begin() + std::min(jobs.size(), i + (size_t)B));
+            try {
+                run_group(grp);
+            } catch (const Error& e) {
+                for (Job* j : grp) if (j->status == 0) j->status = e.code;
+                throw;
+            }
+        }
+    }
+
+    void run_group(std::vector<Job*>& grp) {
+        const Vocab& vocab = hm.vocab;
+        std::vector<JobState> js;
+        SS_HIP(hipEventRecord(ev[0], st));
+        for (size_t i = 0; i < grp.size(); i++) {
+            Job* j = grp[i];
+            Session* s = j->sess;
+            s->segments.clear(); s->tokens.clear(); s->n_encode = s->n_decode = s->n_fail = s->n_windows = 0;
+            if (j->P.no_context) s->prompt_past.clear();
+            JobState q; q.job = j; q.slot = (int)i;
+            j->status = 0;
+            const ss_params& P = j->P;
+            if (P.audio_ctx > n_ctx) { j->status = SS_ERR_AUDIO_CTX; js.push_back(q); continue; }
+            if (P.best_of > ND) { j->status = SS_ERR_ARG; js.push_back(q); continue; }
+            q.prompt_init = {vocab.token_sot};
+            if (vocab.is_multilingual()) {
+                const int lid = lang_id(P.language);
+                if (lid < 0 || lid >= vocab.num_languages()) { j->status = SS_ERR_LANG; js.push_back(q); continue; }
+                q.prompt_init.push_back(vocab.token_sot + 1 + lid);
+                q.prompt_init.push_back(P.translate ? vocab.token_translate : vocab.token_transcribe);
+            }
+            if (P.no_timestamps) q.prompt_init.push_back(vocab.token_not);
+            if (j->n_samples > 0) {
+                q.n_len = mel_n_len(j->n_samples); q.n_len_org = mel_n_len_org(j->n_samples);
+                const float* dp;
+                if (j->pcm_on_device) dp = j->pcm;
+                else {
+                    pcm_d[i].ensure((size_t)j->n_samples * 4);
+                    SS_HIP(hipMemcpyAsync(pcm_d[i].p, j->pcm, (size_t)j->n_samples * 4, hipMemcpyHostToDevice, st));
+                    dp = pcm_d[i].as<float>();
+                }
+                mel_d[i].ensure((size_t)n_mel * q.n_len * 4);
+                fmax_d[i].ensure((size_t)q.n_len * 4);
+                launch_log_mel(mt, dp, j->n_samples, mel_d[i].as<float>(), q.n_len, fmax_d[i].as<float>(), st);
+                q.seek = 0; q.seek_end = q.n_len_org;
+                q.alive = q.seek_end >= 100;  // "if length of spectrogram is less than 1.0s, return"
+            }
+            js.push_back(q);
+        }
+        SS_HIP(hipEventRecord(ev[1], st));
+        float ms_enc = 0.f, ms_dec = 0.f;
+        while (true) {
+            std::vector<Window> wins;
+            for (auto& q : js) {
+                if (!q.alive || q.job->status != 0) continue;
+                if (q.seek + 100 >= q.seek_end) { q.alive = false; continue; }
+                Window w; w.job = q.job; w.cross = (int)wins.size();
+                const ss_params& P = q.job->P;
+                if (P.fixed_steps > 0) w.temperatures = {0.0f};
+                else if (P.temperature_inc > 0.0f) for (float t = P.temperature; t < 1.0f + 1e-6f; t += P.temperature_inc) w.temperatures.push_back(t);
+                else w.temperatures = {P.temperature};
+                // "if there is a very short audio segment left to process, we remove any past prompt"
+                if (q.seek > 0 && q.seek + 500 >= q.seek_end) q.job->sess->prompt_past.clear();
+                launch_mel_window<T>(mel_d[q.slot].template as<float>(), n_mel, q.n_len, q.seek, 2 * n_ctx,
+                                     x0.as<T>() + (size_t)w.cross * (2 * n_ctx + 2) * n_mel, st);
+                wins.push_back(std::move(w));
+            }
+            if (wins.empty()) break;
+            const int Wn = (int)wins.size();
+            hipEvent_t e0, e1, e2;
+            SS_HIP(hipEventCreate(&e0)); SS_HIP(hipEventCreate(&e1)); SS_HIP(hipEventCreate(&e2));
+            SS_HIP(hipEventRecord(e0, st));
+            encoder_pass(Wn, false);
+            cross_kv_pass(Wn);
+            SS_HIP(hipEventRecord(e1, st));
+            for (auto& w : wins) { w.job->sess->n_encode++; w.job->sess->n_windows++; }
+            // temperature ladder
+            int n_pending = Wn;
+            for (int it = 0; n_pending > 0; it++) {
+                std::vector<Window*> run;
+                for (auto& w : wins) if (w.pending) { w.it = it; run.push_back(&w); }
+                decode_windows(run, js);
+                for (Window* w : run) {
+                    const ss_params& P = w->job->P;
+                    double best_score = -INFINITY;
+                    w->best = 0;
+                    for (size_t j = 0; j < w->decs.size(); j++) {
+                        Dec& dq = w->decs[j];
+                        if (dq.failed) continue;
+                        dq.tokens.resize(dq.result_len);
+                        sequence_score(P, dq);
+                        if (P.fixed_steps == 0 && dq.result_len > 32 && dq.entropy < P.entropy_thold) { dq.failed = true; continue; }
+                        if (best_score < dq.score) { best_score = dq.score; w->best = (int)j; }
+                    }
+                    bool success = true;
+                    if (it != (int)w->temperatures.size() - 1) {
+                        const Dec& dq = w->decs[w->best];
+                        if (dq.failed || dq.avg_logprobs < P.logprob_thold) { success = false; w->job->sess->n_fail++; }
+                    }
+                    if (success) { w->pending = false; n_pending--; }
+                }
+            }
+            SS_HIP(hipEventRecord(e2, st));
+            SS_HIP(hipEventSynchronize(e2));
+            float a = 0, b = 0;
+            SS_HIP(hipEventElapsedTime(&a, e0, e1)); SS_HIP(hipEventElapsedTime(&b, e1, e2));
+            ms_enc += a; ms_dec += b;
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+            // emit segments, advance seek
+            for (auto& w : wins) finalize_window(w, js);
+        }
+        SS_HIP(hipEventRecord(ev[2], st));
+        SS_HIP(hipEventSynchronize(ev[2]));
+        float ms_mel = 0, ms_tot = 0;
+        SS_HIP(hipEventElapsedTime(&ms_mel, ev[0], ev[1]));
+        SS_HIP(hipEventElapsedTime(&ms_tot, ev[0], ev[2]));
+        last_ms[0] = ms_mel; last_ms[1] = ms_enc; last_ms[2] = ms_dec; last_ms[3] = ms_tot;
+    }
+
+    JobState& state_of(std::vector<JobState>& js, Job* j) { for (auto& q : js) if (q.job == j) return q; throw Error(-1, "internal: job state"); }
+
+    // Decode all decoders of the given windows at their current ladder temperature, in lock-step rounds.
+    // Round = every active decoder advances to its next sampling point: the first round feeds the whole prompt
+    // ([prev] + past text + sot/lang/task), later rounds one token each.
+    struct RowRef { Window* w; int j; bool sample; };
+    void decode_windows(std::vector<Window*>& run, std::vector<JobState>& js) {
+        int slot = 0;
+        for (Window* w : run) {
+            const ss_params& P = w->job->P;
+            const float t_cur = w->temperatures[w->it];
+            const int nd = (t_cur > 0.0f) ? std::max(1, (int)P.best_of) : 1;
+            // prompt for this attempt (whisper_full: "init prompt and kv cache for the current iteration")
+            Session* s = w->job->sess;
+            JobState& jq = state_of(js, w->job);
+            w->prompt.clear();
+            if (!s->prompt_past.empty() && t_cur < 0.5f && kNMaxTextCtx > 0) {
+                const int n_take = std::min(std::min(kNMaxTextCtx, n_tctx / 2), (int)s->prompt_past.size());
+                w->prompt.push_back(hm.vocab.token_prev);
+                w->prompt.insert(w->prompt.end(), s->prompt_past.end() - n_take, s->prompt_past.end());
+            }
+            w->prompt.insert(w->prompt.end(), jq.prompt_init.begin(), jq.prompt_init.end());
+            w->decs.assign(nd, Dec());
+            for (int j = 0; j < nd; j++) {
+                Dec& q = w->decs[j];
+                q.seek_delta = 100 * kChunkSec; q.active = true; q.slot = slot++;
+            }
+        }
+        if (slot > S) throw Error(-1, "internal: decoder slots exceeded");
+        while (true) {
+            // rows of this round, grouped by rule-constant signature (normally a single group)
+            std::vector<RowRef> all;
+            for (Window* w : run)
+                for (int j = 0; j < (int)w->decs.size(); j++) if (w->decs[j].active) all.push_back({w, j, false});
+            if (all.empty()) break;
+            size_t pos0 = 0;
+            while (pos0 < all.size()) {
+                const ss_params& P0 = all[pos0].w->job->P;
+                auto same = [&](const ss_params& a) {
+                    return a.suppress_blank == P0.suppress_blank && a.no_timestamps == P0.no_timestamps && a.tdrz_enable == P0.tdrz_enable &&
+                           a.max_initial_ts == P0.max_initial_ts && (a.fixed_steps > 0) == (P0.fixed_steps > 0);
+                };
+                std::vector<RowRef> g;
+                while (pos0 < all.size() && same(all[pos0].w->job->P)) g.push_back(all[pos0++]);
+                round_rows(g, js, rule_consts(P0));
+            }
+        }
+    }
+
+    void round_rows(std::vector<RowRef>& decs_in, std::vector<JobState>& js, const RuleConsts& rc) {
+        const Vocab& vocab = hm.vocab;
+        // expand decoders into rows (token, pos), position order within a decoder; split into launches of <= 64 rows
+        std::vector<RowCtl> rows;
+        std::vector<RowRef> refs;
+        for (auto& dr : decs_in) {
+            Window* w = dr.w; Dec& q = w->decs[dr.j];
+            const int n_prompt = (int)w->prompt.size();
+            const int n_feed = q.n_fed < n_prompt ? n_prompt - q.n_fed : 1;
+            for (int k = 0; k < n_feed; k++) {
+                RowCtl c{};
+                const int p = q.n_fed + k;
+                c.token = p < n_prompt ? w->prompt[p] : q.tokens.back().id;
+                c.pos = p; c.slot = q.slot; c.cross = w->cross;
+                const bool last = k == n_feed - 1;
+                if (last) {
+                    c.n_hist = (int)q.tokens.size();
+                    c.last_ts = !q.tokens.empty() && q.tokens.back().id >= vocab.token_beg;
+                    c.penult_ts = q.tokens.size() < 2 || q.tokens[q.tokens.size() - 2].id >= vocab.token_beg;
+                    c.has_ts = q.has_ts; c.ts_min = q.seek_delta / 2;
+                    c.temperature = w->temperatures[w->it];
+                    c.want_probs = c.temperature > 0.0f;
+                }
+                rows.push_back(c);
+                refs.push_back({w, dr.j, last});
+            }
+            q.n_fed += n_feed;
+            if (dr.j == 0) w->job->sess->n_decode++;
+        }
+        for (size_t r0 = 0; r0 < rows.size(); r0 += 64) {
+            const int M = (int)std::min<size_t>(64, rows.size() - r0);
+            std::vector<int> samp_rows;
+            bool any_probs = false;
+            for (int m = 0; m < M; m++) {
+                ctl_h[m] = rows[r0 + m];
+                if (refs[r0 + m].sample) {
+                    ctl_h[64 + samp_rows.size()] = rows[r0 + m];
+                    samp_rows.push_back(m);
+                    any_probs |= rows[r0 + m].want_probs != 0;
+                }
+            }
+            decoder_step(M, rc, samp_rows, any_probs);
+            if (samp_rows.empty()) continue;
+            SS_HIP(hipStreamSynchronize(st));
+            for (size_t k = 0; k < samp_rows.size(); k++) {
+                const RowRef& rr = refs[r0 + samp_rows[k]];
+                accept_sample(*rr.w, rr.w->decs[rr.j], state_of(js, rr.w->job), samp_h[k], probs_h + k * (size_t)n_vocab_pad);
+            }
+        }
+    }
+
+    // whisper_sample_token + "update the decoder state" of whisper_full_with_state for one decoder
+    void accept_sample(Window& w, Dec& q, JobState& jq, const SampleOut& so, const float* pr) {
+        const Vocab& vocab = hm.vocab;
+        const ss_params& P = w.job->P;
+        Session* s = w.job->sess;
+        const int n_max = P.fixed_steps > 0 ? P.fixed_steps : n_tctx / 2 - 4;
+        const float t_cur = w.temperatures[w.it];
+        TokenData tk;
+        if (t_cur < 1e-6f) {
+            tk.id = so.id; tk.tid = so.tid; tk.p = so.p; tk.plog = so.plog; tk.pt = so.pt; tk.ptsum = so.ptsum;
+        } else {
+            std::discrete_distribution<> dist(pr, pr + n_vocab);
+            tk.id = dist(s->rng);
+            tk.p = pr[tk.id];
+            tk.plog = tk.p > 0.0f ? logf(tk.p) : -INFINITY;
+            tk.tid = so.tid; tk.pt = so.pt; tk.ptsum = so.ptsum;
+            if (tk.id >= vocab.token_beg) { tk.tid = tk.id; tk.pt = tk.p; }
+        }
+        q.tokens.push_back(tk);
+        q.sum_logprobs_all += tk.plog;
+        const int i = q.i++;
+        bool done = false;
+        if (tk.id > vocab.token_beg) {
+            const int seek_delta_new = 2 * (tk.id - vocab.token_beg);
+            if (q.has_ts && q.seek_delta > seek_delta_new && q.result_len < i) { q.failed = true; done = true; }
+            else { q.seek_delta = seek_delta_new; q.result_len = i + 1; q.has_ts = true; }
+        }
+        if (!done && P.fixed_steps > 0) {
+            if (i == n_max - 1) { q.result_len = i + 1; q.seek_delta = 100 * kChunkSec; q.completed = true; done = true; }
+        } else if (!done) {
+            if (tk.id == vocab.token_eot || (P.max_tokens > 0 && i >= P.max_tokens) || (q.has_ts && jq.seek + q.seek_delta + 100 >= jq.seek_end)) {
+                if (q.result_len == 0) {
+                    if (jq.seek + q.seek_delta + 100 >= jq.seek_end) q.result_len = i + 1;
+                    else { q.failed = true; done = true; }
+                }
+                if (!done) {
+                    if (P.single_segment) { q.result_len = i + 1; q.seek_delta = 100 * kChunkSec; }
+                    q.completed = true; done = true;
+                }
+            }
+            if (!done && i == n_max - 1 && (q.result_len == 0 || q.seek_delta < 100 * kChunkSec / 2)) { q.failed = true; done = true; }
+        }
+        if (done || q.i >= n_max) q.active = false;
+    }
+
+    void finalize_window(Window& w, std::vector<JobState>& js) {
+        const Vocab& vocab = hm.vocab;
+        const ss_params& P = w.job->P;
+        Session* s = w.job->sess;
+        JobState& jq = state_of(js, w.job);
+        const Dec& bd = w.decs[w.best];
+        const int seek = jq.seek, seek_delta = bd.seek_delta;
+        const std::vector<TokenData>& tk = bd.tokens;
+        for (auto& t : tk) s->tokens.push_back(t);
+        // update prompt_past: the past context that was fed (without [prev] and the task tokens) + this window's text
+        {
+            std::vector<int> np;
+            if (!w.prompt.empty() && w.prompt.front() == vocab.token_prev)
+                np.insert(np.end(), w.prompt.begin() + 1, w.prompt.end() - jq.prompt_init.size());
+            for (int i = 0; i < bd.result_len && i < (int)tk.size(); i++) np.push_back(tk[i].id);
+            s->prompt_past.swap(np);
+        }
+        if (!tk.empty()) {
+            int64_t t0 = seek + 2 * (tk.front().tid - vocab.token_beg);
+            std::string text;
+            bool speaker_turn_next = false;
+            for (int i = 0; i < (int)tk.size(); i++) {
+                if (P.print_special || tk[i].id < vocab.token_eot) text += vocab.id_to_token[tk[i].id];
+                if (P.tdrz_enable && tk[i].id == vocab.token_solm) speaker_turn_next = true;
+                if (tk[i].id > vocab.token_beg && !P.single_segment) {
+                    const int64_t t1 = seek + 2 * (tk[i].tid - vocab.token_beg);
+                    if (!text.empty()) s->segments.push_back({t0, t1, text, speaker_turn_next});
+                    text.clear();
+                    while (i < (int)tk.size() && tk[i].id > vocab.token_beg) i++;
+                    i--;
+                    t0 = t1;
+                    speaker_turn_next = false;
+                }
+            }
+            if (!text.empty()) s->segments.push_back({t0, (int64_t)(seek + seek_delta), text, speaker_turn_next});
+        }
+        jq.seek += seek_delta;
+    }
+
+    // ------------------------------------------------------------------------------------------
+    // stage hooks (host f32 in/out; same kernels as the batch path)
+    // ------------------------------------------------------------------------------------------
+    void log_mel_host(const float* pcm, int n, float* out, int n_len) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        if (n_len != mel_n_len(n)) throw Error(SS_ERR_ARG, "log_mel: n_len mismatch");
+        pcm_d[0].ensure((size_t)std::max(n, 1) * 4);
+        SS_HIP(hipMemcpyAsync(pcm_d[0].p, pcm, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        mel_d[0].ensure((size_t)n_mel * n_len * 4); fmax_d[0].ensure((size_t)n_len * 4);
+        launch_log_mel(mt, pcm_d[0].as<float>(), n, mel_d[0].as<float>(), n_len, fmax_d[0].as<float>(), st);
+        SS_HIP(hipMemcpyAsync(out, mel_d[0].p, (size_t)n_mel * n_len * 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(hipStreamSynchronize(st));
+    }
+    void encode_host(const float* mel, int n_len, int seek, float* enc_out) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        mel_d[0].ensure((size_t)n_mel * n_len * 4);
+        SS_HIP(hipMemcpyAsync(mel_d[0].p, mel, (size_t)n_mel * n_len * 4, hipMemcpyHostToDevice, st));
+        launch_mel_window<T>(mel_d[0].as<float>(), n_mel, n_len, seek, 2 * n_ctx, x0.as<T>(), st);
+        encoder_pass(1, true);
+        SS_HIP(hipMemcpyAsync(enc_out, encF.p, (size_t)n_ctx * da * 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(hipStreamSynchronize(st));
+    }
+    void set_encoder_host(const float* encv) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        SS_HIP(hipMemcpyAsync(encF.p, encv, (size_t)n_ctx * da * 4, hipMemcpyHostToDevice, st));
+        launch_f32_to_T<T>(encF.as<float>(), encT.as<T>(), (size_t)n_ctx * da, st);
+        cross_kv_pass(1);
+        SS_HIP(hipStreamSynchronize(st));
+    }
+    void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        ss_params P; ss_default_params(&P);
+        const RuleConsts rc = rule_consts(P);
+        for (int i = 0; i < n; i++) {
+            RowCtl c{};
+            c.token = tokens[i]; c.pos = n_past + i; c.slot = 0; c.cross = 0; c.n_hist = 1;
+            ctl_h[0] = c; ctl_h[64] = c;
+            std::vector<int> sr;
+            if (i == n - 1) sr.push_back(0);
+            decoder_step(1, rc, sr, false);
+            SS_HIP(hipStreamSynchronize(st));
+        }
+        SS_HIP(hipMemcpy(logits_out, logits.p, (size_t)n_vocab * 4, hipMemcpyDeviceToHost));
+    }
+    void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6]) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        const Vocab& vocab = hm.vocab;
+        SS_HIP(hipMemcpyAsync(logits.p, raw, (size_t)n_vocab * 4, hipMemcpyHostToDevice, st));
+        RowCtl c{};
+        c.n_hist = n_hist;
+        c.last_ts = n_hist > 0 && hist[n_hist - 1] >= vocab.token_beg;
+        c.penult_ts = n_hist < 2 || hist[n_hist - 2] >= vocab.token_beg;
+        c.has_ts = has_ts; c.ts_min = seek_delta / 2; c.temperature = 0.0f;
+        ctl_h[0] = c;
+        SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, sizeof(RowCtl), hipMemcpyHostToDevice, st));
+        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl_d.as<RowCtl>(), 1, rule_consts(P), samp_d.as<SampleOut>(), nullptr, st);
+        SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, sizeof(SampleOut), hipMemcpyDeviceToHost, st));
+        SS_HIP(hipStreamSynchronize(st));
+        out6[0] = (float)samp_h[0].id; out6[1] = samp_h[0].p; out6[2] = samp_h[0].plog; out6[3] = (float)samp_h[0].tid;
+        out6[4] = samp_h[0].pt; out6[5] = samp_h[0].ptsum;
+    }
+    void probe_gemm(int batch, int reps, float* avg_ms, double* flops) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        if (batch < 1 || batch > B) throw Error(SS_ERR_ARG, "probe_gemm: batch out of range");
+        const int M = batch * n_ctx;
+        GemmDesc g = gd(ln.p, da, enc[0].w1, M, 4 * da, da, EPI_GELU_T, enc[0].b1, ff.p, 4 * da);
+        launch_gemm<T>(g, st);
+        SS_HIP(hipEventRecord(ev[0], st));
+        for (int i = 0; i < reps; i++) launch_gemm<T>(g, st);
+        SS_HIP(hipEventRecord(ev[1], st));
+        SS_HIP(hipEventSynchronize(ev[1]));
+        float ms = 0;
+        SS_HIP(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        *avg_ms = ms / reps;
+        *flops = 2.0 * M * (4.0 * da) * da;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// async batch former
+// ------------------------------------------------------------------------------------------------
+void EngineBase::start_worker() {
+    worker = std::thread([this] {
+        while (true) {
+            std::vector<Job*> batch;
+            {
+                std::unique_lock<std::mutex> lk(qmu);
+                qcv.wait(lk, [this] { return stop || !queue.empty(); });
+                if (stop && queue.empty()) return;
+                const int maxb = opts.max_batch > 0 ? opts.max_batch : 8;
+                if ((int)queue.size() < maxb && opts.batch_wait_us > 0)
+                    qcv.wait_for(lk, std::chrono::microseconds(opts.batch_wait_us), [&] { return stop || (int)queue.size() >= maxb; });
+                while (!queue.empty() && (int)batch.size() < maxb) { batch.push_back(queue.front()); queue.pop_front(); }
+            }
+            if (batch.empty()) continue;
+            try { run_jobs(batch); } catch (const Error& e) { for (Job* j : batch) if (j->status == 0) j->status = e.code; }
+            {
+                std::lock_guard<std::mutex> lk(qmu);
+                for (Job* j : batch) j->done = true;
+            }
+            donecv.notify_all();
+        }
+    });
+}
+void EngineBase::stop_worker() {
+    {
+        std::lock_guard<std::mutex> lk(qmu);
+        stop = true;
+    }
+    qcv.notify_all();
+    if (worker.joinable()) worker.join();
+}
+void EngineBase::submit(Job* j) {
+    {
+        std::lock_guard<std::mutex> lk(qmu);
+        queue.push_back(j);
+    }
+    qcv.notify_all();
+}
+void EngineBase::wait(Job* j) {
+    std::unique_lock<std::mutex> lk(qmu);
+    donecv.wait(lk, [&] { return j->done; });
+}
+
+EngineBase* make_engine_bf16(const char* path, const ss_engine_opts& o) { return new EngineT<bf16>(path, o); }
+EngineBase* make_engine_f16(const char* path, const ss_engine_opts& o) { return new EngineT<f16>(path, o); }
+
+}  // namespace ss

@@ -1,0 +1,70 @@
+// Host runtime of the MI355X Whisper path: model residency, batch workspaces, the batched window/decoder state
+// machine (whisper_full_with_state semantics per window, many windows per device batch) and the async batch former.
+#pragma once
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <thread>
+
+#include "../../include/speaksense.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace ss {
+
+struct TokenData { int id = 0, tid = 0; float p = 0, plog = 0, pt = 0, ptsum = 0; };
+struct Segment { int64_t t0, t1; std::string text; bool speaker_turn_next; };
+
+struct Session {
+    struct EngineBase* eng = nullptr;
+    std::vector<Segment> segments;
+    std::vector<TokenData> tokens;
+    int n_encode = 0, n_decode = 0, n_fail = 0, n_windows = 0;
+    std::vector<int> prompt_past;  // whisper_state::prompt_past: text context carried between windows (and calls, unless no_context)
+    std::mt19937 rng{0};  // whisper_state::rng: seeded once per state, never reseeded per call
+};
+
+struct Job {  // one chunk handed to transcribe (== one whisper_full_with_state call)
+    Session* sess = nullptr;
+    const float* pcm = nullptr;
+    int n_samples = 0;
+    bool pcm_on_device = false;
+    ss_params P{};
+    int status = 0;
+    std::vector<float> owned;  // async submit keeps its own copy
+    // async completion
+    bool done = false;
+};
+
+struct EngineBase {
+    HostModel hm;
+    ss_engine_opts opts{};
+    std::mutex mu;  // serialises device work
+    float last_ms[4] = {0, 0, 0, 0};
+    virtual ~EngineBase() {}
+    virtual void run_jobs(std::vector<Job*>& jobs) = 0;  // blocking, any count (grouped by max_batch)
+    virtual void log_mel_host(const float* pcm, int n, float* out, int n_len) = 0;
+    virtual void encode_host(const float* mel, int n_len, int seek, float* enc_out) = 0;
+    virtual void set_encoder_host(const float* enc) = 0;
+    virtual void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out) = 0;
+    virtual void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6]) = 0;
+    virtual void probe_gemm(int batch, int reps, float* avg_ms, double* flops) = 0;
+
+    // async batch former
+    std::thread worker;
+    std::mutex qmu;
+    std::condition_variable qcv, donecv;
+    std::deque<Job*> queue;
+    bool stop = false;
+    void start_worker();
+    void stop_worker();
+    void submit(Job* j);
+    void wait(Job* j);
+};
+
+EngineBase* make_engine_bf16(const char* path, const ss_engine_opts& o);
+EngineBase* make_engine_f16(const char* path, const ss_engine_opts& o);
+
+}  // namespace ss

@@ -1,0 +1,124 @@
+// Launch wrappers for the gfx950 kernels (definitions in kernels_*.hip).  T = ss::bf16 or ss::f16.
+#pragma once
+#include "common.h"
+
+namespace ss {
+
+// ---------------------------------------------------------------------------------------------
+// log-mel (kernels_mel.hip)
+// ---------------------------------------------------------------------------------------------
+struct MelTables {       // device pointers, built once per engine
+    const float* sin_t;  // [400]
+    const float* cos_t;  // [400]
+    const float* hann;   // [400]
+    const float* filt;   // [n_mel][201]
+    int n_mel;
+};
+// pcm: device f32 [n_samples]; mel_out: device f32 [n_mel][n_len]; scratch: device f32 [>= 1 + 2048]
+void launch_log_mel(const MelTables& mt, const float* pcm, int n_samples, float* mel_out, int n_len, float* scratch, hipStream_t st);
+// mel [n_mel][n_len] f32 -> time-major window x0[T2+2][n_mel] (rows 0 and T2+1 zero) in T, frames [seek, seek+T2)
+template <typename T>
+void launch_mel_window(const float* mel, int n_mel, int n_len, int seek, int T2, T* x0, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// MFMA GEMM (kernels_gemm.hip):  D[m][n] = sum_k A[m][k] * W[n][k]   (both operands K-contiguous)
+// ---------------------------------------------------------------------------------------------
+enum EpiKind {
+    EPI_STORE_T = 0,   // out T[m][n] = (acc + bias[n]) * scale
+    EPI_GELU_T,        // out T[m][n] = gelu(acc + bias[n])
+    EPI_RES_F32,       // out f32[m][n] = res[m][n] + acc + bias[n]           (in place on the residual stream)
+    EPI_GELU_POS_F32,  // out f32[m][n] = gelu(acc + bias[n]) + pos[(m % rows_per_batch)][n]   (conv2 + positional embedding)
+    EPI_VT,            // out T: V^T layout [b][h][64][Tpad], b = m / rows_per_batch, t = m % rows_per_batch (acc + bias)
+    EPI_CROSS_KV,      // out T: cross cache [l][b][kv][h][t][64]; n = l*2d + kv*d + h*64 + j; K part scaled by `scale`
+    EPI_STORE_F32,     // out f32[m][n] = acc + bias[n]
+};
+struct GemmDesc {
+    // A operand: row m at A + (m / a_rows_per_batch) * a_batch_stride + (m % a_rows_per_batch) * lda   (elements)
+    const void* A; long lda; long a_rows_per_batch; long a_batch_stride;
+    const void* W;            // [N][K], K contiguous
+    int M, N, K;
+    int kind;
+    const float* bias;        // [N] or null
+    void* out; long ldo;      // row m at out + (m / o_rows_per_batch) * o_batch_stride + (m % o_rows_per_batch) * ldo
+    long o_rows_per_batch; long o_batch_stride;
+    const float* res;         // EPI_RES_F32 (same addressing as out)
+    const float* pos;         // EPI_GELU_POS_F32: [rows_per_batch][N]
+    float scale;              // EPI_STORE_T / EPI_CROSS_KV(K part)
+    int rows_per_batch;       // T (1500) for EPI_VT / EPI_CROSS_KV / EPI_GELU_POS_F32
+    int d, Tpad, n_batch;     // EPI_VT / EPI_CROSS_KV geometry
+    int gelu_f16_in;          // f16 engines: gelu(f16(x)) like ggml's table (no-op for bf16)
+};
+template <typename T> void launch_gemm(const GemmDesc& g, hipStream_t st);
+
+// Skinny GEMM for decode steps: M <= 64 rows, weights streamed once.  out[m][n] = sum_k X[m][k] W[n][k]
+enum SkinnyEpi {
+    SK_STORE_T = 0,  // out T[m][ldo] = (acc + bias) * scale
+    SK_GELU_T,       // out T = gelu(acc + bias)
+    SK_RES_F32,      // out f32[m][n] += acc + bias
+    SK_LOGITS_F32,   // out f32[m][ldo] = acc   (n < n_valid only)
+    SK_SELF_QKV,     // n in [0,d): q -> out T[m][d] * scale; [d,2d): k*scale -> kcache; [2d,3d): v -> vcache  (row m -> slot/pos via ctl)
+};
+struct RowCtl {       // one per decode row; lives in pinned host memory mapped into the device
+    int32_t token;    // input token id
+    int32_t pos;      // position (= n_past)
+    int32_t slot;     // self-KV slot
+    int32_t cross;    // cross-KV index (window in the current batch)
+    int32_t n_hist;   // tokens sampled so far in this window (0 => is_initial)
+    int32_t last_ts, penult_ts;   // rule state (whisper_process_logits)
+    int32_t has_ts, ts_min;       // decoder.has_ts, seek_delta/2
+    float temperature;
+    int32_t want_probs;           // t > 0: also write the full probability row
+    int32_t pad;
+};
+struct SkinnyDesc {
+    const void* X; long ldx;  // T [M][ldx]
+    const void* W;            // T [N][K]
+    int M, N, K;
+    int kind;
+    const float* bias;
+    void* out; long ldo;
+    float scale;
+    int n_valid;              // SK_LOGITS_F32
+    // SK_SELF_QKV
+    const RowCtl* ctl; void* kcache; void* vcache; long slot_stride; int d;  // caches: [slot][n_text_ctx][d] for this layer
+    int gelu_f16_in;
+};
+template <typename T> void launch_skinny(const SkinnyDesc& g, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// attention (kernels_attn.hip)
+// ---------------------------------------------------------------------------------------------
+// Encoder self-attention, non-causal.  q,k: T [B*Tn][ld] (head h at column h*64); vT: T [B][H][64][Tpad]; out T [B*Tn][ldo]
+template <typename T>
+void launch_enc_attention(const T* q, const T* k, long ld, const T* vT, int Tpad, T* out, long ldo, int B, int H, int Tn, hipStream_t st);
+// Decoder self-attention for M rows (one new token each): q T [M][d] (pre-scaled), caches [slot][n_ctx][d]; n_kv = pos+1
+template <typename T>
+void launch_dec_self_attention(const T* q, const T* kcache, const T* vcache, long slot_stride, int d, int H, const RowCtl* ctl, int M, T* out, hipStream_t st);
+// Decoder cross-attention: q T [M][d] (pre-scaled); cross cache for this layer: K [b][h][Tn][64], V same (kv stride between them)
+template <typename T>
+void launch_dec_cross_attention(const T* q, const T* kc, const T* vc, long b_stride, int d, int H, int Tn, const RowCtl* ctl, int M,
+                                float* scratch, T* out, hipStream_t st);
+
+// ---------------------------------------------------------------------------------------------
+// misc (kernels_misc.hip)
+// ---------------------------------------------------------------------------------------------
+// LayerNorm over rows of f32 -> T   (eps 1e-5, double-free two-pass in registers)
+// row_idx (optional): output row r normalises input row row_idx[r] (gather)
+template <typename T> void launch_layernorm(const float* x, const float* w, const float* b, T* y, int rows, int d, const int* row_idx, hipStream_t st);
+template <typename T> void launch_layernorm_f32out(const float* x, const float* w, const float* b, float* y, int rows, int d, hipStream_t st);
+// x[m][:] = te[token_m][:] + pe[pos_m][:]
+template <typename T> void launch_embed(const T* te, const float* pe, const RowCtl* ctl, int M, int d, float* x, hipStream_t st);
+// conversions
+template <typename T> void launch_f32_to_T(const float* in, T* out, size_t n, hipStream_t st);
+template <typename T> void launch_T_to_f32(const T* in, float* out, size_t n, hipStream_t st);
+
+// Fused whisper_process_logits + log-softmax + whisper_sample_token(best) (kernels_misc.hip)
+struct RuleConsts {
+    int32_t n_vocab, eot, sot, translate, transcribe, solm, prev, nosp, not_, beg, blank /* id of " " or -1 */, n_lang;
+    int32_t suppress_blank, no_timestamps, tdrz_enable, max_initial_tid /* -1 = off */, suppress_eot /* Mode F */;
+};
+struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t pad[2]; };
+void launch_logits_rules(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, SampleOut* out, float* probs /* [M][ld] or null */,
+                         hipStream_t st);
+
+}  // namespace ss

@@ -1,0 +1,317 @@
+// Attention kernels for gfx950.
+//  * encoder self-attention (non-causal, T=1500, dh=64): MFMA flash attention with the softmax held entirely in
+//    registers.  S^T = K Q^T is computed with the operands swapped so a lane owns one query column: row max / sum are
+//    in-lane plus two cross-group shuffles, and the exponentiated S^T registers ARE the B operand of the P·V MFMA
+//    (the contraction index is permuted identically on the V^T side, so no LDS round trip and no transposes).
+//  * decoder self-attention over the growing f16/bf16 KV cache and cross-attention over the 1500 encoder positions:
+//    HBM-bound streaming kernels (one new token per row), split over T for occupancy.
+// Replaces ggml's mul_mat(K,Q) -> soft_max(_ext) -> mul_mat(V,P) node chains in whisper.cpp's encoder / decoder graphs
+// (/root/reference/resources/ggml-metal.metal:351-435 kernel_soft_max, :1229-1305 kernel_mul_mv_f16_f16).
+#include "kernels.h"
+
+namespace ss {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct MfmaA;
+template <> struct MfmaA<bf16> {
+    typedef bf16x8 V8; typedef bf16x4 V4;
+    static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct MfmaA<f16> {
+    typedef f16x8 V8; typedef f16x4 V4;
+    static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// encoder flash attention: grid (ceil(Tn/128), H, B), 256 threads; wave w owns 32 query rows (2 column tiles)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, const T* __restrict__ k, long ld, const T* __restrict__ vT,
+                                                       int Tpad, T* __restrict__ out, long ldo, int H, int Tn) {
+    typedef typename MfmaA<T>::V8 V8;
+    typedef typename MfmaA<T>::V4 V4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    if (q0 >= Tn) return;
+    const long rowbase = (long)b * Tn;
+
+    V8 qf[2][2];
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+        int qr = q0 + qi * 16 + frow;
+        if (qr > Tn - 1) qr = Tn - 1;
+        const T* p = q + (rowbase + qr) * ld + h * 64 + fg * 8;
+        qf[qi][0] = *(const V8*)p;
+        qf[qi][1] = *(const V8*)(p + 32);
+    }
+    f32x4 o[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { o[i][0] = (f32x4){0, 0, 0, 0}; o[i][1] = (f32x4){0, 0, 0, 0}; }
+    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+    const T* vbase = vT + ((long)(b * H + h) * 64) * Tpad;
+    const float scale = 0.125f;  // 1/sqrt(64)
+    const int nchunk = (Tn + 31) / 32;
+
+    for (int kc = 0; kc < nchunk; kc++) {
+        const int key0 = kc * 32;
+        V8 kf[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) {
+            int kr = key0 + kt * 16 + frow;
+            if (kr > Tn - 1) kr = Tn - 1;
+            const T* p = k + (rowbase + kr) * ld + h * 64 + fg * 8;
+            kf[kt][0] = *(const V8*)p;
+            kf[kt][1] = *(const V8*)(p + 32);
+        }
+        V8 vf[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) {
+            const T* p = vbase + (long)(dt * 16 + frow) * Tpad + key0 + fg * 4;
+            const V4 lo = *(const V4*)p, hi = *(const V4*)(p + 16);
+            vf[dt] = (V8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+        f32x4 s[2][2];  // [kt][qi]
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+            for (int qi = 0; qi < 2; qi++) {
+                f32x4 a = (f32x4){0, 0, 0, 0};
+                a = MfmaA<T>::mma(kf[kt][0], qf[qi][0], a);
+                a = MfmaA<T>::mma(kf[kt][1], qf[qi][1], a);
+                s[kt][qi] = a;
+            }
+        const bool tail = key0 + 32 > Tn;
+#pragma unroll
+        for (int qi = 0; qi < 2; qi++) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    float v = s[kt][qi][r] * scale;
+                    if (tail && key0 + kt * 16 + fg * 4 + r >= Tn) v = -1e30f;
+                    s[kt][qi][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mnew = fmaxf(mrun[qi], mx);
+            const float alpha = __expf(mrun[qi] - mnew);
+            mrun[qi] = mnew;
+            float psum = 0.f;
+            V8 pf;
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float pv = __expf(s[kt][qi][r] - mnew);
+                    const T pt = (T)pv;
+                    pf[kt * 4 + r] = pt;
+                    psum += (float)pt;   // the sum sees exactly what the P·V MFMA sees
+                }
+            lrun[qi] = lrun[qi] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                o[dt][qi] *= alpha;
+                o[dt][qi] = MfmaA<T>::mma(vf[dt], pf, o[dt][qi]);
+            }
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < 2; qi++) {
+        float l = lrun[qi];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int qr = q0 + qi * 16 + frow;
+        if (qr < Tn) {
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                V4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; r++) ov[r] = (T)(o[dt][qi][r] * inv);
+                *(V4*)(out + (rowbase + qr) * ldo + h * 64 + dt * 16 + fg * 4) = ov;
+            }
+        }
+    }
+}
+
+template <typename T>
+void launch_enc_attention(const T* q, const T* k, long ld, const T* vT, int Tpad, T* out, long ldo, int B, int H, int Tn, hipStream_t st) {
+    dim3 grid((Tn + 127) / 128, H, B);
+    enc_attn_kernel<T><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn);
+}
+template void launch_enc_attention<bf16>(const bf16*, const bf16*, long, const bf16*, int, bf16*, long, int, int, int, hipStream_t);
+template void launch_enc_attention<f16>(const f16*, const f16*, long, const f16*, int, f16*, long, int, int, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// decoder self-attention: grid (H, M), one wave per (row, head); n_kv = pos + 1 <= 448
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kcache, const T* __restrict__ vcache,
+                                                           long slot_stride, int d, const RowCtl* __restrict__ ctl, T* __restrict__ out) {
+    typedef typename MfmaA<T>::V8 V8;
+    __shared__ float s_q[64];
+    __shared__ float s_p[448];
+    const int lane = threadIdx.x, h = blockIdx.x, m = blockIdx.y;
+    const RowCtl c = ctl[m];
+    const int n_kv = c.pos + 1;
+    const T* K = kcache + (long)c.slot * slot_stride + h * 64;
+    const T* V = vcache + (long)c.slot * slot_stride + h * 64;
+    s_q[lane] = (float)q[(long)m * d + h * 64 + lane];
+    __syncthreads();
+    float mx = -1e30f;
+    for (int key = lane; key < n_kv; key += 64) {
+        const T* kr = K + (long)key * d;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const V8 kv = *(const V8*)(kr + j * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc += s_q[j * 8 + e] * (float)kv[e];
+        }
+        s_p[key] = acc;
+        mx = fmaxf(mx, acc);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int key = lane; key < n_kv; key += 64) {
+        const float p = (float)(T)__expf(s_p[key] - mx);
+        s_p[key] = p;
+        sum += p;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __syncthreads();
+    float acc = 0.f;
+    for (int key = 0; key < n_kv; key++) acc += s_p[key] * (float)V[(long)key * d + lane];
+    out[(long)m * d + h * 64 + lane] = (T)(acc / sum);
+}
+
+template <typename T>
+void launch_dec_self_attention(const T* q, const T* kcache, const T* vcache, long slot_stride, int d, int H, const RowCtl* ctl, int M, T* out,
+                               hipStream_t st) {
+    dim3 grid(H, M);
+    dec_self_attn_kernel<T><<<grid, 64, 0, st>>>(q, kcache, vcache, slot_stride, d, ctl, out);
+}
+template void launch_dec_self_attention<bf16>(const bf16*, const bf16*, const bf16*, long, int, int, const RowCtl*, int, bf16*, hipStream_t);
+template void launch_dec_self_attention<f16>(const f16*, const f16*, const f16*, long, int, int, const RowCtl*, int, f16*, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// decoder cross-attention: grid (NSPLIT, H, M), 256 threads; K/V [b][h][Tn][64] contiguous per (b,h);
+// split s covers keys [s*per, (s+1)*per); partial (max, sum, o[64]) to scratch, combined by a second kernel
+// ---------------------------------------------------------------------------------------------
+constexpr int kCrossSplit = 4;
+constexpr int kCrossPart = 66;  // floats per partial: m, l, o[64]
+
+template <typename T>
+__global__ __launch_bounds__(256) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
+                                                             long b_stride, int d, int H, int Tn, const RowCtl* __restrict__ ctl,
+                                                             float* __restrict__ scratch) {
+    typedef typename MfmaA<T>::V8 V8;
+    __shared__ float s_sc[512];
+    __shared__ float s_red[8];
+    __shared__ float s_o[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane >> 3, c = lane & 7;
+    const int sp = blockIdx.x, h = blockIdx.y, m = blockIdx.z;
+    const int per = (Tn + kCrossSplit - 1) / kCrossSplit;
+    const int k_beg = sp * per, k_end = min(Tn, k_beg + per), nk = k_end - k_beg;
+    const RowCtl rc = ctl[m];
+    const T* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
+    const T* V = vc + (long)rc.cross * b_stride + (long)h * Tn * 64;
+    float qv[8];
+    {
+        const V8 t = *(const V8*)(q + (long)m * d + h * 64 + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) qv[e] = (float)t[e];
+    }
+    // phase 1: scores.  One wave-instruction reads 8 key rows x 128 B
+    float mx = -1e30f;
+    for (int i = wave * 8 + r; i < nk; i += 32) {
+        const V8 kv = *(const V8*)(K + (long)(k_beg + i) * 64 + c * 8);
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) a += qv[e] * (float)kv[e];
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        a += __shfl_xor(a, 4);
+        if (c == 0) s_sc[i] = a;
+        mx = fmaxf(mx, a);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sum = 0.f;
+    for (int i = tid; i < nk; i += 256) {
+        const float p = (float)(T)__expf(s_sc[i] - mx);
+        s_sc[i] = p;
+        sum += p;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) s_red[4 + wave] = sum;
+    __syncthreads();
+    sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    // phase 2: o[c*8+e] += p[key] V[key][c*8+e]
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = wave * 8 + r; i < nk; i += 32) {
+        const V8 vv = *(const V8*)(V + (long)(k_beg + i) * 64 + c * 8);
+        const float p = s_sc[i];
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += p * (float)vv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        acc[e] += __shfl_xor(acc[e], 8);
+        acc[e] += __shfl_xor(acc[e], 16);
+        acc[e] += __shfl_xor(acc[e], 32);
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) s_o[wave][c * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    float* part = scratch + ((long)(m * H + h) * kCrossSplit + sp) * kCrossPart;
+    if (tid < 64) part[2 + tid] = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
+    if (tid == 0) { part[0] = mx; part[1] = sum; }
+}
+
+template <typename T>
+__global__ void dec_cross_combine_kernel(const float* __restrict__ scratch, int d, int H, T* __restrict__ out) {
+    const int m = blockIdx.x;
+    for (int col = threadIdx.x; col < d; col += blockDim.x) {
+        const int h = col >> 6, j = col & 63;
+        const float* part = scratch + (long)(m * H + h) * kCrossSplit * kCrossPart;
+        float mx = -1e30f;
+#pragma unroll
+        for (int s = 0; s < kCrossSplit; s++) mx = fmaxf(mx, part[s * kCrossPart]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int s = 0; s < kCrossSplit; s++) {
+            const float w = __expf(part[s * kCrossPart] - mx);
+            num += w * part[s * kCrossPart + 2 + j];
+            den += w * part[s * kCrossPart + 1];
+        }
+        out[(long)m * d + col] = (T)(num / den);
+    }
+}
+
+template <typename T>
+void launch_dec_cross_attention(const T* q, const T* kc, const T* vc, long b_stride, int d, int H, int Tn, const RowCtl* ctl, int M, float* scratch,
+                                T* out, hipStream_t st) {
+    if ((Tn + kCrossSplit - 1) / kCrossSplit > 512) throw Error(-1, "cross attention: n_audio_ctx too large");
+    dim3 grid(kCrossSplit, H, M);
+    dec_cross_attn_kernel<T><<<grid, 256, 0, st>>>(q, kc, vc, b_stride, d, H, Tn, ctl, scratch);
+    dec_cross_combine_kernel<T><<<M, 256, 0, st>>>(scratch, d, H, out);
+}
+template void launch_dec_cross_attention<bf16>(const bf16*, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int, float*, bf16*, hipStream_t);
+template void launch_dec_cross_attention<f16>(const f16*, const f16*, const f16*, long, int, int, int, const RowCtl*, int, float*, f16*, hipStream_t);
+
+}  // namespace ss

@@ -1,0 +1,350 @@
+// MFMA GEMMs for gfx950 (CDNA4): the encoder / cross-KV projections (compute-bound, bf16|f16 MFMA roofline) and the
+// skinny decode-step projections (HBM-bound: weights streamed once per step).
+//
+// Replaces ggml's mul_mat + add + gelu graph nodes that whisper.cpp builds for the encoder conv stem, the QKV/O and
+// FFN projections, the cross-KV precompute and the decoder projections (op inventory in
+// /root/reference/resources/ggml-metal.metal:3861-4003 kernel_mul_mm, :1307-1363 kernel_mul_mv_f16_f32).
+// Not a translation of those: wave64 16x16x32 MFMA tiles, direct global->LDS DMA with a source-side XOR swizzle,
+// operands swapped so each lane owns 4 consecutive output features (8/16-byte stores), epilogues fused.
+#include "kernels.h"
+
+namespace ss {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16> {
+    typedef bf16x8 V8; typedef bf16x4 V4;
+    static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Mfma<f16> {
+    typedef f16x8 V8; typedef f16x4 V4;
+    static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)));  tanh(u) = 1 - 2/(exp(2u)+1)
+    const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
+    const float e = __expf(2.0f * u);
+    const float th = 1.0f - 2.0f / (e + 1.0f);
+    return 0.5f * x * (1.0f + th);
+}
+template <typename T> __device__ __forceinline__ float gelu_in_round(float x, int on);
+template <> __device__ __forceinline__ float gelu_in_round<bf16>(float x, int) { return x; }
+template <> __device__ __forceinline__ float gelu_in_round<f16>(float x, int on) { return on ? (float)(f16)x : x; }
+
+// ---------------------------------------------------------------------------------------------
+// 128 x 128 x 64 tile, 256 threads = 4 waves (2 n x 2 m), each wave 64 x 64 = 4 x 4 MFMA 16x16x32 tiles.
+// LDS: 2 stages x (X tile 16 KB + W tile 16 KB) = 64 KB  ->  2 workgroups / CU.
+// LDS rows are 128 B (64 k); 16-B chunk c of row r is stored at chunk position c ^ ((r>>1)&7): the DMA writes
+// lane-linear, so the permutation is applied to the per-lane SOURCE address and again on the ds_read_b128 side.
+// ---------------------------------------------------------------------------------------------
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kTileBytes = BM * BK * 2;       // 16 KB
+constexpr int kGemmLds = 4 * kTileBytes;      // 64 KB
+
+template <typename T>
+__device__ __forceinline__ void glds16(const T* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Mfma<T>::V8 V8;
+    typedef typename Mfma<T>::V4 V4;
+    constexpr bool SWAP = (KIND == EPI_VT);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int nbn = g.N / BN, nbm = (g.M + BM - 1) / BM;
+    // XCD-aware remap (blocks id, id+8, ... run on one XCD and share its L2): consecutive logical ids on one XCD
+    const int nwg = nbn * nbm;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nb = bid % nbn, mb = bid / nbn;  // n fastest: neighbours share the activation panel
+    const int m0 = mb * BM, n0 = nb * BN;
+
+    const T* __restrict__ A = (const T*)g.A;
+    const T* __restrict__ W = (const T*)g.W;
+
+    // staging: pass p covers tile rows p*32 + tid/8; this lane's LDS chunk position is tid%8
+    const int srow = tid >> 3, cpos = tid & 7;
+    const T* xsrc[4];
+    const T* wsrc[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int r = p * 32 + srow;
+        const int c = cpos ^ ((r >> 1) & 7);
+        long m = m0 + r;
+        if (m > g.M - 1) m = g.M - 1;
+        xsrc[p] = A + (m / g.a_rows_per_batch) * g.a_batch_stride + (m % g.a_rows_per_batch) * g.lda + c * 8;
+        wsrc[p] = W + (long)(n0 + r) * g.K + c * 8;
+    }
+    char* const sX0 = smem;
+    char* const sW0 = smem + 2 * kTileBytes;
+    const int stage_off = (wave * 8) * 128;  // this wave's first row within a 32-row pass
+
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            glds16<T>(xsrc[p] + k0, sX0 + buf * kTileBytes + p * 32 * 128 + stage_off);
+            glds16<T>(wsrc[p] + k0, sW0 + buf * kTileBytes + p * 32 * 128 + stage_off);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fg = lane >> 4, sw = (lane >> 1) & 7;
+    const int nk = g.K / BK;
+    stage(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; kt++) {
+        if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+        const char* bX = sX0 + cur * kTileBytes + (wm * 64 + frow) * 128;
+        const char* bW = sW0 + cur * kTileBytes + (wn * 64 + frow) * 128;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            const int coff = ((kk * 4 + fg) ^ sw) * 16;
+            V8 xf[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xf[i] = *(const V8*)(bX + i * 16 * 128 + coff);
+                wf[i] = *(const V8*)(bW + i * 16 * 128 + coff);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++) {
+                    if (SWAP) acc[ni][mi] = Mfma<T>::mma(xf[mi], wf[ni], acc[ni][mi]);
+                    else acc[ni][mi] = Mfma<T>::mma(wf[ni], xf[mi], acc[ni][mi]);
+                }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---------------- epilogue ----------------
+    if constexpr (!SWAP) {
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) {
+            const long m = m0 + wm * 64 + mi * 16 + frow;
+            if (m >= g.M) continue;
+            const long orow = (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo;
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) {
+                const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+                f32x4 v = acc[ni][mi];
+                if (g.bias) {
+                    const f32x4 b = *(const f32x4*)(g.bias + n);
+                    v += b;
+                }
+                if constexpr (KIND == EPI_STORE_T) {
+                    V4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
+                    *(V4*)((T*)g.out + orow + n) = o;
+                } else if constexpr (KIND == EPI_GELU_T) {
+                    V4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
+                    *(V4*)((T*)g.out + orow + n) = o;
+                } else if constexpr (KIND == EPI_RES_F32) {
+                    const f32x4 rsd = *(const f32x4*)(g.res + orow + n);
+                    *(f32x4*)((float*)g.out + orow + n) = rsd + v;
+                } else if constexpr (KIND == EPI_STORE_F32) {
+                    *(f32x4*)((float*)g.out + orow + n) = v;
+                } else if constexpr (KIND == EPI_GELU_POS_F32) {
+                    const f32x4 pe = *(const f32x4*)(g.pos + (long)(m % g.rows_per_batch) * g.N + n);
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in)) + pe[r];
+                    *(f32x4*)((float*)g.out + orow + n) = o;
+                } else if constexpr (KIND == EPI_CROSS_KV) {
+                    // n = l*2d + kv*d + h*64 + j ; cache [l][b][kv][h][t][64]
+                    const int H = g.d / 64;
+                    const int l = n / (2 * g.d), rem = n % (2 * g.d), kv = rem / g.d, hj = rem % g.d, h = hj >> 6, j = hj & 63;
+                    const int b = (int)(m / g.rows_per_batch), t = (int)(m % g.rows_per_batch);
+                    const float sc = kv == 0 ? g.scale : 1.0f;
+                    V4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
+                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j;
+                    *(V4*)((T*)g.out + off) = o;
+                }
+            }
+        }
+    } else {
+        // D[m][n]: lane owns 4 consecutive m (time) for one n: V^T [b][h][64][Tpad]
+        const int H = g.d / 64;
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) {
+            const int n = n0 + wn * 64 + ni * 16 + frow;
+            const float b = g.bias ? g.bias[n] : 0.0f;
+            const int h = n >> 6, j = n & 63;
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++) {
+                const long m = m0 + wm * 64 + mi * 16 + fg * 4;
+                if (m >= g.M) continue;
+                const int bb = (int)(m / g.rows_per_batch), t = (int)(m % g.rows_per_batch);
+                V4 o;
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[r] = (T)(acc[ni][mi][r] + b);
+                *(V4*)((T*)g.out + (((long)(bb * H + h) * 64 + j) * g.Tpad + t)) = o;
+            }
+        }
+    }
+}
+
+template <typename T, int KIND>
+static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        SS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
+        attr_set = true;
+    }
+    const int nwg = (g.N / BN) * ((g.M + BM - 1) / BM);
+    gemm_kernel<T, KIND><<<nwg, 256, kGemmLds, st>>>(g);
+}
+
+template <typename T>
+void launch_gemm(const GemmDesc& g, hipStream_t st) {
+    if (g.N % BN || g.K % BK || g.M <= 0) throw Error(-1, "gemm: N must be a multiple of 128 and K of 64");
+    switch (g.kind) {
+        case EPI_STORE_T: launch_gemm_kind<T, EPI_STORE_T>(g, st); break;
+        case EPI_GELU_T: launch_gemm_kind<T, EPI_GELU_T>(g, st); break;
+        case EPI_RES_F32: launch_gemm_kind<T, EPI_RES_F32>(g, st); break;
+        case EPI_GELU_POS_F32: launch_gemm_kind<T, EPI_GELU_POS_F32>(g, st); break;
+        case EPI_VT: launch_gemm_kind<T, EPI_VT>(g, st); break;
+        case EPI_CROSS_KV: launch_gemm_kind<T, EPI_CROSS_KV>(g, st); break;
+        case EPI_STORE_F32: launch_gemm_kind<T, EPI_STORE_F32>(g, st); break;
+        default: throw Error(-1, "gemm: bad epilogue kind");
+    }
+}
+template void launch_gemm<bf16>(const GemmDesc&, hipStream_t);
+template void launch_gemm<f16>(const GemmDesc&, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// Skinny GEMM (decode steps).  One workgroup = 16 weight rows; its 4 waves split K and reduce through LDS.
+// W tile is the MFMA A operand (16 n x 32 k per instruction, streamed once from HBM straight to VGPRs: no reuse,
+// so no LDS staging); X^T (up to 64 rows = 4 column tiles) is the B operand, re-read from L2.
+// Each lane loads 32 contiguous bytes of a weight row per pair of MFMAs, so 4 lanes cover one 128-B line.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int KIND, int MT>
+__global__ __launch_bounds__(256) void skinny_kernel(SkinnyDesc g) {
+    typedef typename Mfma<T>::V8 V8;
+    __shared__ float red[4][MT][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const T* __restrict__ W = (const T*)g.W;
+    const T* __restrict__ X = (const T*)g.X;
+    const int kslice = g.K / 4, kbeg = wave * kslice;   // K % 128 == 0 checked on the host
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const T* wp = W + (long)(n0 + frow) * g.K + kbeg + fg * 16;
+    const T* xp[MT];
+    bool xok[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        const int m = i * 16 + frow;
+        xok[i] = m < g.M;
+        xp[i] = X + (long)(xok[i] ? m : 0) * g.ldx + kbeg + fg * 16;
+    }
+    // k-slot mapping: MFMA pair j consumes k = kbeg + 64 j + 16 fg + [0,8) and + [8,16)  (same for W and X)
+    const int npair = kslice / 64, tail32 = (kslice % 64) != 0;  // kslice is a multiple of 32
+    const V8 zero = {};
+    for (int j = 0; j < npair; j++) {
+        const V8 w0 = *(const V8*)(wp + j * 64), w1 = *(const V8*)(wp + j * 64 + 8);
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const V8 x0 = xok[i] ? *(const V8*)(xp[i] + j * 64) : zero;
+            const V8 x1 = xok[i] ? *(const V8*)(xp[i] + j * 64 + 8) : zero;
+            acc[i] = Mfma<T>::mma(w0, x0, acc[i]);
+            acc[i] = Mfma<T>::mma(w1, x1, acc[i]);
+        }
+    }
+    if (tail32) {  // last 32 k of the slice: lane group fg takes 8 contiguous
+        const long o = (long)npair * 64 - fg * 16 + fg * 8;
+        const V8 w0 = *(const V8*)(wp + o);
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const V8 x0 = xok[i] ? *(const V8*)(xp[i] + o) : zero;
+            acc[i] = Mfma<T>::mma(w0, x0, acc[i]);
+        }
+    }
+    // D[n][m]: lane holds n = fg*4 + r, m = frow
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave][i][frow][fg * 4 + r] = acc[i][r];
+    __syncthreads();
+    // 16 n x (MT*16) m outputs; thread -> (m = tid / 16, n = tid % 16) per column tile
+    for (int i = 0; i < MT; i++) {
+        const int m = i * 16 + (tid >> 4), nn = tid & 15, n = n0 + nn;
+        if (m >= g.M) continue;
+        float v = red[0][i][tid >> 4][nn] + red[1][i][tid >> 4][nn] + red[2][i][tid >> 4][nn] + red[3][i][tid >> 4][nn];
+        if (g.bias) v += g.bias[n];
+        if constexpr (KIND == SK_STORE_T) {
+            ((T*)g.out)[(long)m * g.ldo + n] = (T)(v * g.scale);
+        } else if constexpr (KIND == SK_GELU_T) {
+            ((T*)g.out)[(long)m * g.ldo + n] = (T)gelu_tanh_f(gelu_in_round<T>(v, g.gelu_f16_in));
+        } else if constexpr (KIND == SK_RES_F32) {
+            float* o = (float*)g.out + (long)m * g.ldo + n;
+            *o = *o + v;
+        } else if constexpr (KIND == SK_LOGITS_F32) {
+            if (n < g.n_valid) ((float*)g.out)[(long)m * g.ldo + n] = v;
+        } else if constexpr (KIND == SK_SELF_QKV) {
+            const int d = g.d;
+            if (n < d) ((T*)g.out)[(long)m * g.ldo + n] = (T)(v * g.scale);
+            else {
+                const RowCtl c = g.ctl[m];
+                const long off = (long)c.slot * g.slot_stride + (long)c.pos * d;
+                if (n < 2 * d) ((T*)g.kcache)[off + (n - d)] = (T)(v * g.scale);
+                else ((T*)g.vcache)[off + (n - 2 * d)] = (T)v;
+            }
+        }
+    }
+}
+
+template <typename T, int KIND>
+static void launch_skinny_kind(const SkinnyDesc& g, hipStream_t st) {
+    const int blocks = (g.N + 15) / 16;
+    if (g.M <= 16) skinny_kernel<T, KIND, 1><<<blocks, 256, 0, st>>>(g);
+    else if (g.M <= 32) skinny_kernel<T, KIND, 2><<<blocks, 256, 0, st>>>(g);
+    else if (g.M <= 48) skinny_kernel<T, KIND, 3><<<blocks, 256, 0, st>>>(g);
+    else skinny_kernel<T, KIND, 4><<<blocks, 256, 0, st>>>(g);
+}
+
+template <typename T>
+void launch_skinny(const SkinnyDesc& g, hipStream_t st) {
+    if (g.K % 128 || g.M <= 0 || g.M > 64) throw Error(-1, "skinny gemm: K must be a multiple of 128 and 1 <= M <= 64");
+    switch (g.kind) {
+        case SK_STORE_T: launch_skinny_kind<T, SK_STORE_T>(g, st); break;
+        case SK_GELU_T: launch_skinny_kind<T, SK_GELU_T>(g, st); break;
+        case SK_RES_F32: launch_skinny_kind<T, SK_RES_F32>(g, st); break;
+        case SK_LOGITS_F32: launch_skinny_kind<T, SK_LOGITS_F32>(g, st); break;
+        case SK_SELF_QKV: launch_skinny_kind<T, SK_SELF_QKV>(g, st); break;
+        default: throw Error(-1, "skinny gemm: bad epilogue kind");
+    }
+}
+template void launch_skinny<bf16>(const SkinnyDesc&, hipStream_t);
+template void launch_skinny<f16>(const SkinnyDesc&, hipStream_t);
+
+}  // namespace ss

@@ -1,0 +1,136 @@
+// ggml legacy model-file reader for the product path.
+// Replaces what `WhisperContext::new_with_params` does for the reference (/root/reference/src/asr/whisper.rs:21-28),
+// i.e. whisper.cpp's whisper_model_load: magic, 11 hparams, mel filterbank, vocabulary (+ synthesised special
+// tokens), then {n_dims, name_len, type, ne[], name, data} records.  ftype 0/1 (f32 / f16)
+// files are supported; quantised files are rejected with SS_ERR_MODEL.
+#include "common.h"
+
+#include <cstring>
+
+namespace ss {
+
+static const char* const kLang[] = {"en","zh","de","es","ru","ko","fr","ja","pt","tr","pl","ca","nl","ar","sv","it","id","hi","fi","vi",
+    "he","uk","el","ms","cs","ro","da","hu","ta","no","th","ur","hr","bg","lt","la","mi","ml","cy","sk","te","fa","lv","bn","sr","az",
+    "sl","kn","et","mk","br","eu","is","hy","ne","mn","bs","kk","sq","sw","gl","mr","pa","si","km","sn","yo","so","af","oc","ka","be",
+    "tg","sd","gu","am","yi","lo","uz","fo","ht","ps","tk","nn","mt","sa","lb","my","bo","tl","mg","as","tt","haw","ln","ha","ba","jw","su","yue"};
+static const int kNLang = sizeof(kLang) / sizeof(kLang[0]);
+
+int lang_id(const char* code) {
+    for (int i = 0; i < kNLang; i++)
+        if (!strcmp(code, kLang[i])) return i;
+    return -1;
+}
+
+const HostTensor& HostModel::get(const std::string& name) const {
+    auto it = t.find(name);
+    if (it == t.end()) throw Error(-2, "model: missing tensor " + name);
+    return it->second;
+}
+
+static inline float half_to_float(uint16_t h) {
+    uint32_t sign = (uint32_t)(h & 0x8000) << 16, exp = (h >> 10) & 0x1f, man = h & 0x3ff, u;
+    if (exp == 0) {
+        if (man == 0) u = sign;
+        else {
+            int e = -1;
+            do { e++; man <<= 1; } while (!(man & 0x400));
+            u = sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ff) << 13);
+        }
+    } else if (exp == 31) u = sign | 0x7f800000u | (man << 13);
+    else u = sign | ((exp + 112) << 23) | (man << 13);
+    float f; memcpy(&f, &u, 4); return f;
+}
+
+namespace {
+struct File {
+    FILE* f;
+    explicit File(const char* p) : f(fopen(p, "rb")) {}
+    ~File() { if (f) fclose(f); }
+    bool rd(void* p, size_t n) { return fread(p, 1, n, f) == n; }
+};
+}  // namespace
+
+void load_ggml_model(const char* path, HostModel& m) {
+    File F(path);
+    if (!F.f) throw Error(-2, std::string("model: cannot open ") + path);
+    uint32_t magic = 0;
+    if (!F.rd(&magic, 4) || magic != 0x67676d6c) throw Error(-2, "model: bad magic (not a ggml legacy file)");
+    if (!F.rd(&m.hp, sizeof(HParams))) throw Error(-2, "model: truncated header");
+    const HParams& hp = m.hp;
+    if (hp.ftype != 0 && hp.ftype != 1) throw Error(-2, "model: quantised ftype " + std::to_string(hp.ftype) + " not supported (f32/f16 only)");
+    if (hp.n_audio_state % hp.n_audio_head || hp.n_audio_state / hp.n_audio_head != 64 || hp.n_text_state / hp.n_text_head != 64)
+        throw Error(-2, "model: head dim must be 64");
+    int32_t nm = 0, nf = 0;
+    if (!F.rd(&nm, 4) || !F.rd(&nf, 4) || nf != kNBins || nm != hp.n_mels) throw Error(-2, "model: bad mel filterbank header");
+    m.filt_n_mel = nm; m.filt_n_fft = nf;
+    m.filters.resize((size_t)nm * nf);
+    if (!F.rd(m.filters.data(), m.filters.size() * 4)) throw Error(-2, "model: truncated filterbank");
+    int32_t nv = 0;
+    if (!F.rd(&nv, 4) || nv <= 0 || nv > hp.n_vocab) throw Error(-2, "model: bad vocab size");
+    Vocab& v = m.vocab;
+    v.id_to_token.resize(nv);
+    for (int i = 0; i < nv; i++) {
+        uint32_t len = 0;
+        if (!F.rd(&len, 4) || len > 4096) throw Error(-2, "model: bad vocab entry");
+        std::string s(len, '\0');
+        if (len && !F.rd(&s[0], len)) throw Error(-2, "model: truncated vocab");
+        v.id_to_token[i] = s;
+        v.token_to_id[s] = i;
+    }
+    v.n_vocab = hp.n_vocab;
+    if (v.is_multilingual()) {
+        v.token_eot++; v.token_sot++;
+        const int dt = v.num_languages() - 98;
+        v.token_translate += dt; v.token_transcribe += dt; v.token_solm += dt; v.token_prev += dt;
+        v.token_nosp += dt; v.token_not += dt; v.token_beg += dt;
+    }
+    if (nv < hp.n_vocab) {
+        v.id_to_token.resize(hp.n_vocab);
+        for (int i = nv; i < hp.n_vocab; i++) {
+            std::string w;
+            if (i > v.token_beg) w = "[_TT_" + std::to_string(i - v.token_beg) + "]";
+            else if (i == v.token_eot) w = "[_EOT_]";
+            else if (i == v.token_sot) w = "[_SOT_]";
+            else if (i == v.token_translate) w = "[_TRANSLATE_]";
+            else if (i == v.token_transcribe) w = "[_TRANSCRIBE_]";
+            else if (i == v.token_solm) w = "[_SOLM_]";
+            else if (i == v.token_prev) w = "[_PREV_]";
+            else if (i == v.token_nosp) w = "[_NOSP_]";
+            else if (i == v.token_not) w = "[_NOT_]";
+            else if (i == v.token_beg) w = "[_BEG_]";
+            else if (i > v.token_sot && i <= v.token_sot + v.num_languages() && i - v.token_sot - 1 < kNLang)
+                w = std::string("[_LANG_") + kLang[i - v.token_sot - 1] + "]";
+            else w = "[_extra_token_" + std::to_string(i) + "]";
+            v.id_to_token[i] = w;
+            v.token_to_id[w] = i;
+        }
+    }
+    while (true) {
+        int32_t nd = 0, nl = 0, tt = 0;
+        if (!F.rd(&nd, 4)) break;  // clean EOF
+        if (!F.rd(&nl, 4) || !F.rd(&tt, 4) || nd < 1 || nd > 4 || nl <= 0 || nl > 256) throw Error(-2, "model: bad tensor record");
+        HostTensor T;
+        T.ne.resize(nd); T.ttype = tt;
+        size_t n = 1;
+        for (int i = 0; i < nd; i++) {
+            int32_t e = 0;
+            if (!F.rd(&e, 4) || e <= 0) throw Error(-2, "model: bad tensor dims");
+            T.ne[i] = e; n *= (size_t)e;
+        }
+        std::string name(nl, '\0');
+        if (!F.rd(&name[0], nl)) throw Error(-2, "model: truncated tensor name");
+        T.f32.resize(n);
+        if (tt == 0) {
+            if (!F.rd(T.f32.data(), n * 4)) throw Error(-2, "model: truncated tensor " + name);
+        } else if (tt == 1) {
+            std::vector<uint16_t> h(n);
+            if (!F.rd(h.data(), n * 2)) throw Error(-2, "model: truncated tensor " + name);
+            for (size_t i = 0; i < n; i++) T.f32[i] = half_to_float(h[i]);
+        } else {
+            throw Error(-2, "model: unsupported tensor type " + std::to_string(tt) + " for " + name);
+        }
+        m.t[name] = std::move(T);
+    }
+}
+
+}  // namespace ss

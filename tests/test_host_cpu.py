@@ -1,0 +1,113 @@
+"""CPU: model-file I/O, the host-side mirror of the reference's src/asr interface, and the C-ABI surface
+(the library must load without a GPU and export every symbol include/*.h declares; compute needs a GPU and must fail loudly)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from speaksense_amd import asr, ggml_io
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_ggml_roundtrip(tmp_path):
+    p = str(tmp_path / "m.bin")
+    hp = ggml_io.write_model(p, "toy", seed=3)
+    hp2, filt, vocab, t = ggml_io.read_model(p)
+    assert hp2 == hp and filt.shape == (128, 201)
+    assert len(vocab) == 50257 and vocab[220] == b" "
+    names = [n for n, _, _ in ggml_io.tensor_specs(hp)]
+    assert set(names) == set(t)
+    assert t["encoder.conv1.weight"].shape == (128, 128, 3)
+    assert t["decoder.blocks.1.cross_attn.key.weight"].shape == (128, 128)
+    assert "decoder.blocks.0.attn.key.bias" not in t          # whisper has no key bias
+    w = t["decoder.blocks.0.mlp.0.weight"]
+    assert np.array_equal(w, w.astype(np.float16).astype(np.float32))  # 2-D weights are stored f16
+    # same seed -> same bytes
+    p2 = str(tmp_path / "m2.bin")
+    ggml_io.write_model(p2, "toy", seed=3)
+    assert open(p, "rb").read() == open(p2, "rb").read()
+
+
+def test_presets_match_survey():
+    lv3 = ggml_io.PRESETS["large-v3"]
+    assert (lv3.n_vocab, lv3.n_audio_state, lv3.n_audio_head, lv3.n_audio_layer, lv3.n_mels) == (51866, 1280, 20, 32, 128)
+    n_params = sum(int(np.prod(s)) for _, s, _ in ggml_io.tensor_specs(lv3))
+    assert 1.50e9 < n_params < 1.60e9   # 1541 M
+
+
+def test_punctuation_and_promo_filter():
+    # /root/reference/src/asr/whisper.rs:175-201
+    assert asr.add_punctuation("你好吗") == "你好吗？"
+    assert asr.add_punctuation("太棒了") == "太棒了！"
+    assert asr.add_punctuation("hello") == "hello "
+    assert asr.add_punctuation("结束。") == "结束。"
+    assert asr.add_punctuation("为何这样真好") == "为何这样真好？"   # question wins over exclamation
+    # whisper.rs:41-43
+    assert asr.is_promotional_text("感谢观看 请不吝点赞 订阅")
+    assert not asr.is_promotional_text("today's weather")
+
+
+def test_collect_semantics():
+    """whisper.rs:77-128: promo segments dropped, speaker id increments on speaker_turn_next of the PREVIOUS segment,
+    stream mode keeps only the last segment, timestamps passed through as f64 centiseconds."""
+    w = asr.WhisperAsr.__new__(asr.WhisperAsr)
+    res = dict(segments=[
+        dict(text="第一段".encode(), t0=0, t1=250, speaker_turn_next=True),
+        dict(text="请不吝点赞".encode(), t0=250, t1=300, speaker_turn_next=False),
+        dict(text="second".encode(), t0=300, t1=512, speaker_turn_next=False),
+    ])
+    out = w._collect(res, asr.AsrParams(stream_mode=False))
+    assert [s.text for s in out.segments] == ["第一段 ", "second "]
+    # the promo segment `continue`s before the speaker check (whisper.rs:87-97), so segment 0's turn flag is lost -- mirrored
+    assert [s.speaker_id for s in out.segments] == [0, 0]
+    res2 = dict(segments=[dict(text=b"a", t0=0, t1=1, speaker_turn_next=True), dict(text=b"b", t0=1, t1=2, speaker_turn_next=True),
+                          dict(text=b"c", t0=2, t1=3, speaker_turn_next=False)])
+    assert [s.speaker_id for s in w._collect(res2, asr.AsrParams()).segments] == [0, 1, 2]
+    assert out.segments[1].start == 300.0 and out.segments[1].end == 512.0
+    assert out.full_text == "第一段 second "
+    out = w._collect(res, asr.AsrParams(stream_mode=True))
+    assert len(out.segments) == 1 and out.full_text == "second "
+    bad = dict(segments=[dict(text=b"\xff\xfe", t0=0, t1=1, speaker_turn_next=False)])
+    with pytest.raises(UnicodeDecodeError):   # strict UTF-8, as full_get_segment_text (whisper.rs:85)
+        w._collect(bad, asr.AsrParams())
+
+
+def _declared_functions(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    return sorted(set(re.findall(r"\b((?:ss|whisper)_[a-z0-9_]+)\s*\(", src)) - {"whisper_new_segment_callback"})
+
+
+@pytest.mark.parametrize("header", ["speaksense.h", "whisper_compat.h"])
+def test_library_exports_every_declared_symbol(header):
+    from speaksense_amd import binding
+    assert os.path.exists(binding.LIB_PATH), "libspeaksense_hip.so not built (python __graft_entry__.py)"
+    L = ctypes.CDLL(binding.LIB_PATH)
+    fns = _declared_functions(header)
+    assert len(fns) >= 20
+    for f in fns:
+        assert hasattr(L, f), f"{f} declared in include/{header} but not exported"
+
+
+def test_no_cpu_fallback(toy_ml_path):
+    """Without a GPU the product path must fail loudly (SS_ERR_DEVICE), never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from speaksense_amd import binding
+    with pytest.raises(binding.SpeakSenseError) as e:
+        binding.Engine(toy_ml_path)
+    assert e.value.code == -4
+
+
+def test_params_struct_layout_matches_header():
+    from speaksense_amd import binding
+    p = binding.default_params()
+    assert ctypes.sizeof(binding.Params) == 17 * 4 + 8
+    assert (p.best_of, p.no_context, p.suppress_blank, p.language) == (5, 1, 1, b"en")
+    assert abs(p.temperature_inc - 0.2) < 1e-7 and abs(p.entropy_thold - 2.4) < 1e-6 and p.logprob_thold == -1.0
+    assert ctypes.sizeof(binding.EngineOpts) == 32

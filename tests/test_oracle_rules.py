@@ -1,0 +1,72 @@
+"""CPU: whisper_process_logits / whisper_full_with_state semantics of the oracle on synthetic inputs."""
+import numpy as np
+import pytest
+
+from oracle import binding as orc
+from speaksense_amd import synth
+
+
+@pytest.fixture(scope="module")
+def om(toy_ml_path):
+    m = orc.OracleModel(toy_ml_path)
+    yield m
+    m.close()
+
+
+def test_special_token_ids(om, toy_en_path):
+    # large-v3 style vocabulary (51866): SURVEY.md §8 a-8
+    assert (om.eot, om.sot, om.translate, om.transcribe, om.solm, om.prev, om.nosp, om.not_, om.beg) == \
+        (50257, 50258, 50359, 50360, 50361, 50362, 50363, 50364, 50365)
+    en = orc.OracleModel(toy_en_path)
+    assert (en.eot, en.sot, en.beg) == (50256, 50257, 50363)
+    assert en.token_str(en.eot) == b"[_EOT_]" and en.token_str(en.beg + 7) == b"[_TT_7]"
+    en.close()
+
+
+def test_logits_rules(om):
+    rng = np.random.default_rng(0)
+    st = om.new_state()
+    P = orc.default_params()
+    raw = (5 * rng.standard_normal(om.n_vocab)).astype(np.float32)
+    # initial step: EOT and " " suppressed, timestamps > 1.0 s (tid 50) masked
+    r = raw.copy(); r[om.eot] = 100.0
+    tid, lp, _ = st.process_logits(r, [], False, 3000, P)
+    assert tid != om.eot and lp[om.eot] == -np.inf
+    assert np.all(lp[om.beg + 51:] == -np.inf) and lp[om.beg + 50] > -np.inf
+    # special/task/language tokens are never sampled
+    for t in (om.sot, om.nosp, om.not_, om.translate, om.transcribe, om.prev, om.solm, om.sot + 1, om.sot + 100):
+        assert lp[t] == -np.inf
+    # after a lone timestamp: text is masked (next must be timestamp or EOT)
+    tid, lp, _ = st.process_logits(raw, [100, om.beg + 20], True, 40, P)
+    assert np.all(lp[:om.eot] == -np.inf) and tid >= om.eot
+    # ... and timestamps may not decrease
+    assert np.all(lp[om.beg:om.beg + 20] == -np.inf)
+    # after a timestamp pair: no third timestamp
+    tid, lp, _ = st.process_logits(raw, [om.beg + 20, om.beg + 20], True, 40, P)
+    assert np.all(lp[om.beg:] == -np.inf) and tid < om.beg
+    # if timestamps carry more probability mass than the best text token, a timestamp is forced
+    r = raw.copy(); r[om.beg:] = r[:om.beg].max() - 1.0
+    tid, lp, o5 = st.process_logits(r, [5, 6, 7], False, 3000, P)
+    assert tid >= om.beg and np.all(lp[:om.beg] == -np.inf)
+    assert int(o5[2]) == tid
+    st.close()
+
+
+def test_full_structure(om):
+    st = om.new_state(orc.MODE_GGML_F16)
+    r = st.full(synth.speech_like(3), orc.default_params(language="en", temperature_inc=0.0))
+    assert r["n_encode"] >= 1 and len(r["tokens"]) > 0
+    t_prev = -10**9
+    for s in r["segments"]:
+        assert s["t1"] >= s["t0"] and s["t0"] >= t_prev - 1 and len(s["text"]) > 0
+        t_prev = s["t0"]
+    # < 1 s of audio: nothing is decoded (whisper.cpp issue #39 rule)
+    r = st.full(synth.speech_like(3, 8000), orc.default_params(language="en"))
+    assert r["segments"] == [] and r["n_encode"] == 0
+    # unknown language on a multilingual model
+    with pytest.raises(RuntimeError):
+        st.full(synth.speech_like(3, 32000), orc.default_params(language="xx"))
+    # Mode F: one window, exactly N steps
+    r = st.full(synth.speech_like(4), orc.default_params(language="en", fixed_steps=12))
+    assert len(r["tokens"]) == 12 and r["n_encode"] == 1 and om.eot not in list(r["tokens"])
+    st.close()
