@@ -70,6 +70,7 @@ def lib():
         L.orc_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_counters.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_mel_of_state.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_time_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         # cap OpenMP: the GPU box reports 256 logical CPUs; hundreds of spinning threads on tiny decode-step loops
         # (or a cgroup quota below the CPU count) make the oracle orders of magnitude slower
         L.orc_set_threads.argtypes = [C.c_int]
@@ -125,6 +126,12 @@ class OracleModel:
         o = OrcOpts(mode, gelu_erf, default_threads())
         self.L.orc_encode(self.h, _p(mel), mel.shape[1], seek, C.byref(o), _p(out))
         return out
+
+    def time_sample(self, pcm, mode, n_enc_layers, n_cross_layers, n_dec_steps, n_threads):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        out = np.zeros(5, np.float64)
+        self.L.orc_time_sample(self.h, _p(pcm), len(pcm), mode, n_enc_layers, n_cross_layers, n_dec_steps, n_threads, _p(out))
+        return dict(mel_s=out[0], stem_s=out[1], enc_layer_s=out[2], cross_layer_s=out[3], dec_step_s=out[4])
 
     def new_state(self, mode: int = MODE_F32, gelu_erf: int = 0) -> "OracleState":
         return OracleState(self, mode, gelu_erf)

@@ -349,7 +349,8 @@ void attend_row(const float* q, const float* Kc, const float* Vc, int ldkv, int 
 // encoder   (wcpp: whisper_build_graph_conv / _encoder / _cross)
 // ---------------------------------------------------------------------------------------------
 // mel: [n_mel][n_len]; window [seek, seek+2*n_ctx) zero-padded past n_len. enc_out: [n_ctx][d]
-void encode(const Model& m, const float* mel, int n_len, int seek, const Opts& o, float* enc_out) {
+void encode(const Model& m, const float* mel, int n_len, int seek, const Opts& o, float* enc_out, int max_layers = -1, double* t_split = nullptr) {
+    const double t_begin = omp_get_wtime();
     const HParams& hp = m.hp;
     const int n_ctx = hp.n_audio_ctx, d = hp.n_audio_state, H = hp.n_audio_head, dh = d / H, n_mel = hp.n_mels;
     const int T2 = 2 * n_ctx;
@@ -379,7 +380,9 @@ void encode(const Model& m, const float* mel, int n_len, int seek, const Opts& o
     std::vector<float> ln((size_t)n_ctx * d), q((size_t)n_ctx * d), k((size_t)n_ctx * d), v((size_t)n_ctx * d),
         att((size_t)n_ctx * d), tmp((size_t)n_ctx * d), ff((size_t)n_ctx * 4 * d);
     const float scale = 1.0f / sqrtf((float)dh);
-    for (int il = 0; il < hp.n_audio_layer; il++) {
+    const double t_stem_end = omp_get_wtime();
+    const int n_layers_run = max_layers >= 0 ? std::min(max_layers, (int)hp.n_audio_layer) : hp.n_audio_layer;
+    for (int il = 0; il < n_layers_run; il++) {
         const std::string p = "encoder.blocks." + std::to_string(il) + ".";
         layer_norm(x.data(), m.w(p + "attn_ln.weight").data(), m.w(p + "attn_ln.bias").data(), ln.data(), n_ctx, d);
         matmul(ln.data(), d, m.w(p + "attn.query.weight").data(), m.w(p + "attn.query.bias").data(), q.data(), d, n_ctx, d, d, o.mode);
@@ -403,6 +406,7 @@ void encode(const Model& m, const float* mel, int n_len, int seek, const Opts& o
         for (size_t i = 0; i < x.size(); i++) x[i] += tmp[i];
     }
     layer_norm(x.data(), m.w("encoder.ln_post.weight").data(), m.w("encoder.ln_post.bias").data(), enc_out, n_ctx, d);
+    if (t_split) { t_split[0] = t_stem_end - t_begin; t_split[1] = omp_get_wtime() - t_stem_end; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -446,12 +450,13 @@ struct State {
     int n_fail = 0, n_encode = 0, n_decode = 0;
 };
 
-void cross_kv(State& s) {
+void cross_kv(State& s, int max_layers = -1) {
     const Model& m = *s.m; const HParams& hp = m.hp;
     const int n_ctx = hp.n_audio_ctx, d = hp.n_text_state, L = hp.n_text_layer, dh = d / hp.n_text_head;
     const float kscale = powf((float)dh, -0.25f);
     s.ck.resize((size_t)L * n_ctx * d); s.cv.resize((size_t)L * n_ctx * d);
-    for (int il = 0; il < L; il++) {
+    const int Lrun = max_layers >= 0 ? std::min(max_layers, L) : L;
+    for (int il = 0; il < Lrun; il++) {
         const std::string p = "decoder.blocks." + std::to_string(il) + ".cross_attn.";
         float* K = &s.ck[(size_t)il * n_ctx * d]; float* V = &s.cv[(size_t)il * n_ctx * d];
         matmul(s.enc.data(), hp.n_audio_state, m.w(p + "key.weight").data(), nullptr, K, d, n_ctx, d, hp.n_audio_state, s.o.mode);
@@ -853,5 +858,31 @@ void orc_tokens(void* sp, int32_t* ids, float* plog) {
     for (size_t i = 0; i < s->all_tokens.size(); i++) { ids[i] = s->all_tokens[i].id; if (plog) plog[i] = s->all_tokens[i].plog; }
 }
 void orc_counters(void* sp, int32_t* out) { State* s = (State*)sp; out[0] = s->n_encode; out[1] = s->n_decode; out[2] = s->n_fail; }
+// cpu_baseline leg of bench.py: a BOUNDED sample of one 30 s window, timed per stage so the whole-window time can be
+// extrapolated: out = {mel s, conv stem s, s per encoder layer, s per cross-KV layer, s per decode step (prompt+i position)}
+int orc_time_sample(void* mp, const float* pcm, int n, int mode, int n_enc_layers, int n_cross_layers, int n_dec_steps, int n_threads, double* out5) {
+    Model* m = (Model*)mp;
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+    State s; s.m = m; s.o.mode = mode; s.decoders.resize(1);
+    const HParams& hp = m->hp;
+    double t0 = omp_get_wtime();
+    s.n_len = mel_n_len(n); s.mel.resize((size_t)m->filt_n_mel * s.n_len);
+    log_mel(*m, pcm, n, s.mel.data(), s.n_len);
+    out5[0] = omp_get_wtime() - t0;
+    s.enc.resize((size_t)hp.n_audio_ctx * hp.n_audio_state);
+    double ts[2];
+    encode(*m, s.mel.data(), s.n_len, 0, s.o, s.enc.data(), n_enc_layers, ts);
+    out5[1] = ts[0]; out5[2] = ts[1] / std::max(1, std::min(n_enc_layers, (int)hp.n_audio_layer));
+    t0 = omp_get_wtime();
+    cross_kv(s, n_cross_layers);
+    out5[3] = (omp_get_wtime() - t0) / std::max(1, std::min(n_cross_layers, (int)hp.n_text_layer));
+    std::vector<float> lg(hp.n_vocab);
+    int tok = m->vocab.token_sot;
+    decode(s, s.decoders[0], &tok, 1, 0, lg.data());   // warm (allocates the self-KV)
+    t0 = omp_get_wtime();
+    for (int i = 0; i < n_dec_steps; i++) { tok = 1000 + i; decode(s, s.decoders[0], &tok, 1, 1 + i, lg.data()); }
+    out5[4] = (omp_get_wtime() - t0) / std::max(1, n_dec_steps);
+    return 0;
+}
 int orc_mel_of_state(void* sp, float* out) { State* s = (State*)sp; memcpy(out, s->mel.data(), s->mel.size() * 4); return s->n_len; }
 }

@@ -1,0 +1,31 @@
+"""CPU, world_size 2 over gloo: the multi-GPU path of bench.py (round-robin chunk sharding, barrier-bracketed timing,
+MAX-over-ranks reduction).  Chunks are independent, so there is no data-path collective to test."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_chunks_round_robin():
+    sys.path.insert(0, ROOT)
+    import bench
+    parts = [bench.shard_chunks(64, 8, r) for r in range(8)]
+    assert parts[0][:3] == [0, 8, 16] and parts[7][-1] == 63
+    assert sorted(sum(parts, [])) == list(range(64))           # every chunk exactly once
+    assert all(len(p) == 8 for p in parts)                      # weak scaling: fixed work per GPU
+    assert bench.shard_chunks(5, 2, 1) == [1, 3]                # ragged tail
+
+
+def test_two_rank_dry_run_gloo():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--batch", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout           # only rank 0 prints
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["chunks_rank0"] == [0, 2, 4, 6]
+    assert 0 < j["value"] < 2 * 4 * 30 / 0.04 * 1.01   # 8 chunks per 40 ms step at most
