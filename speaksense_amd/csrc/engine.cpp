@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace ss {
@@ -162,6 +163,8 @@ struct EngineT : EngineBase {
         for (auto& e : ev) SS_HIP(hipEventCreate(&e));
         upload_weights();
         alloc_workspaces();
+        plan_decode();
+        use_fused = getenv("SS_DECODE_UNFUSED") == nullptr;
         start_worker();
     }
     ~EngineT() override {
@@ -294,7 +297,7 @@ struct EngineT : EngineBase {
         xd.alloc((size_t)R * d * 4); lnd.alloc((size_t)R * d * 2); qd.alloc((size_t)R * d * 2); attd.alloc((size_t)R * d * 2);
         ffd.alloc((size_t)R * 4 * d * 2); logits.alloc((size_t)R * n_vocab_pad * 4); probs.alloc((size_t)R * n_vocab_pad * 4);
         cscratch.alloc((size_t)R * H * 4 * 66 * 4); ctl_d.alloc(2 * R * sizeof(RowCtl));
-        samp_d.alloc(R * sizeof(SampleOut)); rowidx_d.alloc(R * 4);
+        samp_d.alloc(R * sizeof(SampleOut)); rowidx_d.alloc(R * 4); rules_scratch.alloc((size_t)R * 64 * 8 * 4);
         SS_HIP(hipHostMalloc((void**)&ctl_h, 2 * R * sizeof(RowCtl), hipHostMallocDefault));
         SS_HIP(hipHostMalloc((void**)&samp_h, R * sizeof(SampleOut), hipHostMallocDefault));
         SS_HIP(hipHostMalloc((void**)&probs_h, (size_t)R * n_vocab_pad * 4, hipHostMallocDefault));
@@ -365,11 +368,112 @@ struct EngineT : EngineBase {
         g.gelu_f16_in = dtype_is_f16; g.d = d;
         return g;
     }
+    // ---- fused decode step (M <= 16): 8 launches per layer, see kernels_decode.hip ----
+    struct Plan { int S, NW; };
+    Plan pl_qkv, pl_dd, pl_fc1, pl_fc2, pl_logits;
+    DBuf xa, xb, p1, pq, p2, p3;
+    void plan_decode() {
+        dec_gemv_plan(3 * d, d, &pl_qkv.S, &pl_qkv.NW); pl_qkv.S = 1; fix_nw(pl_qkv, d);
+        dec_gemv_plan(d, d, &pl_dd.S, &pl_dd.NW, true);
+        dec_gemv_plan(4 * d, d, &pl_fc1.S, &pl_fc1.NW); pl_fc1.S = 1; fix_nw(pl_fc1, d);
+        dec_gemv_plan(d, 4 * d, &pl_fc2.S, &pl_fc2.NW);
+        pl_logits.S = 1; fix_nw(pl_logits, d);
+        const size_t pb = (size_t)8 * 16 * d * 4;
+        xa.alloc((size_t)16 * d * 4); xb.alloc((size_t)16 * d * 4); p1.alloc(pb); pq.alloc(pb); p2.alloc(pb); p3.alloc(pb);
+    }
+    void fix_nw(Plan& p, int K) {  // direct epilogues need S == 1: pick the widest block whose per-wave k is a multiple of 32 and <= 320
+        for (int nw = 4; nw >= 1; nw >>= 1) if (K % nw == 0 && (K / nw) % 32 == 0 && K / nw <= 320) { p.NW = nw; p.S = 1; return; }
+        throw Error(SS_ERR_MODEL, "model: width not supported by the fused decode step");
+    }
+    DecGemvDesc dgd(int pro, int epi, const void* Wt, int M, int N, int K, int S) {
+        DecGemvDesc g{};
+        g.pro = pro; g.epi = epi; g.W = Wt; g.M = M; g.N = N; g.K = K; g.S = S; g.scale = 1.0f; g.d = d; g.gelu_f16_in = dtype_is_f16;
+        return g;
+    }
+    void decoder_step_fused(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
+        const int n_samp = (int)samp_rows.size();
+        SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
+        const RowCtl* ctl = ctl_d.as<RowCtl>();
+        const long slot_stride = (long)n_tctx * d, layer_stride = (long)S * slot_stride;
+        const long cb_stride = (long)2 * H * n_ctx * 64, cl_stride = (long)B * cb_stride;
+        float* xcur = xa.as<float>(); float* xnext = xb.as<float>();
+        const float* prev_parts = nullptr; int prev_np = 0; const float* prev_bias = nullptr;
+        for (int il = 0; il < L; il++) {
+            const DecL& e = dec[il];
+            {   // x = [embed | x + b2 + sum P3]; LN1 (one wave per row) -> QKV GEMV, q scaled, K/V appended to the cache
+                DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
+                if (il == 0) { r.ctl = ctl; r.tok_emb = tok_emb; r.pos_emb = dec_pos; }
+                else { r.x_in = xcur; r.parts = prev_parts; r.n_parts = prev_np; r.bias_prev = prev_bias; }
+                r.x_out = xnext; r.ln_w = e.ln1w; r.ln_b = e.ln1b;
+                launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
+                std::swap(xcur, xnext);
+                DecGemvDesc g = dgd(PRO_T, DEPI_QKV, e.wqkv, M, 3 * d, d, 1);
+                g.Xt = lnd.p; g.ldx = d; g.bias = e.bqkv; g.out = qd.p; g.ldo = d; g.scale = qscale;
+                g.ctl_rows = ctl; g.kcache = kself.as<T>() + il * layer_stride; g.vcache = vself.as<T>() + il * layer_stride; g.slot_stride = slot_stride;
+                launch_dec_gemv<T>(g, pl_qkv.NW, st);
+            }
+            launch_dec_self_attention<T>(qd.as<T>(), kself.as<T>() + il * layer_stride, vself.as<T>() + il * layer_stride, slot_stride, d, H, ctl, M,
+                                         attd.as<T>(), st);
+            {   // attention out-projection, split-K partials
+                DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wo, M, d, d, pl_dd.S);
+                g.Xt = attd.p; g.ldx = d; g.part_out = p1.as<float>();
+                launch_dec_gemv<T>(g, pl_dd.NW, st);
+            }
+            {   // x += bo + sum P1; LNc -> cross query partials (reduced, biased and scaled inside the cross-attention kernel)
+                DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
+                r.x_in = xcur; r.x_out = xnext; r.parts = p1.as<float>(); r.n_parts = pl_dd.S; r.bias_prev = e.bo; r.ln_w = e.lncw; r.ln_b = e.lncb;
+                launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
+                std::swap(xcur, xnext);
+                DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wcq, M, d, d, pl_dd.S);
+                g.Xt = lnd.p; g.ldx = d; g.part_out = pq.as<float>();
+                launch_dec_gemv<T>(g, pl_dd.NW, st);
+            }
+            const T* kc = cross.as<T>() + il * cl_stride;
+            launch_dec_cross_attention_q<T>(pq.as<float>(), pl_dd.S, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
+                                            cscratch.as<float>(), st);
+            launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
+            {   // cross out-projection partials
+                DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wco, M, d, d, pl_dd.S);
+                g.Xt = attd.p; g.ldx = d; g.part_out = p2.as<float>();
+                launch_dec_gemv<T>(g, pl_dd.NW, st);
+            }
+            {   // x += bco + sum P2; LN2 -> FC1 + GELU
+                DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
+                r.x_in = xcur; r.x_out = xnext; r.parts = p2.as<float>(); r.n_parts = pl_dd.S; r.bias_prev = e.bco; r.ln_w = e.ln2w; r.ln_b = e.ln2b;
+                launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
+                std::swap(xcur, xnext);
+                DecGemvDesc g = dgd(PRO_T, DEPI_GELU_T, e.w1, M, 4 * d, d, 1);
+                g.Xt = lnd.p; g.ldx = d; g.bias = e.b1; g.out = ffd.p; g.ldo = 4 * d;
+                launch_dec_gemv<T>(g, pl_fc1.NW, st);
+            }
+            {   // FC2 partials (bias and residual are applied by the next reduce)
+                DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.w2, M, d, 4 * d, pl_fc2.S);
+                g.Xt = ffd.p; g.ldx = 4 * d; g.part_out = p3.as<float>();
+                launch_dec_gemv<T>(g, pl_fc2.NW, st);
+            }
+            prev_parts = p3.as<float>(); prev_np = pl_fc2.S; prev_bias = e.b2;
+        }
+        if (n_samp == 0) return;
+        SS_HIP(hipMemcpyAsync(rowidx_d.p, samp_rows.data(), (size_t)n_samp * 4, hipMemcpyHostToDevice, st));
+        {   // final LayerNorm once (gathering the sampling rows, folding FC2's bias + partials), then logits = x . tok_emb^T
+            DecGemvDesc g = dgd(PRO_LN, DEPI_LOGITS, tok_emb, n_samp, n_vocab_pad, d, 1);
+            g.x_in = xcur; g.parts = prev_parts; g.n_parts = prev_np; g.bias_prev = prev_bias; g.ln_w = lnw; g.ln_b = lnb; g.row_idx = rowidx_d.as<int>();
+            launch_dec_reduce_ln<T>(g, lnd.as<T>(), st);
+            DecGemvDesc q = dgd(PRO_T, DEPI_LOGITS, tok_emb, n_samp, n_vocab_pad, d, 1);
+            q.Xt = lnd.p; q.ldx = d; q.out = logits.p; q.ldo = n_vocab_pad; q.n_valid = n_vocab;
+            launch_dec_gemv<T>(q, pl_logits.NW, st);
+        }
+        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st);
+        SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
+        if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
+    }
+
     // One decoder launch over M rows described by ctl_h[0..M).  Rows may belong to the same decoder (a multi-token
     // prompt): K/V of every row are written to the cache before the attention kernels run, and each row attends to
     // cache positions <= its own, so causality holds without a mask.  The n_samp rows listed in samp_rows (with their
     // rule state in ctl_h[64..64+n_samp)) get logits + rules; results land in samp_h[0..n_samp).
     void decoder_step(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
+        if (M <= 16 && use_fused) { decoder_step_fused(M, rc, samp_rows, any_probs); return; }
         const int n_samp = (int)samp_rows.size();
         SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
         const RowCtl* ctl = ctl_d.as<RowCtl>();
@@ -410,11 +514,12 @@ struct EngineT : EngineBase {
             g.n_valid = n_vocab;
             launch_skinny<T>(g, st);
         }
-        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, st);
+        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st);
         SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
         if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
     }
-    DBuf samp_d, rowidx_d;
+    DBuf samp_d, rowidx_d, rules_scratch;
+    bool use_fused = true;
 
     RuleConsts rule_consts(const ss_params& P) {
         const Vocab& v = hm.vocab;
@@ -804,7 +909,7 @@ struct EngineT : EngineBase {
         c.has_ts = has_ts; c.ts_min = seek_delta / 2; c.temperature = 0.0f;
         ctl_h[0] = c;
         SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, sizeof(RowCtl), hipMemcpyHostToDevice, st));
-        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl_d.as<RowCtl>(), 1, rule_consts(P), samp_d.as<SampleOut>(), nullptr, st);
+        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl_d.as<RowCtl>(), 1, rule_consts(P), samp_d.as<SampleOut>(), nullptr, rules_scratch.as<float>(), st);
         SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, sizeof(SampleOut), hipMemcpyDeviceToHost, st));
         SS_HIP(hipStreamSynchronize(st));
         out6[0] = (float)samp_h[0].id; out6[1] = samp_h[0].p; out6[2] = samp_h[0].plog; out6[3] = (float)samp_h[0].tid;

@@ -85,6 +85,35 @@ struct SkinnyDesc {
 };
 template <typename T> void launch_skinny(const SkinnyDesc& g, hipStream_t st);
 
+// Fused decode-step GEMV for M <= 16 rows (kernels_decode.hip): prologue + 16-row weight tiles x split-K + epilogue
+enum DecPro { PRO_LN = 0, PRO_T = 1, PRO_COMBINE = 2 };
+enum DecEpi { DEPI_PART = 0, DEPI_QKV = 1, DEPI_GELU_T = 2, DEPI_LOGITS = 3 };
+struct DecGemvDesc {
+    int pro, epi;
+    // PRO_LN: x = x_in (or tok/pos embedding when ctl != null) + bias_prev + sum_p parts[p]; optional write-back; LayerNorm
+    const float* x_in; float* x_out;
+    const float* parts; int n_parts;        // [n_parts][16][K] f32 split-K partials of the previous projection
+    const float* bias_prev;                 // [K] or null
+    const float* ln_w; const float* ln_b;
+    const RowCtl* ctl; const void* tok_emb; const float* pos_emb;   // embedding prologue (layer 0)
+    const int* row_idx;                     // optional row gather (final LayerNorm of the sampling rows)
+    const void* Xt; long ldx;               // PRO_T: T [M][ldx]
+    const float* cross_parts;               // PRO_COMBINE: [M][H][4][66]
+    const void* W; int M, N, K, S;          // W: T [N][K]
+    const float* bias; void* out; long ldo; float scale; int n_valid;
+    float* part_out;                        // DEPI_PART: [S][16][N]
+    const RowCtl* ctl_rows; void* kcache; void* vcache; long slot_stride; int d;   // DEPI_QKV
+    int gelu_f16_in;
+};
+void dec_gemv_plan(int N, int K, int* S_out, int* NW_out, bool whole_heads = false);
+template <typename T> void launch_dec_gemv(const DecGemvDesc& g, int NW, hipStream_t st);
+// stand-alone prologue: out T [M][K] = LayerNorm(x_in + bias_prev + sum parts) with optional row gather / x_out write-back
+template <typename T> void launch_dec_reduce_ln(const DecGemvDesc& g, T* out, hipStream_t st);
+// cross-attention whose q comes as split-K partials: q = round_T((sum_p qpart[p] + qbias) * qscale); writes (m,l,o[64]) partials
+template <typename T>
+void launch_dec_cross_attention_q(const float* qpart, int n_qpart, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d, int H,
+                                  int Tn, const RowCtl* ctl, int M, float* scratch, hipStream_t st);
+
 // ---------------------------------------------------------------------------------------------
 // attention (kernels_attn.hip)
 // ---------------------------------------------------------------------------------------------
@@ -98,6 +127,9 @@ void launch_dec_self_attention(const T* q, const T* kcache, const T* vcache, lon
 template <typename T>
 void launch_dec_cross_attention(const T* q, const T* kc, const T* vc, long b_stride, int d, int H, int Tn, const RowCtl* ctl, int M,
                                 float* scratch, T* out, hipStream_t st);
+
+// flash-decoding combine of the cross-attention partials: out T [M][d]
+template <typename T> void launch_dec_cross_combine(const float* scratch, int d, int H, int M, T* out, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // misc (kernels_misc.hip)
@@ -118,7 +150,8 @@ struct RuleConsts {
     int32_t suppress_blank, no_timestamps, tdrz_enable, max_initial_tid /* -1 = off */, suppress_eot /* Mode F */;
 };
 struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t pad[2]; };
+// scratch: >= M * 64 * 8 floats
 void launch_logits_rules(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, SampleOut* out, float* probs /* [M][ld] or null */,
-                         hipStream_t st);
+                         float* scratch, hipStream_t st);
 
 }  // namespace ss

@@ -158,29 +158,45 @@ template <typename T>
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kcache, const T* __restrict__ vcache,
                                                            long slot_stride, int d, const RowCtl* __restrict__ ctl, T* __restrict__ out) {
     typedef typename MfmaA<T>::V8 V8;
-    __shared__ float s_q[64];
-    __shared__ float s_p[448];
+    __shared__ float s_p[448 + 64];
     const int lane = threadIdx.x, h = blockIdx.x, m = blockIdx.y;
-    const RowCtl c = ctl[m];
-    const int n_kv = c.pos + 1;
-    const T* K = kcache + (long)c.slot * slot_stride + h * 64;
-    const T* V = vcache + (long)c.slot * slot_stride + h * 64;
-    s_q[lane] = (float)q[(long)m * d + h * 64 + lane];
-    __syncthreads();
+    const int r = lane >> 3, c = lane & 7;   // 8 keys x 8 column chunks per wave-instruction (one 128-B row per 8 lanes)
+    const RowCtl rc = ctl[m];
+    const int n_kv = rc.pos + 1;
+    const T* K = kcache + (long)rc.slot * slot_stride + h * 64 + c * 8;
+    const T* V = vcache + (long)rc.slot * slot_stride + h * 64 + c * 8;
+    float qv[8];
+    {
+        const V8 t = *(const V8*)(q + (long)m * d + h * 64 + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) qv[e] = (float)t[e];
+    }
+    const int nit = (n_kv + 7) / 8;
     float mx = -1e30f;
-    for (int key = lane; key < n_kv; key += 64) {
-        const T* kr = K + (long)key * d;
-        float acc = 0.f;
+    for (int it = 0; it < nit; it += 4) {
+        V8 kv[4];
+        int kk[4];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const V8 kv = *(const V8*)(kr + j * 8);
-#pragma unroll
-            for (int e = 0; e < 8; e++) acc += s_q[j * 8 + e] * (float)kv[e];
+        for (int u = 0; u < 4; u++) {
+            kk[u] = (it + u) * 8 + r;
+            kv[u] = *(const V8*)(K + (long)(kk[u] < n_kv ? kk[u] : 0) * d);
         }
-        s_p[key] = acc;
-        mx = fmaxf(mx, acc);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) a += qv[e] * (float)kv[u][e];
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            a += __shfl_xor(a, 4);
+            if (kk[u] < n_kv) {
+                if (c == 0) s_p[kk[u]] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
     }
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    __syncthreads();
     float sum = 0.f;
     for (int key = lane; key < n_kv; key += 64) {
         const float p = (float)(T)__expf(s_p[key] - mx);
@@ -189,9 +205,35 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     __syncthreads();
-    float acc = 0.f;
-    for (int key = 0; key < n_kv; key++) acc += s_p[key] * (float)V[(long)key * d + lane];
-    out[(long)m * d + h * 64 + lane] = (T)(acc / sum);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int it = 0; it < nit; it += 4) {
+        V8 vv[4];
+        float pw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int key = (it + u) * 8 + r;
+            const bool okk = key < n_kv;
+            vv[u] = *(const V8*)(V + (long)(okk ? key : 0) * d);
+            pw[u] = okk ? s_p[key] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += pw[u] * (float)vv[u][e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        acc[e] += __shfl_xor(acc[e], 8);
+        acc[e] += __shfl_xor(acc[e], 16);
+        acc[e] += __shfl_xor(acc[e], 32);
+    }
+    if (r == 0) {
+        const float inv = 1.0f / sum;
+        V8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o[e] = (T)(acc[e] * inv);
+        *(V8*)(out + (long)m * d + h * 64 + c * 8) = o;
+    }
 }
 
 template <typename T>
@@ -311,6 +353,12 @@ void launch_dec_cross_attention(const T* q, const T* kc, const T* vc, long b_str
     dec_cross_attn_kernel<T><<<grid, 256, 0, st>>>(q, kc, vc, b_stride, d, H, Tn, ctl, scratch);
     dec_cross_combine_kernel<T><<<M, 256, 0, st>>>(scratch, d, H, out);
 }
+template <typename T>
+void launch_dec_cross_combine(const float* scratch, int d, int H, int M, T* out, hipStream_t st) {
+    dec_cross_combine_kernel<T><<<M, 256, 0, st>>>(scratch, d, H, out);
+}
+template void launch_dec_cross_combine<bf16>(const float*, int, int, int, bf16*, hipStream_t);
+template void launch_dec_cross_combine<f16>(const float*, int, int, int, f16*, hipStream_t);
 template void launch_dec_cross_attention<bf16>(const bf16*, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int, float*, bf16*, hipStream_t);
 template void launch_dec_cross_attention<f16>(const f16*, const f16*, const f16*, long, int, int, int, const RowCtl*, int, float*, f16*, hipStream_t);
 

@@ -1,0 +1,447 @@
+// Fused decode-step GEMVs for gfx950 (M <= 16 rows: one token for each of up to 16 sequences).
+//
+// A decoder step is HBM-bound (1.8 GB of weights + B x 246 MB of cross-KV per step for large-v3) but, launched as one
+// small kernel per graph node the way ggml does (/root/reference/resources/ggml-metal.metal:1307-1363 kernel_mul_mv_f16_f32,
+// :571-621 kernel_norm, :54-151 add/mul), it is launch/latency-bound: ~350 dependent launches per step.  Here every
+// projection is ONE launch that fills the chip and carries its neighbours with it:
+//   prologue : residual add + bias of the previous projection + deterministic reduction of its split-K partials
+//              (+ token/positional embedding for layer 0) -> LayerNorm -> f16/bf16 operand tile in LDS;
+//              or the flash-decoding combine of the cross-attention partials
+//   body     : weight fragments are prefetched into VGPRs BEFORE the prologue (both HBM latencies overlap), then
+//              16x16x32 MFMAs with the 16-row weight tile as A operand and the (<=16) token rows as B operand
+//   epilogue : q/k/v scaling + KV-cache append, GELU, logits, or raw split-K partials for the next prologue
+// Split-K goes across workgroups (grid = N/16 x S) so that N = d projections still launch >= 256 workgroups; partials
+// are summed in a fixed order by the consumer, so results are run-to-run identical (no float atomics).
+#include "kernels.h"
+
+namespace ss {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct MfmaD;
+template <> struct MfmaD<bf16> {
+    typedef bf16x8 V8;
+    static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct MfmaD<f16> {
+    typedef f16x8 V8;
+    static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+__device__ __forceinline__ float gelu_tanh_d(float x) {
+    const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
+    const float e = __expf(2.0f * u);
+    return 0.5f * x * (1.0f + (1.0f - 2.0f / (e + 1.0f)));
+}
+template <typename T> __device__ __forceinline__ float gelu_in_round_d(float x, int on);
+template <> __device__ __forceinline__ float gelu_in_round_d<bf16>(float x, int) { return x; }
+template <> __device__ __forceinline__ float gelu_in_round_d<f16>(float x, int on) { return on ? (float)(f16)x : x; }
+
+constexpr int kMaxFrag = 10;      // <= 320 k per wave
+constexpr int kXsPad = 8;         // LDS row padding (elements)
+constexpr int kCrossSplitD = 4, kCrossPartD = 66;
+
+// x = [x_in | tok+pos embedding] + bias_prev + sum_p parts[p]  (fixed order, branch-free: up to 4 partial slots, unused
+// slots re-read slot 0 with weight 0 so that every load is independent and in flight together), optional write-back,
+// LayerNorm over the full row, normalised columns [kbeg, kbeg+kslice) written to dst as T.  One wave per row.
+template <typename T, int NI>
+__device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bool write_x, int kbeg, int kslice, T* dst) {
+    // NI float4 per lane cover the row (d <= NI*256); lanes past the end load a clamped (valid) address and are masked,
+    // so no load sits behind a divergent branch: all of them are in flight together.
+    const int d = g.K;
+    const int r = g.row_idx ? g.row_idx[m] : m;
+    f32x4 v[NI];
+    int cc[NI];
+    bool ok[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) { const int c = (i * 64 + lane) * 4; ok[i] = c < d; cc[i] = ok[i] ? c : 0; }
+    f32x4 ww[NI], bb[NI];   // issued with the row loads: the LayerNorm affine must not cost its own memory round trip
+#pragma unroll
+    for (int i = 0; i < NI; i++) { ww[i] = *(const f32x4*)(g.ln_w + cc[i]); bb[i] = *(const f32x4*)(g.ln_b + cc[i]); }
+    if (g.ctl) {  // layer 0: token + positional embedding (replaces ggml get_rows + add)
+        const RowCtl rc = g.ctl[r];
+        const T* te = (const T*)g.tok_emb + (long)rc.token * d;
+        const float* pe = g.pos_emb + (long)rc.pos * d;
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const f32x4 p4 = *(const f32x4*)(pe + cc[i]);
+            const T* t = te + cc[i];
+            v[i] = (f32x4){(float)t[0] + p4[0], (float)t[1] + p4[1], (float)t[2] + p4[2], (float)t[3] + p4[3]};
+        }
+    } else {
+        const float* xr = g.x_in + (long)r * d;
+        const float wgt[4] = {g.n_parts > 0 ? 1.f : 0.f, g.n_parts > 1 ? 1.f : 0.f, g.n_parts > 2 ? 1.f : 0.f, g.n_parts > 3 ? 1.f : 0.f};
+        const float* pp[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) pp[p] = g.n_parts > 0 ? g.parts + ((long)(p < g.n_parts ? p : 0) * 16 + r) * d : xr;
+        const float bw = g.bias_prev ? 1.f : 0.f;
+        const float* bp = g.bias_prev ? g.bias_prev : xr;
+        f32x4 a[NI], b[NI], q0[NI], q1[NI];
+#pragma unroll
+        for (int i = 0; i < NI; i++) { a[i] = *(const f32x4*)(xr + cc[i]); b[i] = *(const f32x4*)(bp + cc[i]); }
+#pragma unroll
+        for (int i = 0; i < NI; i++) { q0[i] = *(const f32x4*)(pp[0] + cc[i]); q1[i] = *(const f32x4*)(pp[1] + cc[i]); }
+#pragma unroll
+        for (int i = 0; i < NI; i++) v[i] = ((a[i] + b[i] * bw) + q0[i] * wgt[0]) + q1[i] * wgt[1];
+#pragma unroll
+        for (int i = 0; i < NI; i++) { q0[i] = *(const f32x4*)(pp[2] + cc[i]); q1[i] = *(const f32x4*)(pp[3] + cc[i]); }
+#pragma unroll
+        for (int i = 0; i < NI; i++) v[i] = (v[i] + q0[i] * wgt[2]) + q1[i] * wgt[3];
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        if (!ok[i]) v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    if (write_x && g.x_out) {
+#pragma unroll
+        for (int i = 0; i < NI; i++) if (ok[i]) *(f32x4*)(g.x_out + (long)r * d + cc[i]) = v[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / d;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) { v[i][e] = ok[i] ? v[i][e] - mean : 0.f; sq += v[i][e] * v[i][e]; }
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = 1.0f / sqrtf(sq / d + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        const int c = cc[i];
+        if (ok[i] && c >= kbeg && c < kbeg + kslice) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) dst[(c - kbeg) + e] = (T)(v[i][e] * rstd * ww[i][e] + bb[i][e]);
+        }
+    }
+}
+
+// stand-alone form (one wave per row): used in front of GEMVs with thousands of workgroups (logits), where a per-workgroup
+// prologue would repeat the reduction too often
+template <typename T, int NI>
+__global__ __launch_bounds__(64) void dec_reduce_ln_kernel(DecGemvDesc g, T* out) {
+    ln_row<T, NI>(g, blockIdx.x, threadIdx.x, true, 0, g.K, out + (long)blockIdx.x * g.K);
+}
+
+template <typename T, int PRO, int EPI, int NI>
+__global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
+    typedef typename MfmaD<T>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem_d[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16, s = blockIdx.y;
+    const int kslice = g.K / g.S, kbeg = s * kslice, kw = kslice / NW, kwb = wave * kw;   // kw % 32 == 0, kw <= 320
+    const int nfr = kw / 32, npair = nfr / 2;
+    T* xs = (T*)smem_d;                                   // [16][kslice + pad]
+    const int xld = kslice + kXsPad;
+    float* red = (float*)(smem_d + (size_t)16 * xld * sizeof(T));  // [NW][16][17]
+
+    // ---- weight prefetch: lane loads 32 contiguous bytes of its row per MFMA pair ----
+    const T* wp = (const T*)g.W + (long)(n0 + frow) * g.K + kbeg + kwb;
+    V8 wf[kMaxFrag];
+#pragma unroll
+    for (int j = 0; j < kMaxFrag / 2; j++) {
+        if (j < npair) {
+            wf[2 * j] = *(const V8*)(wp + j * 64 + fg * 16);
+            wf[2 * j + 1] = *(const V8*)(wp + j * 64 + fg * 16 + 8);
+        }
+    }
+    V8 wtail = {};
+    if (nfr & 1) wtail = *(const V8*)(wp + npair * 64 + fg * 8);
+
+    // ---- prologue: build the operand tile xs[m][0..kslice) ----
+    if constexpr (PRO == PRO_LN) {
+        for (int m = wave; m < 16; m += NW) {
+            if (m >= g.M) {
+                for (int c = lane; c < kslice; c += 64) xs[m * xld + c] = (T)0.0f;
+                continue;
+            }
+            ln_row<T, NI>(g, m, lane, blockIdx.x == 0 && s == 0, kbeg, kslice, xs + m * xld);
+        }
+    } else if constexpr (PRO == PRO_T) {
+        const T* X = (const T*)g.Xt;
+        const int per = kslice / 8;
+#pragma unroll 4
+        for (int idx = tid; idx < 16 * per; idx += blockDim.x) {
+            const int m = idx / per, c8 = idx % per;
+            V8 t = *(const V8*)(X + (long)(m < g.M ? m : 0) * g.ldx + kbeg + c8 * 8);
+            if (m >= g.M) t = V8{};
+            *(V8*)(xs + m * xld + c8 * 8) = t;
+        }
+    } else if constexpr (PRO == PRO_COMBINE) {
+        // flash-decoding combine of the cross-attention partials for the columns of this K slice
+        const int H = g.K / 64, h0 = kbeg >> 6, hs = kslice >> 6;   // kslice is a multiple of 64 (checked on the host)
+        float* wtab = red;                                           // [16][hs][4] normalised weights (red is reused after the sync)
+        for (int idx = tid; idx < g.M * hs; idx += blockDim.x) {
+            const int m = idx / hs, hh = idx % hs;
+            const float* part = g.cross_parts + (long)(m * H + h0 + hh) * kCrossSplitD * kCrossPartD;
+            const float m0 = part[0], m1 = part[kCrossPartD], m2 = part[2 * kCrossPartD], m3 = part[3 * kCrossPartD];
+            const float l0 = part[1], l1 = part[kCrossPartD + 1], l2 = part[2 * kCrossPartD + 1], l3 = part[3 * kCrossPartD + 1];
+            const float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+            const float w0 = __expf(m0 - mx), w1 = __expf(m1 - mx), w2 = __expf(m2 - mx), w3 = __expf(m3 - mx);
+            const float inv = 1.0f / (((w0 * l0 + w1 * l1) + w2 * l2) + w3 * l3);
+            float* wt = wtab + idx * 4;
+            wt[0] = w0 * inv; wt[1] = w1 * inv; wt[2] = w2 * inv; wt[3] = w3 * inv;
+        }
+        for (int idx = tid + g.M * kslice; idx < 16 * kslice; idx += blockDim.x) xs[(idx / kslice) * xld + idx % kslice] = (T)0.0f;
+        __syncthreads();
+#pragma unroll 4
+        for (int idx = tid; idx < g.M * kslice; idx += blockDim.x) {
+            const int m = idx / kslice, cc = idx % kslice, hh = cc >> 6, j = cc & 63;
+            const float* part = g.cross_parts + (long)(m * H + h0 + hh) * kCrossSplitD * kCrossPartD + 2 + j;
+            const float* wt = wtab + (m * hs + hh) * 4;
+            const float o = ((wt[0] * part[0] + wt[1] * part[kCrossPartD]) + wt[2] * part[2 * kCrossPartD]) + wt[3] * part[3 * kCrossPartD];
+            xs[m * xld + cc] = (T)o;
+        }
+    }
+    __syncthreads();
+
+    // ---- body ----
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const T* xr = xs + frow * xld + kwb;
+#pragma unroll
+    for (int j = 0; j < kMaxFrag / 2; j++) {
+        if (j < npair) {
+            const V8 x0 = *(const V8*)(xr + j * 64 + fg * 16), x1 = *(const V8*)(xr + j * 64 + fg * 16 + 8);
+            acc = MfmaD<T>::mma(wf[2 * j], x0, acc);
+            acc = MfmaD<T>::mma(wf[2 * j + 1], x1, acc);
+        }
+    }
+    if (nfr & 1) {
+        const V8 x0 = *(const V8*)(xr + npair * 64 + fg * 8);
+        acc = MfmaD<T>::mma(wtail, x0, acc);
+    }
+    // D[n][m]: lane holds n = fg*4 + r, m = frow
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[(wave * 16 + frow) * 17 + fg * 4 + r] = acc[r];
+    __syncthreads();
+
+    // ---- epilogue: 16 m x 16 n outputs ----
+    for (int idx = tid; idx < 256; idx += blockDim.x) {
+        const int m = idx >> 4, nn = idx & 15, n = n0 + nn;
+        if (m < g.M) {
+            float v = 0.f;
+            for (int w = 0; w < NW; w++) v += red[(w * 16 + m) * 17 + nn];
+            if constexpr (EPI == DEPI_PART) {
+                g.part_out[((long)s * 16 + m) * g.N + n] = v;
+            } else {
+                if (g.bias) v += g.bias[n];
+                if constexpr (EPI == DEPI_GELU_T) {
+                    ((T*)g.out)[(long)m * g.ldo + n] = (T)gelu_tanh_d(gelu_in_round_d<T>(v, g.gelu_f16_in));
+                } else if constexpr (EPI == DEPI_LOGITS) {
+                    if (n < g.n_valid) ((float*)g.out)[(long)m * g.ldo + n] = v;
+                } else if constexpr (EPI == DEPI_QKV) {
+                    const int d = g.d;
+                    if (n < d) ((T*)g.out)[(long)m * g.ldo + n] = (T)(v * g.scale);
+                    else {
+                        const RowCtl c = g.ctl_rows[m];
+                        const long off = (long)c.slot * g.slot_stride + (long)c.pos * d;
+                        if (n < 2 * d) ((T*)g.kcache)[off + (n - d)] = (T)(v * g.scale);
+                        else ((T*)g.vcache)[off + (n - 2 * d)] = (T)v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int PRO, int EPI, int NI>
+static void launch_dg2(const DecGemvDesc& g, int NW, hipStream_t st) {
+    const int kslice = g.K / g.S;
+    size_t red_f = (size_t)NW * 16 * 17, wtab_f = (size_t)16 * (kslice / 64 + 1) * 4;
+    const size_t lds = (size_t)16 * (kslice + kXsPad) * sizeof(T) + (red_f > wtab_f ? red_f : wtab_f) * 4;
+    static bool attr = false;
+    if (!attr) { SS_HIP(hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    dim3 grid((g.N + 15) / 16, g.S);
+    dec_gemv_kernel<T, PRO, EPI, NI><<<grid, NW * 64, lds, st>>>(g);
+}
+template <typename T, int PRO, int EPI>
+static void launch_dg(const DecGemvDesc& g, int NW, hipStream_t st) {
+    if constexpr (PRO == PRO_LN) {
+        if (g.K <= 512) launch_dg2<T, PRO, EPI, 2>(g, NW, st);
+        else if (g.K <= 1280) launch_dg2<T, PRO, EPI, 5>(g, NW, st);
+        else launch_dg2<T, PRO, EPI, 8>(g, NW, st);
+    } else {
+        launch_dg2<T, PRO, EPI, 1>(g, NW, st);
+    }
+}
+
+// choose split-K so the grid has >= ~256 workgroups; per-wave k must be a multiple of 32 and <= 320
+void dec_gemv_plan(int N, int K, int* S_out, int* NW_out, bool whole_heads) {
+    int bestS = 0, bestNW = 0, bestScore = -1;
+    for (int S = 1; S <= 4; S++) {
+        if (K % S) continue;
+        for (int NW = 4; NW >= 1; NW >>= 1) {
+            const int ks = K / S;
+            if (ks % NW || (whole_heads && ks % 64)) continue;
+            const int kw = ks / NW;
+            if (kw % 32 || kw > 320 || kw < 32) continue;
+            const int blocks = ((N + 15) / 16) * S;
+            // prefer >= 256 blocks, then fewer splits (less partial traffic), then more waves per block
+            int score = (blocks >= 256 ? 1000 : blocks * 3) - S * 8 + NW;
+            if (score > bestScore) { bestScore = score; bestS = S; bestNW = NW; }
+        }
+    }
+    if (!bestS) throw Error(-1, "dec_gemv: no split plan for K=" + std::to_string(K));
+    *S_out = bestS; *NW_out = bestNW;
+}
+
+template <typename T>
+void launch_dec_reduce_ln(const DecGemvDesc& g, T* out, hipStream_t st) {
+    if (g.K > 2048 || g.n_parts > 4) throw Error(-1, "dec_reduce_ln: bad shape");
+    if (g.K <= 512) dec_reduce_ln_kernel<T, 2><<<g.M, 64, 0, st>>>(g, out);
+    else if (g.K <= 1280) dec_reduce_ln_kernel<T, 5><<<g.M, 64, 0, st>>>(g, out);
+    else dec_reduce_ln_kernel<T, 8><<<g.M, 64, 0, st>>>(g, out);
+}
+template void launch_dec_reduce_ln<bf16>(const DecGemvDesc&, bf16*, hipStream_t);
+template void launch_dec_reduce_ln<f16>(const DecGemvDesc&, f16*, hipStream_t);
+
+template <typename T>
+void launch_dec_gemv(const DecGemvDesc& g, int NW, hipStream_t st) {
+    if (g.n_parts > 4) throw Error(-1, "dec_gemv: at most 4 split-K partials");
+    if (g.pro == PRO_COMBINE && (g.K / g.S) % 64) throw Error(-1, "dec_gemv: combine prologue needs K slices of whole heads");
+    if (g.M < 1 || g.M > 16 || g.K % g.S || (g.K / g.S) % NW || ((g.K / g.S) / NW) % 32 || (g.K / g.S) / NW > 320)
+        throw Error(-1, "dec_gemv: bad shape");
+    if (g.epi != DEPI_PART && g.S != 1) throw Error(-1, "dec_gemv: direct epilogues need S == 1");
+    if (g.pro == PRO_LN && g.K > 2048) throw Error(-1, "dec_gemv: LayerNorm prologue needs K <= 2048");
+#define DG(P, E) launch_dg<T, P, E>(g, NW, st)
+    switch (g.pro * 8 + g.epi) {
+        case PRO_LN * 8 + DEPI_QKV: DG(PRO_LN, DEPI_QKV); break;
+        case PRO_LN * 8 + DEPI_PART: DG(PRO_LN, DEPI_PART); break;
+        case PRO_LN * 8 + DEPI_GELU_T: DG(PRO_LN, DEPI_GELU_T); break;
+        case PRO_T * 8 + DEPI_LOGITS: DG(PRO_T, DEPI_LOGITS); break;
+        case PRO_T * 8 + DEPI_PART: DG(PRO_T, DEPI_PART); break;
+        case PRO_T * 8 + DEPI_QKV: DG(PRO_T, DEPI_QKV); break;
+        case PRO_T * 8 + DEPI_GELU_T: DG(PRO_T, DEPI_GELU_T); break;
+        case PRO_COMBINE * 8 + DEPI_PART: DG(PRO_COMBINE, DEPI_PART); break;
+        default: throw Error(-1, "dec_gemv: unsupported prologue/epilogue pair");
+    }
+#undef DG
+}
+template void launch_dec_gemv<bf16>(const DecGemvDesc&, int, hipStream_t);
+template void launch_dec_gemv<f16>(const DecGemvDesc&, int, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// cross-attention with the q projection's split-K reduction in its prologue
+// grid (4 key splits, H, M), 256 threads.  q = round_T((sum_s qpart[s][m][:] + bias) * scale)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __restrict__ qpart, int n_qpart, const float* __restrict__ qbias, float qscale,
+                                                               const T* __restrict__ kc, const T* __restrict__ vc, long b_stride, int d, int H, int Tn,
+                                                               const RowCtl* __restrict__ ctl, float* __restrict__ scratch) {
+    typedef typename MfmaD<T>::V8 V8;
+    __shared__ float s_sc[512 + 128];
+    __shared__ float s_red[8];
+    __shared__ float s_o[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane >> 3, c = lane & 7;
+    const int sp = blockIdx.x, h = blockIdx.y, m = blockIdx.z;
+    const int per = (Tn + kCrossSplitD - 1) / kCrossSplitD;
+    const int k_beg = sp * per, k_end = min(Tn, k_beg + per), nk = k_end - k_beg;
+    const RowCtl rc = ctl[m];
+    const T* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
+    const T* V = vc + (long)rc.cross * b_stride + (long)h * Tn * 64;
+    float qv[8];
+    {
+        const int col = h * 64 + c * 8;
+        f32x4 a0 = *(const f32x4*)(qbias + col), a1 = *(const f32x4*)(qbias + col + 4);
+        f32x4 t0[4], t1[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {   // up to 4 partial slots, unused ones re-read slot 0 with weight 0
+            const float* pp = qpart + ((long)(p < n_qpart ? p : 0) * 16 + m) * d + col;
+            t0[p] = *(const f32x4*)pp; t1[p] = *(const f32x4*)(pp + 4);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) { const float w = p < n_qpart ? 1.f : 0.f; a0 += t0[p] * w; a1 += t1[p] * w; }
+#pragma unroll
+        for (int e = 0; e < 4; e++) { qv[e] = (float)(T)(a0[e] * qscale); qv[4 + e] = (float)(T)(a1[e] * qscale); }
+    }
+    // phase 1: scores.  One wave-instruction reads 8 key rows x 128 B; 4 independent loads in flight per lane
+    float mx = -1e30f;
+    const int nit = (nk + 31) / 32;
+    for (int it = 0; it < nit; it += 4) {
+        V8 kv[4];
+        int ii[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            ii[u] = (it + u) * 32 + wave * 8 + r;
+            kv[u] = *(const V8*)(K + (long)(k_beg + (ii[u] < nk ? ii[u] : 0)) * 64 + c * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; e++) a += qv[e] * (float)kv[u][e];
+            a += __shfl_xor(a, 1);
+            a += __shfl_xor(a, 2);
+            a += __shfl_xor(a, 4);
+            if (ii[u] < nk) {
+                if (c == 0) s_sc[ii[u]] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sum = 0.f;
+    for (int i = tid; i < nk; i += 256) {
+        const float p = (float)(T)__expf(s_sc[i] - mx);
+        s_sc[i] = p;
+        sum += p;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) s_red[4 + wave] = sum;
+    __syncthreads();
+    sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    // phase 2: o[c*8+e] += p[key] V[key][c*8+e]
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int it = 0; it < nit; it += 4) {
+        V8 vv[4];
+        float pw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = (it + u) * 32 + wave * 8 + r;
+            const bool okk = i < nk;
+            vv[u] = *(const V8*)(V + (long)(k_beg + (okk ? i : 0)) * 64 + c * 8);
+            pw[u] = okk ? s_sc[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] += pw[u] * (float)vv[u][e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        acc[e] += __shfl_xor(acc[e], 8);
+        acc[e] += __shfl_xor(acc[e], 16);
+        acc[e] += __shfl_xor(acc[e], 32);
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) s_o[wave][c * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    float* part = scratch + ((long)(m * H + h) * kCrossSplitD + sp) * kCrossPartD;
+    if (tid < 64) part[2 + tid] = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
+    if (tid == 0) { part[0] = mx; part[1] = sum; }
+}
+
+template <typename T>
+void launch_dec_cross_attention_q(const float* qpart, int n_qpart, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d, int H,
+                                  int Tn, const RowCtl* ctl, int M, float* scratch, hipStream_t st) {
+    if ((Tn + kCrossSplitD - 1) / kCrossSplitD > 512) throw Error(-1, "cross attention: n_audio_ctx too large");
+    dim3 grid(kCrossSplitD, H, M);
+    dec_cross_attn_q_kernel<T><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch);
+}
+template void launch_dec_cross_attention_q<bf16>(const float*, int, const float*, float, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int,
+                                                 float*, hipStream_t);
+template void launch_dec_cross_attention_q<f16>(const float*, int, const float*, float, const f16*, const f16*, long, int, int, int, const RowCtl*, int,
+                                                float*, hipStream_t);
+
+}  // namespace ss

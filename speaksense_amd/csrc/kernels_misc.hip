@@ -12,58 +12,71 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, row held in registers (d <= 2048), eps 1e-5
 // ---------------------------------------------------------------------------------------------
-template <typename TO>
+template <typename TO, int NI>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
                                                         TO* __restrict__ y, int rows, int d, const int* __restrict__ row_idx) {
+    // NI float4 per lane (d <= NI*256); out-of-range lanes load a clamped address and are masked, so every load of the
+    // row is issued back to back (a lane-dependent guard around the loads costs one memory round trip per group)
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float* xr = x + (long)(row_idx ? row_idx[row] : row) * d;
-    f32x4 v[8];
+    f32x4 v[NI];
+    int cc[NI];
+    bool ok[NI];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < d) {
-            v[i] = *(const f32x4*)(xr + c);
-            sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-        }
+    for (int i = 0; i < NI; i++) { const int c = (i * 64 + lane) * 4; ok[i] = c < d; cc[i] = ok[i] ? c : 0; }
+#pragma unroll
+    for (int i = 0; i < NI; i++) v[i] = *(const f32x4*)(xr + cc[i]);
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        if (!ok[i]) v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float mean = sum / d;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < d) {
+    for (int i = 0; i < NI; i++) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) { v[i][e] -= mean; sq += v[i][e] * v[i][e]; }
-        }
+        for (int e = 0; e < 4; e++) { v[i][e] = ok[i] ? v[i][e] - mean : 0.f; sq += v[i][e] * v[i][e]; }
     }
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     const float scale = 1.0f / sqrtf(sq / d + 1e-5f);
     TO* yr = y + (long)row * d;
+    f32x4 ww[NI], bb[NI];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int c = (i * 64 + lane) * 4;
-        if (c < d) {
-            const f32x4 ww = *(const f32x4*)(w + c), bb = *(const f32x4*)(b + c);
+    for (int i = 0; i < NI; i++) { ww[i] = *(const f32x4*)(w + cc[i]); bb[i] = *(const f32x4*)(b + cc[i]); }
 #pragma unroll
-            for (int e = 0; e < 4; e++) yr[c + e] = (TO)(v[i][e] * scale * ww[e] + bb[e]);
+    for (int i = 0; i < NI; i++) {
+        if (ok[i]) {
+            typedef TO TO4 __attribute__((ext_vector_type(4)));
+            TO4 o;
+#pragma unroll
+            for (int e = 0; e < 4; e++) o[e] = (TO)(v[i][e] * scale * ww[i][e] + bb[i][e]);
+            *(TO4*)(yr + cc[i]) = o;
         }
     }
 }
 
+template <typename TO>
+static void launch_ln_any(const float* x, const float* w, const float* b, TO* y, int rows, int d, const int* row_idx, hipStream_t st) {
+    if (d > 2048 || d % 4) throw Error(-1, "layernorm: d must be <= 2048 and a multiple of 4");
+    const int grid = (rows + 3) / 4;
+    if (d <= 512) layernorm_kernel<TO, 2><<<grid, 256, 0, st>>>(x, w, b, y, rows, d, row_idx);
+    else if (d <= 1280) layernorm_kernel<TO, 5><<<grid, 256, 0, st>>>(x, w, b, y, rows, d, row_idx);
+    else layernorm_kernel<TO, 8><<<grid, 256, 0, st>>>(x, w, b, y, rows, d, row_idx);
+}
+
 template <typename T>
 void launch_layernorm(const float* x, const float* w, const float* b, T* y, int rows, int d, const int* row_idx, hipStream_t st) {
-    if (d > 2048 || d % 4) throw Error(-1, "layernorm: d must be <= 2048 and a multiple of 4");
-    layernorm_kernel<T><<<(rows + 3) / 4, 256, 0, st>>>(x, w, b, y, rows, d, row_idx);
+    launch_ln_any<T>(x, w, b, y, rows, d, row_idx, st);
 }
 template void launch_layernorm<bf16>(const float*, const float*, const float*, bf16*, int, int, const int*, hipStream_t);
 template void launch_layernorm<f16>(const float*, const float*, const float*, f16*, int, int, const int*, hipStream_t);
 template <typename T>
 void launch_layernorm_f32out(const float* x, const float* w, const float* b, float* y, int rows, int d, hipStream_t st) {
-    if (d > 2048 || d % 4) throw Error(-1, "layernorm: d must be <= 2048 and a multiple of 4");
-    layernorm_kernel<float><<<(rows + 3) / 4, 256, 0, st>>>(x, w, b, y, rows, d, nullptr);
+    launch_ln_any<float>(x, w, b, y, rows, d, nullptr, st);
 }
 template void launch_layernorm_f32out<bf16>(const float*, const float*, const float*, float*, int, int, hipStream_t);
 template void launch_layernorm_f32out<f16>(const float*, const float*, const float*, float*, int, int, hipStream_t);
@@ -111,7 +124,6 @@ template void launch_T_to_f32<f16>(const f16*, float*, size_t, hipStream_t);
 // whisper_process_logits + whisper_sample_token(best), one 1024-thread workgroup per sequence
 // ---------------------------------------------------------------------------------------------
 namespace {
-constexpr int kRuleThreads = 1024;
 constexpr float kNegInf = -__builtin_huge_valf();
 
 __device__ __forceinline__ float masked_logit(int i, float v, const RowCtl& c, const RuleConsts& rc) {
@@ -148,107 +160,123 @@ __device__ __forceinline__ MaxIdx wave_max(MaxIdx a) {
     return a;
 }
 
-__global__ __launch_bounds__(kRuleThreads) void logits_rules_kernel(const float* __restrict__ logits, long ld, const RowCtl* __restrict__ ctl,
-                                                                    RuleConsts rc, SampleOut* __restrict__ out, float* __restrict__ probs) {
-    __shared__ float s_f[3][16];
-    __shared__ MaxIdx s_mi[2][16];
-    __shared__ float s_b[8];
-    const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Stage A: grid (kRuleSlices, M), 256 threads.  Each workgroup scans one slice of the vocabulary and emits
+//   [0] max over all  [1] sum exp(v - max_all)  [2] max over text  [3] argmax text (as float bits)
+//   [4] max over ts   [5] argmax ts             [6] sum_ts exp(v - max_ts)
+// (a 1024-thread workgroup per row spent 73 us per step on 8 CUs; sliced, the same scan uses 64 x M workgroups)
+constexpr int kRuleSlices = 64, kRuleRec = 8;
+
+__global__ __launch_bounds__(256) void logits_rules_scan_kernel(const float* __restrict__ logits, long ld, const RowCtl* __restrict__ ctl, RuleConsts rc,
+                                                                float* __restrict__ scratch) {
+    __shared__ MaxIdx s_t[4], s_s[4];
+    __shared__ float s_f[2][4];
+    const int m = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const RowCtl c = ctl[m];
     const float* raw = logits + (long)m * ld;
-    const int n = rc.n_vocab;
+    const int n = rc.n_vocab, per = (n + kRuleSlices - 1) / kRuleSlices, i0 = sl * per, i1 = min(n, i0 + per);
     const int big = 0x7fffffff;
-
-    // pass 1: maxima over all / text / timestamp tokens
-    float mall = kNegInf, mtext = kNegInf, mts = kNegInf;
-    for (int i = tid; i < n; i += kRuleThreads) {
-        const float v = masked_logit(i, raw[i], c, rc);
-        mall = fmaxf(mall, v);
-        if (i < rc.beg) mtext = fmaxf(mtext, v); else mts = fmaxf(mts, v);
+    MaxIdx mt{kNegInf, big}, ms{kNegInf, big};   // text / timestamp maxima with first-index tie-break
+    float vals[4];
+    // pass 1 (values kept in registers: <= 4 per thread for 16 slices x 256 threads over ~52k tokens)
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * 256 + tid;
+        float v = kNegInf;
+        if (i < i1) v = masked_logit(i, raw[i], c, rc);
+        vals[u] = v;
+        if (i < i1) {
+            MaxIdx cand{v, i};
+            if (i < rc.beg) mt = better(mt, cand); else ms = better(ms, cand);
+        }
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        mall = fmaxf(mall, __shfl_xor(mall, o));
-        mtext = fmaxf(mtext, __shfl_xor(mtext, o));
-        mts = fmaxf(mts, __shfl_xor(mts, o));
-    }
-    if (lane == 0) { s_f[0][wave] = mall; s_f[1][wave] = mtext; s_f[2][wave] = mts; }
+    mt = wave_max(mt); ms = wave_max(ms);
+    if (lane == 0) { s_t[wave] = mt; s_s[wave] = ms; }
     __syncthreads();
-    if (tid == 0) {
-        float a = kNegInf, b = kNegInf, d = kNegInf;
-        for (int w = 0; w < 16; w++) { a = fmaxf(a, s_f[0][w]); b = fmaxf(b, s_f[1][w]); d = fmaxf(d, s_f[2][w]); }
-        s_b[0] = a; s_b[1] = b; s_b[2] = d;
-    }
-    __syncthreads();
-    mall = s_b[0]; mtext = s_b[1]; mts = s_b[2];
-    __syncthreads();
-    // pass 2: sum exp over all (rel. mall) and over timestamps (rel. mts)
+    mt = better(better(s_t[0], s_t[1]), better(s_t[2], s_t[3]));
+    ms = better(better(s_s[0], s_s[1]), better(s_s[2], s_s[3]));
+    const float mall = fmaxf(mt.v, ms.v);
     float sall = 0.f, sts = 0.f;
-    for (int i = tid; i < n; i += kRuleThreads) {
-        const float v = masked_logit(i, raw[i], c, rc);
-        if (v > kNegInf) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * 256 + tid;
+        const float v = vals[u];
+        if (i < i1 && v > kNegInf) {
             sall += expf(v - mall);
-            if (i >= rc.beg) sts += expf(v - mts);
+            if (i >= rc.beg) sts += expf(v - ms.v);
         }
     }
     for (int o = 32; o > 0; o >>= 1) { sall += __shfl_xor(sall, o); sts += __shfl_xor(sts, o); }
     if (lane == 0) { s_f[0][wave] = sall; s_f[1][wave] = sts; }
     __syncthreads();
     if (tid == 0) {
-        float a = 0.f, b = 0.f;
-        for (int w = 0; w < 16; w++) { a += s_f[0][w]; b += s_f[1][w]; }
-        const float lse = logf(a) + mall;
-        // timestamp_logprob = logsumexp over timestamp logprobs; logprob_max over ts = mts - lse
-        const float ts_logprob = b > 0.0f ? logf(b) + (mts - lse) : kNegInf;
-        const float max_text_logprob = mtext - lse;
-        s_b[3] = lse;
-        s_b[4] = ts_logprob > max_text_logprob ? 1.0f : 0.0f;
+        float* o = scratch + ((long)m * kRuleSlices + sl) * kRuleRec;
+        o[0] = mall; o[1] = (s_f[0][0] + s_f[0][1]) + (s_f[0][2] + s_f[0][3]);
+        o[2] = mt.v; o[3] = __int_as_float(mt.i); o[4] = ms.v; o[5] = __int_as_float(ms.i);
+        o[6] = (s_f[1][0] + s_f[1][1]) + (s_f[1][2] + s_f[1][3]);
     }
-    __syncthreads();
-    const float lse = s_b[3];
-    const bool force_ts = s_b[4] != 0.0f;
-    // pass 3: greedy pick over probabilities (first max wins) + timestamp statistics
-    MaxIdx best{-1.0f, big}, best_ts{0.0f, big};
-    float sum_ts = 0.f;
-    for (int i = tid; i < n; i += kRuleThreads) {
-        float v = masked_logit(i, raw[i], c, rc);
+}
+
+// Stage B: one wave per row combines the slices (fixed order) and applies whisper_sample_token(best)
+__global__ __launch_bounds__(64) void logits_rules_pick_kernel(const float* __restrict__ scratch, RuleConsts rc, SampleOut* __restrict__ out) {
+    const int m = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const float* s = scratch + (long)m * kRuleSlices * kRuleRec;
+    const int big = 0x7fffffff;
+    float mall = kNegInf;
+    MaxIdx mt{kNegInf, big}, ms{kNegInf, big};
+    for (int k = 0; k < kRuleSlices; k++) {
+        const float* o = s + k * kRuleRec;
+        mall = fmaxf(mall, o[0]);
+        mt = better(mt, MaxIdx{o[2], __float_as_int(o[3])});
+        ms = better(ms, MaxIdx{o[4], __float_as_int(o[5])});
+    }
+    float sall = 0.f, sts = 0.f;
+    for (int k = 0; k < kRuleSlices; k++) {
+        const float* o = s + k * kRuleRec;
+        if (o[0] > kNegInf) sall += o[1] * expf(o[0] - mall);
+        if (o[4] > kNegInf) sts += o[6] * expf(o[4] - ms.v);
+    }
+    const float lse = logf(sall) + mall;
+    const float ts_logprob = sts > 0.0f ? logf(sts) + (ms.v - lse) : kNegInf;   // logsumexp over timestamp logprobs
+    const float max_text_logprob = mt.v - lse;
+    const bool force_ts = ts_logprob > max_text_logprob;                          // "sample timestamp" rule
+    const MaxIdx best = force_ts ? ms : better(mt, ms);                           // first max wins
+    SampleOut r;
+    const float p_best = best.v > kNegInf ? expf(best.v - lse) : 0.0f;
+    r.id = p_best > 0.0f ? best.i : 0;               // whisper_sample_token: id stays 0 if no prob exceeds 0
+    r.p = p_best;
+    r.plog = p_best > 0.0f ? best.v - lse : 0.0f;
+    const float p_ts = ms.v > kNegInf ? expf(ms.v - lse) : 0.0f;
+    const float sum_ts = sts > 0.0f ? expf(ts_logprob) : 0.0f;
+    r.tid = p_ts > 0.0f ? ms.i : 0;                  // stays 0 if every timestamp prob is 0
+    r.pt = p_ts / (sum_ts + 1e-10f);
+    r.ptsum = sum_ts;
+    if (r.id >= rc.beg) { r.tid = r.id; r.pt = r.p; }
+    r.pad[0] = force_ts; r.pad[1] = __float_as_int(lse);
+    out[m] = r;
+}
+
+// t > 0 only: the full probability row for host-side sampling (probs = 0 where masked, text masked when a timestamp is forced)
+__global__ __launch_bounds__(256) void logits_probs_kernel(const float* __restrict__ logits, long ld, const RowCtl* __restrict__ ctl, RuleConsts rc,
+                                                           const SampleOut* __restrict__ picked, float* __restrict__ probs) {
+    const int m = blockIdx.y;
+    const RowCtl c = ctl[m];
+    const float lse = __int_as_float(picked[m].pad[1]);
+    const bool force_ts = picked[m].pad[0] != 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < rc.n_vocab; i += gridDim.x * 256) {
+        float v = masked_logit(i, logits[(long)m * ld + i], c, rc);
         if (force_ts && i < rc.beg) v = kNegInf;
-        const float p = v == kNegInf ? 0.0f : expf(v - lse);
-        if (probs) probs[(long)m * ld + i] = p;
-        if (p > best.v) { best.v = p; best.i = i; }
-        if (i >= rc.beg) {
-            sum_ts += p;
-            if (p > best_ts.v) { best_ts.v = p; best_ts.i = i; }
-        }
-    }
-    best = wave_max(best);
-    best_ts = wave_max(best_ts);
-    for (int o = 32; o > 0; o >>= 1) sum_ts += __shfl_xor(sum_ts, o);
-    if (lane == 0) { s_mi[0][wave] = best; s_mi[1][wave] = best_ts; s_f[2][wave] = sum_ts; }
-    __syncthreads();
-    if (tid == 0) {
-        MaxIdx a = s_mi[0][0], t = s_mi[1][0];
-        float st = s_f[2][0];
-        for (int w = 1; w < 16; w++) { a = better(a, s_mi[0][w]); t = better(t, s_mi[1][w]); st += s_f[2][w]; }
-        SampleOut r;
-        r.id = a.v > 0.0f ? a.i : 0;           // whisper_sample_token: id stays 0 if no prob exceeds 0
-        r.p = a.v > 0.0f ? a.v : 0.0f;
-        {
-            float v = masked_logit(r.id, raw[r.id], c, rc);
-            if (force_ts && r.id < rc.beg) v = kNegInf;
-            r.plog = a.v > 0.0f ? v - lse : 0.0f;
-        }
-        r.tid = t.v > 0.0f ? t.i : 0;          // stays 0 if every timestamp prob is 0
-        r.pt = t.v / (st + 1e-10f);
-        r.ptsum = st;
-        if (r.id >= rc.beg) { r.tid = r.id; r.pt = r.p; }
-        r.pad[0] = force_ts; r.pad[1] = 0;
-        out[m] = r;
+        probs[(long)m * ld + i] = v == kNegInf ? 0.0f : expf(v - lse);
     }
 }
 }  // namespace
 
-void launch_logits_rules(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, SampleOut* out, float* probs, hipStream_t st) {
-    logits_rules_kernel<<<M, kRuleThreads, 0, st>>>(logits, ld, ctl, rc, out, probs);
+void launch_logits_rules(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, SampleOut* out, float* probs, float* scratch,
+                         hipStream_t st) {
+    if ((rc.n_vocab + kRuleSlices - 1) / kRuleSlices > 4 * 256) throw Error(-1, "logits rules: vocabulary too large for the slice plan");
+    logits_rules_scan_kernel<<<dim3(kRuleSlices, M), 256, 0, st>>>(logits, ld, ctl, rc, scratch);
+    logits_rules_pick_kernel<<<M, 64, 0, st>>>(scratch, rc, out);
+    if (probs) logits_probs_kernel<<<dim3(32, M), 256, 0, st>>>(logits, ld, ctl, rc, out, probs);
 }
 
 }  // namespace ss
