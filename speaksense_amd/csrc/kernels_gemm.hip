@@ -6,6 +6,8 @@
 // /root/reference/resources/ggml-metal.metal:3861-4003 kernel_mul_mm, :1307-1363 kernel_mul_mv_f16_f32).
 // Not a translation of those: wave64 16x16x32 MFMA tiles, direct global->LDS DMA with a source-side XOR swizzle,
 // operands swapped so each lane owns 4 consecutive output features (8/16-byte stores), epilogues fused.
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace ss {
@@ -28,10 +30,9 @@ template <> struct Mfma<f16> {
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     // 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)));  tanh(u) = 1 - 2/(exp(2u)+1)
+    // == x * sigmoid(2u): one v_exp_f32 + one v_rcp_f32
     const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
-    const float e = __expf(2.0f * u);
-    const float th = 1.0f - 2.0f / (e + 1.0f);
-    return 0.5f * x * (1.0f + th);
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
 }
 template <typename T> __device__ __forceinline__ float gelu_in_round(float x, int on);
 template <> __device__ __forceinline__ float gelu_in_round<bf16>(float x, int) { return x; }
@@ -209,12 +210,188 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256 x 256 x 32 tile, 512 threads = 8 waves (4 n x 2 m), each wave 64 n x 128 m = 4 x 8 MFMA tiles (128 acc VGPRs).
+// 4-stage LDS ring (4 x 32 KB), filled by global_load_lds 16 B DMA; three stages stay in flight across the single
+// raw s_barrier per k-step (counted s_waitcnt vmcnt, never 0 in the steady state), which is what hides the ~2 us
+// HBM/L2 latency that the 2-stage kernel above exposes at K = 1280 (20 short k-steps).
+// LDS rows are 64 B (32 k); chunk c of row r sits at position c ^ (3 * ((r >> 3) & 1)), applied on the DMA source
+// address and on the ds_read_b128 side: every 16-lane ds_read_b128 service group then touches 16 distinct 16-B slots.
+// ---------------------------------------------------------------------------------------------
+constexpr int TM = 256, TN = 256, TK = 32, NST = 4;
+constexpr int kStageBytes = (TM + TN) * TK * 2;   // 32 KB
+constexpr int kGemm256Lds = NST * kStageBytes;    // 128 KB -> one workgroup per CU, 2 waves per SIMD
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Mfma<T>::V8 V8;
+    typedef typename Mfma<T>::V4 V4;
+    constexpr bool SWAP = (KIND == EPI_VT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int nbn = g.N / TN, nbm = (g.M + TM - 1) / TM;
+    const int nwg = nbn * nbm;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int nb = bid % nbn, mb = bid / nbn;
+    const int m0 = mb * TM, n0 = nb * TN;
+    const T* __restrict__ A = (const T*)g.A;
+    const T* __restrict__ W = (const T*)g.W;
+
+    // staging: 4 DMA instructions per thread per stage; pass p covers 128 tile rows (16 per wave), 4 lanes per 64-B row
+    const int srow = wave * 16 + (lane >> 2), spos = lane & 3;
+    const T* src[4];
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int r = (p & 1) * 128 + srow;                 // row within the X (p < 2) or W (p >= 2) tile
+        const int c = spos ^ (3 * ((r >> 3) & 1));
+        if (p < 2) {
+            long m = m0 + r;
+            if (m > g.M - 1) m = g.M - 1;
+            src[p] = A + (m / g.a_rows_per_batch) * g.a_batch_stride + (m % g.a_rows_per_batch) * g.lda + c * 8;
+        } else {
+            src[p] = W + (long)(n0 + r) * g.K + c * 8;
+        }
+    }
+    const int wave_off = wave * 16 * 64;
+    auto stage = [&](int buf, int k0) {
+        char* base = smem + buf * kStageBytes;
+#pragma unroll
+        for (int p = 0; p < 4; p++) glds16<T>(src[p] + k0, base + p * (128 * 64) + wave_off);
+    };
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fg = lane >> 4;
+    const int foff = frow * 64 + ((fg ^ (3 * ((frow >> 3) & 1))) * 16);
+    const int xoff = (wm * 128) * 64 + foff, woff = TM * 64 + (wn * 64) * 64 + foff;
+    const int nk = g.K / TK;
+
+    auto compute = [&](int buf) {
+        const char* base = smem + buf * kStageBytes;
+        V8 wf[4], xf[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) wf[i] = *(const V8*)(base + woff + i * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 8; i++) xf[i] = *(const V8*)(base + xoff + i * 16 * 64);
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++)
+#pragma unroll
+            for (int mi = 0; mi < 8; mi++) {
+                if (SWAP) acc[ni][mi] = Mfma<T>::mma(xf[mi], wf[ni], acc[ni][mi]);
+                else acc[ni][mi] = Mfma<T>::mma(wf[ni], xf[mi], acc[ni][mi]);
+            }
+    };
+
+    // prologue: three stages in flight
+    stage(0, 0);
+    if (nk > 1) stage(1, TK);
+    if (nk > 2) stage(2, 2 * TK);
+    for (int kt = 0; kt < nk; kt++) {
+        // my own DMA for stage kt has landed (stages kt+1, kt+2 may still be in flight: 4 DMA ops each) ...
+        if (kt + 2 < nk) wait_vmcnt<8>();
+        else if (kt + 1 < nk) wait_vmcnt<4>();
+        else wait_vmcnt<0>();
+        // ... and after the barrier everyone's has, and everyone is done reading stage kt-1
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nk) stage((kt + 3) & 3, (kt + 3) * TK);
+        compute(kt & 3);
+    }
+
+    // ---------------- epilogue ----------------
+    if constexpr (!SWAP) {
+#pragma unroll
+        for (int mi = 0; mi < 8; mi++) {
+            const long m = m0 + wm * 128 + mi * 16 + frow;
+            if (m >= g.M) continue;
+            const long orow = (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo;
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) {
+                const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+                f32x4 v = acc[ni][mi];
+                if (g.bias) v += *(const f32x4*)(g.bias + n);
+                if constexpr (KIND == EPI_STORE_T) {
+                    V4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
+                    *(V4*)((T*)g.out + orow + n) = o;
+                } else if constexpr (KIND == EPI_GELU_T) {
+                    V4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
+                    *(V4*)((T*)g.out + orow + n) = o;
+                } else if constexpr (KIND == EPI_RES_F32) {
+                    const f32x4 rsd = *(const f32x4*)(g.res + orow + n);
+                    *(f32x4*)((float*)g.out + orow + n) = rsd + v;
+                } else if constexpr (KIND == EPI_STORE_F32) {
+                    *(f32x4*)((float*)g.out + orow + n) = v;
+                } else if constexpr (KIND == EPI_GELU_POS_F32) {
+                    const f32x4 pe = *(const f32x4*)(g.pos + (long)(m % g.rows_per_batch) * g.N + n);
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in)) + pe[r];
+                    *(f32x4*)((float*)g.out + orow + n) = o;
+                } else if constexpr (KIND == EPI_CROSS_KV) {
+                    const int H = g.d / 64;
+                    const int l = n / (2 * g.d), rem = n % (2 * g.d), kv = rem / g.d, hj = rem % g.d, h = hj >> 6, j = hj & 63;
+                    const int b = (int)(m / g.rows_per_batch), t = (int)(m % g.rows_per_batch);
+                    const float sc = kv == 0 ? g.scale : 1.0f;
+                    V4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
+                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j;
+                    *(V4*)((T*)g.out + off) = o;
+                }
+            }
+        }
+    } else {
+        const int H = g.d / 64;
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) {
+            const int n = n0 + wn * 64 + ni * 16 + frow;
+            const float b = g.bias ? g.bias[n] : 0.0f;
+            const int h = n >> 6, j = n & 63;
+#pragma unroll
+            for (int mi = 0; mi < 8; mi++) {
+                const long m = m0 + wm * 128 + mi * 16 + fg * 4;
+                if (m >= g.M) continue;
+                const int bb = (int)(m / g.rows_per_batch), t = (int)(m % g.rows_per_batch);
+                V4 o;
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[r] = (T)(acc[ni][mi][r] + b);
+                *(V4*)((T*)g.out + (((long)(bb * H + h) * 64 + j) * g.Tpad + t)) = o;
+            }
+        }
+    }
+}
+
 template <typename T, int KIND>
 static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         SS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
         attr_set = true;
+    }
+    static const bool force128 = getenv("SS_GEMM128") != nullptr;
+    if (!force128 && g.N % TN == 0 && g.K % TK == 0 && g.M >= 1024) {
+        static bool attr256 = false;
+        if (!attr256) {
+            SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemm256Lds));
+            attr256 = true;
+        }
+        const int nwg256 = (g.N / TN) * ((g.M + TM - 1) / TM);
+        gemm256_kernel<T, KIND><<<nwg256, 512, kGemm256Lds, st>>>(g);
+        return;
     }
     const int nwg = (g.N / BN) * ((g.M + BM - 1) / BM);
     gemm_kernel<T, KIND><<<nwg, 256, kGemmLds, st>>>(g);

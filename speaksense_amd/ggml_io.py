@@ -45,6 +45,8 @@ PRESETS = {
     # toy shapes for fast CPU tests: same context sizes / vocabulary rules, tiny width
     "toy.en": HParams(51864, 1500, 128, 2, 2, 448, 128, 2, 2, 80, 1),
     "toy": HParams(51866, 1500, 128, 2, 2, 448, 128, 2, 2, 128, 1),
+    # width 256: the smallest shape that takes the 256x256-tile GEMM path (N % 256 == 0, M >= 1024)
+    "toy256": HParams(51866, 1500, 256, 4, 2, 448, 256, 4, 2, 128, 1),
 }
 
 

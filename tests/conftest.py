@@ -33,3 +33,8 @@ def toy_en_path(model_dir):
 @pytest.fixture(scope="session")
 def toy_ml_path(model_dir):
     return _model(model_dir, "toy")
+
+
+@pytest.fixture(scope="session")
+def toy256_path(model_dir):
+    return _model(model_dir, "toy256")

@@ -60,9 +60,9 @@ def test_log_mel_matches_oracle(toy_en_path, toy_ml_path, orc, case):
 # ------------------------------------------------------------------------------------------------
 # encoder: conv stem + blocks + ln_post
 # ------------------------------------------------------------------------------------------------
-def test_encoder_matches_oracle(toy_en_path, toy_ml_path, orc, dtype):
+def test_encoder_matches_oracle(toy_en_path, toy_ml_path, toy256_path, orc, dtype):
     from speaksense_amd import binding
-    for path in (toy_en_path, toy_ml_path):
+    for path in (toy_en_path, toy_ml_path, toy256_path):   # toy256 runs the 256x256-tile GEMM, the others the 128x128 one
         om = orc.OracleModel(path)
         eng = _eng(path, dtype, max_batch=1)
         mel = om.log_mel(synth.speech_like(5))
@@ -149,13 +149,13 @@ def _same_result(got, ref, ctx):
     assert got["n_encode"] == ref["n_encode"], ctx
 
 
-@pytest.mark.parametrize("which", ["toy.en", "toy"])
-def test_full_path_greedy_identical_tokens_f16(toy_en_path, toy_ml_path, orc, which):
+@pytest.mark.parametrize("which", ["toy.en", "toy", "toy256"])
+def test_full_path_greedy_identical_tokens_f16(toy_en_path, toy_ml_path, toy256_path, orc, which):
     """Pure greedy (temperature_inc = 0, no fallback ladder): f16 MFMA operands reproduce ggml's CPU arithmetic type,
     so token ids, timestamps and segment texts must match the ggml-faithful oracle exactly.  Covers multi-window
     chunks (seek advance + prompt_past conditioning), timestamp pairs, EOT and the no-timestamp path."""
     from speaksense_amd import binding
-    path = toy_en_path if which == "toy.en" else toy_ml_path
+    path = {"toy.en": toy_en_path, "toy": toy_ml_path, "toy256": toy256_path}[which]
     om = orc.OracleModel(path)
     eng = _eng(path, binding.DTYPE_F16, max_batch=4)
     n_multi = 0

@@ -1,0 +1,65 @@
+// Standalone GEMM micro-benchmark / correctness harness for kernels_gemm.hip (dev tool, run on the GPU box):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip tools/gemm_bench.cpp speaksense_amd/csrc/kernels_gemm.hip -Ispeaksense_amd/csrc -o /tmp/gemm_bench
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "kernels.h"
+using namespace ss;
+
+__global__ void ref_gemm(const f16* A, const f16* W, const float* bias, float* C, int M, int N, int K) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    float acc = 0;
+    for (int k = 0; k < K; k++) acc += (float)A[(long)m * K + k] * (float)W[(long)n * K + k];
+    C[(long)m * N + n] = acc + bias[n];
+}
+__global__ void fill(f16* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 16; x *= 2246822519u; x ^= x >> 13;
+        p[i] = (f16)(((x & 0xffff) / 32768.0f - 1.0f) * scale);
+    }
+}
+int main(int argc, char** argv) {
+    struct Shape { int M, N, K; const char* name; };
+    Shape shapes[] = {{12000, 5120, 1280, "FC1"}, {12000, 1280, 5120, "FC2"}, {12000, 2560, 1280, "QK"}, {12000, 1280, 1280, "O"},
+                      {12000, 81920, 1280, "crossKV"}, {4096, 4096, 4096, "sq4096"}, {8192, 8192, 8192, "sq8192"}};
+    int kinds[] = {EPI_STORE_T, EPI_GELU_T, EPI_RES_F32};
+    const char* kn[] = {"store", "gelu", "res_f32"};
+    hipStream_t st; hipStreamCreate(&st);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (auto& s : shapes) {
+        f16 *A, *W; float *bias, *Cf; void* out;
+        hipMalloc(&A, (size_t)s.M * s.K * 2); hipMalloc(&W, (size_t)s.N * s.K * 2); hipMalloc(&bias, s.N * 4);
+        hipMalloc(&out, (size_t)s.M * s.N * 4);
+        fill<<<1024, 256>>>(A, (size_t)s.M * s.K, 1, 1.0f); fill<<<1024, 256>>>(W, (size_t)s.N * s.K, 2, 0.05f);
+        hipMemset(bias, 0, s.N * 4); hipMemset(out, 0, (size_t)s.M * s.N * 4);
+        for (int ki = 0; ki < 3; ki++) {
+            GemmDesc g{};
+            g.A = A; g.lda = s.K; g.a_rows_per_batch = 1L << 40; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = kinds[ki]; g.bias = bias;
+            g.out = out; g.ldo = s.N; g.o_rows_per_batch = 1L << 40; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500;
+            launch_gemm<f16>(g, st);
+            hipEventRecord(e0, st);
+            const int reps = 10;
+            for (int i = 0; i < reps; i++) launch_gemm<f16>(g, st);
+            hipEventRecord(e1, st); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
+            printf("%-8s M=%5d N=%5d K=%4d %-8s %8.3f ms  %7.1f TF/s\n", s.name, s.M, s.N, s.K, kn[ki], ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+        }
+        if (s.M * (long)s.N <= 12000L * 5120) {  // correctness vs naive reference (EPI_STORE_F32)
+            hipMalloc(&Cf, (size_t)s.M * s.N * 4);
+            ref_gemm<<<dim3((s.N + 255) / 256, s.M), 256>>>(A, W, bias, Cf, s.M, s.N, s.K);
+            GemmDesc g{};
+            g.A = A; g.lda = s.K; g.a_rows_per_batch = 1L << 40; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = EPI_STORE_F32; g.bias = bias;
+            g.out = out; g.ldo = s.N; g.o_rows_per_batch = 1L << 40; g.scale = 1.0f; g.rows_per_batch = 1500;
+            launch_gemm<f16>(g, st); hipDeviceSynchronize();
+            std::vector<float> a((size_t)s.M * s.N), b((size_t)s.M * s.N);
+            hipMemcpy(a.data(), out, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), Cf, b.size() * 4, hipMemcpyDeviceToHost);
+            double mx = 0, ref = 0; for (size_t i = 0; i < a.size(); i++) { mx = fmax(mx, fabs(a[i] - b[i])); ref = fmax(ref, fabs(b[i])); }
+            printf("   check: max|diff| %.3e (max|ref| %.3f)\n", mx, ref);
+            hipFree(Cf);
+        }
+        hipFree(A); hipFree(W); hipFree(bias); hipFree(out);
+    }
+    return 0;
+}
