@@ -7,6 +7,8 @@
 //    HBM-bound streaming kernels (one new token per row), split over T for occupancy.
 // Replaces ggml's mul_mat(K,Q) -> soft_max(_ext) -> mul_mat(V,P) node chains in whisper.cpp's encoder / decoder graphs
 // (/root/reference/resources/ggml-metal.metal:351-435 kernel_soft_max, :1229-1305 kernel_mul_mv_f16_f16).
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace ss {
@@ -28,104 +30,132 @@ template <> struct MfmaA<f16> {
 };
 
 // ---------------------------------------------------------------------------------------------
-// encoder flash attention: grid (ceil(Tn/128), H, B), 256 threads; wave w owns 32 query rows (2 column tiles)
+// encoder flash attention: grid (ceil(Tn/(64*QT)), H, B), 256 threads; wave w owns 16*QT query rows (QT column tiles).
+// K / V^T fragments come straight from L2 into VGPRs (K/V of one head = 384 KB, L2-resident; staging them through LDS
+// measured as pure overhead at this size) and are software-prefetched one 32-key chunk ahead (register double buffer),
+// so the MFMAs of chunk c overlap the loads of chunk c+1.  Each fragment is reused by QT query tiles.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int QT>
 __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, const T* __restrict__ k, long ld, const T* __restrict__ vT,
                                                        int Tpad, T* __restrict__ out, long ldo, int H, int Tn) {
     typedef typename MfmaA<T>::V8 V8;
     typedef typename MfmaA<T>::V4 V4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int frow = lane & 15, fg = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    // XCD-aware remap: the dispatcher places consecutive workgroup ids on different XCDs; give each XCD a contiguous
+    // range of logical ids so the query blocks of one (batch, head) share one L2 (K/V fetched once, not once per XCD:
+    // FETCH_SIZE showed 8x the algorithmic bytes without this)
+    const int nqb = (Tn + 64 * QT - 1) / (64 * QT);
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int qb = bid % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
+    const int q0 = qb * (64 * QT) + wave * (16 * QT);
     if (q0 >= Tn) return;
     const long rowbase = (long)b * Tn;
 
-    V8 qf[2][2];
+    V8 qf[QT][2];
 #pragma unroll
-    for (int qi = 0; qi < 2; qi++) {
+    for (int qi = 0; qi < QT; qi++) {
         int qr = q0 + qi * 16 + frow;
         if (qr > Tn - 1) qr = Tn - 1;
         const T* p = q + (rowbase + qr) * ld + h * 64 + fg * 8;
         qf[qi][0] = *(const V8*)p;
         qf[qi][1] = *(const V8*)(p + 32);
     }
-    f32x4 o[4][2];
+    f32x4 o[4][QT];
 #pragma unroll
-    for (int i = 0; i < 4; i++) { o[i][0] = (f32x4){0, 0, 0, 0}; o[i][1] = (f32x4){0, 0, 0, 0}; }
-    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
-    const T* vbase = vT + ((long)(b * H + h) * 64) * Tpad;
-    const float scale = 0.125f;  // 1/sqrt(64)
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < QT; j++) o[i][j] = (f32x4){0, 0, 0, 0};
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int j = 0; j < QT; j++) { mrun[j] = -1e30f; lrun[j] = 0.f; }
+    const T* vbase = vT + ((long)(b * H + h) * 64) * Tpad + (long)frow * Tpad + fg * 4;
+    const T* kbase = k + rowbase * ld + h * 64 + fg * 8;
+    const float c2 = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e)
     const int nchunk = (Tn + 31) / 32;
 
-    for (int kc = 0; kc < nchunk; kc++) {
+    V8 kf[2][2];
+    V4 vlo[4], vhi[4];
+    auto load_chunk = [&](int kc) {
         const int key0 = kc * 32;
-        V8 kf[2][2];
 #pragma unroll
         for (int kt = 0; kt < 2; kt++) {
             int kr = key0 + kt * 16 + frow;
             if (kr > Tn - 1) kr = Tn - 1;
-            const T* p = k + (rowbase + kr) * ld + h * 64 + fg * 8;
+            const T* p = kbase + (long)kr * ld;
             kf[kt][0] = *(const V8*)p;
             kf[kt][1] = *(const V8*)(p + 32);
         }
-        V8 vf[4];
 #pragma unroll
         for (int dt = 0; dt < 4; dt++) {
-            const T* p = vbase + (long)(dt * 16 + frow) * Tpad + key0 + fg * 4;
-            const V4 lo = *(const V4*)p, hi = *(const V4*)(p + 16);
-            vf[dt] = (V8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const T* p = vbase + (long)(dt * 16) * Tpad + key0;
+            vlo[dt] = *(const V4*)p;
+            vhi[dt] = *(const V4*)(p + 16);
         }
-        f32x4 s[2][2];  // [kt][qi]
+    };
+    load_chunk(0);
+    for (int kc = 0; kc < nchunk; kc++) {
+        const int key0 = kc * 32;
+        // move the prefetched chunk into the working set, then immediately issue the next chunk's loads
+        V8 kw[2][2], vf[4];
 #pragma unroll
-        for (int kt = 0; kt < 2; kt++)
+        for (int kt = 0; kt < 2; kt++) { kw[kt][0] = kf[kt][0]; kw[kt][1] = kf[kt][1]; }
 #pragma unroll
-            for (int qi = 0; qi < 2; qi++) {
-                f32x4 a = (f32x4){0, 0, 0, 0};
-                a = MfmaA<T>::mma(kf[kt][0], qf[qi][0], a);
-                a = MfmaA<T>::mma(kf[kt][1], qf[qi][1], a);
-                s[kt][qi] = a;
-            }
+        for (int dt = 0; dt < 4; dt++) vf[dt] = (V8){vlo[dt][0], vlo[dt][1], vlo[dt][2], vlo[dt][3], vhi[dt][0], vhi[dt][1], vhi[dt][2], vhi[dt][3]};
+        if (kc + 1 < nchunk) load_chunk(kc + 1);
         const bool tail = key0 + 32 > Tn;
 #pragma unroll
-        for (int qi = 0; qi < 2; qi++) {
+        for (int qi = 0; qi < QT; qi++) {
+            f32x4 s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) {
+                f32x4 a = (f32x4){0, 0, 0, 0};
+                a = MfmaA<T>::mma(kw[kt][0], qf[qi][0], a);
+                a = MfmaA<T>::mma(kw[kt][1], qf[qi][1], a);
+                s[kt] = a;
+            }
+            // softmax in the exp2 domain: p = 2^(s*c - m), c = scale*log2(e); m tracks max(s)*c.  One FMA + one v_exp_f32 per score.
             float mx = -1e30f;
 #pragma unroll
             for (int kt = 0; kt < 2; kt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    float v = s[kt][qi][r] * scale;
-                    if (tail && key0 + kt * 16 + fg * 4 + r >= Tn) v = -1e30f;
-                    s[kt][qi][r] = v;
-                    mx = fmaxf(mx, v);
+                    if (tail && key0 + kt * 16 + fg * 4 + r >= Tn) s[kt][r] = -1e30f;
+                    mx = fmaxf(mx, s[kt][r]);
                 }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mnew = fmaxf(mrun[qi], mx);
-            const float alpha = __expf(mrun[qi] - mnew);
-            mrun[qi] = mnew;
+            mx *= c2;
+            if (__any(mx > mrun[qi])) {   // wave-uniform: the running max of most rows stops moving after a few chunks
+                const float mnew = fmaxf(mrun[qi], mx);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[qi] - mnew);
+                mrun[qi] = mnew;
+                lrun[qi] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++) o[dt][qi] *= alpha;
+            }
+            const float mcur = mrun[qi];
             float psum = 0.f;
             V8 pf;
 #pragma unroll
             for (int kt = 0; kt < 2; kt++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float pv = __expf(s[kt][qi][r] - mnew);
-                    const T pt = (T)pv;
-                    pf[kt * 4 + r] = pt;
-                    psum += (float)pt;   // the sum sees exactly what the P·V MFMA sees
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c2, -mcur));
+                    psum += pv;
+                    pf[kt * 4 + r] = (T)pv;
                 }
-            lrun[qi] = lrun[qi] * alpha + psum;
+            lrun[qi] += psum;
 #pragma unroll
-            for (int dt = 0; dt < 4; dt++) {
-                o[dt][qi] *= alpha;
-                o[dt][qi] = MfmaA<T>::mma(vf[dt], pf, o[dt][qi]);
-            }
+            for (int dt = 0; dt < 4; dt++) o[dt][qi] = MfmaA<T>::mma(vf[dt], pf, o[dt][qi]);
         }
     }
 #pragma unroll
-    for (int qi = 0; qi < 2; qi++) {
+    for (int qi = 0; qi < QT; qi++) {
         float l = lrun[qi];
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
@@ -145,8 +175,17 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, 
 
 template <typename T>
 void launch_enc_attention(const T* q, const T* k, long ld, const T* vT, int Tpad, T* out, long ldo, int B, int H, int Tn, hipStream_t st) {
-    dim3 grid((Tn + 127) / 128, H, B);
-    enc_attn_kernel<T><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn);
+    static const int qt = getenv("SS_ATTN_QT") ? atoi(getenv("SS_ATTN_QT")) : 3;
+    if (qt == 4) {
+        dim3 grid(((Tn + 255) / 256) * H * B);
+        enc_attn_kernel<T, 4><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn);
+    } else if (qt == 3) {
+        dim3 grid(((Tn + 191) / 192) * H * B);
+        enc_attn_kernel<T, 3><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn);
+    } else {
+        dim3 grid(((Tn + 127) / 128) * H * B);
+        enc_attn_kernel<T, 2><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn);
+    }
 }
 template void launch_enc_attention<bf16>(const bf16*, const bf16*, long, const bf16*, int, bf16*, long, int, int, int, hipStream_t);
 template void launch_enc_attention<f16>(const f16*, const f16*, long, const f16*, int, f16*, long, int, int, int, hipStream_t);

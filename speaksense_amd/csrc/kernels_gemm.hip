@@ -277,13 +277,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
     const int xoff = (wm * 128) * 64 + foff, woff = TM * 64 + (wn * 64) * 64 + foff;
     const int nk = g.K / TK;
 
-    auto compute = [&](int buf) {
+    // fragment sets A / B (register double buffer): the ds_reads of stage kt+1 are issued before the MFMAs of stage kt,
+    // so the LDS latency right after each barrier no longer stalls both waves of a SIMD at once
+    V8 wfA[4], xfA[8], wfB[4], xfB[8];
+    auto load_frags = [&](int buf, V8 (&wf)[4], V8 (&xf)[8]) {
         const char* base = smem + buf * kStageBytes;
-        V8 wf[4], xf[8];
 #pragma unroll
         for (int i = 0; i < 4; i++) wf[i] = *(const V8*)(base + woff + i * 16 * 64);
 #pragma unroll
         for (int i = 0; i < 8; i++) xf[i] = *(const V8*)(base + xoff + i * 16 * 64);
+    };
+    auto mma_all = [&](const V8 (&wf)[4], const V8 (&xf)[8]) {
 #pragma unroll
         for (int ni = 0; ni < 4; ni++)
 #pragma unroll
@@ -292,20 +296,39 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
                 else acc[ni][mi] = Mfma<T>::mma(wf[ni], xf[mi], acc[ni][mi]);
             }
     };
-
-    // prologue: three stages in flight
-    stage(0, 0);
-    if (nk > 1) stage(1, TK);
-    if (nk > 2) stage(2, 2 * TK);
-    for (int kt = 0; kt < nk; kt++) {
-        // my own DMA for stage kt has landed (stages kt+1, kt+2 may still be in flight: 4 DMA ops each) ...
-        if (kt + 2 < nk) wait_vmcnt<8>();
-        else if (kt + 1 < nk) wait_vmcnt<4>();
+    // wait until MY DMA of stage `st` has landed; stages issued after it (4 DMA ops each) may stay in flight
+    auto wait_stage = [&](int st, int issued) {
+        const int later = issued - 1 - st;
+        if (later >= 2) wait_vmcnt<8>();
+        else if (later == 1) wait_vmcnt<4>();
         else wait_vmcnt<0>();
-        // ... and after the barrier everyone's has, and everyone is done reading stage kt-1
-        __builtin_amdgcn_s_barrier();
-        if (kt + 3 < nk) stage((kt + 3) & 3, (kt + 3) * TK);
-        compute(kt & 3);
+    };
+
+    // prologue: three stages in flight, fragments of stage 0 in registers
+    int issued = 0;
+    for (; issued < 3 && issued < nk; issued++) stage(issued, issued * TK);
+    wait_stage(0, issued);
+    __builtin_amdgcn_s_barrier();
+    load_frags(0, wfA, xfA);
+    for (int kt = 0; kt < nk; kt += 2) {
+        // ---- even step: MFMAs of stage kt from set A while set B is being read from stage kt+1 ----
+        if (kt + 1 < nk) {
+            wait_stage(kt + 1, issued);
+            __builtin_amdgcn_s_barrier();   // stage kt+1 visible to all; every wave already holds stage kt in registers
+            if (issued < nk) { stage(issued & 3, issued * TK); issued++; }   // refills the buffer of stage kt-1
+            load_frags((kt + 1) & 3, wfB, xfB);
+        }
+        mma_all(wfA, xfA);
+        // ---- odd step ----
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) {
+                wait_stage(kt + 2, issued);
+                __builtin_amdgcn_s_barrier();
+                if (issued < nk) { stage(issued & 3, issued * TK); issued++; }
+                load_frags((kt + 2) & 3, wfA, xfA);
+            }
+            mma_all(wfB, xfB);
+        }
     }
 
     // ---------------- epilogue ----------------
