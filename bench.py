@@ -104,6 +104,19 @@ def algorithmic_work(hp, batch: int, n_steps: int, n_prompt: int):
                 dec_bytes_step=float(dec_weight_bytes + batch * cross_kv_bytes))
 
 
+def pmc_traffic(model: str, batch: int, dtype: str):
+    """HBM-side bytes per FC1 launch from the committed rocprofv3 --pmc passes of this command (profiles/pmc_traffic.json):
+    (2 x FETCH_SIZE + WRITE_SIZE) KiB, the x2 being the gfx950 FETCH_SIZE correction for 16-B/lane streams
+    (MI355X_MICROARCH.md, HBM section; validated here on the cross-attention kernel: 62.2 MB measured vs 61.4 MB algorithmic)."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        j = json.load(open(p))
+        k = j.get(f"{model}/batch{batch}/{dtype}")
+        return None if k is None else float(k["bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(path: str, hp, n_steps: int, n_prompt: int):
     """The CPU restatement (oracle, kind 'port') timed on the box's host cores on a bounded sample of the same workload."""
     from oracle import binding as orc
@@ -135,17 +148,22 @@ def main():
     ap.add_argument("--fixed-steps", type=int, default=96, help="Mode F decode steps per chunk; 0 = Mode N (natural EOT, full whisper.cpp rules)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="CPU test of the sharding/timing plumbing: stub workload, gloo backend")
+    ap.add_argument("--dist-backend", default=None, help="override (default nccl on GPU); 'gloo' + SS_BENCH_DEVICE=0 lets several ranks share one GPU for testing")
     args = ap.parse_args()
 
     rank, local_rank, world = dist_env()
+    if os.environ.get("SS_BENCH_DEVICE"):   # test hook: all ranks on one GPU
+        local_rank_dev = int(os.environ["SS_BENCH_DEVICE"])
+    else:
+        local_rank_dev = local_rank
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "gloo" if args.dry_run or not torch.cuda.is_available() else "nccl"
+        backend = args.dist_backend or ("gloo" if args.dry_run or not torch.cuda.is_available() else "nccl")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank_dev)
         dist_mod.init_process_group(backend=backend, rank=rank, world_size=world)
         dist = dist_mod
     n_gpus = world
@@ -168,10 +186,10 @@ def main():
     from speaksense_amd import binding, ggml_io, synth
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback); use --dry-run to test the plumbing")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank_dev)
     path = ensure_model(args.model, local_rank, dist)
     hp = ggml_io.PRESETS.get(args.model)
-    eng = binding.Engine(path, device=local_rank, dtype=binding.DTYPE_F16 if args.dtype == "f16" else binding.DTYPE_BF16, max_batch=args.batch)
+    eng = binding.Engine(path, device=local_rank_dev, dtype=binding.DTYPE_F16 if args.dtype == "f16" else binding.DTYPE_BF16, max_batch=args.batch)
     if hp is None:
         hp = ggml_io.HParams(eng.n_vocab, eng.n_audio_ctx, eng.n_audio_state, eng.n_audio_head, eng.n_audio_layer, eng.n_text_ctx,
                              eng.n_text_state, eng.n_text_head, eng.n_text_layer, eng.n_mels, eng.ftype)
@@ -215,7 +233,8 @@ def main():
             "phase_ms": {"mel": round(float(np.mean([t["mel_ms"] for t in tl])), 3), "encode_cross_kv": round(enc_ms, 2), "decode": round(dec_ms, 2)},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel (encoder FC1: M=batch*1500, N=4d, K=d, fused bias+GELU)",
                          "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None, "avg_launch_ms": round(gemm_ms, 4)},
+                         "traffic": pmc_traffic(args.model, args.batch, args.dtype), "algorithmic_bytes": 2.0 * (args.batch * hp.n_audio_ctx * hp.n_audio_state + 4 * hp.n_audio_state * hp.n_audio_state + 4 * args.batch * hp.n_audio_ctx * hp.n_audio_state),
+                         "avg_launch_ms": round(gemm_ms, 4)},
             "phase_roofline": {
                 "encoder_phase_tflops": round(args.batch * work["enc_flops"] / (enc_ms * 1e-3) / 1e12, 1),
                 "encoder_phase_frac_mfma": round(args.batch * work["enc_flops"] / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),

@@ -1,0 +1,219 @@
+"""GPU parity, part 2: whisper_full parameter variants, multi-call context, long audio, threads, and the whisper.h-compatible shim."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from speaksense_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import binding as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def eng(toy_ml_path):
+    from speaksense_amd import binding
+    e = binding.Engine(toy_ml_path, dtype=binding.DTYPE_F16, max_batch=4)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def om(toy_ml_path, orc):
+    m = orc.OracleModel(toy_ml_path)
+    yield m
+    m.close()
+
+
+def _same(got, ref, ctx):
+    assert list(got["tokens"]) == list(ref["tokens"]), f"{ctx}: token ids differ"
+    assert [(s["t0"], s["t1"], s["text"], s["speaker_turn_next"]) for s in got["segments"]] == \
+        [(s["t0"], s["t1"], s["text"], s["speaker_turn_next"]) for s in ref["segments"]], ctx
+
+
+VARIANTS = {
+    "zh": dict(language="zh"),
+    "ja_translate": dict(language="ja", translate=1),
+    "no_timestamps": dict(language="en", no_timestamps=1),
+    "single_segment": dict(language="en", single_segment=1),
+    "max_tokens": dict(language="en", max_tokens=10),
+    "tdrz": dict(language="en", tdrz_enable=1),
+    "print_special": dict(language="en", print_special=1),
+    "no_suppress_blank": dict(language="en", suppress_blank=0),
+    "max_initial_ts_off": dict(language="en", max_initial_ts=0.0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+def test_param_variants_match_oracle(eng, om, orc, name):
+    from speaksense_amd import binding
+    kw = dict(VARIANTS[name], temperature_inc=0.0)
+    for seed in (3, 5):
+        pcm = synth.speech_like(seed)
+        ref = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(**kw))
+        got = eng.new_session().transcribe(pcm, binding.default_params(**kw))
+        _same(got, ref, f"{name} seed {seed}")
+
+
+def test_context_carries_across_calls_when_no_context_is_false(eng, om, orc):
+    """build_params sets no_context(false) (whisper.rs:159); without stream mode the previous call's text conditions the next."""
+    from speaksense_amd import binding
+    kw = dict(language="en", temperature_inc=0.0, no_context=0)
+    ost = om.new_state(orc.MODE_GGML_F16)
+    ses = eng.new_session()
+    outs = []
+    for seed in (3, 4, 5):
+        pcm = synth.speech_like(seed, 16000 * 12)
+        ref = ost.full(pcm, orc.default_params(**kw))
+        got = ses.transcribe(pcm, binding.default_params(**kw))
+        _same(got, ref, f"call with seed {seed}")
+        outs.append(list(got["tokens"]))
+    # and it really is context dependent: a fresh session gives a different continuation for the last chunk
+    fresh = eng.new_session().transcribe(synth.speech_like(5, 16000 * 12), binding.default_params(**kw))
+    assert list(fresh["tokens"]) != outs[-1]
+
+
+@pytest.mark.parametrize("seconds", [1.0, 7.3, 29.99, 30.08, 47.0, 95.0])
+def test_audio_lengths(eng, om, orc, seconds):
+    from speaksense_amd import binding
+    n = int(seconds * 16000)
+    pcm = synth.speech_like(17, n)
+    kw = dict(language="en", temperature_inc=0.0)
+    ref = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(**kw))
+    got = eng.new_session().transcribe(pcm, binding.default_params(**kw))
+    _same(got, ref, f"{seconds}s")
+    assert got["n_encode"] == ref["n_encode"]
+    if seconds > 60:
+        assert got["n_encode"] >= 3
+
+
+def test_edge_signals(eng, om, orc):
+    from speaksense_amd import binding
+    kw = dict(language="en", temperature_inc=0.0)
+    cases = {"silence": synth.silence(), "noise": synth.noise(5), "clipped": np.clip(4 * synth.speech_like(9), -1, 1).astype(np.float32),
+             "dc": np.full(480000, 0.25, np.float32), "tiny": (1e-6 * synth.speech_like(10)).astype(np.float32)}
+    for name, pcm in cases.items():
+        ref = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(**kw))
+        got = eng.new_session().transcribe(pcm, binding.default_params(**kw))
+        _same(got, ref, name)
+
+
+def test_threads_share_one_engine(eng):
+    """One engine, many sessions, concurrent callers (the reference runs one state per gRPC stream on one context)."""
+    from speaksense_amd import binding
+    P = binding.default_params(language="en", temperature_inc=0.0)
+    pcms = [synth.speech_like(60 + i, 16000 * 10) for i in range(8)]
+    ref = [eng.new_session().transcribe(p, P) for p in pcms]
+    out = [None] * len(pcms)
+
+    def work(i):
+        s = eng.new_session()
+        out[i] = s.wait(s.submit(pcms[i], P))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(pcms))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i, (a, b) in enumerate(zip(out, ref)):
+        _same(a, b, f"thread {i}")
+
+
+def test_unsupported_and_bad_arguments(eng):
+    from speaksense_amd import binding
+    with pytest.raises(binding.SpeakSenseError) as e:
+        eng.new_session().transcribe(synth.speech_like(1, 32000), binding.default_params(language="en", audio_ctx=2000))
+    assert e.value.code == -5      # whisper_full: audio_ctx > n_audio_ctx -> -5
+    with pytest.raises(binding.SpeakSenseError) as e:
+        eng.new_session().transcribe(synth.speech_like(1, 32000), binding.default_params(language="en", best_of=9))
+    assert e.value.code == -1
+
+
+# ------------------------------------------------------------------------------------------------
+# whisper.h-compatible shim (include/whisper_compat.h), driven exactly as whisper-rs-sys would
+# ------------------------------------------------------------------------------------------------
+class WFullParams(C.Structure):
+    _fields_ = [
+        ("strategy", C.c_int), ("n_threads", C.c_int), ("n_max_text_ctx", C.c_int), ("offset_ms", C.c_int), ("duration_ms", C.c_int),
+        ("translate", C.c_bool), ("no_context", C.c_bool), ("no_timestamps", C.c_bool), ("single_segment", C.c_bool), ("print_special", C.c_bool),
+        ("print_progress", C.c_bool), ("print_realtime", C.c_bool), ("print_timestamps", C.c_bool), ("token_timestamps", C.c_bool),
+        ("thold_pt", C.c_float), ("thold_ptsum", C.c_float), ("max_len", C.c_int), ("split_on_word", C.c_bool), ("max_tokens", C.c_int),
+        ("speed_up", C.c_bool), ("debug_mode", C.c_bool), ("audio_ctx", C.c_int), ("tdrz_enable", C.c_bool), ("initial_prompt", C.c_char_p),
+        ("prompt_tokens", C.c_void_p), ("prompt_n_tokens", C.c_int), ("language", C.c_char_p), ("detect_language", C.c_bool),
+        ("suppress_blank", C.c_bool), ("suppress_non_speech_tokens", C.c_bool), ("temperature", C.c_float), ("max_initial_ts", C.c_float),
+        ("length_penalty", C.c_float), ("temperature_inc", C.c_float), ("entropy_thold", C.c_float), ("logprob_thold", C.c_float),
+        ("no_speech_thold", C.c_float), ("greedy_best_of", C.c_int), ("beam_size", C.c_int), ("beam_patience", C.c_float),
+        ("new_segment_callback", C.c_void_p), ("new_segment_callback_user_data", C.c_void_p), ("progress_callback", C.c_void_p),
+        ("progress_callback_user_data", C.c_void_p), ("encoder_begin_callback", C.c_void_p), ("encoder_begin_callback_user_data", C.c_void_p),
+        ("abort_callback", C.c_void_p), ("abort_callback_user_data", C.c_void_p), ("logits_filter_callback", C.c_void_p),
+        ("logits_filter_callback_user_data", C.c_void_p), ("grammar_rules", C.c_void_p), ("n_grammar_rules", C.c_size_t),
+        ("i_start_rule", C.c_size_t), ("grammar_penalty", C.c_float),
+    ]
+
+
+class WCtxParams(C.Structure):
+    _fields_ = [("use_gpu", C.c_bool)]
+
+
+def test_whisper_h_shim_matches_native_api(toy_ml_path, eng, monkeypatch):
+    """The call sequence of /root/reference/src/asr/whisper.rs (new -> create_state -> build_params -> full -> segment getters)."""
+    from speaksense_amd import binding
+    monkeypatch.setenv("SS_DTYPE", "f16")
+    monkeypatch.setenv("SS_MAX_BATCH", "2")
+    L = C.CDLL(binding.LIB_PATH)
+    L.whisper_context_default_params.restype = WCtxParams
+    L.whisper_init_from_file_with_params_no_state.restype = C.c_void_p
+    L.whisper_init_from_file_with_params_no_state.argtypes = [C.c_char_p, WCtxParams]
+    L.whisper_init_state.restype = C.c_void_p
+    L.whisper_init_state.argtypes = [C.c_void_p]
+    L.whisper_full_default_params.restype = WFullParams
+    L.whisper_full_default_params.argtypes = [C.c_int]
+    L.whisper_full_with_state.argtypes = [C.c_void_p, C.c_void_p, WFullParams, C.c_void_p, C.c_int]
+    L.whisper_full_n_segments_from_state.argtypes = [C.c_void_p]
+    L.whisper_full_get_segment_text_from_state.restype = C.c_char_p
+    L.whisper_full_get_segment_text_from_state.argtypes = [C.c_void_p, C.c_int]
+    for f in ("t0", "t1"):
+        fn = getattr(L, f"whisper_full_get_segment_{f}_from_state")
+        fn.restype = C.c_int64
+        fn.argtypes = [C.c_void_p, C.c_int]
+    L.whisper_full_get_segment_speaker_turn_next_from_state.restype = C.c_bool
+    L.whisper_full_get_segment_speaker_turn_next_from_state.argtypes = [C.c_void_p, C.c_int]
+    L.whisper_free_state.argtypes = [C.c_void_p]
+    L.whisper_free.argtypes = [C.c_void_p]
+
+    ctx = L.whisper_init_from_file_with_params_no_state(toy_ml_path.encode(), L.whisper_context_default_params())
+    assert ctx
+    st = L.whisper_init_state(ctx)
+    assert st
+    p = L.whisper_full_default_params(0)   # WHISPER_SAMPLING_GREEDY
+    assert p.greedy_best_of == 5 and p.no_context and abs(p.temperature_inc - 0.2) < 1e-7 and p.language == b"en"
+    # build_params (whisper.rs:131-173) + stream mode (65-69) + language
+    p.n_threads = 16; p.audio_ctx = 1500; p.print_realtime = True; p.print_timestamps = True; p.single_segment = False
+    p.print_progress = True; p.print_special = False; p.suppress_non_speech_tokens = False; p.max_initial_ts = 1.0
+    p.no_context = False; p.token_timestamps = True; p.split_on_word = True; p.temperature = 0.0; p.entropy_thold = 2.4
+    p.logprob_thold = -1.0; p.no_speech_thold = 0.6; p.max_len = 0; p.max_tokens = 0; p.speed_up = False
+    p.thold_pt = 0.01; p.thold_ptsum = 0.01; p.length_penalty = -1.0
+    p.language = b"zh"
+    p.single_segment = False; p.no_context = True; p.audio_ctx = 0
+    p.temperature_inc = 0.0   # keep this comparison deterministic (no sampled fallback)
+    pcm = synth.speech_like(21)
+    rc = L.whisper_full_with_state(ctx, st, p, pcm.ctypes.data_as(C.c_void_p), len(pcm))
+    assert rc == 0
+    ref = eng.new_session().transcribe(pcm, binding.default_params(language="zh", temperature_inc=0.0))
+    n = L.whisper_full_n_segments_from_state(st)
+    assert n == len(ref["segments"]) and n > 0
+    for i, s in enumerate(ref["segments"]):
+        assert L.whisper_full_get_segment_text_from_state(st, i) == s["text"]
+        assert L.whisper_full_get_segment_t0_from_state(st, i) == s["t0"]
+        assert L.whisper_full_get_segment_t1_from_state(st, i) == s["t1"]
+        assert L.whisper_full_get_segment_speaker_turn_next_from_state(st, i) == s["speaker_turn_next"]
+    # features this path does not implement are refused, not ignored
+    q = L.whisper_full_default_params(1)   # beam search
+    q.language = b"en"
+    assert L.whisper_full_with_state(ctx, st, q, pcm.ctypes.data_as(C.c_void_p), len(pcm)) == -9
+    L.whisper_free_state(st)
+    L.whisper_free(ctx)
