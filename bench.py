@@ -231,7 +231,7 @@ def main():
                        "chunks_per_step": n_gpus * args.batch, "parallelism": f"dp{n_gpus} (independent chunks, no collective)"},
             "p50_chunk_latency_ms": round(1e3 * float(np.median(per)), 2),
             "phase_ms": {"mel": round(float(np.mean([t["mel_ms"] for t in tl])), 3), "encode_cross_kv": round(enc_ms, 2), "decode": round(dec_ms, 2)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel (encoder FC1: M=batch*1500, N=4d, K=d, fused bias+GELU)",
+            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel<T, EPI_GELU_T> (encoder FC1: M=batch*1500, N=4d, K=d, fused bias+GELU)",
                          "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                          "traffic": pmc_traffic(args.model, args.batch, args.dtype), "algorithmic_bytes": 2.0 * (args.batch * hp.n_audio_ctx * hp.n_audio_state + 4 * hp.n_audio_state * hp.n_audio_state + 4 * args.batch * hp.n_audio_ctx * hp.n_audio_state),
                          "avg_launch_ms": round(gemm_ms, 4)},
