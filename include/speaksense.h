@@ -40,7 +40,7 @@ enum {
 
 typedef struct ss_engine_opts {
     int32_t device;       /* HIP device ordinal (one engine per GPU; one process per GPU under torchrun) */
-    int32_t dtype;        /* SS_DTYPE_BF16 (default) | SS_DTYPE_F16: MFMA operand / KV-cache type, f32 accumulate */
+    int32_t dtype;        /* SS_DTYPE_F16 (ggml's arithmetic type: the parity configuration; used when opts == NULL) | SS_DTYPE_BF16 */
     int32_t max_batch;    /* windows encoded+decoded together on the device (default 8) */
     int32_t max_decoders; /* decoders per window at temperature > 0 (reference: Greedy{best_of:5}, whisper.rs:132) */
     int32_t batch_wait_us;/* how long the batch former waits for more chunks before launching a partial batch */
@@ -58,7 +58,7 @@ typedef struct ss_params {
     float logprob_thold;      /* -1.0 */
     float max_initial_ts;     /* 1.0 */
     float length_penalty;     /* -1.0 */
-    int32_t no_context;       /* 1 in stream mode (both reference callers); 0 is SS_ERR_UNSUPPORTED for now */
+    int32_t no_context;       /* 1 in stream mode (both reference callers); 0 keeps the session's prompt_past across calls */
     int32_t single_segment;   /* 0 */
     int32_t no_timestamps;    /* 0 */
     int32_t suppress_blank;   /* 1 */
@@ -119,6 +119,18 @@ int ss_session_decode(ss_session* s, const int32_t* tokens, int32_t n_tokens, in
  * hist: tokens sampled so far in this window.  out6: id, p, plog, tid, pt, ptsum. */
 int ss_process_logits(ss_engine* e, const float* raw_logits, const int32_t* hist, int32_t n_hist, int32_t has_ts,
                       int32_t seek_delta, const ss_params* params, float out6[6]);
+
+/* ---- audio pre-stage (SURVEY.md §8f "next" #1) ------------------------------------------------------ */
+/* `denoise_audio(samples, &DenoiseConfig)` of /root/reference/src/audio/mod.rs:507-523 (the call the gRPC handler makes at
+ * src/grpc/handlers/asr.rs:196 and the stream pre-processor at mod.rs:133-134) on the engine's GPU.  Same semantics incl. the
+ * unnormalised inverse FFT and the x10 gain.  frame_size must be 2048 (the default); n >= 2048 (the reference panics below).
+ * force_type: -1 = decide as the reference does; 0/1/2 force Stationary/NonStationary/Mixed (tests). */
+typedef struct ss_denoise_config {   /* DenoiseConfig, mod.rs:41-48 */
+    int32_t frame_size; float overlap; float strength; float noise_gate; int32_t enable_noise_reduction; float threshold;
+} ss_denoise_config;
+void ss_default_denoise_config(ss_denoise_config* c);
+int ss_denoise_audio(ss_engine* e, const float* pcm, int32_t n_samples, const ss_denoise_config* cfg, int32_t force_type, float* out,
+                     int32_t* noise_type, float* norm_var, float* device_ms);
 
 /* ---- timing hooks for bench.py (HIP events on the engine's own stream) ------------------------------ */
 /* ms spent in the phases of the last ss_transcribe_batch: [0] mel, [1] encoder+cross-KV, [2] decode, [3] total */

@@ -71,7 +71,7 @@ def add_punctuation(text: str) -> str:  # whisper.rs:175-201
 class WhisperAsr:
     """`WhisperAsr::new(model_path)` (whisper.rs:21-28) -- loads the ggml model onto one MI355X."""
 
-    def __init__(self, model_path: str, device: int = 0, dtype: int = binding.DTYPE_BF16, max_batch: int = 8):
+    def __init__(self, model_path: str, device: int = 0, dtype: int = binding.DTYPE_F16, max_batch: int = 8):
         try:
             self.engine = binding.Engine(model_path, device=device, dtype=dtype, max_batch=max_batch)
         except binding.SpeakSenseError as e:

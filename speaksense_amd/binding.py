@@ -27,6 +27,11 @@ class Params(C.Structure):
                 ("fixed_steps", C.c_int32), ("language", C.c_char * 8)]
 
 
+class DenoiseConfig(C.Structure):   # DenoiseConfig, /root/reference/src/audio/mod.rs:41-61
+    _fields_ = [("frame_size", C.c_int32), ("overlap", C.c_float), ("strength", C.c_float), ("noise_gate", C.c_float),
+                ("enable_noise_reduction", C.c_int32), ("threshold", C.c_float)]
+
+
 class SpeakSenseError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"speaksense error {code}: {msg}")
@@ -72,6 +77,8 @@ def lib():
         L.ss_session_set_encoder.argtypes = [vp, f32p]
         L.ss_session_decode.argtypes = [vp, vp, i32, i32, f32p]
         L.ss_process_logits.argtypes = [vp, f32p, vp, i32, i32, i32, C.POINTER(Params), f32p]
+        L.ss_default_denoise_config.argtypes = [C.POINTER(DenoiseConfig)]
+        L.ss_denoise_audio.argtypes = [vp, f32p, i32, C.POINTER(DenoiseConfig), i32, f32p, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.ss_engine_last_timing.argtypes = [vp, f32p]
         L.ss_engine_probe_gemm.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_double)]
         _LIB = L
@@ -98,7 +105,7 @@ def default_params(**kw) -> Params:
 
 
 class Engine:
-    def __init__(self, model_path: str, device: int = 0, dtype: int = DTYPE_BF16, max_batch: int = 8, max_decoders: int = 5,
+    def __init__(self, model_path: str, device: int = 0, dtype: int = DTYPE_F16, max_batch: int = 8, max_decoders: int = 5,
                  batch_wait_us: int = 2000):
         self.L = lib()
         o = EngineOpts(device, dtype, max_batch, max_decoders, batch_wait_us)
@@ -168,6 +175,15 @@ class Engine:
             on_dev = 0
         _check(self.L.ss_transcribe_batch(self.h, sh, pp, nn, n, C.byref(params) if params is not None else None, on_dev))
         return [s.result() for s in sessions]
+
+    def denoise_audio(self, samples, config: "DenoiseConfig | None" = None, force_type: int = -1):
+        """`denoise_audio(samples, &config)` (src/audio/mod.rs:507) -> (out, noise_type, normalized_variance, device_ms)."""
+        x = np.ascontiguousarray(samples, np.float32)
+        out = np.empty_like(x)
+        nt, nv, ms = C.c_int32(), C.c_float(), C.c_float()
+        _check(self.L.ss_denoise_audio(self.h, _p(x), len(x), C.byref(config) if config is not None else None, force_type, _p(out),
+                                       C.byref(nt), C.byref(nv), C.byref(ms)))
+        return out, nt.value, nv.value, ms.value
 
     def last_timing(self):
         t = np.zeros(4, np.float32)

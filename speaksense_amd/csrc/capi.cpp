@@ -34,6 +34,7 @@ int ss_engine_create(const char* path, const ss_engine_opts* opts, ss_engine** o
     if (!path || !out) return fail(SS_ERR_ARG, "ss_engine_create: null argument");
     *out = nullptr;
     ss_engine_opts o{};
+    o.dtype = SS_DTYPE_F16;
     if (opts) o = *opts;
     if (o.max_batch <= 0) o.max_batch = 8;
     if (o.max_decoders <= 0) o.max_decoders = 5;
@@ -172,6 +173,22 @@ int ss_engine_last_timing(const ss_engine* e, float out_ms[4]) {
     if (!e || !out_ms) return fail(SS_ERR_ARG, "null argument");
     memcpy(out_ms, e->e->last_ms, 16);
     return SS_OK;
+}
+void ss_default_denoise_config(ss_denoise_config* c) {
+    // DenoiseConfig::default (/root/reference/src/audio/mod.rs:50-61)
+    c->frame_size = 2048; c->overlap = 0.75f; c->strength = 0.2f; c->noise_gate = 0.003f; c->enable_noise_reduction = 1; c->threshold = 0.002f;
+}
+int ss_denoise_audio(ss_engine* e, const float* pcm, int32_t n, const ss_denoise_config* cfg, int32_t force_type, float* out, int32_t* noise_type,
+                     float* norm_var, float* device_ms) {
+    if (!e || !pcm || !out || n <= 0) return fail(SS_ERR_ARG, "ss_denoise_audio: bad argument");
+    ss_denoise_config c;
+    if (cfg) c = *cfg; else ss_default_denoise_config(&c);
+    SS_TRY
+    int nt = 0;
+    e->e->denoise_host(pcm, n, c, force_type, out, &nt, norm_var, device_ms);
+    if (noise_type) *noise_type = nt;
+    return SS_OK;
+    SS_CATCH
 }
 int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_ms, double* flops) {
     if (!e || !avg_ms || !flops || reps <= 0) return fail(SS_ERR_ARG, "bad argument");

@@ -915,6 +915,67 @@ struct EngineT : EngineBase {
         out6[0] = (float)samp_h[0].id; out6[1] = samp_h[0].p; out6[2] = samp_h[0].plog; out6[3] = (float)samp_h[0].tid;
         out6[4] = samp_h[0].pt; out6[5] = samp_h[0].ptsum;
     }
+    // ------------------------------------------------------------------------------------------
+    // STFT denoiser: denoise_audio of /root/reference/src/audio/mod.rs:507-523
+    // ------------------------------------------------------------------------------------------
+    DBuf dn_in, dn_mid, dn_out, dn_power, dn_noise, dn_signal, dn_var, dn_frames, dn_tw;
+    void dn_estimates(const float* x, int n, std::vector<float>* var_h) {
+        const int n_chunks = n / 2048;
+        dn_power.ensure((size_t)std::max(1, n_chunks) * 2048 * 4); dn_noise.ensure(2048 * 4); dn_signal.ensure(2048 * 4);
+        dn_var.ensure((size_t)std::max(1, n_chunks) * 4);
+        launch_dn_chunk_power(x, n_chunks, dn_tw.as<float2>(), dn_power.as<float>(), st);
+        launch_dn_spectra(dn_power.as<float>(), n_chunks, dn_noise.as<float>(), dn_signal.as<float>(), dn_var.as<float>(), st);
+        if (var_h) {
+            var_h->assign(std::max(0, n_chunks - 1), 0.f);
+            if (n_chunks > 1) SS_HIP(hipMemcpyAsync(var_h->data(), dn_var.p, (size_t)(n_chunks - 1) * 4, hipMemcpyDeviceToHost, st));
+            SS_HIP(hipStreamSynchronize(st));
+        }
+    }
+    void dn_pass(int mode, const float* x, int n, int step, float strength, float* y) {
+        const int n_frames = (n - 2048) / step + 1;
+        dn_frames.ensure((size_t)n_frames * 2048 * 4);
+        launch_dn_frames(mode, x, n_frames, step, dn_tw.as<float2>(), dn_noise.as<float>(), dn_signal.as<float>(), strength, dn_frames.as<float>(), st);
+        launch_dn_overlap_add(dn_frames.as<float>(), n_frames, step, n, y, st);
+    }
+    void denoise_host(const float* pcm, int n, const ss_denoise_config& cfg, int force_type, float* out, int* noise_type, float* norm_var, float* ms) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        if (cfg.frame_size != 2048) throw Error(SS_ERR_UNSUPPORTED, "denoise: only frame_size 2048 (the reference default) is implemented");
+        if (n < 2048) throw Error(SS_ERR_ARG, "denoise: fewer samples than one frame (the reference panics in overlap_add)");
+        const int step = (int)(2048.0f * (1.0f - cfg.overlap));
+        if (step < 1 || step > 2048) throw Error(SS_ERR_ARG, "denoise: bad overlap");
+        if (!dn_tw.p) {
+            std::vector<float> tw(2048);
+            for (int k = 0; k < 1024; k++) { tw[2 * k] = (float)cos(-2.0 * M_PI * k / 2048.0); tw[2 * k + 1] = (float)sin(-2.0 * M_PI * k / 2048.0); }
+            dn_tw.alloc(2048 * 4);
+            SS_HIP(hipMemcpy(dn_tw.p, tw.data(), 2048 * 4, hipMemcpyHostToDevice));
+        }
+        dn_in.ensure((size_t)n * 4); dn_mid.ensure((size_t)n * 4); dn_out.ensure((size_t)n * 4);
+        SS_HIP(hipMemcpyAsync(dn_in.p, pcm, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        SS_HIP(hipEventRecord(ev[0], st));
+        // analyze_noise_characteristics (mod.rs:533-579): sum over consecutive chunk pairs of mean squared spectral difference / n
+        std::vector<float> var_h;
+        dn_estimates(dn_in.as<float>(), n, &var_h);
+        float sv = 0.f;
+        for (float v : var_h) sv += v;
+        const float nv = sv / (float)n;
+        int nt = nv < 0.1f ? 0 : (nv > 0.5f ? 1 : 2);
+        if (force_type >= 0 && force_type <= 2) nt = force_type;
+        if (nt == 0) dn_pass(0, dn_in.as<float>(), n, step, cfg.strength, dn_out.as<float>());
+        else if (nt == 1) dn_pass(1, dn_in.as<float>(), n, step, cfg.strength, dn_out.as<float>());
+        else {
+            dn_pass(0, dn_in.as<float>(), n, step, cfg.strength, dn_mid.as<float>());
+            dn_estimates(dn_mid.as<float>(), n, nullptr);   // the Wiener stage estimates its spectra from ITS input
+            dn_pass(1, dn_mid.as<float>(), n, step, cfg.strength, dn_out.as<float>());
+        }
+        SS_HIP(hipEventRecord(ev[1], st));
+        SS_HIP(hipMemcpyAsync(out, dn_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(hipStreamSynchronize(st));
+        if (noise_type) *noise_type = nt;
+        if (norm_var) *norm_var = nv;
+        if (ms) SS_HIP(hipEventElapsedTime(ms, ev[0], ev[1]));
+    }
+
     void probe_gemm(int batch, int reps, float* avg_ms, double* flops) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));

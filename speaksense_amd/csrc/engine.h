@@ -51,6 +51,7 @@ struct EngineBase {
     virtual void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out) = 0;
     virtual void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6]) = 0;
     virtual void probe_gemm(int batch, int reps, float* avg_ms, double* flops) = 0;
+    virtual void denoise_host(const float* pcm, int n, const ss_denoise_config& cfg, int force_type, float* out, int* noise_type, float* norm_var, float* ms) = 0;
 
     // async batch former
     std::thread worker;

@@ -154,4 +154,14 @@ struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t pad[2]; };
 void launch_logits_rules(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, SampleOut* out, float* probs /* [M][ld] or null */,
                          float* scratch, hipStream_t st);
 
+// ---------------------------------------------------------------------------------------------
+// STFT denoiser, frame size 2048 (kernels_denoise.hip) -- SURVEY.md §8f next #1
+// ---------------------------------------------------------------------------------------------
+void launch_dn_chunk_power(const float* x, int n_chunks, const float2* tw, float* power, hipStream_t st);
+void launch_dn_spectra(const float* power, int n_chunks, float* noise, float* signal, float* var_out, hipStream_t st);
+void launch_dn_frames(int mode, const float* x, int n_frames, int step, const float2* tw, const float* noise, const float* signal, float strength,
+                      float* frames_out, hipStream_t st);
+void launch_dn_overlap_add(const float* frames, int n_frames, int step, int n, float* out, hipStream_t st);
+void launch_dn_noise_gate(const float* in, float* out, int n, float gate, hipStream_t st);
+
 }  // namespace ss
