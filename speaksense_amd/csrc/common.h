@@ -24,6 +24,13 @@ struct Error : std::runtime_error {
             throw ss::Error(-4, std::string(#expr) + ": " + hipGetErrorString(_e) + " @" + __FILE__ + ":" + std::to_string(__LINE__)); \
     } while (0)
 
+// after every kernel launch: a bad launch configuration must fail loudly, not leave stale outputs behind
+#define SS_LAUNCH_CHECK()                                                                                    \
+    do {                                                                                                     \
+        hipError_t _e = hipGetLastError();                                                                   \
+        if (_e != hipSuccess) throw ss::Error(-4, std::string("kernel launch failed: ") + hipGetErrorString(_e) + " @" + __FILE__ + ":" + std::to_string(__LINE__)); \
+    } while (0)
+
 // ggml legacy header; field order is the file order
 struct HParams {
     int32_t n_vocab, n_audio_ctx, n_audio_state, n_audio_head, n_audio_layer;

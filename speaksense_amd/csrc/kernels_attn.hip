@@ -178,13 +178,13 @@ void launch_enc_attention(const T* q, const T* k, long ld, const T* vT, int Tpad
     static const int qt = getenv("SS_ATTN_QT") ? atoi(getenv("SS_ATTN_QT")) : 3;
     if (qt == 4) {
         dim3 grid(((Tn + 255) / 256) * H * B);
-        enc_attn_kernel<T, 4><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn);
+        enc_attn_kernel<T, 4><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn); SS_LAUNCH_CHECK();
     } else if (qt == 3) {
         dim3 grid(((Tn + 191) / 192) * H * B);
-        enc_attn_kernel<T, 3><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn);
+        enc_attn_kernel<T, 3><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn); SS_LAUNCH_CHECK();
     } else {
         dim3 grid(((Tn + 127) / 128) * H * B);
-        enc_attn_kernel<T, 2><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn);
+        enc_attn_kernel<T, 2><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn); SS_LAUNCH_CHECK();
     }
 }
 template void launch_enc_attention<bf16>(const bf16*, const bf16*, long, const bf16*, int, bf16*, long, int, int, int, hipStream_t);
@@ -279,7 +279,7 @@ template <typename T>
 void launch_dec_self_attention(const T* q, const T* kcache, const T* vcache, long slot_stride, int d, int H, const RowCtl* ctl, int M, T* out,
                                hipStream_t st) {
     dim3 grid(H, M);
-    dec_self_attn_kernel<T><<<grid, 64, 0, st>>>(q, kcache, vcache, slot_stride, d, ctl, out);
+    dec_self_attn_kernel<T><<<grid, 64, 0, st>>>(q, kcache, vcache, slot_stride, d, ctl, out); SS_LAUNCH_CHECK();
 }
 template void launch_dec_self_attention<bf16>(const bf16*, const bf16*, const bf16*, long, int, int, const RowCtl*, int, bf16*, hipStream_t);
 template void launch_dec_self_attention<f16>(const f16*, const f16*, const f16*, long, int, int, const RowCtl*, int, f16*, hipStream_t);
@@ -389,12 +389,12 @@ void launch_dec_cross_attention(const T* q, const T* kc, const T* vc, long b_str
                                 T* out, hipStream_t st) {
     if ((Tn + kCrossSplit - 1) / kCrossSplit > 512) throw Error(-1, "cross attention: n_audio_ctx too large");
     dim3 grid(kCrossSplit, H, M);
-    dec_cross_attn_kernel<T><<<grid, 256, 0, st>>>(q, kc, vc, b_stride, d, H, Tn, ctl, scratch);
-    dec_cross_combine_kernel<T><<<M, 256, 0, st>>>(scratch, d, H, out);
+    dec_cross_attn_kernel<T><<<grid, 256, 0, st>>>(q, kc, vc, b_stride, d, H, Tn, ctl, scratch); SS_LAUNCH_CHECK();
+    dec_cross_combine_kernel<T><<<M, 256, 0, st>>>(scratch, d, H, out); SS_LAUNCH_CHECK();
 }
 template <typename T>
 void launch_dec_cross_combine(const float* scratch, int d, int H, int M, T* out, hipStream_t st) {
-    dec_cross_combine_kernel<T><<<M, 256, 0, st>>>(scratch, d, H, out);
+    dec_cross_combine_kernel<T><<<M, 256, 0, st>>>(scratch, d, H, out); SS_LAUNCH_CHECK();
 }
 template void launch_dec_cross_combine<bf16>(const float*, int, int, int, bf16*, hipStream_t);
 template void launch_dec_cross_combine<f16>(const float*, int, int, int, f16*, hipStream_t);

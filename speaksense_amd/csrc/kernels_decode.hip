@@ -257,7 +257,7 @@ static void launch_dg2(const DecGemvDesc& g, int NW, hipStream_t st) {
     static bool attr = false;
     if (!attr) { SS_HIP(hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     dim3 grid((g.N + 15) / 16, g.S);
-    dec_gemv_kernel<T, PRO, EPI, NI><<<grid, NW * 64, lds, st>>>(g);
+    dec_gemv_kernel<T, PRO, EPI, NI><<<grid, NW * 64, lds, st>>>(g); SS_LAUNCH_CHECK();
 }
 template <typename T, int PRO, int EPI>
 static void launch_dg(const DecGemvDesc& g, int NW, hipStream_t st) {
@@ -293,9 +293,9 @@ void dec_gemv_plan(int N, int K, int* S_out, int* NW_out, bool whole_heads) {
 template <typename T>
 void launch_dec_reduce_ln(const DecGemvDesc& g, T* out, hipStream_t st) {
     if (g.K > 2048 || g.n_parts > 4) throw Error(-1, "dec_reduce_ln: bad shape");
-    if (g.K <= 512) dec_reduce_ln_kernel<T, 2><<<g.M, 64, 0, st>>>(g, out);
-    else if (g.K <= 1280) dec_reduce_ln_kernel<T, 5><<<g.M, 64, 0, st>>>(g, out);
-    else dec_reduce_ln_kernel<T, 8><<<g.M, 64, 0, st>>>(g, out);
+    if (g.K <= 512) { dec_reduce_ln_kernel<T, 2><<<g.M, 64, 0, st>>>(g, out); SS_LAUNCH_CHECK(); }
+    else if (g.K <= 1280) { dec_reduce_ln_kernel<T, 5><<<g.M, 64, 0, st>>>(g, out); SS_LAUNCH_CHECK(); }
+    else { dec_reduce_ln_kernel<T, 8><<<g.M, 64, 0, st>>>(g, out); SS_LAUNCH_CHECK(); }
 }
 template void launch_dec_reduce_ln<bf16>(const DecGemvDesc&, bf16*, hipStream_t);
 template void launch_dec_reduce_ln<f16>(const DecGemvDesc&, f16*, hipStream_t);
@@ -437,7 +437,7 @@ void launch_dec_cross_attention_q(const float* qpart, int n_qpart, const float* 
                                   int Tn, const RowCtl* ctl, int M, float* scratch, hipStream_t st) {
     if ((Tn + kCrossSplitD - 1) / kCrossSplitD > 512) throw Error(-1, "cross attention: n_audio_ctx too large");
     dim3 grid(kCrossSplitD, H, M);
-    dec_cross_attn_q_kernel<T><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch);
+    dec_cross_attn_q_kernel<T><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch); SS_LAUNCH_CHECK();
 }
 template void launch_dec_cross_attention_q<bf16>(const float*, int, const float*, float, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int,
                                                  float*, hipStream_t);

@@ -130,22 +130,22 @@ __global__ void dn_noise_gate_kernel(const float* __restrict__ in, float* __rest
 }  // namespace
 
 void launch_dn_chunk_power(const float* x, int n_chunks, const float2* tw, float* power, hipStream_t st) {
-    if (n_chunks > 0) dn_chunk_power_kernel<<<n_chunks, kThreads, 0, st>>>(x, tw, power);
+    if (n_chunks > 0) { dn_chunk_power_kernel<<<n_chunks, kThreads, 0, st>>>(x, tw, power); SS_LAUNCH_CHECK(); }
 }
 void launch_dn_spectra(const float* power, int n_chunks, float* noise, float* signal, float* var_out, hipStream_t st) {
-    dn_spectra_kernel<<<kFs / 256, 256, 0, st>>>(power, n_chunks, noise, signal);
-    if (n_chunks > 1) dn_variance_kernel<<<n_chunks - 1, kThreads, 0, st>>>(power, var_out);
+    dn_spectra_kernel<<<kFs / 256, 256, 0, st>>>(power, n_chunks, noise, signal); SS_LAUNCH_CHECK();
+    if (n_chunks > 1) { dn_variance_kernel<<<n_chunks - 1, kThreads, 0, st>>>(power, var_out); SS_LAUNCH_CHECK(); }
 }
 void launch_dn_frames(int mode, const float* x, int n_frames, int step, const float2* tw, const float* noise, const float* signal, float strength,
                       float* frames_out, hipStream_t st) {
-    if (mode == 0) dn_frame_kernel<0><<<n_frames, kThreads, 0, st>>>(x, step, tw, noise, signal, strength, frames_out);
-    else dn_frame_kernel<1><<<n_frames, kThreads, 0, st>>>(x, step, tw, noise, signal, strength, frames_out);
+    if (mode == 0) { dn_frame_kernel<0><<<n_frames, kThreads, 0, st>>>(x, step, tw, noise, signal, strength, frames_out); SS_LAUNCH_CHECK(); }
+    else { dn_frame_kernel<1><<<n_frames, kThreads, 0, st>>>(x, step, tw, noise, signal, strength, frames_out); SS_LAUNCH_CHECK(); }
 }
 void launch_dn_overlap_add(const float* frames, int n_frames, int step, int n, float* out, hipStream_t st) {
-    dn_overlap_add_kernel<<<(n + 255) / 256, 256, 0, st>>>(frames, n_frames, step, n, out);
+    dn_overlap_add_kernel<<<(n + 255) / 256, 256, 0, st>>>(frames, n_frames, step, n, out); SS_LAUNCH_CHECK();
 }
 void launch_dn_noise_gate(const float* in, float* out, int n, float gate, hipStream_t st) {
-    dn_noise_gate_kernel<<<(n + 255) / 256, 256, 0, st>>>(in, out, n, gate);
+    dn_noise_gate_kernel<<<(n + 255) / 256, 256, 0, st>>>(in, out, n, gate); SS_LAUNCH_CHECK();
 }
 
 }  // namespace ss

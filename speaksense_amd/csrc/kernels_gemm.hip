@@ -436,11 +436,11 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
             attr256 = true;
         }
         const int nwg256 = (g.N / TN) * ((g.M + TM - 1) / TM);
-        gemm256_kernel<T, KIND><<<nwg256, 512, kGemm256Lds, st>>>(g);
+        gemm256_kernel<T, KIND><<<nwg256, 512, kGemm256Lds, st>>>(g); SS_LAUNCH_CHECK();
         return;
     }
     const int nwg = (g.N / BN) * ((g.M + BM - 1) / BM);
-    gemm_kernel<T, KIND><<<nwg, 256, kGemmLds, st>>>(g);
+    gemm_kernel<T, KIND><<<nwg, 256, kGemmLds, st>>>(g); SS_LAUNCH_CHECK();
 }
 
 template <typename T>
@@ -549,10 +549,10 @@ __global__ __launch_bounds__(256) void skinny_kernel(SkinnyDesc g) {
 template <typename T, int KIND>
 static void launch_skinny_kind(const SkinnyDesc& g, hipStream_t st) {
     const int blocks = (g.N + 15) / 16;
-    if (g.M <= 16) skinny_kernel<T, KIND, 1><<<blocks, 256, 0, st>>>(g);
-    else if (g.M <= 32) skinny_kernel<T, KIND, 2><<<blocks, 256, 0, st>>>(g);
-    else if (g.M <= 48) skinny_kernel<T, KIND, 3><<<blocks, 256, 0, st>>>(g);
-    else skinny_kernel<T, KIND, 4><<<blocks, 256, 0, st>>>(g);
+    if (g.M <= 16) { skinny_kernel<T, KIND, 1><<<blocks, 256, 0, st>>>(g); SS_LAUNCH_CHECK(); }
+    else if (g.M <= 32) { skinny_kernel<T, KIND, 2><<<blocks, 256, 0, st>>>(g); SS_LAUNCH_CHECK(); }
+    else if (g.M <= 48) { skinny_kernel<T, KIND, 3><<<blocks, 256, 0, st>>>(g); SS_LAUNCH_CHECK(); }
+    else { skinny_kernel<T, KIND, 4><<<blocks, 256, 0, st>>>(g); SS_LAUNCH_CHECK(); }
 }
 
 template <typename T>

@@ -161,17 +161,17 @@ void launch_log_mel(const MelTables& mt, const float* pcm, int n_samples, float*
     // frames whose 400-sample window starts at or beyond the end of the audio (offset >= 200 + n) are all-zero
     int n_active = (200 + n_samples + kHop - 1) / kHop;
     if (n_active > n_len) n_active = n_len;
-    mel_frame_kernel<<<n_len, kFrameThreads, 0, st>>>(mt, pcm, n_samples, mel_out, n_len, n_active, scratch);
+    mel_frame_kernel<<<n_len, kFrameThreads, 0, st>>>(mt, pcm, n_samples, mel_out, n_len, n_active, scratch); SS_LAUNCH_CHECK();
     const size_t n = (size_t)mt.n_mel * n_len;
     int blocks = (int)((n + 255) / 256);
     if (blocks > 1024) blocks = 1024;
-    mel_norm_kernel<<<blocks, 256, 0, st>>>(mel_out, n, scratch, n_len);
+    mel_norm_kernel<<<blocks, 256, 0, st>>>(mel_out, n, scratch, n_len); SS_LAUNCH_CHECK();
 }
 
 template <typename T>
 void launch_mel_window(const float* mel, int n_mel, int n_len, int seek, int T2, T* x0, hipStream_t st) {
     dim3 grid((T2 + 31) / 32, (n_mel + 31) / 32);
-    mel_window_kernel<T><<<grid, 256, 0, st>>>(mel, n_mel, n_len, seek, T2, x0);
+    mel_window_kernel<T><<<grid, 256, 0, st>>>(mel, n_mel, n_len, seek, T2, x0); SS_LAUNCH_CHECK();
 }
 template void launch_mel_window<bf16>(const float*, int, int, int, int, bf16*, hipStream_t);
 template void launch_mel_window<f16>(const float*, int, int, int, int, f16*, hipStream_t);

@@ -63,9 +63,9 @@ template <typename TO>
 static void launch_ln_any(const float* x, const float* w, const float* b, TO* y, int rows, int d, const int* row_idx, hipStream_t st) {
     if (d > 2048 || d % 4) throw Error(-1, "layernorm: d must be <= 2048 and a multiple of 4");
     const int grid = (rows + 3) / 4;
-    if (d <= 512) layernorm_kernel<TO, 2><<<grid, 256, 0, st>>>(x, w, b, y, rows, d, row_idx);
-    else if (d <= 1280) layernorm_kernel<TO, 5><<<grid, 256, 0, st>>>(x, w, b, y, rows, d, row_idx);
-    else layernorm_kernel<TO, 8><<<grid, 256, 0, st>>>(x, w, b, y, rows, d, row_idx);
+    if (d <= 512) { layernorm_kernel<TO, 2><<<grid, 256, 0, st>>>(x, w, b, y, rows, d, row_idx); SS_LAUNCH_CHECK(); }
+    else if (d <= 1280) { layernorm_kernel<TO, 5><<<grid, 256, 0, st>>>(x, w, b, y, rows, d, row_idx); SS_LAUNCH_CHECK(); }
+    else { layernorm_kernel<TO, 8><<<grid, 256, 0, st>>>(x, w, b, y, rows, d, row_idx); SS_LAUNCH_CHECK(); }
 }
 
 template <typename T>
@@ -92,7 +92,7 @@ __global__ void embed_kernel(const T* __restrict__ te, const float* __restrict__
 }
 template <typename T>
 void launch_embed(const T* te, const float* pe, const RowCtl* ctl, int M, int d, float* x, hipStream_t st) {
-    embed_kernel<T><<<M, 256, 0, st>>>(te, pe, ctl, d, x);
+    embed_kernel<T><<<M, 256, 0, st>>>(te, pe, ctl, d, x); SS_LAUNCH_CHECK();
 }
 template void launch_embed<bf16>(const bf16*, const float*, const RowCtl*, int, int, float*, hipStream_t);
 template void launch_embed<f16>(const f16*, const float*, const RowCtl*, int, int, float*, hipStream_t);
@@ -106,14 +106,14 @@ void launch_f32_to_T(const float* in, T* out, size_t n, hipStream_t st) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    convert_kernel<float, T><<<blocks, 256, 0, st>>>(in, out, n);
+    convert_kernel<float, T><<<blocks, 256, 0, st>>>(in, out, n); SS_LAUNCH_CHECK();
 }
 template <typename T>
 void launch_T_to_f32(const T* in, float* out, size_t n, hipStream_t st) {
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    convert_kernel<T, float><<<blocks, 256, 0, st>>>(in, out, n);
+    convert_kernel<T, float><<<blocks, 256, 0, st>>>(in, out, n); SS_LAUNCH_CHECK();
 }
 template void launch_f32_to_T<bf16>(const float*, bf16*, size_t, hipStream_t);
 template void launch_f32_to_T<f16>(const float*, f16*, size_t, hipStream_t);
@@ -274,9 +274,9 @@ __global__ __launch_bounds__(256) void logits_probs_kernel(const float* __restri
 void launch_logits_rules(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, SampleOut* out, float* probs, float* scratch,
                          hipStream_t st) {
     if ((rc.n_vocab + kRuleSlices - 1) / kRuleSlices > 4 * 256) throw Error(-1, "logits rules: vocabulary too large for the slice plan");
-    logits_rules_scan_kernel<<<dim3(kRuleSlices, M), 256, 0, st>>>(logits, ld, ctl, rc, scratch);
-    logits_rules_pick_kernel<<<M, 64, 0, st>>>(scratch, rc, out);
-    if (probs) logits_probs_kernel<<<dim3(32, M), 256, 0, st>>>(logits, ld, ctl, rc, out, probs);
+    logits_rules_scan_kernel<<<dim3(kRuleSlices, M), 256, 0, st>>>(logits, ld, ctl, rc, scratch); SS_LAUNCH_CHECK();
+    logits_rules_pick_kernel<<<M, 64, 0, st>>>(scratch, rc, out); SS_LAUNCH_CHECK();
+    if (probs) { logits_probs_kernel<<<dim3(32, M), 256, 0, st>>>(logits, ld, ctl, rc, out, probs); SS_LAUNCH_CHECK(); }
 }
 
 }  // namespace ss

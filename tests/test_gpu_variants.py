@@ -217,3 +217,35 @@ def test_whisper_h_shim_matches_native_api(toy_ml_path, eng, monkeypatch):
     assert L.whisper_full_with_state(ctx, st, q, pcm.ctypes.data_as(C.c_void_p), len(pcm)) == -9
     L.whisper_free_state(st)
     L.whisper_free(ctx)
+
+
+# ------------------------------------------------------------------------------------------------
+# the host-side mirror of the reference's AsrEngine (speaksense_amd/asr.py) end to end
+# ------------------------------------------------------------------------------------------------
+def test_whisper_asr_mirror_end_to_end(toy_ml_path, om, orc):
+    """Mirrors the reference's only test that crosses this boundary (test_transcribe_processor,
+    /root/reference/src/schedule/processors/transcribe.rs:248-304: asserts non-empty text and segments), plus what that test
+    could not check: the exact segments, the stream-mode last-segment rule and the punctuation pass."""
+    from speaksense_amd import asr
+    eng = asr.WhisperAsr(toy_ml_path, max_batch=4)
+    pcm = synth.speech_like(3)
+    p = asr.AsrParams(language="zh", stream_mode=True)     # what both reference callers set (transcribe.rs:66-70, asr.rs:154-157)
+    st = eng.create_state()
+    res = eng.transcribe_with_state(st, pcm, p)
+    assert len(res.full_text) > 0 and len(res.segments) == 1           # stream mode keeps only the last segment (whisper.rs:102-111)
+    # same chunk without stream mode: every (non-promotional) segment, texts post-processed by add_punctuation
+    p2 = asr.AsrParams(language="zh", stream_mode=False)
+    res2 = eng.transcribe(pcm, p2)
+    ref = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(language="zh", no_context=0))
+    if ref["n_fail"] == 0:
+        kept = [s for s in ref["segments"] if not asr.is_promotional_text(s["text"].decode())]
+        assert [s.text for s in res2.segments] == [asr.add_punctuation(s["text"].decode()) for s in kept]
+        assert [(s.start, s.end) for s in res2.segments] == [(float(s["t0"]), float(s["t1"])) for s in kept]
+    assert res2.full_text == "".join(s.text for s in res2.segments)
+    assert res.segments[0].text == res.full_text
+    # batched form: identical per-chunk results
+    pcms = [synth.speech_like(70 + i, 16000 * 8) for i in range(3)]
+    single = [eng.transcribe(x, p) for x in pcms]
+    many = eng.transcribe_many([eng.create_state() for _ in pcms], pcms, p)
+    assert [r.full_text for r in many] == [r.full_text for r in single]
+    eng.engine.close()
