@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     const int nfr = kw / 32, npair = nfr / 2;
     T* xs = (T*)smem_d;                                   // [16][kslice + pad]
     const int xld = kslice + kXsPad;
-    float* red = (float*)(smem_d + (size_t)16 * xld * sizeof(T));  // [NW][16][17]
+    float* red = (float*)(smem_d + (PRO == PRO_T ? (size_t)0 : (size_t)16 * xld * sizeof(T)));  // [NW][16][17]
 
     // ---- weight prefetch: lane loads 32 contiguous bytes of its row per MFMA pair ----
     const T* wp = (const T*)g.W + (long)(n0 + frow) * g.K + kbeg + kwb;
@@ -161,16 +161,6 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
                 continue;
             }
             ln_row<T, NI>(g, m, lane, blockIdx.x == 0 && s == 0, kbeg, kslice, xs + m * xld);
-        }
-    } else if constexpr (PRO == PRO_T) {
-        const T* X = (const T*)g.Xt;
-        const int per = kslice / 8;
-#pragma unroll 4
-        for (int idx = tid; idx < 16 * per; idx += blockDim.x) {
-            const int m = idx / per, c8 = idx % per;
-            V8 t = *(const V8*)(X + (long)(m < g.M ? m : 0) * g.ldx + kbeg + c8 * 8);
-            if (m >= g.M) t = V8{};
-            *(V8*)(xs + m * xld + c8 * 8) = t;
         }
     } else if constexpr (PRO == PRO_COMBINE) {
         // flash-decoding combine of the cross-attention partials for the columns of this K slice
@@ -198,22 +188,44 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
             xs[m * xld + cc] = (T)o;
         }
     }
-    __syncthreads();
-
-    // ---- body ----
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const T* xr = xs + frow * xld + kwb;
+    if constexpr (PRO == PRO_T) {
+        // activations: B fragments straight from L2 into VGPRs, issued together with the weight prefetch (no LDS staging,
+        // no barrier before the MFMAs).  Token rows >= M read row 0: MFMA columns are independent and never stored.
+        const T* xg = (const T*)g.Xt + (long)(frow < g.M ? frow : 0) * g.ldx + kbeg + kwb;
+        V8 xf[kMaxFrag];
 #pragma unroll
-    for (int j = 0; j < kMaxFrag / 2; j++) {
-        if (j < npair) {
-            const V8 x0 = *(const V8*)(xr + j * 64 + fg * 16), x1 = *(const V8*)(xr + j * 64 + fg * 16 + 8);
-            acc = MfmaD<T>::mma(wf[2 * j], x0, acc);
-            acc = MfmaD<T>::mma(wf[2 * j + 1], x1, acc);
+        for (int j = 0; j < kMaxFrag / 2; j++) {
+            if (j < npair) {
+                xf[2 * j] = *(const V8*)(xg + j * 64 + fg * 16);
+                xf[2 * j + 1] = *(const V8*)(xg + j * 64 + fg * 16 + 8);
+            }
         }
-    }
-    if (nfr & 1) {
-        const V8 x0 = *(const V8*)(xr + npair * 64 + fg * 8);
-        acc = MfmaD<T>::mma(wtail, x0, acc);
+        V8 xtail = {};
+        if (nfr & 1) xtail = *(const V8*)(xg + npair * 64 + fg * 8);
+#pragma unroll
+        for (int j = 0; j < kMaxFrag / 2; j++) {
+            if (j < npair) {
+                acc = MfmaD<T>::mma(wf[2 * j], xf[2 * j], acc);
+                acc = MfmaD<T>::mma(wf[2 * j + 1], xf[2 * j + 1], acc);
+            }
+        }
+        if (nfr & 1) acc = MfmaD<T>::mma(wtail, xtail, acc);
+    } else {
+        __syncthreads();
+        const T* xr = xs + frow * xld + kwb;
+#pragma unroll
+        for (int j = 0; j < kMaxFrag / 2; j++) {
+            if (j < npair) {
+                const V8 x0 = *(const V8*)(xr + j * 64 + fg * 16), x1 = *(const V8*)(xr + j * 64 + fg * 16 + 8);
+                acc = MfmaD<T>::mma(wf[2 * j], x0, acc);
+                acc = MfmaD<T>::mma(wf[2 * j + 1], x1, acc);
+            }
+        }
+        if (nfr & 1) {
+            const V8 x0 = *(const V8*)(xr + npair * 64 + fg * 8);
+            acc = MfmaD<T>::mma(wtail, x0, acc);
+        }
     }
     // D[n][m]: lane holds n = fg*4 + r, m = frow
 #pragma unroll
@@ -253,7 +265,7 @@ template <typename T, int PRO, int EPI, int NI>
 static void launch_dg2(const DecGemvDesc& g, int NW, hipStream_t st) {
     const int kslice = g.K / g.S;
     size_t red_f = (size_t)NW * 16 * 17, wtab_f = (size_t)16 * (kslice / 64 + 1) * 4;
-    const size_t lds = (size_t)16 * (kslice + kXsPad) * sizeof(T) + (red_f > wtab_f ? red_f : wtab_f) * 4;
+    const size_t lds = (PRO == PRO_T ? 0 : (size_t)16 * (kslice + kXsPad) * sizeof(T)) + (red_f > wtab_f ? red_f : wtab_f) * 4;
     static bool attr = false;
     if (!attr) { SS_HIP(hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     dim3 grid((g.N + 15) / 16, g.S);
