@@ -165,6 +165,7 @@ struct EngineT : EngineBase {
         alloc_workspaces();
         plan_decode();
         use_fused = getenv("SS_DECODE_UNFUSED") == nullptr;
+        cross_direct = getenv("SS_CROSS_DIRECT") != nullptr;
         start_worker();
     }
     ~EngineT() override {
@@ -429,9 +430,14 @@ struct EngineT : EngineBase {
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
             }
             const T* kc = cross.as<T>() + il * cl_stride;
-            launch_dec_cross_attention_q<T>(pq.as<float>(), pl_dd.S, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
-                                            cscratch.as<float>(), st);
-            launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
+            if (cross_direct) {
+                launch_dec_cross_attention_direct<T>(pq.as<float>(), pl_dd.S, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
+                                                     attd.as<T>(), st);
+            } else {
+                launch_dec_cross_attention_q<T>(pq.as<float>(), pl_dd.S, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
+                                                cscratch.as<float>(), st);
+                launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
+            }
             {   // cross out-projection partials
                 DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wco, M, d, d, pl_dd.S);
                 g.Xt = attd.p; g.ldx = d; g.part_out = p2.as<float>();
@@ -519,7 +525,7 @@ struct EngineT : EngineBase {
         if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
     }
     DBuf samp_d, rowidx_d, rules_scratch;
-    bool use_fused = true;
+    bool use_fused = true, cross_direct = false;
 
     RuleConsts rule_consts(const ss_params& P) {
         const Vocab& v = hm.vocab;

@@ -128,6 +128,10 @@ template <typename T>
 void launch_dec_cross_attention(const T* q, const T* kc, const T* vc, long b_stride, int d, int H, int Tn, const RowCtl* ctl, int M,
                                 float* scratch, T* out, hipStream_t st);
 
+// unsplit variant: one workgroup per (row, head) writes the normalised output T [M][d] directly (no partials, no combine launch)
+template <typename T>
+void launch_dec_cross_attention_direct(const float* qpart, int n_qpart, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d,
+                                       int H, int Tn, const RowCtl* ctl, int M, T* out, hipStream_t st);
 // flash-decoding combine of the cross-attention partials: out T [M][d]
 template <typename T> void launch_dec_cross_combine(const float* scratch, int d, int H, int M, T* out, hipStream_t st);
 

@@ -341,18 +341,18 @@ template void launch_dec_gemv<f16>(const DecGemvDesc&, int, hipStream_t);
 // cross-attention with the q projection's split-K reduction in its prologue
 // grid (4 key splits, H, M), 256 threads.  q = round_T((sum_s qpart[s][m][:] + bias) * scale)
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int NSPLIT>
 __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __restrict__ qpart, int n_qpart, const float* __restrict__ qbias, float qscale,
                                                                const T* __restrict__ kc, const T* __restrict__ vc, long b_stride, int d, int H, int Tn,
-                                                               const RowCtl* __restrict__ ctl, float* __restrict__ scratch) {
+                                                               const RowCtl* __restrict__ ctl, float* __restrict__ scratch, T* __restrict__ out_direct) {
     typedef typename MfmaD<T>::V8 V8;
-    __shared__ float s_sc[512 + 128];
+    __shared__ float s_sc[(NSPLIT == 1 ? 1536 : 512) + 128];
     __shared__ float s_red[8];
     __shared__ float s_o[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 3, c = lane & 7;
     const int sp = blockIdx.x, h = blockIdx.y, m = blockIdx.z;
-    const int per = (Tn + kCrossSplitD - 1) / kCrossSplitD;
+    const int per = (Tn + NSPLIT - 1) / NSPLIT;
     const int k_beg = sp * per, k_end = min(Tn, k_beg + per), nk = k_end - k_beg;
     const RowCtl rc = ctl[m];
     const T* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
@@ -439,17 +439,33 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
         for (int e = 0; e < 8; e++) s_o[wave][c * 8 + e] = acc[e];
     }
     __syncthreads();
-    float* part = scratch + ((long)(m * H + h) * kCrossSplitD + sp) * kCrossPartD;
-    if (tid < 64) part[2 + tid] = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
-    if (tid == 0) { part[0] = mx; part[1] = sum; }
+    if constexpr (NSPLIT == 1) {
+        if (tid < 64) out_direct[(long)m * d + h * 64 + tid] = (T)((s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid]) / sum);
+    } else {
+        float* part = scratch + ((long)(m * H + h) * kCrossSplitD + sp) * kCrossPartD;
+        if (tid < 64) part[2 + tid] = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
+        if (tid == 0) { part[0] = mx; part[1] = sum; }
+    }
 }
+
+template <typename T>
+void launch_dec_cross_attention_direct(const float* qpart, int n_qpart, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d,
+                                       int H, int Tn, const RowCtl* ctl, int M, T* out, hipStream_t st) {
+    if (Tn > 1536) throw Error(-1, "cross attention: n_audio_ctx too large");
+    dim3 grid(1, H, M);
+    dec_cross_attn_q_kernel<T, 1><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, nullptr, out); SS_LAUNCH_CHECK();
+}
+template void launch_dec_cross_attention_direct<bf16>(const float*, int, const float*, float, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int,
+                                                      bf16*, hipStream_t);
+template void launch_dec_cross_attention_direct<f16>(const float*, int, const float*, float, const f16*, const f16*, long, int, int, int, const RowCtl*, int,
+                                                     f16*, hipStream_t);
 
 template <typename T>
 void launch_dec_cross_attention_q(const float* qpart, int n_qpart, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d, int H,
                                   int Tn, const RowCtl* ctl, int M, float* scratch, hipStream_t st) {
     if ((Tn + kCrossSplitD - 1) / kCrossSplitD > 512) throw Error(-1, "cross attention: n_audio_ctx too large");
     dim3 grid(kCrossSplitD, H, M);
-    dec_cross_attn_q_kernel<T><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch); SS_LAUNCH_CHECK();
+    dec_cross_attn_q_kernel<T, kCrossSplitD><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch, nullptr); SS_LAUNCH_CHECK();
 }
 template void launch_dec_cross_attention_q<bf16>(const float*, int, const float*, float, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int,
                                                  float*, hipStream_t);

@@ -38,6 +38,30 @@ template <typename T> __device__ __forceinline__ float gelu_in_round(float x, in
 template <> __device__ __forceinline__ float gelu_in_round<bf16>(float x, int) { return x; }
 template <> __device__ __forceinline__ float gelu_in_round<f16>(float x, int on) { return on ? (float)(f16)x : x; }
 
+// Tile rasterisation.  The dispatcher places workgroup b on XCD b % 8 (observed; used for speed only), each XCD has a private
+// 4 MB L2 and runs ~32 tiles at a time.  (1) bijective remap: every XCD gets a contiguous range of logical ids;
+// (2) logical ids walk the grid in column groups of GN n-panels with m fastest inside a group, so the ~32 concurrent tiles of
+// an XCD form a ~GN x (32/GN) patch: fabric traffic per launch ~ A_bytes*nbn/GN + W_bytes*nbm*GN/32, minimal near GN = sqrt(32).
+// With plain n-fastest order an XCD swept all nbn weight panels (13 MB for FC1 >> L2) for every ~1.6 tile rows: rocprofv3
+// FETCH_SIZE showed 460 MB per FC1 launch against 44 MB of operands, and the kernel sat on the ~10 B/clk/CU miss rate.
+__device__ __forceinline__ void tile_of_block(int bid, int nbm, int nbn, int* mb, int* nb) {
+    const int nwg = nbm * nbn;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int GN = nbn;
+    if (nbn > 8) {
+        GN = 5;
+        if (nbn % 5 != 0) { if (nbn % 6 == 0) GN = 6; else if (nbn % 4 == 0) GN = 4; else if (nbn % 7 == 0) GN = 7; }
+    }
+    const int per_group = nbm * GN, full = nbn / GN;
+    int g = bid / per_group, rem = bid - g * per_group, gn = GN;
+    if (g >= full) { g = full; rem = bid - full * per_group; gn = nbn - full * GN; }
+    *mb = rem / gn;
+    *nb = g * GN + rem % gn;
+}
+
 // ---------------------------------------------------------------------------------------------
 // 128 x 128 x 64 tile, 256 threads = 4 waves (2 n x 2 m), each wave 64 x 64 = 4 x 4 MFMA 16x16x32 tiles.
 // LDS: 2 stages x (X tile 16 KB + W tile 16 KB) = 64 KB  ->  2 workgroups / CU.
@@ -64,14 +88,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wm = wave & 1;
     const int nbn = g.N / BN, nbm = (g.M + BM - 1) / BM;
-    // XCD-aware remap (blocks id, id+8, ... run on one XCD and share its L2): consecutive logical ids on one XCD
-    const int nwg = nbn * nbm;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int nb = bid % nbn, mb = bid / nbn;  // n fastest: neighbours share the activation panel
+    int mb, nb;
+    tile_of_block(blockIdx.x, nbm, nbn, &mb, &nb);
     const int m0 = mb * BM, n0 = nb * BN;
 
     const T* __restrict__ A = (const T*)g.A;
@@ -233,14 +251,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wm = wave & 1;
     const int nbn = g.N / TN, nbm = (g.M + TM - 1) / TM;
-    const int nwg = nbn * nbm;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int nb = bid % nbn, mb = bid / nbn;
+    // persistent: one workgroup per CU walks tiles vb = blockIdx.x + j*gridDim.x (gridDim.x is a multiple of 8, so the XCD
+    // of the remap is preserved); the next tile's DMA prologue is issued right behind the previous tile's output stores
+    for (int vb = blockIdx.x; vb < nbn * nbm; vb += gridDim.x) {
+    int mb, nb;
+    tile_of_block(vb, nbm, nbn, &mb, &nb);
     const int m0 = mb * TM, n0 = nb * TN;
+    __builtin_amdgcn_s_barrier();   // every wave is done with the previous tile's LDS stages
     const T* __restrict__ A = (const T*)g.A;
     const T* __restrict__ W = (const T*)g.W;
 
@@ -419,6 +436,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
             }
         }
     }
+    }  // tile loop
 }
 
 template <typename T, int KIND>
@@ -436,7 +454,9 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
             attr256 = true;
         }
         const int nwg256 = (g.N / TN) * ((g.M + TM - 1) / TM);
-        gemm256_kernel<T, KIND><<<nwg256, 512, kGemm256Lds, st>>>(g); SS_LAUNCH_CHECK();
+        static int n_cu = 0;
+        if (!n_cu) { hipDeviceProp_t p; int dev = 0; SS_HIP(hipGetDevice(&dev)); SS_HIP(hipGetDeviceProperties(&p, dev)); n_cu = p.multiProcessorCount / 8 * 8; if (n_cu < 8) n_cu = 8; }
+        gemm256_kernel<T, KIND><<<nwg256 < n_cu ? nwg256 : n_cu, 512, kGemm256Lds, st>>>(g); SS_LAUNCH_CHECK();
         return;
     }
     const int nwg = (g.N / BN) * ((g.M + BM - 1) / BM);
