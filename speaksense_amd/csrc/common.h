@@ -1,6 +1,7 @@
 // Shared declarations for the MI355X (gfx950) Whisper path.  Product code: never includes anything from oracle/.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -30,6 +31,31 @@ struct Error : std::runtime_error {
         hipError_t _e = hipGetLastError();                                                                   \
         if (_e != hipSuccess) throw ss::Error(-4, std::string("kernel launch failed: ") + hipGetErrorString(_e) + " @" + __FILE__ + ":" + std::to_string(__LINE__)); \
     } while (0)
+
+// Run `fn` once per HIP device (kernel attributes such as the dynamic-LDS limit are per device; one process may hold one
+// engine per GPU).  `mask` is a function-local static owned by the caller.
+template <typename F>
+inline void once_per_device(std::atomic<uint64_t>& mask, F fn) {
+    int dev = 0;
+    SS_HIP(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_acquire) & bit) return;
+    fn();
+    mask.fetch_or(bit, std::memory_order_release);
+}
+inline int device_cu_count() {   // cached per device: hipGetDeviceProperties is far too slow for a launch path
+    static std::atomic<int> cu[64];
+    int dev = 0;
+    SS_HIP(hipGetDevice(&dev));
+    int v = cu[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+        hipDeviceProp_t p;
+        SS_HIP(hipGetDeviceProperties(&p, dev));
+        v = p.multiProcessorCount;
+        cu[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
 
 // ggml legacy header; field order is the file order
 struct HParams {

@@ -266,8 +266,8 @@ static void launch_dg2(const DecGemvDesc& g, int NW, hipStream_t st) {
     const int kslice = g.K / g.S;
     size_t red_f = (size_t)NW * 16 * 17, wtab_f = (size_t)16 * (kslice / 64 + 1) * 4;
     const size_t lds = (PRO == PRO_T ? 0 : (size_t)16 * (kslice + kXsPad) * sizeof(T)) + (red_f > wtab_f ? red_f : wtab_f) * 4;
-    static bool attr = false;
-    if (!attr) { SS_HIP(hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    static std::atomic<uint64_t> attr{0};
+    once_per_device(attr, [] { SS_HIP(hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
     dim3 grid((g.N + 15) / 16, g.S);
     dec_gemv_kernel<T, PRO, EPI, NI><<<grid, NW * 64, lds, st>>>(g); SS_LAUNCH_CHECK();
 }

@@ -441,21 +441,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
 
 template <typename T, int KIND>
 static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        SS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> attr128{0};
+    once_per_device(attr128, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds)); });
     static const bool force128 = getenv("SS_GEMM128") != nullptr;
     if (!force128 && g.N % TN == 0 && g.K % TK == 0 && g.M >= 1024) {
-        static bool attr256 = false;
-        if (!attr256) {
-            SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemm256Lds));
-            attr256 = true;
-        }
+        static std::atomic<uint64_t> attr256{0};
+        once_per_device(attr256, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemm256Lds)); });
         const int nwg256 = (g.N / TN) * ((g.M + TM - 1) / TM);
-        static int n_cu = 0;
-        if (!n_cu) { hipDeviceProp_t p; int dev = 0; SS_HIP(hipGetDevice(&dev)); SS_HIP(hipGetDeviceProperties(&p, dev)); n_cu = p.multiProcessorCount / 8 * 8; if (n_cu < 8) n_cu = 8; }
+        int n_cu = device_cu_count() / 8 * 8;   // persistent grid: one workgroup per CU, a multiple of 8 so the XCD of the remap is preserved
+        if (n_cu < 8) n_cu = 8;
         gemm256_kernel<T, KIND><<<nwg256 < n_cu ? nwg256 : n_cu, 512, kGemm256Lds, st>>>(g); SS_LAUNCH_CHECK();
         return;
     }

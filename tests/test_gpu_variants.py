@@ -249,3 +249,20 @@ def test_whisper_asr_mirror_end_to_end(toy_ml_path, om, orc):
     many = eng.transcribe_many([eng.create_state() for _ in pcms], pcms, p)
     assert [r.full_text for r in many] == [r.full_text for r in single]
     eng.engine.close()
+
+
+def test_two_engines_in_one_process(toy_ml_path, toy_en_path):
+    """A service process may hold several engines (one per GPU; here two models on one GPU): kernel attributes and
+    caches must not be process-global in a way that breaks the second engine."""
+    from speaksense_amd import binding
+    e1 = binding.Engine(toy_ml_path, max_batch=2)
+    e2 = binding.Engine(toy_en_path, dtype=binding.DTYPE_BF16, max_batch=2)
+    pcm = synth.speech_like(33, 16000 * 9)
+    P = binding.default_params(language="en", temperature_inc=0.0)
+    a1 = e1.new_session().transcribe(pcm, P)
+    b1 = e2.new_session().transcribe(pcm, P)
+    a2 = e1.new_session().transcribe(pcm, P)
+    b2 = e2.new_session().transcribe(pcm, P)
+    assert list(a1["tokens"]) == list(a2["tokens"]) and list(b1["tokens"]) == list(b2["tokens"])
+    assert len(a1["tokens"]) > 0 and len(b1["tokens"]) > 0
+    e1.close(); e2.close()
