@@ -132,6 +132,27 @@ void ss_default_denoise_config(ss_denoise_config* c);
 int ss_denoise_audio(ss_engine* e, const float* pcm, int32_t n_samples, const ss_denoise_config* cfg, int32_t force_type, float* out,
                      int32_t* noise_type, float* norm_var, float* device_ms);
 
+/* ---- file front end (SURVEY.md §8f "next" #4) --------------------------------------------------------- */
+/* `create_resampler(from, 16000)` + `resample_chunk` per 4096-sample read (/root/reference/src/audio/mod.rs:235-257: rubato 0.16.0
+ * SincFixedIn, sinc_len 256, cutoff 0.95, linear, oversampling 256, BlackmanHarris2) for a whole MONO stream in one call.
+ * Only the n / 4096 full read chunks are resampled: the reference's resampler rejects the short last read (and every read of a
+ * multi-channel file), which ends that file's processing.  chunk_lens (optional, n / 4096 entries): samples produced per read chunk,
+ * i.e. the normalisation chunks ss_preprocess_stream needs.  out_cap >= ss_resample_max_out(n, from_rate). */
+int64_t ss_resample_max_out(int64_t n_samples, int32_t from_rate);
+int ss_resample_stream(ss_engine* e, const float* pcm, int64_t n_samples, int32_t from_rate, float* out, int64_t out_cap, int64_t* n_out,
+                       int32_t* chunk_lens, float* device_ms);
+
+/* The stream pre-processor in front of the REST path: `StreamAudioProcessor` (/root/reference/src/audio/mod.rs:67-155) as
+ * parse_audio_file_stream drives it (mod.rs:158-233), for a whole mono 16 kHz stream in one call: per-read-chunk peak normalisation
+ * (mod.rs:91, 408-411), 2048-sample frames (last one zero padded, mod.rs:143-154), energy gain (110-130; incl. the reference's NaN noise floor,
+ * which makes the gain 0.1), per-frame denoise_audio (133-134) and the noise gate (138).  Read chunks: `chunk_lens[n_chunks]` (what the
+ * resampler returned per 4096-sample read) or, when NULL, uniform `chunk_len` (4096 / channels for a 16 kHz file).
+ * out: ss_preprocess_n_out(n) floats = the concatenated callbacks the REST chunker (schedule/processors/transcribe.rs:100-142) buffers.
+ * gains_out (optional): one gain per frame. */
+int64_t ss_preprocess_n_out(int64_t n_samples);
+int ss_preprocess_stream(ss_engine* e, const float* pcm, int64_t n_samples, const int32_t* chunk_lens, int32_t n_chunks, int32_t chunk_len,
+                         const ss_denoise_config* cfg, float* out, float* gains_out, float* device_ms);
+
 /* ---- timing hooks for bench.py (HIP events on the engine's own stream) ------------------------------ */
 /* ms spent in the phases of the last ss_transcribe_batch: [0] mel, [1] encoder+cross-KV, [2] decode, [3] total */
 int ss_engine_last_timing(const ss_engine* e, float out_ms[4]);

@@ -71,9 +71,13 @@ def add_punctuation(text: str) -> str:  # whisper.rs:175-201
 class WhisperAsr:
     """`WhisperAsr::new(model_path)` (whisper.rs:21-28) -- loads the ggml model onto one MI355X."""
 
-    def __init__(self, model_path: str, device: int = 0, dtype: int = binding.DTYPE_F16, max_batch: int = 8):
+    def __init__(self, model_path: str, device: int = 0, dtype: int = binding.DTYPE_F16, max_batch: int = 8, batch_across_callers: bool = False,
+                 batch_wait_us: int = 2000):
+        # batch_across_callers: transcribe_with_state goes through ss_submit/ss_wait, so chunks that concurrent callers (one thread
+        # per gRPC stream, asr.rs:164) hand in at about the same time share one device batch; results are identical either way.
+        self.batch_across_callers = batch_across_callers
         try:
-            self.engine = binding.Engine(model_path, device=device, dtype=dtype, max_batch=max_batch)
+            self.engine = binding.Engine(model_path, device=device, dtype=dtype, max_batch=max_batch, batch_wait_us=batch_wait_us)
         except binding.SpeakSenseError as e:
             raise RuntimeError(f"failed to open whisper model: {e}") from e  # whisper.rs:24
 
@@ -114,7 +118,10 @@ class WhisperAsr:
         return out
 
     def transcribe_with_state(self, state: binding.Session, audio, user_params: AsrParams) -> TranscribeResult:  # whisper.rs:45-129
-        res = state.transcribe(np.asarray(audio, np.float32), self.build_params(user_params))
+        if self.batch_across_callers:
+            res = state.wait(state.submit(np.asarray(audio, np.float32), self.build_params(user_params)))
+        else:
+            res = state.transcribe(np.asarray(audio, np.float32), self.build_params(user_params))
         return self._collect(res, user_params)
 
     def transcribe(self, audio, params: AsrParams) -> TranscribeResult:  # mod.rs:69-72

@@ -79,6 +79,12 @@ def lib():
         L.ss_process_logits.argtypes = [vp, f32p, vp, i32, i32, i32, C.POINTER(Params), f32p]
         L.ss_default_denoise_config.argtypes = [C.POINTER(DenoiseConfig)]
         L.ss_denoise_audio.argtypes = [vp, f32p, i32, C.POINTER(DenoiseConfig), i32, f32p, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.ss_resample_max_out.argtypes = [C.c_int64, i32]
+        L.ss_resample_max_out.restype = C.c_int64
+        L.ss_resample_stream.argtypes = [vp, f32p, C.c_int64, i32, f32p, C.c_int64, C.POINTER(C.c_int64), vp, C.POINTER(C.c_float)]
+        L.ss_preprocess_n_out.argtypes = [C.c_int64]
+        L.ss_preprocess_n_out.restype = C.c_int64
+        L.ss_preprocess_stream.argtypes = [vp, f32p, C.c_int64, vp, i32, i32, C.POINTER(DenoiseConfig), f32p, f32p, C.POINTER(C.c_float)]
         L.ss_engine_last_timing.argtypes = [vp, f32p]
         L.ss_engine_probe_gemm.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_double)]
         _LIB = L
@@ -110,6 +116,7 @@ class Engine:
         self.L = lib()
         o = EngineOpts(device, dtype, max_batch, max_decoders, batch_wait_us)
         h = C.c_void_p()
+        self.model_path = model_path
         _check(self.L.ss_engine_create(model_path.encode(), C.byref(o), C.byref(h)))
         self.h = h
         hp = np.zeros(11, np.int32)
@@ -184,6 +191,29 @@ class Engine:
         _check(self.L.ss_denoise_audio(self.h, _p(x), len(x), C.byref(config) if config is not None else None, force_type, _p(out),
                                        C.byref(nt), C.byref(nv), C.byref(ms)))
         return out, nt.value, nv.value, ms.value
+
+    def resample_stream(self, mono, from_rate: int):
+        """rubato SincFixedIn per 4096-sample read (src/audio/mod.rs:235-257) over a whole mono stream -> (samples @16 kHz, chunk_lens, device_ms)."""
+        x = np.ascontiguousarray(mono, np.float32)
+        cap = self.L.ss_resample_max_out(len(x), from_rate)
+        out = np.empty(max(cap, 1), np.float32)
+        lens = np.zeros(max(len(x) // 4096, 1), np.int32)
+        n_out, ms = C.c_int64(), C.c_float()
+        _check(self.L.ss_resample_stream(self.h, _p(x), len(x), from_rate, _p(out), cap, C.byref(n_out), lens.ctypes.data_as(C.c_void_p), C.byref(ms)))
+        return out[: n_out.value].copy(), lens[: len(x) // 4096].copy(), ms.value
+
+    def preprocess_stream(self, samples, chunk_len: int = 4096, chunk_lens=None, config: "DenoiseConfig | None" = None):
+        """`StreamAudioProcessor` over a whole mono 16 kHz stream (src/audio/mod.rs:67-155) -> (frames [n_frames, 2048], gains, device_ms)."""
+        x = np.ascontiguousarray(samples, np.float32)
+        n_out = self.L.ss_preprocess_n_out(len(x))
+        out = np.empty(max(n_out, 0), np.float32)
+        gains = np.empty(max(n_out // 2048, 0), np.float32)
+        ms = C.c_float()
+        cl = np.ascontiguousarray(chunk_lens, np.int32) if chunk_lens is not None else None
+        _check(self.L.ss_preprocess_stream(self.h, _p(x), len(x), cl.ctypes.data_as(C.c_void_p) if cl is not None else None,
+                                           len(cl) if cl is not None else 0, chunk_len, C.byref(config) if config is not None else None,
+                                           _p(out), _p(gains), C.byref(ms)))
+        return out.reshape(-1, 2048), gains, ms.value
 
     def last_timing(self):
         t = np.zeros(4, np.float32)

@@ -190,6 +190,23 @@ int ss_denoise_audio(ss_engine* e, const float* pcm, int32_t n, const ss_denoise
     return SS_OK;
     SS_CATCH
 }
+int64_t ss_resample_max_out(int64_t n, int32_t from_rate) {
+    if (n <= 0 || from_rate <= 0) return 0;
+    return (int64_t)((double)(n / 4096) * (4096.0 * 16000.0 / (double)from_rate + 2.0)) + 16;
+}
+int ss_resample_stream(ss_engine* e, const float* pcm, int64_t n, int32_t from_rate, float* out, int64_t out_cap, int64_t* n_out, int32_t* chunk_lens,
+                       float* device_ms) {
+    if (!e || !pcm || !out || n <= 0 || out_cap <= 0) return fail(SS_ERR_ARG, "ss_resample_stream: bad argument");
+    SS_TRY e->e->resample_stream_host(pcm, n, from_rate, out, out_cap, n_out, chunk_lens, device_ms); return SS_OK; SS_CATCH
+}
+int64_t ss_preprocess_n_out(int64_t n_samples) { return n_samples <= 0 ? 0 : (n_samples + 2047) / 2048 * 2048; }
+int ss_preprocess_stream(ss_engine* e, const float* pcm, int64_t n, const int32_t* chunk_lens, int32_t n_chunks, int32_t chunk_len,
+                         const ss_denoise_config* cfg, float* out, float* gains_out, float* device_ms) {
+    if (!e || !pcm || !out || n <= 0 || (chunk_lens && n_chunks <= 0)) return fail(SS_ERR_ARG, "ss_preprocess_stream: bad argument");
+    ss_denoise_config c;
+    if (cfg) c = *cfg; else ss_default_denoise_config(&c);
+    SS_TRY e->e->preprocess_stream_host(pcm, n, chunk_lens, n_chunks, chunk_len, c, out, gains_out, device_ms); return SS_OK; SS_CATCH
+}
 int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_ms, double* flops) {
     if (!e || !avg_ms || !flops || reps <= 0) return fail(SS_ERR_ARG, "bad argument");
     SS_TRY e->e->probe_gemm(batch, reps, avg_ms, flops); return SS_OK; SS_CATCH

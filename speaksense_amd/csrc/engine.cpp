@@ -924,7 +924,8 @@ struct EngineT : EngineBase {
     // ------------------------------------------------------------------------------------------
     // STFT denoiser: denoise_audio of /root/reference/src/audio/mod.rs:507-523
     // ------------------------------------------------------------------------------------------
-    DBuf dn_in, dn_mid, dn_out, dn_power, dn_noise, dn_signal, dn_var, dn_frames, dn_tw;
+    DBuf dn_in, dn_mid, dn_out, dn_power, dn_noise, dn_signal, dn_var, dn_frames, dn_tw, pp_small, rs_sincs, rs_idx, rs_chunk;
+    int rs_rate = 0;
     void dn_estimates(const float* x, int n, std::vector<float>* var_h) {
         const int n_chunks = n / 2048;
         dn_power.ensure((size_t)std::max(1, n_chunks) * 2048 * 4); dn_noise.ensure(2048 * 4); dn_signal.ensure(2048 * 4);
@@ -950,12 +951,7 @@ struct EngineT : EngineBase {
         if (n < 2048) throw Error(SS_ERR_ARG, "denoise: fewer samples than one frame (the reference panics in overlap_add)");
         const int step = (int)(2048.0f * (1.0f - cfg.overlap));
         if (step < 1 || step > 2048) throw Error(SS_ERR_ARG, "denoise: bad overlap");
-        if (!dn_tw.p) {
-            std::vector<float> tw(2048);
-            for (int k = 0; k < 1024; k++) { tw[2 * k] = (float)cos(-2.0 * M_PI * k / 2048.0); tw[2 * k + 1] = (float)sin(-2.0 * M_PI * k / 2048.0); }
-            dn_tw.alloc(2048 * 4);
-            SS_HIP(hipMemcpy(dn_tw.p, tw.data(), 2048 * 4, hipMemcpyHostToDevice));
-        }
+        dn_twiddles();
         dn_in.ensure((size_t)n * 4); dn_mid.ensure((size_t)n * 4); dn_out.ensure((size_t)n * 4);
         SS_HIP(hipMemcpyAsync(dn_in.p, pcm, (size_t)n * 4, hipMemcpyHostToDevice, st));
         SS_HIP(hipEventRecord(ev[0], st));
@@ -979,6 +975,126 @@ struct EngineT : EngineBase {
         SS_HIP(hipStreamSynchronize(st));
         if (noise_type) *noise_type = nt;
         if (norm_var) *norm_var = nv;
+        if (ms) SS_HIP(hipEventElapsedTime(ms, ev[0], ev[1]));
+    }
+
+    void dn_twiddles() {
+        if (dn_tw.p) return;
+        std::vector<float> tw(2048);
+        for (int k = 0; k < 1024; k++) { tw[2 * k] = (float)cos(-2.0 * M_PI * k / 2048.0); tw[2 * k + 1] = (float)sin(-2.0 * M_PI * k / 2048.0); }
+        dn_tw.alloc(2048 * 4);
+        SS_HIP(hipMemcpy(dn_tw.p, tw.data(), 2048 * 4, hipMemcpyHostToDevice));
+    }
+    // StreamAudioProcessor over a whole stream (src/audio/mod.rs:67-155): see kernels_denoise.hip
+    void preprocess_stream_host(const float* pcm, int64_t n, const int32_t* chunk_lens, int n_chunks, int chunk_len, const ss_denoise_config& cfg, float* out,
+                                float* gains_out, float* ms) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        if (cfg.frame_size != 2048) throw Error(SS_ERR_UNSUPPORTED, "preprocess: only frame_size 2048 (the reference default) is implemented");
+        dn_twiddles();
+        std::vector<long> off;
+        if (chunk_lens) {
+            off.resize(n_chunks + 1);
+            off[0] = 0;
+            for (int i = 0; i < n_chunks; i++) {
+                if (chunk_lens[i] <= 0) throw Error(SS_ERR_ARG, "preprocess: empty read chunk");
+                off[i + 1] = off[i] + chunk_lens[i];
+            }
+            if (off[n_chunks] != n) throw Error(SS_ERR_ARG, "preprocess: chunk lengths do not add up to n");
+        } else {
+            if (chunk_len <= 0) throw Error(SS_ERR_ARG, "preprocess: chunk_len must be positive");
+            n_chunks = (int)((n + chunk_len - 1) / chunk_len);
+        }
+        const int n_frames = (int)((n + 2047) / 2048);
+        dn_in.ensure((size_t)n * 4); dn_mid.ensure((size_t)n * 4); dn_out.ensure((size_t)n_frames * 2048 * 4);
+        pp_small.ensure((size_t)n_frames * 4 * 4 + (off.size() + 1) * 8);
+        float* energy = pp_small.as<float>();
+        float* sub = energy + n_frames;
+        float* gain = sub + 2 * n_frames;
+        long* d_off = nullptr;
+        if (!off.empty()) {
+            d_off = (long*)(gain + n_frames + (n_frames & 1));
+            SS_HIP(hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, st));
+        }
+        SS_HIP(hipMemcpyAsync(dn_in.p, pcm, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        SS_HIP(hipEventRecord(ev[0], st));
+        launch_pp_stream(dn_in.as<float>(), (long)n, d_off, n_chunks, chunk_len, n_frames, dn_tw.as<float2>(), cfg.strength, cfg.noise_gate,
+                         cfg.enable_noise_reduction, dn_mid.as<float>(), energy, sub, gain, dn_out.as<float>(), st);
+        SS_HIP(hipEventRecord(ev[1], st));
+        SS_HIP(hipMemcpyAsync(out, dn_out.p, (size_t)n_frames * 2048 * 4, hipMemcpyDeviceToHost, st));
+        if (gains_out) SS_HIP(hipMemcpyAsync(gains_out, gain, (size_t)n_frames * 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(hipStreamSynchronize(st));
+        if (ms) SS_HIP(hipEventElapsedTime(ms, ev[0], ev[1]));
+    }
+
+    // rubato SincFixedIn as create_resampler configures it (src/audio/mod.rs:235-250); see kernels_resample.hip
+    static void rs_make_sincs(float f_cutoff, std::vector<float>& sincs) {
+        const int npoints = 256, factor = 256, tot = npoints * factor;
+        std::vector<float> y(tot);
+        float sum = 0.0f;
+        for (int x = 0; x < tot; x++) {
+            const float x_pi = (float)x * (float)(2.0 * M_PI) / (float)tot;
+            float w = 0.35875f - 0.48829f * cosf(x_pi) + 0.14128f * cosf(2.0f * x_pi) - 0.01168f * cosf(3.0f * x_pi);
+            w = w * w;
+            const float v = ((float)x - (float)(tot / 2)) * f_cutoff / (float)factor;
+            const float a = v * (float)M_PI;
+            const float sc = v == 0.0f ? 1.0f : sinf(a) / a;
+            y[x] = w * sc;
+            sum += y[x];
+        }
+        sum /= (float)factor;
+        sincs.assign((size_t)tot, 0.f);
+        for (int p = 0; p < npoints; p++)
+            for (int n = 0; n < factor; n++) sincs[(size_t)(factor - n - 1) * npoints + p] = y[factor * p + n] / sum;
+    }
+    void resample_stream_host(const float* pcm, int64_t n, int from_rate, float* out, int64_t out_cap, int64_t* n_out, int32_t* chunk_lens, float* ms) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        if (from_rate <= 0 || from_rate == 16000) throw Error(SS_ERR_ARG, "resample: from_rate must be positive and different from 16000");
+        const double ratio = 16000.0 / (double)from_rate;
+        if (rs_rate != from_rate) {
+            std::vector<float> sincs;
+            rs_make_sincs(ratio >= 1.0 ? 0.95f : 0.95f * (float)ratio, sincs);
+            rs_sincs.ensure(sincs.size() * 4);
+            SS_HIP(hipMemcpy(rs_sincs.p, sincs.data(), sincs.size() * 4, hipMemcpyHostToDevice));
+            rs_rate = from_rate;
+        }
+        // the output instants: process_into_buffer's `while idx < end_idx { idx += t_ratio; ... }`, last_index carried between chunks
+        const int chunk = 4096, sinc_len = 256;
+        const int64_t n_chunks = n / chunk;
+        const double t_ratio = 1.0 / ratio;
+        const double end_idx = (double)(chunk - (sinc_len + 1) - (long)ceil(t_ratio));
+        std::vector<double> idx_rel;
+        std::vector<int> chunk_of;
+        idx_rel.reserve((size_t)((double)n * ratio) + 16);
+        chunk_of.reserve(idx_rel.capacity());
+        double last_index = -(double)(sinc_len / 2);
+        for (int64_t c = 0; c < n_chunks; c++) {
+            double idx = last_index;
+            int cnt = 0;
+            while (idx < end_idx) {
+                idx += t_ratio;
+                idx_rel.push_back(idx);
+                chunk_of.push_back((int)c);
+                cnt++;
+            }
+            last_index = idx - (double)chunk;
+            if (chunk_lens) chunk_lens[c] = cnt;
+        }
+        const int64_t total = (int64_t)idx_rel.size();
+        if (n_out) *n_out = total;
+        if (total > out_cap) throw Error(SS_ERR_ARG, "resample: output buffer too small (ss_resample_max_out)");
+        if (total == 0) { if (ms) *ms = 0.f; return; }
+        dn_in.ensure((size_t)n_chunks * chunk * 4); dn_out.ensure((size_t)total * 4);
+        rs_idx.ensure((size_t)total * 8); rs_chunk.ensure((size_t)total * 4);
+        SS_HIP(hipMemcpyAsync(dn_in.p, pcm, (size_t)n_chunks * chunk * 4, hipMemcpyHostToDevice, st));
+        SS_HIP(hipMemcpyAsync(rs_idx.p, idx_rel.data(), (size_t)total * 8, hipMemcpyHostToDevice, st));
+        SS_HIP(hipMemcpyAsync(rs_chunk.p, chunk_of.data(), (size_t)total * 4, hipMemcpyHostToDevice, st));
+        SS_HIP(hipEventRecord(ev[0], st));
+        launch_resample(dn_in.as<float>(), rs_idx.as<double>(), rs_chunk.as<int>(), (long)total, rs_sincs.as<float>(), dn_out.as<float>(), st);
+        SS_HIP(hipEventRecord(ev[1], st));
+        SS_HIP(hipMemcpyAsync(out, dn_out.p, (size_t)total * 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(hipStreamSynchronize(st));
         if (ms) SS_HIP(hipEventElapsedTime(ms, ev[0], ev[1]));
     }
 

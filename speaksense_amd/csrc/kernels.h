@@ -167,5 +167,10 @@ void launch_dn_frames(int mode, const float* x, int n_frames, int step, const fl
                       float* frames_out, hipStream_t st);
 void launch_dn_overlap_add(const float* frames, int n_frames, int step, int n, float* out, hipStream_t st);
 void launch_dn_noise_gate(const float* in, float* out, int n, float gate, hipStream_t st);
+// sinc resampler (kernels_resample.hip) -- SURVEY.md §8f next #4: y[k] at instant idx_rel[k] of read chunk chunk_of[k]
+void launch_resample(const float* x, const double* idx_rel, const int* chunk_of, long n_out, const float* sincs, float* y, hipStream_t st);
+// stream pre-processor (StreamAudioProcessor, src/audio/mod.rs:67-155) over a whole mono 16 kHz stream; frames of 2048, last one zero padded
+void launch_pp_stream(const float* x, long n, const long* chunk_off, int n_chunks, int chunk_len, int n_frames, const float2* tw, float strength, float gate,
+                      int denoise, float* y, float* energy, float* sub_energy, float* gain, float* out, hipStream_t st);
 
 }  // namespace ss

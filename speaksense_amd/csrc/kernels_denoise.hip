@@ -127,7 +127,116 @@ __global__ void dn_noise_gate_kernel(const float* __restrict__ in, float* __rest
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const float v = in[i]; out[i] = fabsf(v) < gate ? 0.0f : v; }
 }
+// ------------------------------------------------------------------------------------------------
+// stream pre-processor (StreamAudioProcessor, /root/reference/src/audio/mod.rs:67-155) for a whole 16 kHz mono stream at once:
+// per-read-chunk peak normalisation -> per-2048-frame pre-emphasis energy -> the (sequential, scalar) gain recurrence ->
+// one fused kernel per frame: gain, single-frame spectral subtraction, Hann^2 normalisation x10, noise gate.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    for (int o = 32; o > 0; o >>= 1) { const float u = __shfl_xor(v, o); v = is_max ? fmaxf(v, u) : v + u; }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < kThreads / 64; i++) r = is_max ? fmaxf(r, red[i]) : r + red[i];
+    return r;
+}
+// normalize_audio (mod.rs:408-411) per read chunk: x / max|x| (an all-zero chunk becomes NaN, as in the reference)
+__global__ __launch_bounds__(kThreads) void pp_normalize_kernel(const float* __restrict__ x, long n, const long* __restrict__ chunk_off, int chunk_len,
+                                                                float* __restrict__ y) {
+    __shared__ float red[kThreads / 64];
+    const long b = chunk_off ? chunk_off[blockIdx.x] : (long)blockIdx.x * chunk_len;
+    long e = chunk_off ? chunk_off[blockIdx.x + 1] : b + chunk_len;
+    if (e > n) e = n;
+    float m = 0.0f;
+    for (long i = b + threadIdx.x; i < e; i += kThreads) m = fmaxf(m, fabsf(x[i]));
+    m = block_reduce(m, red, true);
+    for (long i = b + threadIdx.x; i < e; i += kThreads) y[i] = x[i] / m;
+}
+// per frame: mean of the squared pre-emphasised samples (mod.rs:110-113), and the two 1024-sample energies estimate_noise_floor looks at
+__global__ __launch_bounds__(kThreads) void pp_energy_kernel(const float* __restrict__ y, long n, float* __restrict__ energy, float* __restrict__ sub_energy) {
+    __shared__ float red[kThreads / 64];
+    const long base = (long)blockIdx.x * kFs;
+    float acc = 0.f, lo = 0.f, hi = 0.f;
+    for (int i = threadIdx.x; i < kFs; i += kThreads) {
+        const float cur = base + i < n ? y[base + i] : 0.0f;
+        const float prev = (i > 0 && base + i - 1 < n) ? y[base + i - 1] : 0.0f;
+        const float p = i == 0 ? cur : cur - 0.97f * prev;
+        acc += p * p;
+        if (i < 1024) lo += cur * cur; else hi += cur * cur;
+    }
+    acc = block_reduce(acc, red, false);
+    lo = block_reduce(lo, red, false);
+    hi = block_reduce(hi, red, false);
+    if (threadIdx.x == 0) { energy[blockIdx.x] = acc / (float)kFs; sub_energy[2 * blockIdx.x] = lo / 1024.0f; sub_energy[2 * blockIdx.x + 1] = hi / 1024.0f; }
+}
+// the scalar recurrence over frames (mod.rs:97-99,114-127).  fmaxf/fminf ignore NaN exactly as Rust's f32::max/min do, so the
+// reference's NaN noise floor (estimate_noise_floor keeps (2 as f32 * 0.1) as usize == 0 frames -> 0/0) yields gain 0.1 here too.
+__global__ void pp_gain_kernel(const float* __restrict__ energy, const float* __restrict__ sub_energy, int n_frames, float* __restrict__ gain) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float noise_floor = 0.0f, prev_energy = 0.0f;
+    for (int f = 0; f < n_frames; f++) {
+        if (noise_floor == 0.0f) {
+            float e0 = sub_energy[2 * f], e1 = sub_energy[2 * f + 1];
+            if (e1 < e0) { const float t = e0; e0 = e1; e1 = t; }
+            const int cnt = (int)(2.0f * 0.1f);
+            float s = 0.0f;
+            if (cnt > 0) s += e0;
+            if (cnt > 1) s += e1;
+            volatile float den = (float)cnt;
+            noise_floor = s / den;
+        }
+        const float e = energy[f];
+        const float threshold = noise_floor * 1.2f + prev_energy * 0.1f;
+        gain[f] = e > threshold ? 1.0f : fmaxf(e / threshold, 0.1f);
+        prev_energy = e;
+        noise_floor = noise_floor * 0.95f + fminf(e, noise_floor) * 0.05f;
+    }
+}
+// gain -> denoise_audio on the single frame (noise type is Stationary for one chunk: variance 0) -> noise gate
+__global__ __launch_bounds__(kThreads) void pp_frame_kernel(const float* __restrict__ y, long n, const float* __restrict__ gain, const float2* __restrict__ tw,
+                                                            float strength, float gate, int denoise, float* __restrict__ out) {
+    __shared__ float2 s[kFs];
+    __shared__ float2 t[kFs];
+    const long base = (long)blockIdx.x * kFs;
+    const float g = gain[blockIdx.x];
+    if (!denoise) {
+        for (int i = threadIdx.x; i < kFs; i += kThreads) {
+            const float v = (base + i < n ? y[base + i] : 0.0f) * g;
+            out[base + i] = fabsf(v) < gate ? 0.0f : v;
+        }
+        return;
+    }
+    for (int i = threadIdx.x; i < kFs; i += kThreads) s[bitrev11(i)] = make_float2(((base + i < n ? y[base + i] : 0.0f) * g) * hann_dn(i), 0.0f);
+    __syncthreads();
+    fft2048(s, tw, false);
+    for (int i = threadIdx.x; i < kFs; i += kThreads) {
+        const float2 c = s[i];
+        const float power = c.x * c.x + c.y * c.y;
+        const float noise = 0.0f + power / 20.0f;    // estimate_noise_spectrum over this one chunk (mod.rs:664-686)
+        const float freq_factor = fminf((float)i / (float)kFs, 1.0f);
+        const float freq_strength = strength * (1.0f - 0.3f * freq_factor);
+        const float gn = sqrtf(fmaxf(1.0f - 1.0f * powf(noise / (power + 1e-6f), freq_strength), 0.1f));
+        t[bitrev11(i)] = make_float2(c.x * gn, c.y * gn);
+    }
+    __syncthreads();
+    fft2048(t, tw, true);
+    for (int i = threadIdx.x; i < kFs; i += kThreads) {
+        const float w = hann_dn(i);
+        const float acc = t[i].x * w, norm = w * w;
+        const float v = norm > 1e-10f ? (acc / norm) * 10.0f : acc;
+        out[base + i] = fabsf(v) < gate ? 0.0f : v;
+    }
+}
 }  // namespace
+
+void launch_pp_stream(const float* x, long n, const long* chunk_off, int n_chunks, int chunk_len, int n_frames, const float2* tw, float strength, float gate,
+                      int denoise, float* y, float* energy, float* sub_energy, float* gain, float* out, hipStream_t st) {
+    pp_normalize_kernel<<<n_chunks, kThreads, 0, st>>>(x, n, chunk_off, chunk_len, y); SS_LAUNCH_CHECK();
+    pp_energy_kernel<<<n_frames, kThreads, 0, st>>>(y, n, energy, sub_energy); SS_LAUNCH_CHECK();
+    pp_gain_kernel<<<1, 64, 0, st>>>(energy, sub_energy, n_frames, gain); SS_LAUNCH_CHECK();
+    pp_frame_kernel<<<n_frames, kThreads, 0, st>>>(y, n, gain, tw, strength, gate, denoise, out); SS_LAUNCH_CHECK();
+}
 
 void launch_dn_chunk_power(const float* x, int n_chunks, const float2* tw, float* power, hipStream_t st) {
     if (n_chunks > 0) { dn_chunk_power_kernel<<<n_chunks, kThreads, 0, st>>>(x, tw, power); SS_LAUNCH_CHECK(); }

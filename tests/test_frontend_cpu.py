@@ -1,0 +1,95 @@
+"""CPU: oracles of the file front end (resampler, stream pre-processor, REST chunker) and the REST schemas of speaksense_amd/rest.py.
+Expectations are hand-derived from /root/reference/src/audio/mod.rs, src/schedule/**, src/web/handlers/asr.rs (cited per test)."""
+import json
+
+import numpy as np
+import pytest
+
+from oracle import preprocess_oracle as ppo
+from oracle import resample_oracle as rso
+from speaksense_amd import rest, synth
+
+
+def test_noise_floor_of_one_frame_is_nan_and_gain_is_a_tenth():
+    # estimate_noise_floor (mod.rs:744-762) on one 2048-sample frame keeps (2 * 0.1) as usize == 0 energies -> 0/0
+    x = synth.speech_like(1, 2048 * 5)
+    assert np.isnan(ppo.estimate_noise_floor(x[:2048]))
+    frames, gains = ppo.preprocess_stream(x)
+    assert frames.shape == (5, 2048) and gains == [pytest.approx(0.1)] * 5
+    assert not np.isnan(frames).any()
+
+
+def test_preprocessor_structure():
+    x = synth.speech_like(2, 4096 * 3 + 700)             # last read chunk short, last frame zero padded by finish()
+    frames, _ = ppo.preprocess_stream(x)
+    assert frames.shape == ((len(x) + 2047) // 2048, 2048)
+    # per-read-chunk normalisation: scaling one 4096-sample read leaves the output unchanged (mod.rs:91, 408-411)
+    y = x.copy(); y[4096:8192] *= 0.25
+    frames2, _ = ppo.preprocess_stream(y)
+    np.testing.assert_allclose(frames2, frames, rtol=2e-4, atol=2e-2)
+    # noise reduction disabled: the frame is the normalised input * 0.1, gated at 0.003
+    cfg = ppo.dn.DenoiseConfig(enable_noise_reduction=False)
+    f3, _ = ppo.preprocess_stream(x[:4096], config=cfg)
+    want = (x[:4096] / np.abs(x[:4096]).max()).astype(np.float32) * np.float32(0.1)
+    want[np.abs(want) < np.float32(0.003)] = 0
+    np.testing.assert_allclose(f3.reshape(-1), want, rtol=1e-6, atol=1e-7)
+
+
+def test_rest_chunker_sizes():
+    # transcribe.rs:100-142: 2048-sample callbacks accumulate until >= 480 000 -> 235 frames = 481 280 samples per chunk
+    frames = np.zeros((500, 2048), np.float32)
+    ch = ppo.rest_chunks(frames)
+    assert [len(c) for c in ch] == [481280, 481280, 30 * 2048]
+    assert [len(c) for c in rest.rest_chunks(frames)] == [481280, 481280, 30 * 2048]
+    assert rest.rest_chunks(np.zeros((0, 2048), np.float32)) == []
+
+
+def test_resampler_oracle_properties():
+    r = rso.SincFixedIn(16000.0 / 44100.0)
+    assert r.sincs.shape == (256, 256)
+    np.testing.assert_allclose(r.sincs.sum(axis=1), 1.0, atol=2e-3)        # every sub-phase has ~unit DC gain
+    sr = 44100
+    t = np.arange(4096 * 4) / sr
+    x = (0.5 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    chunks, tail = rso.resample_stream(x, sr)
+    assert [len(c) for c in chunks] == [1439, 1486, 1486, 1486] and not tail  # first chunk starts sinc_len/2 early, then 4096*16000/44100
+    y = np.concatenate(chunks)
+    k = np.arange(len(y))
+    ref = 0.5 * np.sin(2 * np.pi * 440 * (((k + 1) * (sr / 16000.0) - 1) / sr))
+    assert np.abs(y - ref)[300:].max() < 5e-4
+    _, tail = rso.resample_stream(x[:-5], sr)
+    assert tail
+    with pytest.raises(ValueError):
+        r.process(np.zeros(2048, np.float32))       # rubato: wrong number of input frames
+
+
+def test_rest_schemas():
+    req = rest.TranscribeRequest.from_json(json.dumps(dict(path="/data/a.wav", path_type="Local", callback_url="http://cb", language="zh",
+                                                          speaker_diarization=True, emotion_recognition=False, filter_dirty_words=False)))
+    cfg = rest.task_config_from_request(req)
+    assert cfg["params"] == {"type": "Transcribe", "params": {"language": "zh", "speaker_diarization": True, "emotion_recognition": False,
+                                                                "filter_dirty_words": False}}
+    assert cfg["callback_type"] == {"type": "Http", "config": {"url": "http://cb"}}
+    assert (cfg["priority"], cfg["retry_count"], cfg["max_retries"], cfg["timeout"]) == ("Normal", 0, 3, None)   # handlers/asr.rs:77-92
+    rest.validate_params(cfg["params"])
+    with pytest.raises(ValueError, match="Unsupported language: fr"):
+        rest.validate_params({"type": "Transcribe", "params": {"language": "fr"}})
+    with pytest.raises(ValueError):
+        rest.TranscribeRequest.from_json('{"path": "x", "path_type": "Ftp", "callback_url": "", "speaker_diarization": false, '
+                                         '"emotion_recognition": false, "filter_dirty_words": false}')
+    with pytest.raises(ValueError, match="missing field"):
+        rest.TranscribeRequest.from_json('{"path": "x", "path_type": "Url"}')
+    r = rest.TaskTranscribeResult("hi", [rest.TaskSegment("hi", 0, 0.0, 120.0)])
+    assert rest.callback_on_complete("t1", r) == {"task_id": "t1", "status": "Completed", "data": {"type": "Transcribe", "result": {
+        "text": "hi", "segments": [{"text": "hi", "speaker_id": 0, "start_time": 0.0, "end_time": 120.0}]}}}
+    assert rest.callback_on_error("t1", "boom") == {"task_id": "t1", "status": {"Failed": "boom"}, "data": "boom"}
+    assert rest.http_response(0, "Task added successfully", "id") == {"code": 0, "message": "Task added successfully", "data": "id"}
+
+
+def test_convert_to_mono_per_read_chunk():
+    x = np.arange(4096 + 6, dtype=np.float32)
+    m = rest.convert_to_mono(x, 2)
+    assert len(m) == 2048 + 3 and m[0] == 0.5 and m[2048] == (4096 + 4097) / 2
+    m3 = rest.convert_to_mono(np.ones(4096, np.float32), 3)        # 4096 = 1365*3 + 1: the dangling sample is still divided by 3
+    assert len(m3) == 1366 and m3[-1] == pytest.approx(1 / 3)
+    np.testing.assert_array_equal(ppo.convert_to_mono(np.ones(4096, np.float32), 3), m3)
