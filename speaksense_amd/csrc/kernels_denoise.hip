@@ -172,11 +172,12 @@ __global__ __launch_bounds__(kThreads) void pp_energy_kernel(const float* __rest
 }
 // the scalar recurrence over frames (mod.rs:97-99,114-127).  fmaxf/fminf ignore NaN exactly as Rust's f32::max/min do, so the
 // reference's NaN noise floor (estimate_noise_floor keeps (2 as f32 * 0.1) as usize == 0 frames -> 0/0) yields gain 0.1 here too.
-__global__ void pp_gain_kernel(const float* __restrict__ energy, const float* __restrict__ sub_energy, int n_frames, float* __restrict__ gain) {
+__global__ void pp_gain_kernel(const float* __restrict__ energy, const float* __restrict__ sub_energy, int n_frames, int n_full_frames,
+                               float* __restrict__ gain) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float noise_floor = 0.0f, prev_energy = 0.0f;
     for (int f = 0; f < n_frames; f++) {
-        if (noise_floor == 0.0f) {
+        if (noise_floor == 0.0f && f < n_full_frames) {   // only process_chunk initialises the floor, finish() (the padded frame) does not
             float e0 = sub_energy[2 * f], e1 = sub_energy[2 * f + 1];
             if (e1 < e0) { const float t = e0; e0 = e1; e1 = t; }
             const int cnt = (int)(2.0f * 0.1f);
@@ -234,7 +235,7 @@ void launch_pp_stream(const float* x, long n, const long* chunk_off, int n_chunk
                       int denoise, float* y, float* energy, float* sub_energy, float* gain, float* out, hipStream_t st) {
     pp_normalize_kernel<<<n_chunks, kThreads, 0, st>>>(x, n, chunk_off, chunk_len, y); SS_LAUNCH_CHECK();
     pp_energy_kernel<<<n_frames, kThreads, 0, st>>>(y, n, energy, sub_energy); SS_LAUNCH_CHECK();
-    pp_gain_kernel<<<1, 64, 0, st>>>(energy, sub_energy, n_frames, gain); SS_LAUNCH_CHECK();
+    pp_gain_kernel<<<1, 64, 0, st>>>(energy, sub_energy, n_frames, (int)(n / kFs), gain); SS_LAUNCH_CHECK();
     pp_frame_kernel<<<n_frames, kThreads, 0, st>>>(y, n, gain, tw, strength, gate, denoise, out); SS_LAUNCH_CHECK();
 }
 

@@ -1,4 +1,4 @@
 mkdir -p gpurun_out
 export OMP_WAIT_POLICY=passive
-timeout 1500 python -m pytest tests -q -m gpu -x --durations=8 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+timeout 1500 python -m pytest tests -q -m gpu --durations=8 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
 tail -25 gpurun_out/pytest_gpu.log
