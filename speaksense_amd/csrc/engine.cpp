@@ -166,6 +166,7 @@ struct EngineT : EngineBase {
         plan_decode();
         use_fused = getenv("SS_DECODE_UNFUSED") == nullptr;
         cross_direct = getenv("SS_CROSS_DIRECT") != nullptr;
+        combine_separate = getenv("SS_COMBINE_FUSED") == nullptr;   // fused prologue measured slower (865 vs 940 xRT): opt-in only
         start_worker();
     }
     ~EngineT() override {
@@ -436,9 +437,13 @@ struct EngineT : EngineBase {
             } else {
                 launch_dec_cross_attention_q<T>(pq.as<float>(), pl_dd.S, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
                                                 cscratch.as<float>(), st);
-                launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
+                if (combine_separate) launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
             }
-            {   // cross out-projection partials
+            if (!cross_direct && !combine_separate) {   // cross out-projection partials; the split-key combine is this GEMV's prologue
+                DecGemvDesc g = dgd(PRO_COMBINE, DEPI_PART, e.wco, M, d, d, pl_dd.S);
+                g.cross_parts = cscratch.as<float>(); g.part_out = p2.as<float>();
+                launch_dec_gemv<T>(g, pl_dd.NW, st);
+            } else {
                 DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wco, M, d, d, pl_dd.S);
                 g.Xt = attd.p; g.ldx = d; g.part_out = p2.as<float>();
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
@@ -525,7 +530,7 @@ struct EngineT : EngineBase {
         if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
     }
     DBuf samp_d, rowidx_d, rules_scratch;
-    bool use_fused = true, cross_direct = false;
+    bool use_fused = true, cross_direct = false, combine_separate = true;
 
     RuleConsts rule_consts(const ss_params& P) {
         const Vocab& v = hm.vocab;

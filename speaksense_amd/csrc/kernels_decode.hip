@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     } else if constexpr (PRO == PRO_COMBINE) {
         // flash-decoding combine of the cross-attention partials for the columns of this K slice
         const int H = g.K / 64, h0 = kbeg >> 6, hs = kslice >> 6;   // kslice is a multiple of 64 (checked on the host)
-        float* wtab = red;                                           // [16][hs][4] normalised weights (red is reused after the sync)
+        float* wtab = red;                                           // [16][hs][5] split weights + denominator (red is reused after the sync)
         for (int idx = tid; idx < g.M * hs; idx += blockDim.x) {
             const int m = idx / hs, hh = idx % hs;
             const float* part = g.cross_parts + (long)(m * H + h0 + hh) * kCrossSplitD * kCrossPartD;
@@ -173,9 +173,10 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
             const float l0 = part[1], l1 = part[kCrossPartD + 1], l2 = part[2 * kCrossPartD + 1], l3 = part[3 * kCrossPartD + 1];
             const float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
             const float w0 = __expf(m0 - mx), w1 = __expf(m1 - mx), w2 = __expf(m2 - mx), w3 = __expf(m3 - mx);
-            const float inv = 1.0f / (((w0 * l0 + w1 * l1) + w2 * l2) + w3 * l3);
-            float* wt = wtab + idx * 4;
-            wt[0] = w0 * inv; wt[1] = w1 * inv; wt[2] = w2 * inv; wt[3] = w3 * inv;
+            float den = 0.f;                     // same order as dec_cross_combine_kernel: num / den
+            den += w0 * l0; den += w1 * l1; den += w2 * l2; den += w3 * l3;
+            float* wt = wtab + idx * 5;
+            wt[0] = w0; wt[1] = w1; wt[2] = w2; wt[3] = w3; wt[4] = den;
         }
         for (int idx = tid + g.M * kslice; idx < 16 * kslice; idx += blockDim.x) xs[(idx / kslice) * xld + idx % kslice] = (T)0.0f;
         __syncthreads();
@@ -183,9 +184,10 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
         for (int idx = tid; idx < g.M * kslice; idx += blockDim.x) {
             const int m = idx / kslice, cc = idx % kslice, hh = cc >> 6, j = cc & 63;
             const float* part = g.cross_parts + (long)(m * H + h0 + hh) * kCrossSplitD * kCrossPartD + 2 + j;
-            const float* wt = wtab + (m * hs + hh) * 4;
-            const float o = ((wt[0] * part[0] + wt[1] * part[kCrossPartD]) + wt[2] * part[2 * kCrossPartD]) + wt[3] * part[3 * kCrossPartD];
-            xs[m * xld + cc] = (T)o;
+            const float* wt = wtab + (m * hs + hh) * 5;
+            float num = 0.f;
+            num += wt[0] * part[0]; num += wt[1] * part[kCrossPartD]; num += wt[2] * part[2 * kCrossPartD]; num += wt[3] * part[3 * kCrossPartD];
+            xs[m * xld + cc] = (T)(num / wt[4]);
         }
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
 template <typename T, int PRO, int EPI, int NI>
 static void launch_dg2(const DecGemvDesc& g, int NW, hipStream_t st) {
     const int kslice = g.K / g.S;
-    size_t red_f = (size_t)NW * 16 * 17, wtab_f = (size_t)16 * (kslice / 64 + 1) * 4;
+    size_t red_f = (size_t)NW * 16 * 17, wtab_f = (size_t)16 * (kslice / 64 + 1) * 5;
     const size_t lds = (PRO == PRO_T ? 0 : (size_t)16 * (kslice + kXsPad) * sizeof(T)) + (red_f > wtab_f ? red_f : wtab_f) * 4;
     static std::atomic<uint64_t> attr{0};
     once_per_device(attr, [] { SS_HIP(hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
