@@ -136,6 +136,7 @@ struct EngineT : EngineBase {
     DBuf x0, h1, x, ln, qk, vT, att, ff, encT, encF, cross, kself, vself;
     DBuf xd, lnd, qd, attd, ffd, logits, probs, cscratch, ctl_d;
     RowCtl* ctl_h = nullptr;       // pinned, mapped
+    int* rowidx_h = nullptr;       // pinned
     SampleOut* samp_h = nullptr;   // pinned, mapped
     float* probs_h = nullptr;      // pinned: [S][n_vocab_pad] for t > 0 sampling
     hipEvent_t ev[4];
@@ -167,11 +168,14 @@ struct EngineT : EngineBase {
         use_fused = getenv("SS_DECODE_UNFUSED") == nullptr;
         cross_direct = getenv("SS_CROSS_DIRECT") != nullptr;
         combine_separate = getenv("SS_COMBINE_FUSED") == nullptr;   // fused prologue measured slower (865 vs 940 xRT): opt-in only
+        { const char* gv = getenv("SS_DECODE_GRAPH"); use_graph = !(gv && gv[0] == '0'); }
         start_worker();
     }
     ~EngineT() override {
         stop_worker();
         if (ctl_h) (void)hipHostFree(ctl_h);
+        if (rowidx_h) (void)hipHostFree(rowidx_h);
+        for (auto& kv : step_graphs) { if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph); }
         if (samp_h) (void)hipHostFree(samp_h);
         if (probs_h) (void)hipHostFree(probs_h);
         for (auto& e : ev) (void)hipEventDestroy(e);
@@ -302,6 +306,7 @@ struct EngineT : EngineBase {
         samp_d.alloc(R * sizeof(SampleOut)); rowidx_d.alloc(R * 4); rules_scratch.alloc((size_t)R * 64 * 8 * 4);
         SS_HIP(hipHostMalloc((void**)&ctl_h, 2 * R * sizeof(RowCtl), hipHostMallocDefault));
         SS_HIP(hipHostMalloc((void**)&samp_h, R * sizeof(SampleOut), hipHostMallocDefault));
+        SS_HIP(hipHostMalloc((void**)&rowidx_h, R * sizeof(int), hipHostMallocDefault));
         SS_HIP(hipHostMalloc((void**)&probs_h, (size_t)R * n_vocab_pad * 4, hipHostMallocDefault));
     }
 
@@ -392,9 +397,38 @@ struct EngineT : EngineBase {
         g.pro = pro; g.epi = epi; g.W = Wt; g.M = M; g.N = N; g.K = K; g.S = S; g.scale = 1.0f; g.d = d; g.gelu_f16_in = dtype_is_f16;
         return g;
     }
+    // The step is a fixed sequence of ~13 L dependent launches whose arguments do not change between steps (tokens, positions and
+    // slots travel in ctl_d): after one plain pass per (M, n_samp) shape it is captured into a hipGraph and replayed.
+    struct StepGraph { int uses = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    std::map<int, StepGraph> step_graphs;
     void decoder_step_fused(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
         const int n_samp = (int)samp_rows.size();
         SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
+        if (n_samp) {
+            memcpy(rowidx_h, samp_rows.data(), (size_t)n_samp * 4);
+            SS_HIP(hipMemcpyAsync(rowidx_d.p, rowidx_h, (size_t)n_samp * 4, hipMemcpyHostToDevice, st));
+        }
+        if (!use_graph) fused_body(M, n_samp);
+        else {
+            StepGraph& sg = step_graphs[M * 1024 + n_samp];
+            if (sg.uses++ == 0) fused_body(M, n_samp);
+            else {
+                if (!sg.exec) {
+                    SS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                    try { fused_body(M, n_samp); } catch (...) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); throw; }
+                    SS_HIP(hipStreamEndCapture(st, &sg.graph));
+                    SS_HIP(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+                }
+                SS_HIP(hipGraphLaunch(sg.exec, st));
+            }
+        }
+        if (n_samp == 0) return;
+        const RowCtl* ctl = ctl_d.as<RowCtl>();
+        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st);
+        SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
+        if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
+    }
+    void fused_body(int M, int n_samp) {
         const RowCtl* ctl = ctl_d.as<RowCtl>();
         const long slot_stride = (long)n_tctx * d, layer_stride = (long)S * slot_stride;
         const long cb_stride = (long)2 * H * n_ctx * 64, cl_stride = (long)B * cb_stride;
@@ -465,7 +499,6 @@ struct EngineT : EngineBase {
             prev_parts = p3.as<float>(); prev_np = pl_fc2.S; prev_bias = e.b2;
         }
         if (n_samp == 0) return;
-        SS_HIP(hipMemcpyAsync(rowidx_d.p, samp_rows.data(), (size_t)n_samp * 4, hipMemcpyHostToDevice, st));
         {   // final LayerNorm once (gathering the sampling rows, folding FC2's bias + partials), then logits = x . tok_emb^T
             DecGemvDesc g = dgd(PRO_LN, DEPI_LOGITS, tok_emb, n_samp, n_vocab_pad, d, 1);
             g.x_in = xcur; g.parts = prev_parts; g.n_parts = prev_np; g.bias_prev = prev_bias; g.ln_w = lnw; g.ln_b = lnb; g.row_idx = rowidx_d.as<int>();
@@ -474,9 +507,6 @@ struct EngineT : EngineBase {
             q.Xt = lnd.p; q.ldx = d; q.out = logits.p; q.ldo = n_vocab_pad; q.n_valid = n_vocab;
             launch_dec_gemv<T>(q, pl_logits.NW, st);
         }
-        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st);
-        SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
-        if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
     }
 
     // One decoder launch over M rows described by ctl_h[0..M).  Rows may belong to the same decoder (a multi-token
@@ -530,7 +560,7 @@ struct EngineT : EngineBase {
         if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
     }
     DBuf samp_d, rowidx_d, rules_scratch;
-    bool use_fused = true, cross_direct = false, combine_separate = true;
+    bool use_fused = true, cross_direct = false, combine_separate = true, use_graph = true;
 
     RuleConsts rule_consts(const ss_params& P) {
         const Vocab& v = hm.vocab;

@@ -14,6 +14,15 @@
 // are summed in a fixed order by the consumer, so results are run-to-run identical (no float atomics).
 #include "kernels.h"
 
+// streamed-once operands (decoder weights, cross K/V).  Non-temporal loads (MI355X_MICROARCH.md "nt-weights") measured 1.2 % SLOWER here
+// (A/B/A/B on one box: 2.28 vs 2.25 ms per step), so plain loads are the default; -DSS_NT builds the nt variant.
+#ifdef SS_NT
+#define SS_LDW(p) __builtin_nontemporal_load(p)
+#else
+#define SS_LDW(p) (*(p))
+#endif
+
+
 namespace ss {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -146,12 +155,12 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
 #pragma unroll
     for (int j = 0; j < kMaxFrag / 2; j++) {
         if (j < npair) {
-            wf[2 * j] = *(const V8*)(wp + j * 64 + fg * 16);
-            wf[2 * j + 1] = *(const V8*)(wp + j * 64 + fg * 16 + 8);
+            wf[2 * j] = SS_LDW((const V8*)(wp + j * 64 + fg * 16));
+            wf[2 * j + 1] = SS_LDW((const V8*)(wp + j * 64 + fg * 16 + 8));
         }
     }
     V8 wtail = {};
-    if (nfr & 1) wtail = *(const V8*)(wp + npair * 64 + fg * 8);
+    if (nfr & 1) wtail = SS_LDW((const V8*)(wp + npair * 64 + fg * 8));
 
     // ---- prologue: build the operand tile xs[m][0..kslice) ----
     if constexpr (PRO == PRO_LN) {
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             ii[u] = (it + u) * 32 + wave * 8 + r;
-            kv[u] = *(const V8*)(K + (long)(k_beg + (ii[u] < nk ? ii[u] : 0)) * 64 + c * 8);
+            kv[u] = SS_LDW((const V8*)(K + (long)(k_beg + (ii[u] < nk ? ii[u] : 0)) * 64 + c * 8));
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -422,7 +431,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
         for (int u = 0; u < 4; u++) {
             const int i = (it + u) * 32 + wave * 8 + r;
             const bool okk = i < nk;
-            vv[u] = *(const V8*)(V + (long)(k_beg + (okk ? i : 0)) * 64 + c * 8);
+            vv[u] = SS_LDW((const V8*)(V + (long)(k_beg + (okk ? i : 0)) * 64 + c * 8));
             pw[u] = okk ? s_sc[i] : 0.f;
         }
 #pragma unroll
