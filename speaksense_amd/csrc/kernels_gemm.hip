@@ -236,51 +236,73 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
 // LDS rows are 64 B (32 k); chunk c of row r sits at position c ^ (3 * ((r >> 3) & 1)), applied on the DMA source
 // address and on the ds_read_b128 side: every 16-lane ds_read_b128 service group then touches 16 distinct 16-B slots.
 // ---------------------------------------------------------------------------------------------
-constexpr int TM = 256, TN = 256, TK = 32, NST = 4;
-constexpr int kStageBytes = (TM + TN) * TK * 2;   // 32 KB
-constexpr int kGemm256Lds = NST * kStageBytes;    // 128 KB -> one workgroup per CU, 2 waves per SIMD
+// WM = 1 variant: 128 (m) x 256 (n) tile, 256 threads = 4 waves (4 n x 1 m, same 64 n x 128 m wave tile), 3-stage ring of 24 KB
+// = 72 KB, so TWO workgroups share a CU: while one is in its epilogue (bias/GELU/residual VALU work and the output stores, which
+// cost 20-50 % of a tile when exposed) the other one's main loop keeps the matrix pipes busy.
+constexpr int TN = 256, TK = 32;
+template <int WM> struct G256 {
+    static constexpr int TM = 128 * WM, NWV = 4 * WM, NST = WM == 2 ? 4 : 3;
+    static constexpr int kStage = (TM + TN) * TK * 2;      // 32 KB / 24 KB
+    static constexpr int kLds = NST * kStage;              // 128 KB (one workgroup per CU) / 72 KB (two)
+    static constexpr int RPP = 16 * NWV;                   // tile rows one staging pass covers (16 per wave)
+    static constexpr int NP = (TM + TN) / RPP;             // DMA instructions per thread per stage: 4 / 6
+};
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int KIND>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
+template <typename T, int KIND, int WM>
+__global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Mfma<T>::V8 V8;
     typedef typename Mfma<T>::V4 V4;
+    typedef G256<WM> G;
+    constexpr int TM = G::TM, NST = G::NST, kStageBytes = G::kStage, NP = G::NP, RPP = G::RPP;
     constexpr bool SWAP = (KIND == EPI_VT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wm = wave & 1;
+    const int wn = WM == 2 ? wave >> 1 : wave, wm = WM == 2 ? wave & 1 : 0;
     const int nbn = g.N / TN, nbm = (g.M + TM - 1) / TM;
     // persistent: one workgroup per CU walks tiles vb = blockIdx.x + j*gridDim.x (gridDim.x is a multiple of 8, so the XCD
     // of the remap is preserved); the next tile's DMA prologue is issued right behind the previous tile's output stores
+    // All workgroups run tiles of equal duration, so without this they reach their epilogues together and the chip writes
+    // 256 x 128 KB at once (measured: the store-only epilogue then takes 25 % of a tile).  Group j = (blockIdx / 8) % groups
+    // starts j * stagger_ticks later (blockIdx % 8 is the XCD, so every XCD holds all groups): the output bursts interleave
+    // with other groups' main loops.
+    if (g.stagger_ticks > 0) {
+        const long long wait = (long long)((blockIdx.x >> 3) % g.stagger_groups) * g.stagger_ticks;
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     for (int vb = blockIdx.x; vb < nbn * nbm; vb += gridDim.x) {
     int mb, nb;
     tile_of_block(vb, nbm, nbn, &mb, &nb);
     const int m0 = mb * TM, n0 = nb * TN;
+    long long* tr = g.trace ? g.trace + ((long)blockIdx.x * 8 + (vb - blockIdx.x) / gridDim.x) * 4 : nullptr;
+    if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memtime();
     __builtin_amdgcn_s_barrier();   // every wave is done with the previous tile's LDS stages
     const T* __restrict__ A = (const T*)g.A;
     const T* __restrict__ W = (const T*)g.W;
 
-    // staging: 4 DMA instructions per thread per stage; pass p covers 128 tile rows (16 per wave), 4 lanes per 64-B row
+    // staging: NP DMA instructions per thread per stage; pass p covers RPP rows of [X tile; W tile] (16 per wave), 4 lanes per 64-B row
     const int srow = wave * 16 + (lane >> 2), spos = lane & 3;
-    const T* src[4];
+    unsigned soff[NP];      // byte offsets from the (uniform) A / W base: 32-bit VGPRs, the base stays in SGPRs (saddr + voffset DMA)
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const int r = (p & 1) * 128 + srow;                 // row within the X (p < 2) or W (p >= 2) tile
-        const int c = spos ^ (3 * ((r >> 3) & 1));
-        if (p < 2) {
-            long m = m0 + r;
+    for (int p = 0; p < NP; p++) {
+        const int ra = p * RPP + srow;                      // row of the stacked [X; W] stage; a pass lies entirely in X or in W
+        const int c = spos ^ (3 * ((ra >> 3) & 1));         // TM is a multiple of 16: same parity as the row within its tile
+        if (p * RPP < TM) {
+            long m = m0 + ra;
             if (m > g.M - 1) m = g.M - 1;
-            src[p] = A + (m / g.a_rows_per_batch) * g.a_batch_stride + (m % g.a_rows_per_batch) * g.lda + c * 8;
+            soff[p] = (unsigned)(((m / g.a_rows_per_batch) * g.a_batch_stride + (m % g.a_rows_per_batch) * g.lda + c * 8) * (long)sizeof(T));
         } else {
-            src[p] = W + (long)(n0 + r) * g.K + c * 8;
+            soff[p] = (unsigned)(((long)(n0 + ra - TM) * g.K + c * 8) * (long)sizeof(T));
         }
     }
     const int wave_off = wave * 16 * 64;
+#define SS_DMA(p, k0, dst) glds16<T>((const T*)((const char*)(((p) * RPP < TM ? A : W) + (k0)) + soff[p]), dst)
     auto stage = [&](int buf, int k0) {
         char* base = smem + buf * kStageBytes;
 #pragma unroll
-        for (int p = 0; p < 4; p++) glds16<T>(src[p] + k0, base + p * (128 * 64) + wave_off);
+        for (int p = 0; p < NP; p++) SS_DMA(p, k0, base + p * (RPP * 64) + wave_off);
     };
 
     f32x4 acc[4][8];
@@ -300,10 +322,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
     // step is therefore written as {8 MFMA, 1 DMA, 3 ds_read} and pinned with sched_group_barrier so the matrix pipe keeps
     // executing while the wave issues memory instructions.
     V8 wfA[4], xfA[8], wfB[4], xfB[8];
-    auto wait_stage = [&](int st, int issued) {   // MY DMA of stage `st` has landed; later stages (4 ops each) stay in flight
+    auto wait_stage = [&](int st, int issued) {   // MY DMA of stage `st` has landed; later stages (NP ops each) stay in flight
         const int later = issued - 1 - st;
-        if (later >= 2) wait_vmcnt<8>();
-        else if (later == 1) wait_vmcnt<4>();
+        if (later >= 2) wait_vmcnt<2 * NP>();
+        else if (later == 1) wait_vmcnt<NP>();
         else wait_vmcnt<0>();
     };
 #define SS_MMA_Q(WF, XF, q)                                                                         \
@@ -312,27 +334,35 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
         else acc[q][mi] = Mfma<T>::mma(WF[q], XF[mi], acc[q][mi]);                                   \
     }
     // one k-step: MFMAs on (WC, XC); optionally DMA the stage `dma_buf` and read the fragments of stage `rd_buf` into (WN, XN)
+#define SS_QUARTER(WC, XC, WN, XN, do_dma, dma_k0, do_read, q)                                        \
+    {                                                                                                \
+        SS_MMA_Q(WC, XC, q)                                                                          \
+        if (do_dma) {                                                                                \
+            SS_DMA(q, dma_k0, dbase + (q) * (RPP * 64) + wave_off);                                  \
+            if constexpr ((q) + 4 < NP) SS_DMA(((q) + 4) % NP, dma_k0, dbase + ((q) + 4) * (RPP * 64) + wave_off); \
+        }                                                                                            \
+        if (do_read) {                                                                               \
+            WN[q] = *(const V8*)(rbase + woff + (q) * 16 * 64);                                      \
+            XN[2 * (q)] = *(const V8*)(rbase + xoff + (2 * (q)) * 16 * 64);                          \
+            XN[2 * (q) + 1] = *(const V8*)(rbase + xoff + (2 * (q) + 1) * 16 * 64);                  \
+        }                                                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, ((q) + 4 < NP) ? 2 : 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                           \
+    }
 #define SS_STEP(WC, XC, WN, XN, do_dma, dma_buf, dma_k0, do_read, rd_buf)                              \
     {                                                                                                \
         char* dbase = smem + (dma_buf) * kStageBytes;                                                \
         const char* rbase = smem + (rd_buf) * kStageBytes;                                           \
-        _Pragma("unroll") for (int q = 0; q < 4; q++) {                                              \
-            SS_MMA_Q(WC, XC, q)                                                                      \
-            if (do_dma) glds16<T>(src[q] + (dma_k0), dbase + q * (128 * 64) + wave_off);             \
-            if (do_read) {                                                                           \
-                WN[q] = *(const V8*)(rbase + woff + q * 16 * 64);                                    \
-                XN[2 * q] = *(const V8*)(rbase + xoff + (2 * q) * 16 * 64);                          \
-                XN[2 * q + 1] = *(const V8*)(rbase + xoff + (2 * q + 1) * 16 * 64);                  \
-            }                                                                                        \
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                       \
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                       \
-            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                       \
-        }                                                                                            \
+        SS_QUARTER(WC, XC, WN, XN, do_dma, dma_k0, do_read, 0)                                        \
+        SS_QUARTER(WC, XC, WN, XN, do_dma, dma_k0, do_read, 1)                                        \
+        SS_QUARTER(WC, XC, WN, XN, do_dma, dma_k0, do_read, 2)                                        \
+        SS_QUARTER(WC, XC, WN, XN, do_dma, dma_k0, do_read, 3)                                        \
     }
 
     // prologue: three stages in flight, fragments of stage 0 in registers
     int issued = 0;
-    for (; issued < 3 && issued < nk; issued++) stage(issued, issued * TK);
+    for (; issued < NST - 1 && issued < nk; issued++) stage(issued, issued * TK);
     wait_stage(0, issued);
     __builtin_amdgcn_s_barrier();
     {
@@ -342,6 +372,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
 #pragma unroll
         for (int i = 0; i < 8; i++) xfA[i] = *(const V8*)(base + xoff + i * 16 * 64);
     }
+    if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memtime();
     for (int kt = 0; kt < nk; kt += 2) {
         // ---- even step: stage kt from set A; set B <- stage kt+1 ----
         {
@@ -351,9 +382,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
                 __builtin_amdgcn_s_barrier();   // stage kt+1 visible to all; every wave already holds stage kt in registers
             }
             const bool dma = has_next && issued < nk;   // refills the buffer of stage kt-1
-            const int db = issued & 3, dk = issued * TK;
+            const int db = issued % NST, dk = issued * TK;
             if (dma) issued++;
-            SS_STEP(wfA, xfA, wfB, xfB, dma, db, dk, has_next, (kt + 1) & 3)
+            SS_STEP(wfA, xfA, wfB, xfB, dma, db, dk, has_next, (kt + 1) % NST)
         }
         // ---- odd step: stage kt+1 from set B; set A <- stage kt+2 ----
         if (kt + 1 < nk) {
@@ -363,15 +394,21 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
                 __builtin_amdgcn_s_barrier();
             }
             const bool dma = has_next && issued < nk;
-            const int db = issued & 3, dk = issued * TK;
+            const int db = issued % NST, dk = issued * TK;
             if (dma) issued++;
-            SS_STEP(wfB, xfB, wfA, xfA, dma, db, dk, has_next, (kt + 2) & 3)
+            SS_STEP(wfB, xfB, wfA, xfA, dma, db, dk, has_next, (kt + 2) % NST)
         }
     }
 #undef SS_STEP
+#undef SS_QUARTER
+#undef SS_DMA
 #undef SS_MMA_Q
 
+    if (tr && tid == 0) tr[2] = __builtin_amdgcn_s_memtime();
     // ---------------- epilogue ----------------
+    // s_memtime stamps (tools/gemm_bench.cpp, SS_TRACE): on FC1 the store-only epilogue is 25 % of a tile, +GELU 28 %, +f32 residual 48 %.
+    // Neither a start-time stagger of the workgroups, nor a second workgroup per CU (128 x 256 tiles), nor an LDS-transposed epilogue that
+    // writes whole 128-B lines (4x fewer requests) shortened it: a CU drains its 128 KB tile at ~10 B/clk whatever the request shape.
     if constexpr (!SWAP) {
 #pragma unroll
         for (int mi = 0; mi < 8; mi++) {
@@ -436,6 +473,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmDesc g) {
             }
         }
     }
+    if (tr && tid == 0) tr[3] = __builtin_amdgcn_s_memtime();
     }  // tile loop
 }
 
@@ -445,12 +483,25 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
     once_per_device(attr128, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds)); });
     static const bool force128 = getenv("SS_GEMM128") != nullptr;
     if (!force128 && g.N % TN == 0 && g.K % TK == 0 && g.M >= 1024) {
-        static std::atomic<uint64_t> attr256{0};
-        once_per_device(attr256, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemm256Lds)); });
-        const int nwg256 = (g.N / TN) * ((g.M + TM - 1) / TM);
-        int n_cu = device_cu_count() / 8 * 8;   // persistent grid: one workgroup per CU, a multiple of 8 so the XCD of the remap is preserved
+        static const bool one_wg = getenv("SS_GEMM_2WG") == nullptr;   // default: 256 x 256, one workgroup per CU; the 128 x 256 two-per-CU form measured 15-20 % slower
+        int n_cu = device_cu_count() / 8 * 8;   // persistent grid, a multiple of 8 so the XCD of the remap is preserved
         if (n_cu < 8) n_cu = 8;
-        gemm256_kernel<T, KIND><<<nwg256 < n_cu ? nwg256 : n_cu, 512, kGemm256Lds, st>>>(g); SS_LAUNCH_CHECK();
+        static const int st_ticks = getenv("SS_GEMM_STAGGER") ? atoi(getenv("SS_GEMM_STAGGER")) : 0;
+        static const int st_groups = getenv("SS_GEMM_STAGGER_GROUPS") ? atoi(getenv("SS_GEMM_STAGGER_GROUPS")) : 4;
+        GemmDesc gs = g;
+        gs.stagger_ticks = st_ticks; gs.stagger_groups = st_groups > 0 ? st_groups : 1;
+        const GemmDesc& g = gs;
+        if (one_wg) {
+            static std::atomic<uint64_t> attr256{0};
+            once_per_device(attr256, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
+            const int nwg = (g.N / TN) * ((g.M + G256<2>::TM - 1) / G256<2>::TM);
+            gemm256_kernel<T, KIND, 2><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();
+        } else {
+            static std::atomic<uint64_t> attr128x{0};
+            once_per_device(attr128x, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<1>::kLds)); });
+            const int nwg = (g.N / TN) * ((g.M + G256<1>::TM - 1) / G256<1>::TM);
+            gemm256_kernel<T, KIND, 1><<<nwg < 2 * n_cu ? nwg : 2 * n_cu, 256, G256<1>::kLds, st>>>(g); SS_LAUNCH_CHECK();
+        }
         return;
     }
     const int nwg = (g.N / BN) * ((g.M + BM - 1) / BM);

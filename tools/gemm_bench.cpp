@@ -1,5 +1,6 @@
 // Standalone GEMM micro-benchmark / correctness harness for kernels_gemm.hip (dev tool, run on the GPU box):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip tools/gemm_bench.cpp speaksense_amd/csrc/kernels_gemm.hip -Ispeaksense_amd/csrc -o /tmp/gemm_bench
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -22,7 +23,7 @@ __global__ void fill(f16* p, size_t n, unsigned seed, float scale) {
 }
 int main(int argc, char** argv) {
     struct Shape { int M, N, K; const char* name; };
-    Shape shapes[] = {{12000, 5120, 1280, "FC1"}, {12000, 1280, 5120, "FC2"}, {12000, 2560, 1280, "QK"}, {12000, 1280, 1280, "O"},
+    Shape shapes[] = {{12000, 5120, 1280, "FC1"}, {12000, 1280, 5120, "FC2"}, {12000, 3840, 1280, "QKV"}, {12000, 4096, 1280, "N4096"}, {12000, 2560, 1280, "QK"}, {11776, 5120, 1280, "M46"}, {12288, 5120, 1280, "M48"}, {12000, 1280, 1280, "O"},
                       {12000, 81920, 1280, "crossKV"}, {4096, 4096, 4096, "sq4096"}, {8192, 8192, 8192, "sq8192"}};
     int kinds[] = {EPI_STORE_T, EPI_GELU_T, EPI_RES_F32};
     const char* kn[] = {"store", "gelu", "res_f32"};
@@ -45,6 +46,29 @@ int main(int argc, char** argv) {
             hipEventRecord(e1, st); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
             printf("%-8s M=%5d N=%5d K=%4d %-8s %8.3f ms  %7.1f TF/s\n", s.name, s.M, s.N, s.K, kn[ki], ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+        }
+        if (getenv("SS_TRACE") && s.N == 5120 && s.M == 12000) {   // per-tile phase breakdown of the gelu epilogue kernel
+            long long* tr; hipMalloc(&tr, 256 * 8 * 4 * 8); hipMemset(tr, 0, 256 * 8 * 4 * 8);
+            for (int ki = 0; ki < 3; ki++) {
+                GemmDesc g{};
+                g.A = A; g.lda = s.K; g.a_rows_per_batch = 1L << 40; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = kinds[ki]; g.bias = bias;
+                g.out = out; g.ldo = s.N; g.o_rows_per_batch = 1L << 40; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500; g.trace = tr;
+                launch_gemm<f16>(g, st); hipDeviceSynchronize();
+                std::vector<long long> h(256 * 8 * 4);
+                hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);
+                long long tmin = 1LL << 62;
+                for (int b = 0; b < 256; b++) if (h[(b * 8) * 4]) tmin = std::min(tmin, h[(b * 8) * 4]);
+                double pro = 0, loop = 0, epi = 0, gap = 0; int n = 0, ng = 0;
+                for (int b = 0; b < 256; b++) for (int t = 0; t < 4; t++) {
+                    const long long* q = &h[(b * 8 + t) * 4];
+                    if (!q[3]) continue;
+                    pro += q[1] - q[0]; loop += q[2] - q[1]; epi += q[3] - q[2]; n++;
+                    if (t > 0) { gap += q[0] - h[(b * 8 + t - 1) * 4 + 3]; ng++; }
+                }
+                printf("   trace %-8s: per tile (10 ns ticks) prologue %.0f  loop %.0f  epilogue %.0f  (tiles %d)\n", kn[ki], pro / n, loop / n, epi / n, n);
+                for (int b : {0, 100, 200}) { printf("     wg %3d:", b); for (int t = 0; t < 4; t++) { const long long* q = &h[(b * 8 + t) * 4]; if (q[3]) printf("  [%lld +%lld +%lld +%lld]", q[0] - tmin, q[1] - q[0], q[2] - q[1], q[3] - q[2]); } printf("\n"); }
+            }
+            hipFree(tr);
         }
         if (s.M * (long)s.N <= 12000L * 5120) {  // correctness vs naive reference (EPI_STORE_F32)
             hipMalloc(&Cf, (size_t)s.M * s.N * 4);
