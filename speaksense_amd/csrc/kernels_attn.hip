@@ -10,6 +10,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace ss {
 
@@ -28,6 +29,7 @@ template <> struct MfmaA<f16> {
     typedef f16x8 V8; typedef f16x4 V4;
     static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
+
 
 // ---------------------------------------------------------------------------------------------
 // encoder flash attention: grid (ceil(Tn/(64*QT)), H, B), 256 threads; wave w owns 16*QT query rows (QT column tiles).
@@ -127,8 +129,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, 
                     if (tail && key0 + kt * 16 + fg * 4 + r >= Tn) s[kt][r] = -1e30f;
                     mx = fmaxf(mx, s[kt][r]);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            mx = rows_max(mx);   // VALU permlane swaps, not ds_bpermute: this sits in the softmax dependency chain
             mx *= c2;
             if (__any(mx > mrun[qi])) {   // wave-uniform: the running max of most rows stops moving after a few chunks
                 const float mnew = fmaxf(mrun[qi], mx);
@@ -156,9 +157,7 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, 
     }
 #pragma unroll
     for (int qi = 0; qi < QT; qi++) {
-        float l = lrun[qi];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        const float l = rows_sum(lrun[qi]);
         const float inv = 1.0f / l;
         const int qr = q0 + qi * 16 + frow;
         if (qr < Tn) {
@@ -225,16 +224,14 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__
             float a = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; e++) a += qv[e] * (float)kv[u][e];
-            a += __shfl_xor(a, 1);
-            a += __shfl_xor(a, 2);
-            a += __shfl_xor(a, 4);
+            a = sum_lanes8(a);
             if (kk[u] < n_kv) {
                 if (c == 0) s_p[kk[u]] = a;
                 mx = fmaxf(mx, a);
             }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max(mx);
     __syncthreads();
     float sum = 0.f;
     for (int key = lane; key < n_kv; key += 64) {
@@ -242,7 +239,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__
         s_p[key] = p;
         sum += p;
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum(sum);
     __syncthreads();
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int it = 0; it < nit; it += 4) {
@@ -262,9 +259,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__
     }
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        acc[e] += __shfl_xor(acc[e], 8);
-        acc[e] += __shfl_xor(acc[e], 16);
-        acc[e] += __shfl_xor(acc[e], 32);
+        acc[e] = sum_stride8(acc[e]);
     }
     if (r == 0) {
         const float inv = 1.0f / sum;
@@ -320,13 +315,11 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const T* __restrict
         float a = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; e++) a += qv[e] * (float)kv[e];
-        a += __shfl_xor(a, 1);
-        a += __shfl_xor(a, 2);
-        a += __shfl_xor(a, 4);
+        a = sum_lanes8(a);
         if (c == 0) s_sc[i] = a;
         mx = fmaxf(mx, a);
     }
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max(mx);
     if (lane == 0) s_red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
@@ -336,7 +329,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const T* __restrict
         s_sc[i] = p;
         sum += p;
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum(sum);
     if (lane == 0) s_red[4 + wave] = sum;
     __syncthreads();
     sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
@@ -350,9 +343,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_kernel(const T* __restrict
     }
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        acc[e] += __shfl_xor(acc[e], 8);
-        acc[e] += __shfl_xor(acc[e], 16);
-        acc[e] += __shfl_xor(acc[e], 32);
+        acc[e] = sum_stride8(acc[e]);
     }
     if (r == 0) {
 #pragma unroll

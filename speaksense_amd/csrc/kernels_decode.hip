@@ -13,6 +13,7 @@
 // Split-K goes across workgroups (grid = N/16 x S) so that N = d projections still launch >= 256 workgroups; partials
 // are summed in a fixed order by the consumer, so results are run-to-run identical (no float atomics).
 #include "kernels.h"
+#include "wave_ops.h"
 
 // streamed-once operands (decoder weights, cross K/V).  Non-temporal loads (MI355X_MICROARCH.md "nt-weights") measured 1.2 % SLOWER here
 // (A/B/A/B on one box: 2.28 vs 2.25 ms per step), so plain loads are the default; -DSS_NT builds the nt variant.
@@ -109,7 +110,7 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
 #pragma unroll
         for (int i = 0; i < NI; i++) if (ok[i]) *(f32x4*)(g.x_out + (long)r * d + cc[i]) = v[i];
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum(sum);
     const float mean = sum / d;
     float sq = 0.f;
 #pragma unroll
@@ -117,7 +118,7 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
 #pragma unroll
         for (int e = 0; e < 4; e++) { v[i][e] = ok[i] ? v[i][e] - mean : 0.f; sq += v[i][e] * v[i][e]; }
     }
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    sq = wave_sum(sq);
     const float rstd = 1.0f / sqrtf(sq / d + 1e-5f);
 #pragma unroll
     for (int i = 0; i < NI; i++) {
@@ -399,16 +400,14 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
             float a = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; e++) a += qv[e] * (float)kv[u][e];
-            a += __shfl_xor(a, 1);
-            a += __shfl_xor(a, 2);
-            a += __shfl_xor(a, 4);
+            a = sum_lanes8(a);
             if (ii[u] < nk) {
                 if (c == 0) s_sc[ii[u]] = a;
                 mx = fmaxf(mx, a);
             }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    mx = wave_max(mx);
     if (lane == 0) s_red[wave] = mx;
     __syncthreads();
     mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
@@ -418,7 +417,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
         s_sc[i] = p;
         sum += p;
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum(sum);
     if (lane == 0) s_red[4 + wave] = sum;
     __syncthreads();
     sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
@@ -441,9 +440,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
     }
 #pragma unroll
     for (int e = 0; e < 8; e++) {
-        acc[e] += __shfl_xor(acc[e], 8);
-        acc[e] += __shfl_xor(acc[e], 16);
-        acc[e] += __shfl_xor(acc[e], 32);
+        acc[e] = sum_stride8(acc[e]);
     }
     if (r == 0) {
 #pragma unroll

@@ -6,6 +6,7 @@
 // HBM/latency-bound: one workgroup per 2048-sample frame; window, radix-2 FFT, per-bin gain and inverse FFT stay in LDS,
 // overlap-add is a gather (each output sample sums its <= 4 covering frames in frame order: deterministic, no atomics).
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace ss {
 
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(kThreads) void dn_variance_kernel(const float* __re
     const float* b = a + kFs;
     float acc = 0.f;
     for (int i = threadIdx.x; i < kFs; i += kThreads) { const float d = b[i] - a[i]; acc += d * d; }
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) var_out[blockIdx.x] = (red[0] + red[1] + red[2] + red[3]) / (float)kFs;
@@ -133,7 +134,7 @@ __global__ void dn_noise_gate_kernel(const float* __restrict__ in, float* __rest
 // one fused kernel per frame: gain, single-frame spectral subtraction, Hann^2 normalisation x10, noise gate.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
-    for (int o = 32; o > 0; o >>= 1) { const float u = __shfl_xor(v, o); v = is_max ? fmaxf(v, u) : v + u; }
+    v = is_max ? wave_max(v) : wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();

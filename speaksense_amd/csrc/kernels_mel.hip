@@ -6,6 +6,7 @@
 // To stay within 1e-4 of the CPU path in low-energy bins the FFT keeps whisper.cpp's structure and op order:
 // radix-2 decimation in time down to 16 DFT-25 leaves, f32, un-fused multiply/add, sin/cos from a 400-entry table.
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace ss {
 
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(kFrameThreads) void mel_frame_kernel(MelTables mt, 
         mel[(size_t)j * n_len + frame] = v;
         vmax = fmaxf(vmax, v);
     }
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    vmax = wave_max(vmax);
     if ((tid & 63) == 0) s_red[tid >> 6] = vmax;
     __syncthreads();
     if (tid == 0) {
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void mel_norm_kernel(float* __restrict__ mel, 
     __shared__ double s_mmax;
     float m = -1e30f;
     for (int i = threadIdx.x; i < n_frames; i += 256) m = fmaxf(m, frame_max[i]);
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    m = wave_max(m);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) s_mmax = (double)fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3])) - 8.0;

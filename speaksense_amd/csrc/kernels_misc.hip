@@ -4,6 +4,7 @@
 // whisper_sample_token(best) loops over the vocabulary, which here never leave the GPU:
 // only {id, p, plog, tid, pt, ptsum} per sequence cross PCIe each step.
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace ss {
 
@@ -33,7 +34,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if (!ok[i]) v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum(sum);
     const float mean = sum / d;
     float sq = 0.f;
 #pragma unroll
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; e++) { v[i][e] = ok[i] ? v[i][e] - mean : 0.f; sq += v[i][e] * v[i][e]; }
     }
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    sq = wave_sum(sq);
     const float scale = 1.0f / sqrtf(sq / d + 1e-5f);
     TO* yr = y + (long)row * d;
     f32x4 ww[NI], bb[NI];
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(256) void logits_rules_scan_kernel(const float* __r
             if (i >= rc.beg) sts += expf(v - ms.v);
         }
     }
-    for (int o = 32; o > 0; o >>= 1) { sall += __shfl_xor(sall, o); sts += __shfl_xor(sts, o); }
+    sall = wave_sum(sall); sts = wave_sum(sts);
     if (lane == 0) { s_f[0][wave] = sall; s_f[1][wave] = sts; }
     __syncthreads();
     if (tid == 0) {
