@@ -155,7 +155,7 @@ struct EngineT : EngineBase {
         d = hp.n_text_state; da = hp.n_audio_state; H = hp.n_text_head; Ha = hp.n_audio_head; L = hp.n_text_layer; La = hp.n_audio_layer;
         n_mel = hp.n_mels; n_ctx = hp.n_audio_ctx; n_tctx = hp.n_text_ctx; n_vocab = hp.n_vocab; n_vocab_pad = round_up(n_vocab, 64);
         K1 = round_up(3 * n_mel, 64);
-        Tpad = round_up(n_ctx, 32);
+        Tpad = round_up(n_ctx, 64);   // V^T rows padded (zero) to whole 64-key chunks for the LDS-staged attention kernel
         qscale = powf(64.0f, -0.25f);
         dtype_is_f16 = sizeof(T) == 2 && std::is_same<T, f16>::value;
         if (d % 128 || da % 128) throw Error(SS_ERR_MODEL, "model: state size must be a multiple of 128");

@@ -7,6 +7,8 @@
 //    HBM-bound streaming kernels (one new token per row), split over T for occupancy.
 // Replaces ggml's mul_mat(K,Q) -> soft_max(_ext) -> mul_mat(V,P) node chains in whisper.cpp's encoder / decoder graphs
 // (/root/reference/resources/ggml-metal.metal:351-435 kernel_soft_max, :1229-1305 kernel_mul_mv_f16_f16).
+#include <atomic>
+#include <type_traits>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -172,9 +174,195 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// encoder flash attention, LDS-staged form: grid ceil(Tn / (64 QT)) * H * B workgroups of 256 threads; wave w owns 16 QT query rows.
+// The version above lets every wave pull its own K / V^T fragments from L2 in 32-key chunks: 8-B pieces of V^T rows and half lines of
+// K rows, i.e. 3x the useful bytes through the CU's L1, re-read by every wave.  Here K and V^T tiles of 64 keys (whole 128-B lines)
+// are DMA'd global -> LDS once per workgroup (global_load_lds, 3-stage ring, one s_barrier per chunk) and shared by the four waves.
+//  * S^T = K Q^T with the K rows of a 32-key group permuted (MFMA row i of tile t <-> key (i>>2)*8 + (t&1)*4 + (i&3)), so the
+//    exponentiated scores a lane holds are 8 CONSECUTIVE keys = the B operand of P.V with V^T fragments read as plain ds_read_b128.
+//  * LDS rows are 128 B (8 chunks of 16 B); chunk c of row r sits at position c ^ ((r & 3) | ((r >> 3) & 1) << 2), applied on the DMA
+//    source side: every 16-lane ds_read_b128 service group then touches 16 distinct 16-B slots for both the K and the V^T reads.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int attn_swz(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+template <typename T, int QT>
+__global__ __launch_bounds__(256, 2) void enc_attn_lds_kernel(const T* __restrict__ q, const T* __restrict__ k, long ld, const T* __restrict__ vT,
+                                                              int Tpad, T* __restrict__ out, long ldo, int H, int Tn) {
+    typedef typename MfmaA<T>::V8 V8;
+    typedef typename MfmaA<T>::V4 V4;
+    constexpr int NS = 3, kStage = 16384;            // K tile 64 keys x 128 B, then V^T tile 64 dh rows x 128 B
+    extern __shared__ __attribute__((aligned(16))) char smem_a[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int nqb = (Tn + 64 * QT - 1) / (64 * QT);
+    int bid = blockIdx.x;
+    {   // XCD-aware remap (see enc_attn_kernel)
+        const int nwg = gridDim.x, qq = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int qb = bid % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
+    const int q0 = qb * (64 * QT) + wave * (16 * QT);
+    const long rowbase = (long)b * Tn;
+
+    V8 qf[QT][2];
+#pragma unroll
+    for (int qi = 0; qi < QT; qi++) {
+        int qr = q0 + qi * 16 + frow;
+        if (qr > Tn - 1) qr = Tn - 1;
+        const T* p = q + (rowbase + qr) * ld + h * 64 + fg * 8;
+        qf[qi][0] = *(const V8*)p;
+        qf[qi][1] = *(const V8*)(p + 32);
+    }
+    // DMA sources: wave w stages 8-row blocks {2w, 2w+1} of the K tile and of the V^T tile; lane L -> row L/8, position L%8
+    const int srow = lane >> 3, spos = lane & 7;
+    const T* ksrc[2]; const T* vsrc[2];
+    int krow[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int r = (2 * wave + j) * 8 + srow;
+        const int c = spos ^ attn_swz(r);
+        krow[j] = r;
+        ksrc[j] = k + rowbase * ld + h * 64 + c * 8;
+        vsrc[j] = vT + ((long)(b * H + h) * 64 + r) * Tpad + c * 8;
+    }
+    auto stage = [&](int buf, int key0) {
+        char* base = smem_a + buf * kStage;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            int kr = key0 + krow[j];
+            if (kr > Tn - 1) kr = Tn - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc[j] + (long)kr * ld),
+                                             (__attribute__((address_space(3))) void*)(base + (2 * wave + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc[j] + key0),
+                                             (__attribute__((address_space(3))) void*)(base + 8192 + (2 * wave + j) * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 o[4][QT];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < QT; j++) o[i][j] = (f32x4){0, 0, 0, 0};
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int j = 0; j < QT; j++) { mrun[j] = -1e30f; lrun[j] = 0.f; }
+    const float c2 = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e)
+    const int nchunk = (Tn + 63) / 64;
+
+    // fragment read offsets (bytes within a stage)
+    int koff[4][2], voff[4][2];
+#pragma unroll
+    for (int kt = 0; kt < 4; kt++) {
+        const int key = (kt >> 1) * 32 + (frow >> 2) * 8 + (kt & 1) * 4 + (frow & 3);
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) koff[kt][hh] = key * 128 + (((hh * 4 + fg) ^ attn_swz(key)) * 16);
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; dt++) {
+        const int r = dt * 16 + frow;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) voff[dt][ks] = 8192 + r * 128 + (((ks * 4 + fg) ^ attn_swz(r)) * 16);
+    }
+
+    // one 64-key chunk; TAIL (only the last chunk of a Tn that is not a multiple of 64) masks the keys beyond Tn
+    auto chunk = [&](auto tail_tag, int kc) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        if (kc + 1 < nchunk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // chunk kc has landed for every wave; everyone is done reading chunk kc-1
+        if (kc + 2 < nchunk) stage((kc + 2) % NS, (kc + 2) * 64);
+        const char* base = smem_a + (kc % NS) * kStage;
+        V8 kf[4][2], vf[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++) { kf[kt][0] = *(const V8*)(base + koff[kt][0]); kf[kt][1] = *(const V8*)(base + koff[kt][1]); }
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) { vf[dt][0] = *(const V8*)(base + voff[dt][0]); vf[dt][1] = *(const V8*)(base + voff[dt][1]); }
+        const int key0 = kc * 64;
+#pragma unroll
+        for (int qi = 0; qi < QT; qi++) {
+            f32x4 s[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; kt++) {
+                f32x4 a = (f32x4){0, 0, 0, 0};
+                a = MfmaA<T>::mma(kf[kt][0], qf[qi][0], a);
+                a = MfmaA<T>::mma(kf[kt][1], qf[qi][1], a);
+                s[kt] = a;
+            }
+            float mx = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if constexpr (TAIL) { if (key0 + (kt >> 1) * 32 + fg * 8 + (kt & 1) * 4 + r >= Tn) s[kt][r] = -1e30f; }
+                    mx = fmaxf(mx, s[kt][r]);
+                }
+            mx = rows_max(mx);
+            mx *= c2;
+            if (__any(mx > mrun[qi])) {
+                const float mnew = fmaxf(mrun[qi], mx);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[qi] - mnew);
+                mrun[qi] = mnew;
+                lrun[qi] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++) o[dt][qi] *= alpha;
+            }
+            const float mcur = mrun[qi];
+            float psum = 0.f;
+            V8 pf[2];
+#pragma unroll
+            for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c2, -mcur));
+                    psum += pv;
+                    pf[kt >> 1][(kt & 1) * 4 + r] = (T)pv;
+                }
+            lrun[qi] += psum;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                o[dt][qi] = MfmaA<T>::mma(vf[dt][0], pf[0], o[dt][qi]);
+                o[dt][qi] = MfmaA<T>::mma(vf[dt][1], pf[1], o[dt][qi]);
+            }
+        }
+    };
+    stage(0, 0);
+    if (nchunk > 1) stage(1, 64);
+    const int nfull = (Tn % 64) ? nchunk - 1 : nchunk;
+    for (int kc = 0; kc < nfull; kc++) chunk(std::false_type{}, kc);
+    if (nfull < nchunk) chunk(std::true_type{}, nchunk - 1);
+#pragma unroll
+    for (int qi = 0; qi < QT; qi++) {
+        const float l = rows_sum(lrun[qi]);
+        const float inv = 1.0f / l;
+        const int qr = q0 + qi * 16 + frow;
+        if (qr < Tn) {
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                V4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; r++) ov[r] = (T)(o[dt][qi][r] * inv);
+                *(V4*)(out + (rowbase + qr) * ldo + h * 64 + dt * 16 + fg * 4) = ov;
+            }
+        }
+    }
+}
+
+template <typename T, int QT>
+static void launch_enc_attention_lds(const T* q, const T* k, long ld, const T* vT, int Tpad, T* out, long ldo, int B, int H, int Tn, hipStream_t st) {
+    if (Tpad < (Tn + 63) / 64 * 64) throw Error(-1, "enc_attention: V^T rows must be padded to a multiple of 64 keys");
+    static std::atomic<uint64_t> attr{0};
+    once_per_device(attr, [] { SS_HIP(hipFuncSetAttribute((const void*)enc_attn_lds_kernel<T, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16384)); });
+    dim3 grid(((Tn + 64 * QT - 1) / (64 * QT)) * H * B);
+    enc_attn_lds_kernel<T, QT><<<grid, 256, 3 * 16384, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn); SS_LAUNCH_CHECK();
+}
+
 template <typename T>
 void launch_enc_attention(const T* q, const T* k, long ld, const T* vT, int Tpad, T* out, long ldo, int B, int H, int Tn, hipStream_t st) {
     static const int qt = getenv("SS_ATTN_QT") ? atoi(getenv("SS_ATTN_QT")) : 3;
+    static const int lds_qt = getenv("SS_ATTN_LDS") ? atoi(getenv("SS_ATTN_LDS")) : 4;   // 0 = the direct-from-L2 kernel
+    if (lds_qt == 4) { launch_enc_attention_lds<T, 4>(q, k, ld, vT, Tpad, out, ldo, B, H, Tn, st); return; }
+    if (lds_qt == 3) { launch_enc_attention_lds<T, 3>(q, k, ld, vT, Tpad, out, ldo, B, H, Tn, st); return; }
+    if (lds_qt == 2) { launch_enc_attention_lds<T, 2>(q, k, ld, vT, Tpad, out, ldo, B, H, Tn, st); return; }
     if (qt == 4) {
         dim3 grid(((Tn + 255) / 256) * H * B);
         enc_attn_kernel<T, 4><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn); SS_LAUNCH_CHECK();
