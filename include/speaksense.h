@@ -106,6 +106,15 @@ int32_t ss_result_n_tokens(const ss_session* s);                      /* accepte
 int ss_result_tokens(const ss_session* s, int32_t* ids, float* plog); /* plog may be NULL */
 int ss_result_counters(const ss_session* s, int32_t out4[4]);         /* n_encode, n_decode_steps, n_fail, n_windows */
 
+/* ---- the session's sampler state --------------------------------------------------------------------- */
+/* whisper_state owns one std::mt19937(0) that the temperature-fallback sampler draws from and that is never reseeded, so in the reference
+ * (one state per stream / per REST task, chunks one after another) a chunk that falls back to sampling sees a generator advanced by every
+ * earlier chunk's draws.  ss_session_rng_draws: generator invocations consumed by this session so far.  ss_session_rng_discard: advance
+ * the generator of a (fresh) session by n invocations -- with the two, chunks of one reference state can be decoded as a batch on fresh
+ * sessions and still give the serial result (speaksense_amd/rest.py::TranscribeProcessor). */
+int64_t ss_session_rng_draws(const ss_session* s);
+int ss_session_rng_discard(ss_session* s, int64_t n);
+
 /* ---- per-stage hooks for parity tests (host f32 in / out; each runs the same device kernels) -------- */
 int32_t ss_mel_n_len(int32_t n_samples);
 int ss_log_mel(ss_engine* e, const float* pcm, int32_t n_samples, float* mel_out /* [n_mel][n_len] */, int32_t n_len);

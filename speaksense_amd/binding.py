@@ -71,6 +71,9 @@ def lib():
         L.ss_result_n_tokens.argtypes = [vp]
         L.ss_result_tokens.argtypes = [vp, vp, vp]
         L.ss_result_counters.argtypes = [vp, vp]
+        L.ss_session_rng_draws.argtypes = [vp]
+        L.ss_session_rng_draws.restype = C.c_int64
+        L.ss_session_rng_discard.argtypes = [vp, C.c_int64]
         L.ss_mel_n_len.argtypes = [i32]
         L.ss_log_mel.argtypes = [vp, f32p, i32, f32p, i32]
         L.ss_encode.argtypes = [vp, f32p, i32, i32, f32p]
@@ -268,6 +271,13 @@ class Session:
         c = np.zeros(4, np.int32)
         self.L.ss_result_counters(self.h, _p(c))
         return dict(segments=segs, tokens=ids, plog=plog, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]), n_windows=int(c[3]))
+
+    def rng_draws(self) -> int:
+        """Invocations of the session's std::mt19937 so far (whisper_state::rng, consumed only by temperature-fallback sampling)."""
+        return int(self.L.ss_session_rng_draws(self.h))
+
+    def rng_discard(self, n: int):
+        _check(self.L.ss_session_rng_discard(self.h, int(n)))
 
     def set_encoder(self, enc: np.ndarray):
         enc = np.ascontiguousarray(enc, np.float32)

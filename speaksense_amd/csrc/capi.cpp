@@ -144,6 +144,13 @@ int ss_result_counters(const ss_session* s, int32_t out4[4]) {
     return SS_OK;
 }
 
+int64_t ss_session_rng_draws(const ss_session* s) { return s ? (int64_t)s->s.rng.n : 0; }
+int ss_session_rng_discard(ss_session* s, int64_t n) {
+    if (!s || n < 0) return fail(SS_ERR_ARG, "ss_session_rng_discard: bad argument");
+    s->s.rng.discard((uint64_t)n);
+    return SS_OK;
+}
+
 int32_t ss_mel_n_len(int32_t n_samples) { return mel_n_len(n_samples); }
 int ss_log_mel(ss_engine* e, const float* pcm, int32_t n, float* out, int32_t n_len) {
     if (!e || !pcm || !out || n <= 0) return fail(SS_ERR_ARG, "ss_log_mel: bad argument");

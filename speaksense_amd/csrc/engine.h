@@ -17,13 +17,25 @@ namespace ss {
 struct TokenData { int id = 0, tid = 0; float p = 0, plog = 0, pt = 0, ptsum = 0; };
 struct Segment { int64_t t0, t1; std::string text; bool speaker_turn_next; };
 
+// std::mt19937 that counts how often it was invoked: a session's sampling history is then summarised by one number, and a fresh session
+// can be put into the state an older one had (`discard`), which is what lets independent chunks of one reference state run as a batch.
+struct CountingRng {
+    typedef std::mt19937::result_type result_type;
+    std::mt19937 g{0};
+    uint64_t n = 0;
+    static constexpr result_type min() { return std::mt19937::min(); }
+    static constexpr result_type max() { return std::mt19937::max(); }
+    result_type operator()() { n++; return g(); }
+    void discard(uint64_t k) { g.discard(k); n += k; }
+};
+
 struct Session {
     struct EngineBase* eng = nullptr;
     std::vector<Segment> segments;
     std::vector<TokenData> tokens;
     int n_encode = 0, n_decode = 0, n_fail = 0, n_windows = 0;
     std::vector<int> prompt_past;  // whisper_state::prompt_past: text context carried between windows (and calls, unless no_context)
-    std::mt19937 rng{0};  // whisper_state::rng: seeded once per state, never reseeded per call
+    CountingRng rng;  // whisper_state::rng (std::mt19937 seeded with 0 once per state, never reseeded per call)
 };
 
 struct Job {  // one chunk handed to transcribe (== one whisper_full_with_state call)

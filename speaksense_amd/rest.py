@@ -163,8 +163,24 @@ class TranscribeProcessor:    # transcribe.rs:21-166
         frames = self.preprocess(np.asarray(interleaved, np.float32), channels, sample_rate)
         p = asr_mod.AsrParams(language=language, speaker_diarization=speaker_diarization, stream_mode=True)   # transcribe.rs:66-70
         chunks = rest_chunks(frames)
-        if self.batched:
-            results = self.asr.transcribe_many([self.asr.create_state() for _ in chunks], chunks, p) if chunks else []
+        if self.batched and chunks:
+            # The reference runs the chunks one after another on ONE state.  With no_context they share nothing but the state's sampler
+            # (std::mt19937, never reseeded): a chunk that falls back to temperature sampling draws from a generator advanced by all earlier
+            # chunks' draws.  All chunks go out as one batch on fresh sessions; a chunk that sampled although earlier chunks had already
+            # drawn is redone with its generator advanced to the serial position.  Chunks that never sample (the normal case) need no redo.
+            states = [self.asr.create_state() for _ in chunks]
+            results = self.asr.transcribe_many(states, chunks, p)
+            prefix = 0
+            for k, st in enumerate(states):
+                draws = st.rng_draws()
+                if prefix > 0 and draws > 0:
+                    st = self.asr.create_state()
+                    st.rng_discard(prefix)
+                    results[k] = self.asr.transcribe_with_state(st, chunks[k], p)
+                    draws = st.rng_draws() - prefix
+                prefix += draws
+        elif self.batched:
+            results = []
         else:
             state = self.asr.create_state()
             results = [self.asr.transcribe_with_state(state, c, p) for c in chunks]
