@@ -169,6 +169,7 @@ struct EngineT : EngineBase {
         cross_direct = getenv("SS_CROSS_DIRECT") != nullptr;
         combine_separate = getenv("SS_COMBINE_FUSED") == nullptr;   // fused prologue measured slower (865 vs 940 xRT): opt-in only
         { const char* gv = getenv("SS_DECODE_GRAPH"); use_graph = !(gv && gv[0] == '0'); }
+        ln_fused = getenv("SS_DECODE_LN_FUSED") ? atoi(getenv("SS_DECODE_LN_FUSED")) : 0;   // 1 both seams, 2 self-attention seam only, 3 cross-attention seam only
         start_worker();
     }
     ~EngineT() override {
@@ -377,7 +378,7 @@ struct EngineT : EngineBase {
     }
     // ---- fused decode step (M <= 16): 8 launches per layer, see kernels_decode.hip ----
     struct Plan { int S, NW; };
-    Plan pl_qkv, pl_dd, pl_fc1, pl_fc2, pl_logits;
+    Plan pl_qkv, pl_dd, pl_d1, pl_fc1, pl_fc2, pl_logits;
     DBuf xa, xb, p1, pq, p2, p3;
     void plan_decode() {
         dec_gemv_plan(3 * d, d, &pl_qkv.S, &pl_qkv.NW); pl_qkv.S = 1; fix_nw(pl_qkv, d);
@@ -385,6 +386,7 @@ struct EngineT : EngineBase {
         dec_gemv_plan(4 * d, d, &pl_fc1.S, &pl_fc1.NW); pl_fc1.S = 1; fix_nw(pl_fc1, d);
         dec_gemv_plan(d, 4 * d, &pl_fc2.S, &pl_fc2.NW);
         pl_logits.S = 1; fix_nw(pl_logits, d);
+        fix_nw(pl_d1, d);   // d x d projections with the whole K sum in one workgroup (residual epilogue, LayerNorm prologue)
         const size_t pb = (size_t)8 * 16 * d * 4;
         xa.alloc((size_t)16 * d * 4); xb.alloc((size_t)16 * d * 4); p1.alloc(pb); pq.alloc(pb); p2.alloc(pb); p3.alloc(pb);
     }
@@ -450,12 +452,25 @@ struct EngineT : EngineBase {
             }
             launch_dec_self_attention<T>(qd.as<T>(), kself.as<T>() + il * layer_stride, vself.as<T>() + il * layer_stride, slot_stride, d, H, ctl, M,
                                          attd.as<T>(), st);
-            {   // attention out-projection, split-K partials
-                DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wo, M, d, d, pl_dd.S);
-                g.Xt = attd.p; g.ldx = d; g.part_out = p1.as<float>();
-                launch_dec_gemv<T>(g, pl_dd.NW, st);
-            }
-            {   // x += bo + sum P1; LNc -> cross query partials (reduced, biased and scaled inside the cross-attention kernel)
+            int n_qpart = pl_dd.S;
+            if (ln_fused == 1 || ln_fused == 2) {
+                // out-projection with the whole K sum in one workgroup: its epilogue IS the residual update (x = x + bo + W a), and the
+                // LayerNorm in front of the cross query is the next GEMV's prologue: two launches instead of four
+                DecGemvDesc g = dgd(PRO_T, DEPI_RES, e.wo, M, d, d, 1);
+                g.Xt = attd.p; g.ldx = d; g.bias = e.bo; g.x_in = xcur; g.x_out = xnext;
+                launch_dec_gemv<T>(g, pl_d1.NW, st);
+                std::swap(xcur, xnext);
+                DecGemvDesc q = dgd(PRO_LN, DEPI_PART, e.wcq, M, d, d, 1);
+                q.x_in = xcur; q.ln_w = e.lncw; q.ln_b = e.lncb; q.part_out = pq.as<float>();
+                launch_dec_gemv<T>(q, pl_d1.NW, st);
+                n_qpart = 1;
+            } else {
+                {   // attention out-projection, split-K partials
+                    DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wo, M, d, d, pl_dd.S);
+                    g.Xt = attd.p; g.ldx = d; g.part_out = p1.as<float>();
+                    launch_dec_gemv<T>(g, pl_dd.NW, st);
+                }
+                // x += bo + sum P1; LNc -> cross query partials (reduced, biased and scaled inside the cross-attention kernel)
                 DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
                 r.x_in = xcur; r.x_out = xnext; r.parts = p1.as<float>(); r.n_parts = pl_dd.S; r.bias_prev = e.bo; r.ln_w = e.lncw; r.ln_b = e.lncb;
                 launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
@@ -466,10 +481,10 @@ struct EngineT : EngineBase {
             }
             const T* kc = cross.as<T>() + il * cl_stride;
             if (cross_direct) {
-                launch_dec_cross_attention_direct<T>(pq.as<float>(), pl_dd.S, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
+                launch_dec_cross_attention_direct<T>(pq.as<float>(), n_qpart, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
                                                      attd.as<T>(), st);
             } else {
-                launch_dec_cross_attention_q<T>(pq.as<float>(), pl_dd.S, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
+                launch_dec_cross_attention_q<T>(pq.as<float>(), n_qpart, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
                                                 cscratch.as<float>(), st);
                 if (combine_separate) launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
             }
@@ -477,12 +492,21 @@ struct EngineT : EngineBase {
                 DecGemvDesc g = dgd(PRO_COMBINE, DEPI_PART, e.wco, M, d, d, pl_dd.S);
                 g.cross_parts = cscratch.as<float>(); g.part_out = p2.as<float>();
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
+            } else if (ln_fused == 1 || ln_fused == 3) {
+                DecGemvDesc g = dgd(PRO_T, DEPI_RES, e.wco, M, d, d, 1);
+                g.Xt = attd.p; g.ldx = d; g.bias = e.bco; g.x_in = xcur; g.x_out = xnext;
+                launch_dec_gemv<T>(g, pl_d1.NW, st);
+                std::swap(xcur, xnext);
             } else {
                 DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wco, M, d, d, pl_dd.S);
                 g.Xt = attd.p; g.ldx = d; g.part_out = p2.as<float>();
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
             }
-            {   // x += bco + sum P2; LN2 -> FC1 + GELU
+            if ((ln_fused == 1 || ln_fused == 3) && !cross_direct && combine_separate) {   // LN2 is FC1's prologue
+                DecGemvDesc g = dgd(PRO_LN, DEPI_GELU_T, e.w1, M, 4 * d, d, 1);
+                g.x_in = xcur; g.ln_w = e.ln2w; g.ln_b = e.ln2b; g.bias = e.b1; g.out = ffd.p; g.ldo = 4 * d;
+                launch_dec_gemv<T>(g, pl_fc1.NW, st);
+            } else {   // x += bco + sum P2; LN2 -> FC1 + GELU
                 DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
                 r.x_in = xcur; r.x_out = xnext; r.parts = p2.as<float>(); r.n_parts = pl_dd.S; r.bias_prev = e.bco; r.ln_w = e.ln2w; r.ln_b = e.ln2b;
                 launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
@@ -561,6 +585,7 @@ struct EngineT : EngineBase {
     }
     DBuf samp_d, rowidx_d, rules_scratch;
     bool use_fused = true, cross_direct = false, combine_separate = true, use_graph = true;
+    int ln_fused = 0;
 
     RuleConsts rule_consts(const ss_params& P) {
         const Vocab& v = hm.vocab;

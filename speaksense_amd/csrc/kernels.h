@@ -89,7 +89,7 @@ template <typename T> void launch_skinny(const SkinnyDesc& g, hipStream_t st);
 
 // Fused decode-step GEMV for M <= 16 rows (kernels_decode.hip): prologue + 16-row weight tiles x split-K + epilogue
 enum DecPro { PRO_LN = 0, PRO_T = 1, PRO_COMBINE = 2 };
-enum DecEpi { DEPI_PART = 0, DEPI_QKV = 1, DEPI_GELU_T = 2, DEPI_LOGITS = 3 };
+enum DecEpi { DEPI_PART = 0, DEPI_QKV = 1, DEPI_GELU_T = 2, DEPI_LOGITS = 3, DEPI_RES = 4 };
 struct DecGemvDesc {
     int pro, epi;
     // PRO_LN: x = x_in (or tok/pos embedding when ctl != null) + bias_prev + sum_p parts[p]; optional write-back; LayerNorm

@@ -56,7 +56,7 @@ constexpr int kCrossSplitD = 4, kCrossPartD = 66;
 // x = [x_in | tok+pos embedding] + bias_prev + sum_p parts[p]  (fixed order, branch-free: up to 4 partial slots, unused
 // slots re-read slot 0 with weight 0 so that every load is independent and in flight together), optional write-back,
 // LayerNorm over the full row, normalised columns [kbeg, kbeg+kslice) written to dst as T.  One wave per row.
-template <typename T, int NI>
+template <typename T, int NI, bool PLAIN = false>   // PLAIN: x = x_in only (no embedding, partials, bias or write-back): the fused-prologue form
 __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bool write_x, int kbeg, int kslice, T* dst) {
     // NI float4 per lane cover the row (d <= NI*256); lanes past the end load a clamped (valid) address and are masked,
     // so no load sits behind a divergent branch: all of them are in flight together.
@@ -70,7 +70,11 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
     f32x4 ww[NI], bb[NI];   // issued with the row loads: the LayerNorm affine must not cost its own memory round trip
 #pragma unroll
     for (int i = 0; i < NI; i++) { ww[i] = *(const f32x4*)(g.ln_w + cc[i]); bb[i] = *(const f32x4*)(g.ln_b + cc[i]); }
-    if (g.ctl) {  // layer 0: token + positional embedding (replaces ggml get_rows + add)
+    if constexpr (PLAIN) {
+        const float* xr = g.x_in + (long)r * d;
+#pragma unroll
+        for (int i = 0; i < NI; i++) v[i] = *(const f32x4*)(xr + cc[i]);
+    } else if (g.ctl) {  // layer 0: token + positional embedding (replaces ggml get_rows + add)
         const RowCtl rc = g.ctl[r];
         const T* te = (const T*)g.tok_emb + (long)rc.token * d;
         const float* pe = g.pos_emb + (long)rc.pos * d;
@@ -106,9 +110,11 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
         if (!ok[i]) v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
-    if (write_x && g.x_out) {
+    if constexpr (!PLAIN) {
+        if (write_x && g.x_out) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) if (ok[i]) *(f32x4*)(g.x_out + (long)r * d + cc[i]) = v[i];
+            for (int i = 0; i < NI; i++) if (ok[i]) *(f32x4*)(g.x_out + (long)r * d + cc[i]) = v[i];
+        }
     }
     sum = wave_sum(sum);
     const float mean = sum / d;
@@ -170,7 +176,8 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
                 for (int c = lane; c < kslice; c += 64) xs[m * xld + c] = (T)0.0f;
                 continue;
             }
-            ln_row<T, NI>(g, m, lane, blockIdx.x == 0 && s == 0, kbeg, kslice, xs + m * xld);
+            if (g.n_parts == 0 && !g.bias_prev && !g.ctl) ln_row<T, NI, true>(g, m, lane, false, kbeg, kslice, xs + m * xld);
+            else ln_row<T, NI>(g, m, lane, blockIdx.x == 0 && s == 0, kbeg, kslice, xs + m * xld);
         }
     } else if constexpr (PRO == PRO_COMBINE) {
         // flash-decoding combine of the cross-attention partials for the columns of this K slice
@@ -252,6 +259,8 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
             for (int w = 0; w < NW; w++) v += red[(w * 16 + m) * 17 + nn];
             if constexpr (EPI == DEPI_PART) {
                 g.part_out[((long)s * 16 + m) * g.N + n] = v;
+            } else if constexpr (EPI == DEPI_RES) {   // residual stream: x_out = x_in + bias + W a  (S == 1: the whole K sum is here)
+                g.x_out[(long)m * g.N + n] = (g.x_in[(long)m * g.N + n] + g.bias[n]) + v;
             } else {
                 if (g.bias) v += g.bias[n];
                 if constexpr (EPI == DEPI_GELU_T) {
@@ -339,6 +348,7 @@ void launch_dec_gemv(const DecGemvDesc& g, int NW, hipStream_t st) {
         case PRO_LN * 8 + DEPI_GELU_T: DG(PRO_LN, DEPI_GELU_T); break;
         case PRO_T * 8 + DEPI_LOGITS: DG(PRO_T, DEPI_LOGITS); break;
         case PRO_T * 8 + DEPI_PART: DG(PRO_T, DEPI_PART); break;
+        case PRO_T * 8 + DEPI_RES: DG(PRO_T, DEPI_RES); break;
         case PRO_T * 8 + DEPI_QKV: DG(PRO_T, DEPI_QKV); break;
         case PRO_T * 8 + DEPI_GELU_T: DG(PRO_T, DEPI_GELU_T); break;
         case PRO_COMBINE * 8 + DEPI_PART: DG(PRO_COMBINE, DEPI_PART); break;
