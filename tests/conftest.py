@@ -38,3 +38,13 @@ def toy_ml_path(model_dir):
 @pytest.fixture(scope="session")
 def toy256_path(model_dir):
     return _model(model_dir, "toy256")
+
+
+@pytest.fixture(scope="session")
+def tiny_en_path(model_dir):
+    return _model(model_dir, "tiny.en")
+
+
+@pytest.fixture(scope="session")
+def base_en_path(model_dir):
+    return _model(model_dir, "base.en")

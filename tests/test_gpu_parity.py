@@ -170,6 +170,36 @@ def test_full_path_greedy_identical_tokens_f16(toy_en_path, toy_ml_path, toy256_
     eng.close(); om.close()
 
 
+@pytest.mark.parametrize("which", ["tiny.en", "base.en"])
+def test_full_path_real_widths_f16(tiny_en_path, base_en_path, orc, which):
+    """The real tiny.en / base.en shapes (d = 384 / 512, 6 / 8 heads, 80 mels; random weights): widths that are not multiples of 256
+    take the 128x128 GEMM, other LayerNorm / GEMV register tilings and other split-K plans than large-v3 and the toy models.
+    Random weights at these widths put the top-2 logits within ~1e-2 sigma of each other on some steps while the f16-rounded
+    activations of two correct implementations differ by ~3e-3 sigma (tools/stage_check.py), so an argmax can legitimately flip on a
+    near tie: every chunk must agree with the oracle up to its first flip and most chunks must agree completely."""
+    from speaksense_amd import binding
+    path = tiny_en_path if which == "tiny.en" else base_en_path
+    om = orc.OracleModel(path)
+    eng = _eng(path, binding.DTYPE_F16, max_batch=2)
+    same = 0
+    cases = ((3, 12), (4, 30), (5, 20), (6, 8))
+    for seed, seconds in cases:
+        pcm = synth.speech_like(seed, 16000 * seconds)
+        ref = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(language="en", temperature_inc=0.0))
+        got = eng.new_session().transcribe(pcm, binding.default_params(language="en", temperature_inc=0.0))
+        a, b = list(got["tokens"]), list(ref["tokens"])
+        if a == b:
+            _same_result(got, ref, f"{which} seed {seed}")
+            same += 1
+        else:
+            k = next(i for i in range(min(len(a), len(b)) + 1) if i >= min(len(a), len(b)) or a[i] != b[i])
+            assert k >= 1, f"{which} seed {seed}: diverges at the first token"
+            np.testing.assert_allclose(got["plog"][:k], ref["plog"][:k], atol=5e-2)   # the shared prefix carries the same probabilities
+    print(f"{which}: {same}/{len(cases)} chunks identical to the oracle")
+    assert same * 2 >= len(cases)
+    eng.close(); om.close()
+
+
 @pytest.mark.parametrize("which", ["toy.en", "toy"])
 def test_full_path_default_ladder_f16(toy_en_path, toy_ml_path, orc, which):
     """The reference's real parameters (temperature ladder 0.0..1.0, best_of 5).  Windows that never leave t = 0 must
