@@ -169,11 +169,15 @@ struct EngineT : EngineBase {
         cross_direct = getenv("SS_CROSS_DIRECT") != nullptr;
         combine_separate = getenv("SS_COMBINE_FUSED") == nullptr;   // fused prologue measured slower (865 vs 940 xRT): opt-in only
         { const char* gv = getenv("SS_DECODE_GRAPH"); use_graph = !(gv && gv[0] == '0'); }
+        step_timing = getenv("SS_STEP_TIMING") != nullptr;
         ln_fused = getenv("SS_DECODE_LN_FUSED") ? atoi(getenv("SS_DECODE_LN_FUSED")) : 0;   // 1 both seams, 2 self-attention seam only, 3 cross-attention seam only
         start_worker();
     }
     ~EngineT() override {
         stop_worker();
+        if (step_timing && tm_n > 1)
+            fprintf(stderr, "[ss] decode steps %ld: launch call %.1f us, wait for samples %.1f us, host between steps %.1f us (averages)\n", tm_n, tm_launch / tm_n,
+                    tm_wait / tm_n, tm_host / (tm_n - 1));
         if (ctl_h) (void)hipHostFree(ctl_h);
         if (rowidx_h) (void)hipHostFree(rowidx_h);
         for (auto& kv : step_graphs) { if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph); }
@@ -586,6 +590,7 @@ struct EngineT : EngineBase {
     DBuf samp_d, rowidx_d, rules_scratch;
     bool use_fused = true, cross_direct = false, combine_separate = true, use_graph = true;
     int ln_fused = 0;
+    bool step_timing = false; double tm_launch = 0, tm_wait = 0, tm_host = 0; long tm_n = 0; std::chrono::steady_clock::time_point tm_prev;
 
     RuleConsts rule_consts(const ss_params& P) {
         const Vocab& v = hm.vocab;
@@ -821,9 +826,18 @@ struct EngineT : EngineBase {
                     any_probs |= rows[r0 + m].want_probs != 0;
                 }
             }
+            const auto tt0 = std::chrono::steady_clock::now();
             decoder_step(M, rc, samp_rows, any_probs);
+            const auto tt1 = std::chrono::steady_clock::now();
             if (samp_rows.empty()) continue;
             SS_HIP(hipStreamSynchronize(st));
+            const auto tt2 = std::chrono::steady_clock::now();
+            if (step_timing) {   // SS_STEP_TIMING=1: where the host spends a decode step (printed when the engine is destroyed)
+                tm_launch += std::chrono::duration<double, std::micro>(tt1 - tt0).count();
+                tm_wait += std::chrono::duration<double, std::micro>(tt2 - tt1).count();
+                if (tm_n > 0) tm_host += std::chrono::duration<double, std::micro>(tt0 - tm_prev).count();
+                tm_prev = tt2; tm_n++;
+            }
             for (size_t k = 0; k < samp_rows.size(); k++) {
                 const RowRef& rr = refs[r0 + samp_rows[k]];
                 accept_sample(*rr.w, rr.w->decs[rr.j], state_of(js, rr.w->job), samp_h[k], probs_h + k * (size_t)n_vocab_pad);
