@@ -138,6 +138,9 @@ struct EngineT : EngineBase {
     RowCtl* ctl_h = nullptr;       // pinned, mapped
     int* rowidx_h = nullptr;       // pinned
     SampleOut* samp_h = nullptr;   // pinned, mapped
+    SampleOut* samp_hb[2] = {nullptr, nullptr};   // fused steps alternate between two result buffers (a chained step may be in flight)
+    hipEvent_t ev_step[2];
+    int step_parity = 0;
     float* probs_h = nullptr;      // pinned: [S][n_vocab_pad] for t > 0 sampling
     hipEvent_t ev[4];
 
@@ -162,6 +165,7 @@ struct EngineT : EngineBase {
         if (n_ctx % 4 || n_tctx > 448) throw Error(SS_ERR_MODEL, "model: unsupported context sizes");
         SS_HIP(hipStreamCreate(&st));
         for (auto& e : ev) SS_HIP(hipEventCreate(&e));
+        for (auto& e : ev_step) SS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         upload_weights();
         alloc_workspaces();
         plan_decode();
@@ -170,6 +174,7 @@ struct EngineT : EngineBase {
         combine_separate = getenv("SS_COMBINE_FUSED") == nullptr;   // fused prologue measured slower (865 vs 940 xRT): opt-in only
         { const char* gv = getenv("SS_DECODE_GRAPH"); use_graph = !(gv && gv[0] == '0'); }
         step_timing = getenv("SS_STEP_TIMING") != nullptr;
+        { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }
         ln_fused = getenv("SS_DECODE_LN_FUSED") ? atoi(getenv("SS_DECODE_LN_FUSED")) : 0;   // 1 both seams, 2 self-attention seam only, 3 cross-attention seam only
         start_worker();
     }
@@ -310,7 +315,8 @@ struct EngineT : EngineBase {
         cscratch.alloc((size_t)R * H * 4 * 66 * 4); ctl_d.alloc(2 * R * sizeof(RowCtl));
         samp_d.alloc(R * sizeof(SampleOut)); rowidx_d.alloc(R * 4); rules_scratch.alloc((size_t)R * 64 * 8 * 4);
         SS_HIP(hipHostMalloc((void**)&ctl_h, 2 * R * sizeof(RowCtl), hipHostMallocDefault));
-        SS_HIP(hipHostMalloc((void**)&samp_h, R * sizeof(SampleOut), hipHostMallocDefault));
+        SS_HIP(hipHostMalloc((void**)&samp_h, 2 * R * sizeof(SampleOut), hipHostMallocDefault));
+        samp_hb[0] = samp_h; samp_hb[1] = samp_h + R;
         SS_HIP(hipHostMalloc((void**)&rowidx_h, R * sizeof(int), hipHostMallocDefault));
         SS_HIP(hipHostMalloc((void**)&probs_h, (size_t)R * n_vocab_pad * 4, hipHostMallocDefault));
     }
@@ -407,12 +413,15 @@ struct EngineT : EngineBase {
     // slots travel in ctl_d): after one plain pass per (M, n_samp) shape it is captured into a hipGraph and replayed.
     struct StepGraph { int uses = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
     std::map<int, StepGraph> step_graphs;
-    void decoder_step_fused(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
+    // chained = true: the control blocks are already on the device (the previous step's pick kernel advanced them), nothing is uploaded
+    void decoder_step_fused(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs, bool chained = false) {
         const int n_samp = (int)samp_rows.size();
-        SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
-        if (n_samp) {
-            memcpy(rowidx_h, samp_rows.data(), (size_t)n_samp * 4);
-            SS_HIP(hipMemcpyAsync(rowidx_d.p, rowidx_h, (size_t)n_samp * 4, hipMemcpyHostToDevice, st));
+        if (!chained) {
+            SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
+            if (n_samp) {
+                memcpy(rowidx_h, samp_rows.data(), (size_t)n_samp * 4);
+                SS_HIP(hipMemcpyAsync(rowidx_d.p, rowidx_h, (size_t)n_samp * 4, hipMemcpyHostToDevice, st));
+            }
         }
         if (!use_graph) fused_body(M, n_samp);
         else {
@@ -430,9 +439,12 @@ struct EngineT : EngineBase {
         }
         if (n_samp == 0) return;
         const RowCtl* ctl = ctl_d.as<RowCtl>();
-        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st);
-        SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
+        step_parity ^= 1;
+        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st,
+                            any_probs ? nullptr : ctl_d.as<RowCtl>(), rowidx_d.as<int>());
+        SS_HIP(hipMemcpyAsync(samp_hb[step_parity], samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
         if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(hipEventRecord(ev_step[step_parity], st));
     }
     void fused_body(int M, int n_samp) {
         const RowCtl* ctl = ctl_d.as<RowCtl>();
@@ -541,8 +553,9 @@ struct EngineT : EngineBase {
     // prompt): K/V of every row are written to the cache before the attention kernels run, and each row attends to
     // cache positions <= its own, so causality holds without a mask.  The n_samp rows listed in samp_rows (with their
     // rule state in ctl_h[64..64+n_samp)) get logits + rules; results land in samp_h[0..n_samp).
-    void decoder_step(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
-        if (M <= 16 && use_fused) { decoder_step_fused(M, rc, samp_rows, any_probs); return; }
+    // returns the parity of the result buffer / event to wait on for a fused step, -1 for the skinny path (samp_h after a stream sync)
+    int decoder_step(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
+        if (M <= 16 && use_fused) { decoder_step_fused(M, rc, samp_rows, any_probs); return step_parity; }
         const int n_samp = (int)samp_rows.size();
         SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
         const RowCtl* ctl = ctl_d.as<RowCtl>();
@@ -574,7 +587,7 @@ struct EngineT : EngineBase {
             launch_skinny<T>(sd(lnd.p, d, e.w1, M, 4 * d, d, SK_GELU_T, e.b1, ffd.p, 4 * d), st);
             launch_skinny<T>(sd(ffd.p, 4 * d, e.w2, M, d, 4 * d, SK_RES_F32, e.b2, xd.p, d), st);
         }
-        if (n_samp == 0) return;
+        if (n_samp == 0) return -1;
         // gather the sampling rows: final LayerNorm reads x[samp_rows[i]] and writes compact row i
         SS_HIP(hipMemcpyAsync(rowidx_d.p, samp_rows.data(), (size_t)n_samp * 4, hipMemcpyHostToDevice, st));
         launch_layernorm<T>(xd.as<float>(), lnw, lnb, lnd.as<T>(), n_samp, d, rowidx_d.as<int>(), st);
@@ -586,10 +599,12 @@ struct EngineT : EngineBase {
         launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st);
         SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
         if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
+        return -1;
     }
     DBuf samp_d, rowidx_d, rules_scratch;
     bool use_fused = true, cross_direct = false, combine_separate = true, use_graph = true;
     int ln_fused = 0;
+    bool chain_steps = true;
     bool step_timing = false; double tm_launch = 0, tm_wait = 0, tm_host = 0; long tm_n = 0; std::chrono::steady_clock::time_point tm_prev;
 
     RuleConsts rule_consts(const ss_params& P) {
@@ -742,7 +757,9 @@ struct EngineT : EngineBase {
     // Round = every active decoder advances to its next sampling point: the first round feeds the whole prompt
     // ([prev] + past text + sot/lang/task), later rounds one token each.
     struct RowRef { Window* w; int j; bool sample; };
+    struct Spec { bool valid = false; int parity = 0; RuleConsts rc; std::vector<std::pair<Window*, int>> decs; } spec;   // a chained step in flight
     void decode_windows(std::vector<Window*>& run, std::vector<JobState>& js) {
+        spec.valid = false;   // a chained step left in flight by the previous attempt belongs to decoders that no longer exist
         int slot = 0;
         for (Window* w : run) {
             const ss_params& P = w->job->P;
@@ -814,6 +831,48 @@ struct EngineT : EngineBase {
             q.n_fed += n_feed;
             if (dr.j == 0) w->job->sess->n_decode++;
         }
+        // ---- chained greedy steps -------------------------------------------------------------------------------------------------
+        // A round in which every decoder feeds exactly one token and samples greedily is fully determined on the device: the pick kernel
+        // of step t has already written the control blocks of step t+1.  Such a step is enqueued BEFORE the host waits for step t, so
+        // the GPU never idles through the sample -> host -> upload -> launch turnaround.  The host still accepts every sample with the
+        // same rules one step behind; decoders that end simply ignore their row of the step that was already in flight.
+        const bool simple = chain_steps && use_fused && rows.size() == decs_in.size() && rows.size() <= 16 &&
+                            std::all_of(rows.begin(), rows.end(), [](const RowCtl& c) { return c.temperature <= 0.0f; });
+        auto may_continue = [&]() {   // is there a decoder that will still be running after the step that is in flight?
+            for (auto& dr : decs_in) {
+                const ss_params& P = dr.w->job->P;
+                const int n_max = P.fixed_steps > 0 ? P.fixed_steps : n_tctx / 2 - 4;
+                if (dr.w->decs[dr.j].i + 1 < n_max) return true;
+            }
+            return false;
+        };
+        auto launch_chained = [&]() {
+            std::vector<int> sr(rows.size());
+            for (size_t i = 0; i < sr.size(); i++) sr[i] = (int)i;
+            decoder_step_fused((int)rows.size(), rc, sr, false, true);
+            spec.valid = true; spec.parity = step_parity; spec.rc = rc;
+            spec.decs.clear();
+            for (auto& dr : decs_in) spec.decs.push_back({dr.w, dr.j});
+        };
+        if (spec.valid) {
+            Spec cur = spec;
+            spec.valid = false;
+            std::vector<int> kmap;
+            bool ok = simple && memcmp(&cur.rc, &rc, sizeof(RuleConsts)) == 0;
+            for (size_t i = 0; ok && i < decs_in.size(); i++) {
+                int k = -1;
+                for (size_t t = 0; t < cur.decs.size(); t++) if (cur.decs[t].first == decs_in[i].w && cur.decs[t].second == decs_in[i].j) { k = (int)t; break; }
+                if (k < 0) ok = false; else kmap.push_back(k);
+            }
+            if (ok) {   // this round IS the step already in flight
+                if (decs_in.size() == cur.decs.size() && may_continue()) launch_chained();
+                SS_HIP(hipEventSynchronize(ev_step[cur.parity]));
+                for (size_t i = 0; i < decs_in.size(); i++)
+                    accept_sample(*decs_in[i].w, decs_in[i].w->decs[decs_in[i].j], state_of(js, decs_in[i].w->job), samp_hb[cur.parity][kmap[i]], nullptr);
+                return;
+            }
+            // not usable (sampled attempt, prompt rows, other rules): it finishes in stream order and is ignored
+        }
         for (size_t r0 = 0; r0 < rows.size(); r0 += 64) {
             const int M = (int)std::min<size_t>(64, rows.size() - r0);
             std::vector<int> samp_rows;
@@ -827,10 +886,12 @@ struct EngineT : EngineBase {
                 }
             }
             const auto tt0 = std::chrono::steady_clock::now();
-            decoder_step(M, rc, samp_rows, any_probs);
+            const int par = decoder_step(M, rc, samp_rows, any_probs);
             const auto tt1 = std::chrono::steady_clock::now();
             if (samp_rows.empty()) continue;
-            SS_HIP(hipStreamSynchronize(st));
+            if (simple && par >= 0 && may_continue()) launch_chained();
+            if (par >= 0) SS_HIP(hipEventSynchronize(ev_step[par])); else SS_HIP(hipStreamSynchronize(st));
+            const SampleOut* res = par >= 0 ? samp_hb[par] : samp_h;
             const auto tt2 = std::chrono::steady_clock::now();
             if (step_timing) {   // SS_STEP_TIMING=1: where the host spends a decode step (printed when the engine is destroyed)
                 tm_launch += std::chrono::duration<double, std::micro>(tt1 - tt0).count();
@@ -840,7 +901,7 @@ struct EngineT : EngineBase {
             }
             for (size_t k = 0; k < samp_rows.size(); k++) {
                 const RowRef& rr = refs[r0 + samp_rows[k]];
-                accept_sample(*rr.w, rr.w->decs[rr.j], state_of(js, rr.w->job), samp_h[k], probs_h + k * (size_t)n_vocab_pad);
+                accept_sample(*rr.w, rr.w->decs[rr.j], state_of(js, rr.w->job), res[k], probs_h + k * (size_t)n_vocab_pad);
             }
         }
     }

@@ -157,8 +157,10 @@ struct RuleConsts {
 };
 struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t pad[2]; };
 // scratch: >= M * 64 * 8 floats
+// ctl_upd (optional): base of the step's device control blocks; the pick kernel then rewrites rows [64 + m] and [row_of[m]] into the
+// control block of the next greedy step (token = the pick, pos + 1, rule state advanced)
 void launch_logits_rules(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, SampleOut* out, float* probs /* [M][ld] or null */,
-                         float* scratch, hipStream_t st);
+                         float* scratch, hipStream_t st, RowCtl* ctl_upd = nullptr, const int* row_of = nullptr);
 
 // ---------------------------------------------------------------------------------------------
 // STFT denoiser, frame size 2048 (kernels_denoise.hip) -- SURVEY.md §8f next #1

@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void logits_rules_scan_kernel(const float* __r
 }
 
 // Stage B: one wave per row combines the slices (fixed order) and applies whisper_sample_token(best)
-__global__ __launch_bounds__(64) void logits_rules_pick_kernel(const float* __restrict__ scratch, RuleConsts rc, SampleOut* __restrict__ out) {
+__global__ __launch_bounds__(64) void logits_rules_pick_kernel(const float* __restrict__ scratch, RuleConsts rc, SampleOut* __restrict__ out,
+                                                               RowCtl* __restrict__ ctl_upd, const int* __restrict__ row_of) {
     const int m = blockIdx.x;
     if (threadIdx.x != 0) return;
     const float* s = scratch + (long)m * kRuleSlices * kRuleRec;
@@ -255,6 +256,20 @@ __global__ __launch_bounds__(64) void logits_rules_pick_kernel(const float* __re
     if (r.id >= rc.beg) { r.tid = r.id; r.pt = r.p; }
     r.pad[0] = force_ts; r.pad[1] = __float_as_int(lse);
     out[m] = r;
+    if (ctl_upd) {
+        // the row's control block for the NEXT step, exactly as the host derives it from this sample when it is accepted greedily
+        // (engine.cpp round_rows / accept_sample): lets step t+1 be enqueued before the host has seen step t
+        RowCtl c = ctl_upd[64 + m];
+        const int nh = c.n_hist + 1;
+        c.penult_ts = nh < 2 ? 1 : c.last_ts;
+        c.last_ts = r.id >= rc.beg;
+        c.n_hist = nh;
+        c.token = r.id;
+        c.pos += 1;
+        if (r.id > rc.beg) { c.has_ts = 1; c.ts_min = r.id - rc.beg; }
+        ctl_upd[64 + m] = c;
+        ctl_upd[row_of[m]] = c;
+    }
 }
 
 // t > 0 only: the full probability row for host-side sampling (probs = 0 where masked, text masked when a timestamp is forced)
@@ -273,10 +288,10 @@ __global__ __launch_bounds__(256) void logits_probs_kernel(const float* __restri
 }  // namespace
 
 void launch_logits_rules(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, SampleOut* out, float* probs, float* scratch,
-                         hipStream_t st) {
+                         hipStream_t st, RowCtl* ctl_upd, const int* row_of) {
     if ((rc.n_vocab + kRuleSlices - 1) / kRuleSlices > 4 * 256) throw Error(-1, "logits rules: vocabulary too large for the slice plan");
     logits_rules_scan_kernel<<<dim3(kRuleSlices, M), 256, 0, st>>>(logits, ld, ctl, rc, scratch); SS_LAUNCH_CHECK();
-    logits_rules_pick_kernel<<<M, 64, 0, st>>>(scratch, rc, out); SS_LAUNCH_CHECK();
+    logits_rules_pick_kernel<<<M, 64, 0, st>>>(scratch, rc, out, ctl_upd, row_of); SS_LAUNCH_CHECK();
     if (probs) { logits_probs_kernel<<<dim3(32, M), 256, 0, st>>>(logits, ld, ctl, rc, out, probs); SS_LAUNCH_CHECK(); }
 }
 
