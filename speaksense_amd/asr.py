@@ -76,6 +76,7 @@ class WhisperAsr:
         # batch_across_callers: transcribe_with_state goes through ss_submit/ss_wait, so chunks that concurrent callers (one thread
         # per gRPC stream, asr.rs:164) hand in at about the same time share one device batch; results are identical either way.
         self.batch_across_callers = batch_across_callers
+        self.params_hook = None    # benchmarks only: callable(binding.Params) applied after build_params (e.g. Mode F fixed_steps on random weights)
         try:
             self.engine = binding.Engine(model_path, device=device, dtype=dtype, max_batch=max_batch, batch_wait_us=batch_wait_us)
         except binding.SpeakSenseError as e:
@@ -94,6 +95,8 @@ class WhisperAsr:
             p.single_segment = 0
             p.no_context = 1
             p.audio_ctx = 0
+        if self.params_hook is not None:
+            self.params_hook(p)
         return p
 
     def _collect(self, res: dict, user_params: AsrParams) -> TranscribeResult:  # whisper.rs:77-128
