@@ -95,7 +95,7 @@ class WhisperAsr:
             p.single_segment = 0
             p.no_context = 1
             p.audio_ctx = 0
-        if self.params_hook is not None:
+        if getattr(self, "params_hook", None) is not None:
             self.params_hook(p)
         return p
 

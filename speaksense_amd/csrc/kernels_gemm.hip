@@ -272,31 +272,25 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
         const long long t0 = __builtin_amdgcn_s_memtime();
         while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
     }
-    for (int vb = blockIdx.x; vb < nbn * nbm; vb += gridDim.x) {
-    int mb, nb;
-    tile_of_block(vb, nbm, nbn, &mb, &nb);
-    const int m0 = mb * TM, n0 = nb * TN;
-    long long* tr = g.trace ? g.trace + ((long)blockIdx.x * 8 + (vb - blockIdx.x) / gridDim.x) * 4 : nullptr;
-    if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_barrier();   // every wave is done with the previous tile's LDS stages
     const T* __restrict__ A = (const T*)g.A;
     const T* __restrict__ W = (const T*)g.W;
-
     // staging: NP DMA instructions per thread per stage; pass p covers RPP rows of [X tile; W tile] (16 per wave), 4 lanes per 64-B row
     const int srow = wave * 16 + (lane >> 2), spos = lane & 3;
     unsigned soff[NP];      // byte offsets from the (uniform) A / W base: 32-bit VGPRs, the base stays in SGPRs (saddr + voffset DMA)
+    auto set_tile = [&](int m0, int n0) {
 #pragma unroll
-    for (int p = 0; p < NP; p++) {
-        const int ra = p * RPP + srow;                      // row of the stacked [X; W] stage; a pass lies entirely in X or in W
-        const int c = spos ^ (3 * ((ra >> 3) & 1));         // TM is a multiple of 16: same parity as the row within its tile
-        if (p * RPP < TM) {
-            long m = m0 + ra;
-            if (m > g.M - 1) m = g.M - 1;
-            soff[p] = (unsigned)(((m / g.a_rows_per_batch) * g.a_batch_stride + (m % g.a_rows_per_batch) * g.lda + c * 8) * (long)sizeof(T));
-        } else {
-            soff[p] = (unsigned)(((long)(n0 + ra - TM) * g.K + c * 8) * (long)sizeof(T));
+        for (int p = 0; p < NP; p++) {
+            const int ra = p * RPP + srow;                      // row of the stacked [X; W] stage; a pass lies entirely in X or in W
+            const int c = spos ^ (3 * ((ra >> 3) & 1));         // TM is a multiple of 16: same parity as the row within its tile
+            if (p * RPP < TM) {
+                long m = m0 + ra;
+                if (m > g.M - 1) m = g.M - 1;
+                soff[p] = (unsigned)(((m / g.a_rows_per_batch) * g.a_batch_stride + (m % g.a_rows_per_batch) * g.lda + c * 8) * (long)sizeof(T));
+            } else {
+                soff[p] = (unsigned)(((long)(n0 + ra - TM) * g.K + c * 8) * (long)sizeof(T));
+            }
         }
-    }
+    };
     const int wave_off = wave * 16 * 64;
 #define SS_DMA(p, k0, dst) glds16<T>((const T*)((const char*)(((p) * RPP < TM ? A : W) + (k0)) + soff[p]), dst)
     auto stage = [&](int buf, int k0) {
@@ -304,6 +298,26 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
 #pragma unroll
         for (int p = 0; p < NP; p++) SS_DMA(p, k0, base + p * (RPP * 64) + wave_off);
     };
+    // Early prologue (one workgroup per CU form): the first NST-1 DMA stages of tile i+1 are issued BEFORE the output stores of tile i, so
+    // their HBM/L2 latency (7 % of an FC1 tile when exposed) hides under the epilogue.  gfx9's vmcnt retires in order and counts stores:
+    // the waits for those stages must therefore allow the `carry` stores issued after them to remain outstanding.
+    constexpr bool EARLY = WM == 2;
+    constexpr int kCarry = 24;        // a full interior tile issues 32 output stores per thread after the prologue; 8 kept as margin
+    bool pro_issued = false;
+    int issued = 0, carry = 0;
+    for (int vb = blockIdx.x; vb < nbn * nbm; vb += gridDim.x) {
+    int mb, nb;
+    tile_of_block(vb, nbm, nbn, &mb, &nb);
+    const int m0 = mb * TM, n0 = nb * TN;
+    long long* tr = g.trace ? g.trace + ((long)blockIdx.x * 8 + (vb - blockIdx.x) / gridDim.x) * 4 : nullptr;
+    if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memtime();
+    const int nk = g.K / TK;
+    if (!pro_issued) {
+        __builtin_amdgcn_s_barrier();   // every wave is done with the previous tile's LDS stages
+        set_tile(m0, n0);
+        carry = 0;
+        for (issued = 0; issued < NST - 1 && issued < nk; issued++) stage(issued, issued * TK);
+    }
 
     f32x4 acc[4][8];
 #pragma unroll
@@ -314,7 +328,6 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     const int frow = lane & 15, fg = lane >> 4;
     const int foff = frow * 64 + ((fg ^ (3 * ((frow >> 3) & 1))) * 16);
     const int xoff = (wm * 128) * 64 + foff, woff = TM * 64 + (wn * 64) * 64 + foff;
-    const int nk = g.K / TK;
 
     // fragment sets A / B (register double buffer): the ds_reads of stage kt+1 are issued among the MFMAs of stage kt.
     // An LDS-DMA instruction costs ~60-185 issue cycles (MI355X_MICROARCH.md): left to itself the compiler clusters the
@@ -324,7 +337,11 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     V8 wfA[4], xfA[8], wfB[4], xfB[8];
     auto wait_stage = [&](int st, int issued) {   // MY DMA of stage `st` has landed; later stages (NP ops each) stay in flight
         const int later = issued - 1 - st;
-        if (later >= 2) wait_vmcnt<2 * NP>();
+        if (carry && st < NST - 1) {              // a prologue stage of an early-issued tile: the previous tile's stores came after it
+            if (later >= 2) wait_vmcnt<2 * NP + kCarry>();
+            else if (later == 1) wait_vmcnt<NP + kCarry>();
+            else wait_vmcnt<kCarry>();
+        } else if (later >= 2) wait_vmcnt<2 * NP>();
         else if (later == 1) wait_vmcnt<NP>();
         else wait_vmcnt<0>();
     };
@@ -360,9 +377,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
         SS_QUARTER(WC, XC, WN, XN, do_dma, dma_k0, do_read, 3)                                        \
     }
 
-    // prologue: three stages in flight, fragments of stage 0 in registers
-    int issued = 0;
-    for (; issued < NST - 1 && issued < nk; issued++) stage(issued, issued * TK);
+    // prologue (issued above or behind the previous tile's main loop): NST-1 stages in flight, fragments of stage 0 into registers
     wait_stage(0, issued);
     __builtin_amdgcn_s_barrier();
     {
@@ -405,11 +420,74 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
 #undef SS_MMA_Q
 
     if (tr && tid == 0) tr[2] = __builtin_amdgcn_s_memtime();
+    // bias for this tile's columns, loaded BEFORE the next tile's DMAs are queued: vmcnt retires in order, so a load issued behind them
+    // would make the epilogue wait for their whole HBM round trip (the fragment registers are dead here, so this costs no pressure)
+    f32x4 bias_v[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+        bias_v[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+            if constexpr (SWAP) bias_v[ni][0] = g.bias[n0 + wn * 64 + ni * 16 + frow];
+            else bias_v[ni] = *(const f32x4*)(g.bias + n0 + wn * 64 + ni * 16 + fg * 4);
+        }
+        // the values must exist HERE: otherwise the compiler sinks the loads next to their uses -- 32 loads, each followed by
+        // s_waitcnt vmcnt(0), which (in-order vmcnt) made every output store wait for the previous one to complete
+        asm volatile("" : "+v"(bias_v[ni][0]), "+v"(bias_v[ni][1]), "+v"(bias_v[ni][2]), "+v"(bias_v[ni][3]));
+    }
+    pro_issued = false;
+    if constexpr (EARLY) {
+        const int vbn = vb + gridDim.x;
+        if (vbn < nbn * nbm) {
+            int mbn, nbn2;
+            tile_of_block(vbn, nbm, nbn, &mbn, &nbn2);
+            __builtin_amdgcn_s_barrier();   // every wave has read its last fragments: the ring is free
+            set_tile(mbn * TM, nbn2 * TN);
+            for (issued = 0; issued < NST - 1 && issued < nk; issued++) stage(issued, issued * TK);
+            carry = (m0 + TM <= g.M) ? kCarry : 0;   // the stores of a partial tile are predicated: count none of them
+            pro_issued = true;
+        }
+    }
     // ---------------- epilogue ----------------
     // s_memtime stamps (tools/gemm_bench.cpp, SS_TRACE): on FC1 the store-only epilogue is 25 % of a tile, +GELU 28 %, +f32 residual 48 %.
     // Neither a start-time stagger of the workgroups, nor a second workgroup per CU (128 x 256 tiles), nor an LDS-transposed epilogue that
     // writes whole 128-B lines (4x fewer requests) shortened it: a CU drains its 128 KB tile at ~10 B/clk whatever the request shape.
-    if constexpr (!SWAP) {
+    if constexpr (KIND == EPI_RES_F32 || KIND == EPI_GELU_POS_F32) {
+        // f32 output added to a second f32 operand (residual / positional embedding): the operand rows are loaded one row group AHEAD of
+        // the stores, so each wait for loads leaves the previous group's stores in flight (the compiler counts them into its vmcnt)
+        auto src_of = [&](int mi, int ni) -> const float* {
+            long m = m0 + wm * 128 + mi * 16 + frow;
+            if (m > g.M - 1) m = g.M - 1;
+            const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+            if constexpr (KIND == EPI_RES_F32) return g.res + (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo + n;
+            else return g.pos + (long)(m % g.rows_per_batch) * g.N + n;
+        };
+        f32x4 nxt[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) nxt[ni] = *(const f32x4*)src_of(0, ni);
+#pragma unroll
+        for (int mi = 0; mi < 8; mi++) {
+            f32x4 cur[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) cur[ni] = nxt[ni];
+            if (mi + 1 < 8) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ni++) nxt[ni] = *(const f32x4*)src_of(mi + 1, ni);
+            }
+            const long m = m0 + wm * 128 + mi * 16 + frow;
+            if (m >= g.M) continue;
+            const long orow = (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo;
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) {
+                const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+                f32x4 v = acc[ni][mi] + bias_v[ni];
+                if constexpr (KIND == EPI_GELU_POS_F32) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
+                }
+                *(f32x4*)((float*)g.out + orow + n) = cur[ni] + v;
+            }
+        }
+    } else if constexpr (!SWAP) {
 #pragma unroll
         for (int mi = 0; mi < 8; mi++) {
             const long m = m0 + wm * 128 + mi * 16 + frow;
@@ -418,8 +496,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
 #pragma unroll
             for (int ni = 0; ni < 4; ni++) {
                 const int n = n0 + wn * 64 + ni * 16 + fg * 4;
-                f32x4 v = acc[ni][mi];
-                if (g.bias) v += *(const f32x4*)(g.bias + n);
+                f32x4 v = acc[ni][mi] + bias_v[ni];
                 if constexpr (KIND == EPI_STORE_T) {
                     V4 o;
 #pragma unroll
@@ -459,7 +536,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
 #pragma unroll
         for (int ni = 0; ni < 4; ni++) {
             const int n = n0 + wn * 64 + ni * 16 + frow;
-            const float b = g.bias ? g.bias[n] : 0.0f;
+            const float b = bias_v[ni][0];
             const int h = n >> 6, j = n & 63;
 #pragma unroll
             for (int mi = 0; mi < 8; mi++) {
