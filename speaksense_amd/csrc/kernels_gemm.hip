@@ -250,7 +250,9 @@ template <int WM> struct G256 {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int KIND, int WM>
+// DMA4 (WM = 2 only): waves 0-3 issue ALL the LDS-DMA (two 16-row slots each per pass) and are the only ones that wait on vmcnt; waves 4-7
+// never wait on it inside the main loop, so THEIR output stores of the previous tile drain in the background for a whole tile.
+template <typename T, int KIND, int WM, bool DMA4 = false>
 __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Mfma<T>::V8 V8;
@@ -275,25 +277,32 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     const T* __restrict__ A = (const T*)g.A;
     const T* __restrict__ W = (const T*)g.W;
     // staging: NP DMA instructions per thread per stage; pass p covers RPP rows of [X tile; W tile] (16 per wave), 4 lanes per 64-B row
-    const int srow = wave * 16 + (lane >> 2), spos = lane & 3;
-    unsigned soff[NP];      // byte offsets from the (uniform) A / W base: 32-bit VGPRs, the base stays in SGPRs (saddr + voffset DMA)
+    constexpr int NSLOT = DMA4 ? 2 : 1;                 // 16-row slots of a pass this wave stages (slot = wave, and wave + 4 with DMA4)
+    const bool dma_wave = !DMA4 || wave < 4;
+    const int spos = lane & 3;
+    unsigned soff[NP * NSLOT];   // byte offsets from the (uniform) A / W base: 32-bit VGPRs, the base stays in SGPRs (saddr + voffset DMA)
     auto set_tile = [&](int m0, int n0) {
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            const int ra = p * RPP + srow;                      // row of the stacked [X; W] stage; a pass lies entirely in X or in W
-            const int c = spos ^ (3 * ((ra >> 3) & 1));         // TM is a multiple of 16: same parity as the row within its tile
-            if (p * RPP < TM) {
-                long m = m0 + ra;
-                if (m > g.M - 1) m = g.M - 1;
-                soff[p] = (unsigned)(((m / g.a_rows_per_batch) * g.a_batch_stride + (m % g.a_rows_per_batch) * g.lda + c * 8) * (long)sizeof(T));
-            } else {
-                soff[p] = (unsigned)(((long)(n0 + ra - TM) * g.K + c * 8) * (long)sizeof(T));
+#pragma unroll
+            for (int u = 0; u < NSLOT; u++) {
+                const int ra = p * RPP + (wave + 4 * u) * 16 + (lane >> 2);   // row of the stacked [X; W] stage; a pass lies entirely in X or in W
+                const int c = spos ^ (3 * ((ra >> 3) & 1));     // TM is a multiple of 16: same parity as the row within its tile
+                if (p * RPP < TM) {
+                    long m = m0 + ra;
+                    if (m > g.M - 1) m = g.M - 1;
+                    soff[p * NSLOT + u] = (unsigned)(((m / g.a_rows_per_batch) * g.a_batch_stride + (m % g.a_rows_per_batch) * g.lda + c * 8) * (long)sizeof(T));
+                } else {
+                    soff[p * NSLOT + u] = (unsigned)(((long)(n0 + ra - TM) * g.K + c * 8) * (long)sizeof(T));
+                }
             }
         }
     };
     const int wave_off = wave * 16 * 64;
-#define SS_DMA(p, k0, dst) glds16<T>((const T*)((const char*)(((p) * RPP < TM ? A : W) + (k0)) + soff[p]), dst)
+#define SS_DMA1(p, u, k0, dst) glds16<T>((const T*)((const char*)(((p) * RPP < TM ? A : W) + (k0)) + soff[(p) * NSLOT + (u)]), (dst) + (u) * (4 * 16 * 64))
+#define SS_DMA(p, k0, dst) { SS_DMA1(p, 0, k0, dst); if constexpr (DMA4) SS_DMA1(p, 1, k0, dst); }
     auto stage = [&](int buf, int k0) {
+        if (!dma_wave) return;
         char* base = smem + buf * kStageBytes;
 #pragma unroll
         for (int p = 0; p < NP; p++) SS_DMA(p, k0, base + p * (RPP * 64) + wave_off);
@@ -335,14 +344,16 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     // step is therefore written as {8 MFMA, 1 DMA, 3 ds_read} and pinned with sched_group_barrier so the matrix pipe keeps
     // executing while the wave issues memory instructions.
     V8 wfA[4], xfA[8], wfB[4], xfB[8];
-    auto wait_stage = [&](int st, int issued) {   // MY DMA of stage `st` has landed; later stages (NP ops each) stay in flight
+    constexpr int OPS = NP * NSLOT;               // DMA instructions a staging wave issues per stage
+    auto wait_stage = [&](int st, int issued) {   // MY DMA of stage `st` has landed; later stages (OPS each) stay in flight
+        if (!dma_wave) return;                    // the barrier that follows publishes the staging waves' data
         const int later = issued - 1 - st;
         if (carry && st < NST - 1) {              // a prologue stage of an early-issued tile: the previous tile's stores came after it
-            if (later >= 2) wait_vmcnt<2 * NP + kCarry>();
-            else if (later == 1) wait_vmcnt<NP + kCarry>();
+            if (later >= 2) wait_vmcnt<2 * OPS + kCarry>();
+            else if (later == 1) wait_vmcnt<OPS + kCarry>();
             else wait_vmcnt<kCarry>();
-        } else if (later >= 2) wait_vmcnt<2 * NP>();
-        else if (later == 1) wait_vmcnt<NP>();
+        } else if (later >= 2) wait_vmcnt<2 * OPS>();
+        else if (later == 1) wait_vmcnt<OPS>();
         else wait_vmcnt<0>();
     };
 #define SS_MMA_Q(WF, XF, q)                                                                         \
@@ -354,7 +365,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
 #define SS_QUARTER(WC, XC, WN, XN, do_dma, dma_k0, do_read, q)                                        \
     {                                                                                                \
         SS_MMA_Q(WC, XC, q)                                                                          \
-        if (do_dma) {                                                                                \
+        if ((do_dma) && dma_wave) {                                                                  \
             SS_DMA(q, dma_k0, dbase + (q) * (RPP * 64) + wave_off);                                  \
             if constexpr ((q) + 4 < NP) SS_DMA(((q) + 4) % NP, dma_k0, dbase + ((q) + 4) * (RPP * 64) + wave_off); \
         }                                                                                            \
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
             XN[2 * (q) + 1] = *(const V8*)(rbase + xoff + (2 * (q) + 1) * 16 * 64);                  \
         }                                                                                            \
         __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                           \
-        __builtin_amdgcn_sched_group_barrier(0x020, ((q) + 4 < NP) ? 2 : 1, 0);                      \
+        __builtin_amdgcn_sched_group_barrier(0x020, (((q) + 4 < NP) ? 2 : 1) * NSLOT, 0);            \
         __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                           \
     }
 #define SS_STEP(WC, XC, WN, XN, do_dma, dma_buf, dma_k0, do_read, rd_buf)                              \
@@ -417,6 +428,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
 #undef SS_STEP
 #undef SS_QUARTER
 #undef SS_DMA
+#undef SS_DMA1
 #undef SS_MMA_Q
 
     if (tr && tid == 0) tr[2] = __builtin_amdgcn_s_memtime();
@@ -569,9 +581,19 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
         gs.stagger_ticks = st_ticks; gs.stagger_groups = st_groups > 0 ? st_groups : 1;
         const GemmDesc& g = gs;
         if (one_wg) {
+            // f16-output kinds: half the waves do all the staging (main loop -9 %, their partners' stores drain unobserved); the f32 residual
+            // kinds move 4x the epilogue bytes and measured 20 % slower that way (tools/gemm_bench.cpp)
+            static const char* dma4_env = getenv("SS_GEMM_DMA4");
+            const bool dma4 = dma4_env ? dma4_env[0] == '1' : (KIND == EPI_STORE_T || KIND == EPI_GELU_T || KIND == EPI_CROSS_KV);
+            const int nwg = (g.N / TN) * ((g.M + G256<2>::TM - 1) / G256<2>::TM);
+            if (dma4) {
+                static std::atomic<uint64_t> attr256d{0};
+                once_per_device(attr256d, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
+                gemm256_kernel<T, KIND, 2, true><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();
+                return;
+            }
             static std::atomic<uint64_t> attr256{0};
             once_per_device(attr256, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
-            const int nwg = (g.N / TN) * ((g.M + G256<2>::TM - 1) / G256<2>::TM);
             gemm256_kernel<T, KIND, 2><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();
         } else {
             static std::atomic<uint64_t> attr128x{0};
