@@ -454,7 +454,9 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
             tile_of_block(vbn, nbm, nbn, &mbn, &nbn2);
             __builtin_amdgcn_s_barrier();   // every wave has read its last fragments: the ring is free
             set_tile(mbn * TM, nbn2 * TN);
-            for (issued = 0; issued < NST - 1 && issued < nk; issued++) stage(issued, issued * TK);
+#pragma unroll
+            for (int i = 0; i < NST - 1; i++) stage(i, i * TK);   // straight-line (nk >= NST - 1 is checked at launch): the compiler's vmcnt bookkeeping stays exact
+            issued = NST - 1;
             carry = (m0 + TM <= g.M) ? kCarry : 0;   // the stores of a partial tile are predicated: count none of them
             pro_issued = true;
         }
@@ -466,12 +468,17 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     if constexpr (KIND == EPI_RES_F32 || KIND == EPI_GELU_POS_F32) {
         // f32 output added to a second f32 operand (residual / positional embedding): the operand rows are loaded one row group AHEAD of
         // the stores, so each wait for loads leaves the previous group's stores in flight (the compiler counts them into its vmcnt)
+        // every element is read and then written by the same thread exactly once, so treating operand and output as non-aliasing is safe even
+        // when they are the same buffer (x += ...); without it the compiler drains all stores (vmcnt(0)) before each group of loads
+        const float* __restrict__ resp = g.res;
+        const float* __restrict__ posp = g.pos;
+        float* __restrict__ outp = (float*)g.out;
         auto src_of = [&](int mi, int ni) -> const float* {
             long m = m0 + wm * 128 + mi * 16 + frow;
             if (m > g.M - 1) m = g.M - 1;
             const int n = n0 + wn * 64 + ni * 16 + fg * 4;
-            if constexpr (KIND == EPI_RES_F32) return g.res + (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo + n;
-            else return g.pos + (long)(m % g.rows_per_batch) * g.N + n;
+            if constexpr (KIND == EPI_RES_F32) return resp + (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo + n;
+            else return posp + (long)(m % g.rows_per_batch) * g.N + n;
         };
         f32x4 nxt[4];
 #pragma unroll
@@ -496,7 +503,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) v[r] = gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
                 }
-                *(f32x4*)((float*)g.out + orow + n) = cur[ni] + v;
+                *(f32x4*)(outp + orow + n) = cur[ni] + v;
             }
         }
     } else if constexpr (!SWAP) {
@@ -571,7 +578,7 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
     static std::atomic<uint64_t> attr128{0};
     once_per_device(attr128, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds)); });
     static const bool force128 = getenv("SS_GEMM128") != nullptr;
-    if (!force128 && g.N % TN == 0 && g.K % TK == 0 && g.M >= 1024) {
+    if (!force128 && g.N % TN == 0 && g.K % TK == 0 && g.K >= 4 * TK && g.M >= 1024) {
         static const bool one_wg = getenv("SS_GEMM_2WG") == nullptr;   // default: 256 x 256, one workgroup per CU; the 128 x 256 two-per-CU form measured 15-20 % slower
         int n_cu = device_cu_count() / 8 * 8;   // persistent grid, a multiple of 8 so the XCD of the remap is preserved
         if (n_cu < 8) n_cu = 8;
