@@ -169,6 +169,11 @@ int ss_engine_last_timing(const ss_engine* e, float out_ms[4]);
  * engine's stream, and its algorithmic FLOPs per launch: the roofline probe bench.py reports. */
 int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_ms, double* flops_per_launch);
 
+/* Self-test of the tiled MFMA GEMM at an arbitrary shape (N % 128 == 0, K % 64 == 0) in the engine's operand type: seeded operands, result
+ * compared on the device with a one-thread-per-output reference.  kind: 0 bias -> T, 1 bias + GELU -> T, 2 bias + f32 residual (in place),
+ * 6 bias -> f32.  The parity tests run small models (one tile per workgroup); this reaches the multi-tile paths at the large-v3 shapes. */
+int ss_engine_selftest_gemm(ss_engine* e, int32_t M, int32_t N, int32_t K, int32_t kind, float* max_err, float* max_ref);
+
 #ifdef __cplusplus
 }
 #endif

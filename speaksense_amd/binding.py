@@ -90,6 +90,7 @@ def lib():
         L.ss_preprocess_stream.argtypes = [vp, f32p, C.c_int64, vp, i32, i32, C.POINTER(DenoiseConfig), f32p, f32p, C.POINTER(C.c_float)]
         L.ss_engine_last_timing.argtypes = [vp, f32p]
         L.ss_engine_probe_gemm.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        L.ss_engine_selftest_gemm.argtypes = [vp, i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
 
@@ -217,6 +218,12 @@ class Engine:
                                            len(cl) if cl is not None else 0, chunk_len, C.byref(config) if config is not None else None,
                                            _p(out), _p(gains), C.byref(ms)))
         return out.reshape(-1, 2048), gains, ms.value
+
+    def selftest_gemm(self, M: int, N: int, K: int, kind: int):
+        """Tiled GEMM vs the on-device reference -> (max |diff|, max |ref|).  kind: 0 store, 1 GELU, 2 f32 residual, 6 f32 store."""
+        err, ref = C.c_float(), C.c_float()
+        _check(self.L.ss_engine_selftest_gemm(self.h, M, N, K, kind, C.byref(err), C.byref(ref)))
+        return err.value, ref.value
 
     def last_timing(self):
         t = np.zeros(4, np.float32)

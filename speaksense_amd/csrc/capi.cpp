@@ -214,6 +214,10 @@ int ss_preprocess_stream(ss_engine* e, const float* pcm, int64_t n, const int32_
     if (cfg) c = *cfg; else ss_default_denoise_config(&c);
     SS_TRY e->e->preprocess_stream_host(pcm, n, chunk_lens, n_chunks, chunk_len, c, out, gains_out, device_ms); return SS_OK; SS_CATCH
 }
+int ss_engine_selftest_gemm(ss_engine* e, int32_t M, int32_t N, int32_t K, int32_t kind, float* max_err, float* max_ref) {
+    if (!e || !max_err || !max_ref) return fail(SS_ERR_ARG, "bad argument");
+    SS_TRY e->e->selftest_gemm(M, N, K, kind, max_err, max_ref); return SS_OK; SS_CATCH
+}
 int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_ms, double* flops) {
     if (!e || !avg_ms || !flops || reps <= 0) return fail(SS_ERR_ARG, "bad argument");
     SS_TRY e->e->probe_gemm(batch, reps, avg_ms, flops); return SS_OK; SS_CATCH

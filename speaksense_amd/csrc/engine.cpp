@@ -1233,6 +1233,13 @@ struct EngineT : EngineBase {
         if (ms) SS_HIP(hipEventElapsedTime(ms, ev[0], ev[1]));
     }
 
+    void selftest_gemm(int M, int N, int K, int kind, float* max_err, float* max_ref) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        if (M < 1 || N % 128 || K % 64 || N < 128 || K < 64) throw Error(SS_ERR_ARG, "selftest_gemm: N must be a multiple of 128 and K of 64");
+        gemm_selftest<T>(M, N, K, kind, max_err, max_ref, st);
+    }
+
     void probe_gemm(int batch, int reps, float* avg_ms, double* flops) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));

@@ -64,6 +64,7 @@ struct EngineBase {
     virtual void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6]) = 0;
     virtual void probe_gemm(int batch, int reps, float* avg_ms, double* flops) = 0;
     virtual void denoise_host(const float* pcm, int n, const ss_denoise_config& cfg, int force_type, float* out, int* noise_type, float* norm_var, float* ms) = 0;
+    virtual void selftest_gemm(int M, int N, int K, int kind, float* max_err, float* max_ref) = 0;
     virtual void resample_stream_host(const float* pcm, int64_t n, int from_rate, float* out, int64_t out_cap, int64_t* n_out, int32_t* chunk_lens, float* ms) = 0;
     virtual void preprocess_stream_host(const float* pcm, int64_t n, const int32_t* chunk_lens, int n_chunks, int chunk_len, const ss_denoise_config& cfg,
                                         float* out, float* gains_out, float* ms) = 0;

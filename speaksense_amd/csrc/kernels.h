@@ -51,6 +51,8 @@ struct GemmDesc {
     long long* trace;         // dev tool (tools/gemm_bench.cpp): per workgroup and tile {start, loop start, loop end, stores issued} s_memtime stamps; null in the product
 };
 template <typename T> void launch_gemm(const GemmDesc& g, hipStream_t st);
+// self-test: tiled kernel vs a one-thread-per-output reference on seeded operands; kind in {EPI_STORE_T, EPI_GELU_T, EPI_RES_F32, EPI_STORE_F32}
+template <typename T> void gemm_selftest(int M, int N, int K, int kind, float* max_err, float* max_ref, hipStream_t st);
 
 // Skinny GEMM for decode steps: M <= 64 rows, weights streamed once.  out[m][n] = sum_k X[m][k] W[n][k]
 enum SkinnyEpi {

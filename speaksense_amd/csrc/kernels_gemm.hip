@@ -741,4 +741,69 @@ void launch_skinny(const SkinnyDesc& g, hipStream_t st) {
 template void launch_skinny<bf16>(const SkinnyDesc&, hipStream_t);
 template void launch_skinny<f16>(const SkinnyDesc&, hipStream_t);
 
+
+// ---------------------------------------------------------------------------------------------
+// self-test hook (ss_selftest_gemm): the tiled kernels against a one-thread-per-output reference on seeded operands.  The parity tests
+// run toy models whose GEMMs are one tile per workgroup; this drives the multi-tile machinery (early prologue, store-aware vmcnt,
+// DMA4, partial tiles) at the large-v3 shapes.
+// ---------------------------------------------------------------------------------------------
+namespace {
+template <typename T>
+__global__ void st_fill(T* p, size_t n, unsigned seed, float scale) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 16; x *= 2246822519u; x ^= x >> 13;
+        p[i] = (T)(((x & 0xffff) / 32768.0f - 1.0f) * scale);
+    }
+}
+template <typename T>
+__global__ void st_ref(const T* A, const T* W, const float* bias, const float* res, float* C, int M, int N, int K, int kind) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int k = 0; k < K; k++) acc += (float)A[(long)m * K + k] * (float)W[(long)n * K + k];
+    acc += bias[n];
+    if (kind == EPI_GELU_T) acc = gelu_tanh_f(acc);
+    if (kind == EPI_RES_F32) acc += res[(long)m * N + n];
+    C[(long)m * N + n] = acc;
+}
+template <typename T>
+__global__ void st_diff(const void* out, const float* ref, size_t n, int f32out, float* maxes /* [2]: max |diff|, max |ref| */) {
+    float d = 0.f, r = 0.f;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float o = f32out ? ((const float*)out)[i] : (float)((const T*)out)[i];
+        d = fmaxf(d, fabsf(o - ref[i])); r = fmaxf(r, fabsf(ref[i]));
+    }
+    atomicMax((int*)maxes, __float_as_int(d));       // non-negative floats order like their bit patterns
+    atomicMax((int*)maxes + 1, __float_as_int(r));
+}
+}  // namespace
+
+template <typename T>
+void gemm_selftest(int M, int N, int K, int kind, float* max_err, float* max_ref, hipStream_t st) {
+    if (kind != EPI_STORE_T && kind != EPI_GELU_T && kind != EPI_RES_F32 && kind != EPI_STORE_F32) throw Error(-1, "gemm selftest: kind not covered");
+    T *A, *W; float *bias, *res, *ref, *mx; void* out;
+    const bool f32out = kind == EPI_RES_F32 || kind == EPI_STORE_F32;
+    SS_HIP(hipMalloc(&A, (size_t)M * K * sizeof(T))); SS_HIP(hipMalloc(&W, (size_t)N * K * sizeof(T))); SS_HIP(hipMalloc(&bias, (size_t)N * 4));
+    SS_HIP(hipMalloc(&res, (size_t)M * N * 4)); SS_HIP(hipMalloc(&ref, (size_t)M * N * 4)); SS_HIP(hipMalloc(&out, (size_t)M * N * 4)); SS_HIP(hipMalloc(&mx, 8));
+    st_fill<T><<<1024, 256, 0, st>>>(A, (size_t)M * K, 11, 1.0f);
+    st_fill<T><<<1024, 256, 0, st>>>(W, (size_t)N * K, 12, 0.05f);
+    st_fill<float><<<64, 256, 0, st>>>(bias, (size_t)N, 13, 0.5f);
+    st_fill<float><<<1024, 256, 0, st>>>(res, (size_t)M * N, 14, 2.0f);
+    SS_HIP(hipMemsetAsync(mx, 0, 8, st));
+    st_ref<T><<<dim3((N + 255) / 256, M), 256, 0, st>>>(A, W, bias, res, ref, M, N, K, kind);
+    GemmDesc g{};
+    g.A = A; g.lda = K; g.a_rows_per_batch = 1L << 40; g.W = W; g.M = M; g.N = N; g.K = K; g.kind = kind; g.bias = bias; g.out = out; g.ldo = N;
+    g.o_rows_per_batch = 1L << 40; g.scale = 1.0f; g.rows_per_batch = 1500;
+    if (kind == EPI_RES_F32) { SS_HIP(hipMemcpyAsync(out, res, (size_t)M * N * 4, hipMemcpyDeviceToDevice, st)); g.res = (const float*)out; }   // in place, as the engine uses it
+    launch_gemm<T>(g, st);
+    st_diff<T><<<1024, 256, 0, st>>>(out, ref, (size_t)M * N, f32out, mx);
+    float h[2];
+    SS_HIP(hipMemcpyAsync(h, mx, 8, hipMemcpyDeviceToHost, st));
+    SS_HIP(hipStreamSynchronize(st));
+    *max_err = h[0]; *max_ref = h[1];
+    (void)hipFree(A); (void)hipFree(W); (void)hipFree(bias); (void)hipFree(res); (void)hipFree(ref); (void)hipFree(out); (void)hipFree(mx);
+}
+template void gemm_selftest<bf16>(int, int, int, int, float*, float*, hipStream_t);
+template void gemm_selftest<f16>(int, int, int, int, float*, float*, hipStream_t);
+
 }  // namespace ss

@@ -1,0 +1,40 @@
+"""GPU: the tiled MFMA GEMM against a one-thread-per-output device reference at the large-v3 encoder shapes (ss_engine_selftest_gemm).
+The model-level parity tests run small models whose GEMMs are one tile per workgroup; the persistent multi-tile machinery (early
+prologue with store-aware vmcnt, DMA by half the waves, grouped rasterisation, partial last tiles) only runs at these sizes."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STORE, GELU, RES, STORE_F32 = 0, 1, 2, 6
+
+
+@pytest.fixture(scope="module", params=["f16", "bf16"])
+def eng(request, toy_ml_path):
+    from speaksense_amd import binding
+    e = binding.Engine(toy_ml_path, dtype=binding.DTYPE_F16 if request.param == "f16" else binding.DTYPE_BF16, max_batch=1)
+    e.dtype_name = request.param
+    yield e
+    e.close()
+
+
+@pytest.mark.parametrize("M,N,K,kind", [
+    (12000, 5120, 1280, GELU),       # FC1 at batch 8: 940 tiles on 256 workgroups, partial last row tile, DMA4 + early prologue
+    (12000, 5120, 1280, STORE),
+    (12000, 3840, 1280, STORE),      # QKV
+    (12000, 1280, 5120, RES),        # FC2: f32 residual in place, 160 k-steps
+    (12000, 1280, 1280, RES),        # attention out-projection
+    (12000, 5120, 1280, STORE_F32),
+    (1500, 1280, 1280, STORE),       # one window: fewer tiles than workgroups
+    (24000, 5120, 1280, GELU),       # batch 16: more rounds per workgroup
+    (3000, 384, 1152, STORE),        # N not a multiple of 256: the 128 x 128 kernel
+    (777, 256, 128, RES),            # small M: the 128 x 128 kernel, ragged rows
+])
+def test_gemm_matches_reference(eng, M, N, K, kind):
+    err, ref = eng.selftest_gemm(M, N, K, kind)
+    assert ref > 0.5
+    f32_out = kind in (RES, STORE_F32)
+    if f32_out:
+        tol = 2e-5 * ref if eng.dtype_name == "f16" else 2e-5 * ref     # same operands, only the accumulation order differs
+    else:
+        tol = (1.2e-3 if eng.dtype_name == "f16" else 9e-3) * ref        # + one rounding of the output to f16 / bf16
+    assert err <= tol, f"max |diff| {err} vs max |ref| {ref}"
