@@ -47,6 +47,9 @@ PRESETS = {
     "toy": HParams(51866, 1500, 128, 2, 2, 448, 128, 2, 2, 128, 1),
     # width 256: the smallest shape that takes the 256x256-tile GEMM path (N % 256 == 0, M >= 1024)
     "toy256": HParams(51866, 1500, 256, 4, 2, 448, 256, 4, 2, 128, 1),
+    # large-v3's width, head count, mel count and vocabulary with 2 layers per stack: every large-v3 kernel configuration (split-K plans,
+    # LayerNorm register tiling, 20-head attention) at 1/16 of the oracle's cost
+    "wide2": HParams(51866, 1500, 1280, 20, 2, 448, 1280, 20, 2, 128, 1),
 }
 
 

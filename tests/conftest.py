@@ -48,3 +48,8 @@ def tiny_en_path(model_dir):
 @pytest.fixture(scope="session")
 def base_en_path(model_dir):
     return _model(model_dir, "base.en")
+
+
+@pytest.fixture(scope="session")
+def wide2_path(model_dir):
+    return _model(model_dir, "wide2")
