@@ -180,6 +180,7 @@ struct EngineT : EngineBase {
     }
     ~EngineT() override {
         stop_worker();
+        if (st) (void)hipStreamSynchronize(st);   // a chained decode step may still be in flight: it writes into the pinned buffers freed below
         if (step_timing && tm_n > 1)
             fprintf(stderr, "[ss] decode steps %ld: launch call %.1f us, wait for samples %.1f us, host between steps %.1f us (averages)\n", tm_n, tm_launch / tm_n,
                     tm_wait / tm_n, tm_host / (tm_n - 1));
