@@ -14,6 +14,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 
 namespace ss {
 
@@ -141,7 +142,8 @@ struct EngineT : EngineBase {
     SampleOut* samp_hb[2] = {nullptr, nullptr};   // fused steps alternate between two result buffers (a chained step may be in flight)
     hipEvent_t ev_step[2];
     int step_parity = 0;
-    float* probs_h = nullptr;      // pinned: [S][n_vocab_pad] for t > 0 sampling
+    double* u_h = nullptr;         // pinned: one uniform draw per sampled row (t > 0)
+    DBuf u_d;
     hipEvent_t ev[4];
 
     EngineT(const char* path, const ss_engine_opts& o) {
@@ -188,7 +190,7 @@ struct EngineT : EngineBase {
         if (rowidx_h) (void)hipHostFree(rowidx_h);
         for (auto& kv : step_graphs) { if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph); }
         if (samp_h) (void)hipHostFree(samp_h);
-        if (probs_h) (void)hipHostFree(probs_h);
+        if (u_h) (void)hipHostFree(u_h);
         for (auto& e : ev) (void)hipEventDestroy(e);
         if (st) (void)hipStreamDestroy(st);
     }
@@ -319,7 +321,8 @@ struct EngineT : EngineBase {
         SS_HIP(hipHostMalloc((void**)&samp_h, 2 * R * sizeof(SampleOut), hipHostMallocDefault));
         samp_hb[0] = samp_h; samp_hb[1] = samp_h + R;
         SS_HIP(hipHostMalloc((void**)&rowidx_h, R * sizeof(int), hipHostMallocDefault));
-        SS_HIP(hipHostMalloc((void**)&probs_h, (size_t)R * n_vocab_pad * 4, hipHostMallocDefault));
+        SS_HIP(hipHostMalloc((void**)&u_h, (size_t)R * sizeof(double), hipHostMallocDefault));
+        u_d.alloc((size_t)R * sizeof(double));
     }
 
     // ------------------------------------------------------------------------------------------
@@ -443,8 +446,8 @@ struct EngineT : EngineBase {
         step_parity ^= 1;
         launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st,
                             any_probs ? nullptr : ctl_d.as<RowCtl>(), rowidx_d.as<int>());
+        if (any_probs) draw_on_device(ctl + 64, n_samp);
         SS_HIP(hipMemcpyAsync(samp_hb[step_parity], samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
-        if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
         SS_HIP(hipEventRecord(ev_step[step_parity], st));
     }
     void fused_body(int M, int n_samp) {
@@ -554,6 +557,11 @@ struct EngineT : EngineBase {
     // prompt): K/V of every row are written to the cache before the attention kernels run, and each row attends to
     // cache positions <= its own, so causality holds without a mask.  The n_samp rows listed in samp_rows (with their
     // rule state in ctl_h[64..64+n_samp)) get logits + rules; results land in samp_h[0..n_samp).
+    // the sampled rows' draws: u_h[k] was filled by round_rows (one generate_canonical per sampled row, in row order)
+    void draw_on_device(const RowCtl* ctl_rows, int n_samp) {
+        SS_HIP(hipMemcpyAsync(u_d.p, u_h, (size_t)n_samp * sizeof(double), hipMemcpyHostToDevice, st));
+        launch_sample_draw(probs.as<float>(), n_vocab_pad, n_vocab, ctl_rows, n_samp, u_d.as<double>(), samp_d.as<SampleOut>(), st);
+    }
     // returns the parity of the result buffer / event to wait on for a fused step, -1 for the skinny path (samp_h after a stream sync)
     int decoder_step(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
         if (M <= 16 && use_fused) { decoder_step_fused(M, rc, samp_rows, any_probs); return step_parity; }
@@ -598,8 +606,8 @@ struct EngineT : EngineBase {
             launch_skinny<T>(g, st);
         }
         launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st);
+        if (any_probs) draw_on_device(ctl + 64, n_samp);
         SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
-        if (any_probs) SS_HIP(hipMemcpyAsync(probs_h, probs.p, (size_t)n_samp * n_vocab_pad * 4, hipMemcpyDeviceToHost, st));
         return -1;
     }
     DBuf samp_d, rowidx_d, rules_scratch;
@@ -882,8 +890,11 @@ struct EngineT : EngineBase {
                 ctl_h[m] = rows[r0 + m];
                 if (refs[r0 + m].sample) {
                     ctl_h[64 + samp_rows.size()] = rows[r0 + m];
+                    if (rows[r0 + m].want_probs) {   // whisper_sample_token: dist(state.rng), one draw per sampled decoder in decoder order
+                        any_probs = true;
+                        u_h[samp_rows.size()] = std::generate_canonical<double, std::numeric_limits<double>::digits>(refs[r0 + m].w->job->sess->rng);
+                    }
                     samp_rows.push_back(m);
-                    any_probs |= rows[r0 + m].want_probs != 0;
                 }
             }
             const auto tt0 = std::chrono::steady_clock::now();
@@ -902,7 +913,7 @@ struct EngineT : EngineBase {
             }
             for (size_t k = 0; k < samp_rows.size(); k++) {
                 const RowRef& rr = refs[r0 + samp_rows[k]];
-                accept_sample(*rr.w, rr.w->decs[rr.j], state_of(js, rr.w->job), res[k], probs_h + k * (size_t)n_vocab_pad);
+                accept_sample(*rr.w, rr.w->decs[rr.j], state_of(js, rr.w->job), res[k], nullptr);
             }
         }
     }
@@ -918,9 +929,8 @@ struct EngineT : EngineBase {
         if (t_cur < 1e-6f) {
             tk.id = so.id; tk.tid = so.tid; tk.p = so.p; tk.plog = so.plog; tk.pt = so.pt; tk.ptsum = so.ptsum;
         } else {
-            std::discrete_distribution<> dist(pr, pr + n_vocab);
-            tk.id = dist(s->rng);
-            tk.p = pr[tk.id];
+            tk.id = so.id;    // the draw itself ran on the device (sample_draw_kernel) with the uniform this session's generator produced
+            tk.p = so.p;
             tk.plog = tk.p > 0.0f ? logf(tk.p) : -INFINITY;
             tk.tid = so.tid; tk.pt = so.pt; tk.ptsum = so.ptsum;
             if (tk.id >= vocab.token_beg) { tk.tid = tk.id; tk.pt = tk.p; }

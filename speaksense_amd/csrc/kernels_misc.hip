@@ -285,7 +285,52 @@ __global__ __launch_bounds__(256) void logits_probs_kernel(const float* __restri
         probs[(long)m * ld + i] = v == kNegInf ? 0.0f : expf(v - lse);
     }
 }
+// t > 0: std::discrete_distribution's draw on the device.  libstdc++ normalises the weights by their sum, forms the running sums and returns
+// lower_bound(cumulative, u) for u = generate_canonical<double, 53>(rng); the host draws u (so the generator is consumed exactly as
+// whisper_sample_token consumes it) and this kernel finds the index: 256 contiguous segments summed in double, a scan of the 256 partial
+// sums, then the owning segment is walked again.  Only the association of the double additions differs from the sequential scan (a draw
+// would have to land within ~1e-16 of a boundary to notice); it replaces a 200 KB device-to-host copy and three passes over the
+// vocabulary per decoder per step on the host.
+__global__ __launch_bounds__(256) void sample_draw_kernel(const float* __restrict__ probs, long ld, int n_vocab, const RowCtl* __restrict__ ctl,
+                                                          const double* __restrict__ u, SampleOut* __restrict__ out) {
+    __shared__ double s_sum[256];
+    __shared__ double s_pre[257];
+    const int m = blockIdx.x, t = threadIdx.x;
+    if (!ctl[m].want_probs) return;
+    const float* p = probs + (long)m * ld;
+    const int seg = (n_vocab + 255) / 256, b = t * seg, e = min(n_vocab, b + seg);
+    double loc = 0.0;
+    for (int i = b; i < e; i++) loc += (double)p[i];
+    s_sum[t] = loc;
+    __syncthreads();
+    if (t == 0) {
+        double run = 0.0;
+        for (int i = 0; i < 256; i++) { s_pre[i] = run; run += s_sum[i]; }
+        s_pre[256] = run;
+    }
+    __syncthreads();
+    const double total = s_pre[256];
+    const double target = u[m];
+    const double lo = s_pre[t] / total, hi = t == 255 ? 1.0 : s_pre[t + 1] / total;   // the last cumulative value is forced to 1
+    if (b < e && lo < target && target <= hi) {   // lower_bound: the first index whose cumulative value is >= u
+        double run = s_pre[t];
+        int id = e - 1;
+        for (int i = b; i < e; i++) {
+            run += (double)p[i];
+            if (run / total >= target) { id = i; break; }
+        }
+        out[m].id = id;
+        out[m].p = p[id];
+    } else if (t == 0 && !(target > 0.0)) {       // u == 0: the first element
+        out[m].id = 0;
+        out[m].p = p[0];
+    }
+}
 }  // namespace
+
+void launch_sample_draw(const float* probs, long ld, int n_vocab, const RowCtl* ctl, int M, const double* u, SampleOut* out, hipStream_t st) {
+    sample_draw_kernel<<<M, 256, 0, st>>>(probs, ld, n_vocab, ctl, u, out); SS_LAUNCH_CHECK();
+}
 
 void launch_logits_rules(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, SampleOut* out, float* probs, float* scratch,
                          hipStream_t st, RowCtl* ctl_upd, const int* row_of) {
