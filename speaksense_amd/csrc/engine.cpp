@@ -567,6 +567,32 @@ struct EngineT : EngineBase {
         if (M <= 16 && use_fused) { decoder_step_fused(M, rc, samp_rows, any_probs); return step_parity; }
         const int n_samp = (int)samp_rows.size();
         SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
+        if (n_samp) {
+            memcpy(rowidx_h, samp_rows.data(), (size_t)n_samp * 4);
+            SS_HIP(hipMemcpyAsync(rowidx_d.p, rowidx_h, (size_t)n_samp * 4, hipMemcpyHostToDevice, st));
+        }
+        const RowCtl* ctl = ctl_d.as<RowCtl>();
+        if (!use_graph) skinny_body(M, n_samp);
+        else {   // the 17..64-row steps of the sampled attempts and long prompts replay a captured graph too (host launch cost: ~0.7 ms per step)
+            StepGraph& sg = step_graphs[(1 << 20) + M * 1024 + n_samp];
+            if (sg.uses++ == 0) skinny_body(M, n_samp);
+            else {
+                if (!sg.exec) {
+                    SS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                    try { skinny_body(M, n_samp); } catch (...) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); throw; }
+                    SS_HIP(hipStreamEndCapture(st, &sg.graph));
+                    SS_HIP(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+                }
+                SS_HIP(hipGraphLaunch(sg.exec, st));
+            }
+        }
+        if (n_samp == 0) return -1;
+        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st);
+        if (any_probs) draw_on_device(ctl + 64, n_samp);
+        SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
+        return -1;
+    }
+    void skinny_body(int M, int n_samp) {
         const RowCtl* ctl = ctl_d.as<RowCtl>();
         launch_embed<T>(tok_emb, dec_pos, ctl, M, d, xd.as<float>(), st);
         const long slot_stride = (long)n_tctx * d, layer_stride = (long)S * slot_stride;
@@ -596,19 +622,14 @@ struct EngineT : EngineBase {
             launch_skinny<T>(sd(lnd.p, d, e.w1, M, 4 * d, d, SK_GELU_T, e.b1, ffd.p, 4 * d), st);
             launch_skinny<T>(sd(ffd.p, 4 * d, e.w2, M, d, 4 * d, SK_RES_F32, e.b2, xd.p, d), st);
         }
-        if (n_samp == 0) return -1;
+        if (n_samp == 0) return;
         // gather the sampling rows: final LayerNorm reads x[samp_rows[i]] and writes compact row i
-        SS_HIP(hipMemcpyAsync(rowidx_d.p, samp_rows.data(), (size_t)n_samp * 4, hipMemcpyHostToDevice, st));
         launch_layernorm<T>(xd.as<float>(), lnw, lnb, lnd.as<T>(), n_samp, d, rowidx_d.as<int>(), st);
         {
             SkinnyDesc g = sd(lnd.p, d, tok_emb, n_samp, n_vocab_pad, d, SK_LOGITS_F32, nullptr, logits.p, n_vocab_pad);
             g.n_valid = n_vocab;
             launch_skinny<T>(g, st);
         }
-        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st);
-        if (any_probs) draw_on_device(ctl + 64, n_samp);
-        SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
-        return -1;
     }
     DBuf samp_d, rowidx_d, rules_scratch;
     bool use_fused = true, cross_direct = false, combine_separate = true, use_graph = true;
