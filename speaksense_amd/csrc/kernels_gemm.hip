@@ -239,9 +239,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
 // WM = 1 variant: 128 (m) x 256 (n) tile, 256 threads = 4 waves (4 n x 1 m, same 64 n x 128 m wave tile), 3-stage ring of 24 KB
 // = 72 KB, so TWO workgroups share a CU: while one is in its epilogue (bias/GELU/residual VALU work and the output stores, which
 // cost 20-50 % of a tile when exposed) the other one's main loop keeps the matrix pipes busy.
+#ifndef SS_RING
+#define SS_RING 4   // LDS ring depth of the 256 x 256 kernel (-DSS_RING=3|5 for experiments): 3 stages measured +40 % main-loop time, 5 (all 160 KB) +27 %
+#endif
 constexpr int TN = 256, TK = 32;
 template <int WM> struct G256 {
-    static constexpr int TM = 128 * WM, NWV = 4 * WM, NST = WM == 2 ? 4 : 3;
+    static constexpr int TM = 128 * WM, NWV = 4 * WM, NST = WM == 2 ? SS_RING : 3;
     static constexpr int kStage = (TM + TN) * TK * 2;      // 32 KB / 24 KB
     static constexpr int kLds = NST * kStage;              // 128 KB (one workgroup per CU) / 72 KB (two)
     static constexpr int RPP = 16 * NWV;                   // tile rows one staging pass covers (16 per wave)
@@ -349,10 +352,12 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
         if (!dma_wave) return;                    // the barrier that follows publishes the staging waves' data
         const int later = issued - 1 - st;
         if (carry && st < NST - 1) {              // a prologue stage of an early-issued tile: the previous tile's stores came after it
-            if (later >= 2) wait_vmcnt<2 * OPS + kCarry>();
+            if (NST >= 5 && later >= 3) wait_vmcnt<(NST >= 5 ? 3 : 2) * OPS + kCarry>();
+            else if (later >= 2) wait_vmcnt<2 * OPS + kCarry>();
             else if (later == 1) wait_vmcnt<OPS + kCarry>();
             else wait_vmcnt<kCarry>();
-        } else if (later >= 2) wait_vmcnt<2 * OPS>();
+        } else if (NST >= 5 && later >= 3) wait_vmcnt<(NST >= 5 ? 3 : 2) * OPS>();
+        else if (later >= 2) wait_vmcnt<2 * OPS>();
         else if (later == 1) wait_vmcnt<OPS>();
         else wait_vmcnt<0>();
     };

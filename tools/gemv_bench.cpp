@@ -1,6 +1,7 @@
 // Decode GEMV micro-benchmark (dev tool): time dec_gemv_kernel for the large-v3 decode shapes over (S, NW) plans.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip tools/gemv_bench.cpp speaksense_amd/csrc/kernels_decode.hip -Ispeaksense_amd/csrc -o tools/gemv_bench.bin
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "kernels.h"
 using namespace ss;
@@ -11,7 +12,7 @@ int main() {
     Shape shapes[] = {{3840, 1280, "QKV", DEPI_PART}, {5120, 1280, "FC1", DEPI_GELU_T}, {1280, 5120, "FC2", DEPI_PART}, {1280, 1280, "O", DEPI_PART}, {51904, 1280, "logits", DEPI_LOGITS}};
     const int M = 8;
     // many distinct weight copies so every launch streams cold weights from HBM like a real step (32 layers)
-    const int NCOPY = 24;
+    const int NCOPY = getenv("NCOPY") ? atoi(getenv("NCOPY")) : 24;
     for (auto& s : shapes) {
         f16* W; hipMalloc(&W, (size_t)NCOPY * s.N * s.K * 2); hipMemset(W, 0, (size_t)NCOPY * s.N * s.K * 2);
         f16* X; hipMalloc(&X, (size_t)16 * s.K * 2); hipMemset(X, 0, 16 * s.K * 2);
