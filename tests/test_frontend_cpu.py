@@ -93,3 +93,69 @@ def test_convert_to_mono_per_read_chunk():
     m3 = rest.convert_to_mono(np.ones(4096, np.float32), 3)        # 4096 = 1365*3 + 1: the dangling sample is still divided by 3
     assert len(m3) == 1366 and m3[-1] == pytest.approx(1 / 3)
     np.testing.assert_array_equal(ppo.convert_to_mono(np.ones(4096, np.float32), 3), m3)
+
+
+def test_batched_rest_chunks_replay_the_serial_sampler_order():
+    """TranscribeProcessor(batched=True) with a stub engine: a chunk that drew from the sampler after earlier chunks had drawn is redone on a
+    session whose generator was advanced by the earlier chunks' draws (whisper_state::rng is never reseeded, so the reference's serial order
+    hands every chunk a generator advanced by all earlier draws)."""
+    from speaksense_amd import asr as asr_mod
+
+    class StubState:
+        def __init__(self):
+            self.draws, self.skipped = 0, 0
+        def rng_draws(self):
+            return self.draws
+        def rng_discard(self, n):
+            self.skipped += n; self.draws += n
+
+    class StubAsr:
+        """chunk k samples `need[k]` draws; the text records the generator position the chunk started from"""
+        def __init__(self, need):
+            self.need, self.calls = need, []
+            class E:   # engine facade used by preprocess(): identity pre-processor
+                @staticmethod
+                def preprocess_stream(mono, chunk_len, chunk_lens=None):
+                    n = (len(mono) + 2047) // 2048
+                    f = np.zeros(n * 2048, np.float32); f[:len(mono)] = mono
+                    return f.reshape(n, 2048), None, 0.0
+            self.engine = E()
+        def create_state(self):
+            return StubState()
+        def _run(self, st, k):
+            start = st.draws
+            st.draws += self.need[k]
+            self.calls.append((k, start))
+            seg = asr_mod.TranscribeSegment(f"<{k}@{start}>", 0, 0.0, 1.0)
+            return asr_mod.TranscribeResult(segments=[seg], full_text=seg.text)
+        def _index(self, audio):
+            return int(round(float(audio[0])))
+        def transcribe_many(self, states, audios, p):
+            return [self._run(s, self._index(a)) for s, a in zip(states, audios)]
+        def transcribe_with_state(self, st, audio, p):
+            return self._run(st, self._index(audio))
+
+    # 4 chunks of 235 frames; the first sample of each chunk carries its index
+    x = np.zeros(4 * 481280, np.float32)
+    for k in range(4):
+        x[k * 481280] = k
+    for need, want in [
+        ([0, 0, 0, 0], "<0@0><1@0><2@0><3@0>"),          # nobody samples: one batch, nothing redone
+        ([6, 0, 0, 0], "<0@0><1@0><2@0><3@0>"),          # only the first chunk draws: later chunks never touch the generator
+        ([0, 4, 0, 2], "<0@0><1@0><2@0><3@4>"),          # chunk 3 sampled after chunk 1 had drawn 4: redone from position 4
+        ([2, 2, 2, 0], "<0@0><1@2><2@4><3@0>"),          # a chain: each redo starts where the serial order would be
+    ]:
+        stub = StubAsr(need)
+        out = rest.TranscribeProcessor(stub, batched=True).process_samples(x, 1, 16000, "zh", False)
+        assert out.text == want, (need, out.text)
+        serial = rest.TranscribeProcessor(StubAsr(need), batched=False)
+        # the serial order on ONE state: positions accumulate
+        st_text = serial.process_samples(x, 1, 16000, "zh", False).text
+        pos, exp = 0, ""
+        for k in range(4):
+            exp += f"<{k}@{pos}>"; pos += need[k]
+        assert st_text == exp
+        # batched differs from serial only in the positions of chunks that never sample (their text does not depend on the generator)
+        for k in range(4):
+            if need[k]:
+                assert f"<{k}@{[p for kk, p in zip(range(4), np.cumsum([0] + need[:-1])) if kk == k][0]}>" in out.text
