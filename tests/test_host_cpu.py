@@ -111,3 +111,25 @@ def test_params_struct_layout_matches_header():
     assert (p.best_of, p.no_context, p.suppress_blank, p.language) == (5, 1, 1, b"en")
     assert abs(p.temperature_inc - 0.2) < 1e-7 and abs(p.entropy_thold - 2.4) < 1e-6 and p.logprob_thold == -1.0
     assert ctypes.sizeof(binding.EngineOpts) == 32
+
+
+def _build_c_harness(tmp_path):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from speaksense_amd import build
+    lib = build.build()
+    exe = str(tmp_path / "harness")
+    cmd = ["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c_harness", "harness.c"), "-o", exe,
+           "-L", os.path.dirname(lib), "-lspeaksense_hip", "-lm", f"-Wl,-rpath,{os.path.dirname(lib)}", "-Wl,-rpath,/opt/rocm/lib", "-L/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_public_headers_compile_as_c_and_link(tmp_path):
+    """include/speaksense.h and include/whisper_compat.h are consumed by a C11 translation unit (what bindgen / cgo / a C service would do) and
+    every symbol it uses resolves against libspeaksense_hip.so.  Running it needs a GPU (tests/test_gpu_variants.py)."""
+    import subprocess
+    exe = _build_c_harness(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
