@@ -68,7 +68,16 @@ typedef struct ss_params {
     int32_t audio_ctx;        /* 0 = full (1500) */
     int32_t translate;        /* 0 */
     int32_t fixed_steps;      /* bench Mode F: >0 = exactly this many greedy steps, EOT suppressed, no fallback */
-    char language[8];         /* "en" default; AsrParams.language */
+    char language[8];         /* "en" default; AsrParams.language.  "auto" or "" = detect (whisper_lang_auto_detect on the first window) */
+    /* ---- whisper_full_params fields the reference leaves at their defaults but a whisper-rs caller can reach ---- */
+    int32_t n_max_text_ctx;   /* 16384: how much of prompt_past conditions the next window (min with n_text_ctx/2) */
+    int32_t offset_ms;        /* 0: start offset */
+    int32_t duration_ms;      /* 0 = to the end */
+    int32_t detect_language;  /* 1 = only detect the language (result: ss_result_lang_id), no transcription */
+    const int32_t* prompt_tokens;  /* prepended to the session's prompt_past (whisper_full_params.prompt_tokens); copied by the call */
+    int32_t prompt_n_tokens;
+    int32_t reserved0;
+    const char* initial_prompt;    /* used when prompt_tokens is NULL: tokenised with the model's vocabulary (whisper_tokenize) */
 } ss_params;
 
 void ss_default_params(ss_params* p);
@@ -80,6 +89,11 @@ void ss_engine_free(ss_engine* e);
 int ss_engine_hparams(const ss_engine* e, int32_t out11[11]);       /* n_vocab ... ftype, ggml header order */
 int ss_engine_special_tokens(const ss_engine* e, int32_t out9[9]);  /* eot sot translate transcribe solm prev nosp not beg */
 const char* ss_engine_token_str(const ss_engine* e, int32_t id);
+/* whisper_tokenize: text -> ids with whisper.cpp's rule (GPT-2 pre-split, then greedy longest match in the vocabulary).
+ * Returns the number of tokens, or -(needed) when n_max is too small. */
+int ss_engine_tokenize(const ss_engine* e, const char* text, int32_t* ids, int32_t n_max);
+/* the same with only the vocabulary of a model file loaded (host only: no GPU, no engine); negative = error */
+int ss_model_tokenize(const char* ggml_model_path, const char* text, int32_t* ids, int32_t n_max);
 
 ss_session* ss_session_create(ss_engine* e);
 void ss_session_free(ss_session* s);
@@ -104,6 +118,11 @@ int64_t ss_result_segment_t1(const ss_session* s, int32_t i);
 int32_t ss_result_segment_speaker_turn_next(const ss_session* s, int32_t i);
 int32_t ss_result_n_tokens(const ss_session* s);                      /* accepted tokens over all windows */
 int ss_result_tokens(const ss_session* s, int32_t* ids, float* plog); /* plog may be NULL */
+/* every id the winning decoder of each window SAMPLED, in order, including the tail past result_len that whisper.cpp (and ss_result_tokens)
+ * drops: the stream a step-by-step replay on another implementation needs (tests: forced replay on the oracle) */
+int32_t ss_result_n_sampled_tokens(const ss_session* s);
+int ss_result_sampled_tokens(const ss_session* s, int32_t* ids);
+int32_t ss_result_lang_id(const ss_session* s);                        /* language used by the last chunk (whisper_full_lang_id), -1 for .en models */
 int ss_result_counters(const ss_session* s, int32_t out4[4]);         /* n_encode, n_decode_steps, n_fail, n_windows */
 
 /* ---- the session's sampler state --------------------------------------------------------------------- */

@@ -25,6 +25,8 @@ class FullParams(C.Structure):
         ("no_context", C.c_int32), ("single_segment", C.c_int32), ("no_timestamps", C.c_int32), ("suppress_blank", C.c_int32),
         ("tdrz_enable", C.c_int32), ("print_special", C.c_int32), ("max_tokens", C.c_int32), ("n_max_text_ctx", C.c_int32),
         ("audio_ctx", C.c_int32), ("translate", C.c_int32), ("fixed_steps", C.c_int32), ("language", C.c_char * 8),
+        ("offset_ms", C.c_int32), ("duration_ms", C.c_int32), ("detect_language", C.c_int32), ("prompt_n_tokens", C.c_int32),
+        ("prompt_tokens", C.c_void_p), ("initial_prompt", C.c_char_p),
     ]
 
 
@@ -58,6 +60,11 @@ def lib():
         L.orc_process_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(FullParams), C.c_void_p, C.c_void_p]
         L.orc_full_default_params.argtypes = [C.POINTER(FullParams)]
         L.orc_full.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FullParams)]
+        L.orc_full_forced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FullParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_n_sampled.argtypes = [C.c_void_p]
+        L.orc_lang_id.argtypes = [C.c_void_p]
+        L.orc_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+        L.orc_sampled.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_n_segments.argtypes = [C.c_void_p]
         L.orc_segment_text.restype = C.c_char_p
         L.orc_segment_text.argtypes = [C.c_void_p, C.c_int]
@@ -79,12 +86,23 @@ def lib():
     return _LIB
 
 
+_THREADS_CAP = 16
+
+
+def set_thread_cap(n: int):
+    """Tests that run the oracle at full large-v3 depth raise the cap (the default 16 keeps hundreds of threads from spinning on tiny loops)."""
+    global _THREADS_CAP
+    _THREADS_CAP = max(1, int(n))
+    if _LIB is not None:
+        _LIB.orc_set_threads(default_threads())
+
+
 def default_threads() -> int:
     try:
         n = len(os.sched_getaffinity(0))
     except AttributeError:
         n = os.cpu_count() or 1
-    return max(1, min(16, n))
+    return max(1, min(_THREADS_CAP, n))
 
 
 def _p(a: np.ndarray):
@@ -112,6 +130,13 @@ class OracleModel:
 
     def token_str(self, i: int) -> bytes:
         return self.L.orc_token_str(self.h, i)
+
+    def tokenize(self, text) -> list:
+        b = text.encode("utf-8") if isinstance(text, str) else text
+        ids = np.zeros(max(16, 2 * len(b)), np.int32)
+        n = self.L.orc_tokenize(self.h, b, _p(ids), len(ids))
+        assert n >= 0
+        return [int(x) for x in ids[:n]]
 
     def log_mel(self, pcm: np.ndarray) -> np.ndarray:
         pcm = np.ascontiguousarray(pcm, np.float32)
@@ -144,8 +169,14 @@ def default_params(**kw) -> FullParams:
     lib().orc_full_default_params(C.byref(p))
     p.no_context = 1
     for k, v in kw.items():
-        if k == "language":
+        if k in ("language", "initial_prompt"):
             v = v.encode() if isinstance(v, str) else v
+        if k == "prompt_tokens":
+            arr = np.ascontiguousarray(v, np.int32)
+            p._keep = arr                      # the struct holds a raw pointer
+            p.prompt_tokens = arr.ctypes.data
+            p.prompt_n_tokens = len(arr)
+            continue
         setattr(p, k, v)
     return p
 
@@ -186,10 +217,21 @@ class OracleState:
         tid = self.L.orc_process_logits(self.h, _p(raw), _p(h), len(h), int(has_ts), seek_delta, C.byref(params), _p(lp), _p(o5))
         return tid, lp, o5
 
-    def full(self, pcm: np.ndarray, params: FullParams | None = None):
+    def full(self, pcm: np.ndarray, params: FullParams | None = None, forced=None):
+        """`forced` (test hook): token ids of another implementation; greedy step g takes forced[g] instead of the argmax and the result
+        carries `forced_gap[g]` = logprob(oracle's best) - logprob(forced[g]) and `forced_best[g]` = the oracle's own pick at that step."""
         pcm = np.ascontiguousarray(pcm, np.float32)
         params = params or default_params()
-        rc = self.L.orc_full(self.h, _p(pcm), len(pcm), C.byref(params))
+        extra = {}
+        if forced is None:
+            rc = self.L.orc_full(self.h, _p(pcm), len(pcm), C.byref(params))
+        else:
+            ids = np.ascontiguousarray(forced, np.int32)
+            gaps = np.zeros(max(1, len(ids)), np.float32)
+            best = np.zeros(max(1, len(ids)), np.int32)
+            used = np.zeros(1, np.int32)
+            rc = self.L.orc_full_forced(self.h, _p(pcm), len(pcm), C.byref(params), _p(ids), len(ids), _p(gaps), _p(best), _p(used))
+            extra = dict(forced_gap=gaps[: int(used[0])].copy(), forced_best=best[: int(used[0])].copy())
         if rc != 0:
             raise RuntimeError(f"orc_full -> {rc}")
         segs = []
@@ -201,6 +243,12 @@ class OracleState:
         plog = np.zeros(n, np.float32)
         if n:
             self.L.orc_tokens(self.h, _p(ids), _p(plog))
+        ns = self.L.orc_n_sampled(self.h)
+        sampled = np.zeros(ns, np.int32)
+        if ns:
+            self.L.orc_sampled(self.h, _p(sampled))
+        extra["sampled"] = sampled
+        extra["lang_id"] = int(self.L.orc_lang_id(self.h))
         c = np.zeros(3, np.int32)
         self.L.orc_counters(self.h, _p(c))
-        return dict(segments=segs, tokens=ids, plog=plog, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]))
+        return dict(segments=segs, tokens=ids, plog=plog, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]), **extra)

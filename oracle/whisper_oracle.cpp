@@ -24,6 +24,7 @@
 #include <cstring>
 #include <map>
 #include <random>
+#include <regex>
 #include <string>
 #include <vector>
 #include <immintrin.h>
@@ -88,6 +89,38 @@ const char* const k_lang[] = {"en","zh","de","es","ru","ko","fr","ja","pt","tr",
     "tg","sd","gu","am","yi","lo","uz","fo","ht","ps","tk","nn","mt","sa","lb","my","bo","tl","mg","as","tt","haw","ln","ha","ba","jw","su","yue"};
 const int k_n_lang = 100;
 int lang_id(const char* s) { for (int i = 0; i < k_n_lang; i++) if (!strcmp(s, k_lang[i])) return i; return -1; }
+
+// wcpp: tokenize(vocab, text) -- GPT-2 pre-split with std::regex, then greedy longest match per word ("unknown token" bytes are skipped)
+std::vector<int> tokenize(const Vocab& vocab, const std::string& text) {
+    std::vector<std::string> words;
+    {
+        std::string str = text;
+        std::string pat = R"('s|'t|'re|'ve|'m|'ll|'d| ?[[:alpha:]]+| ?[[:digit:]]+| ?[^\s[:alpha:][:digit:]]+|\s+(?!\S)|\s+)";
+        std::regex re(pat);
+        std::smatch m;
+        while (std::regex_search(str, m, re)) {
+            for (auto x : m) words.push_back(x);
+            str = m.suffix();
+        }
+    }
+    std::vector<int> tokens;
+    for (const auto& word : words) {
+        if (word.empty()) continue;
+        int i = 0;
+        const int n = (int)word.size();
+        while (i < n) {
+            int j = n;
+            bool found = false;
+            while (j > i) {
+                auto it = vocab.token_to_id.find(word.substr(i, j - i));
+                if (it != vocab.token_to_id.end()) { tokens.push_back(it->second); i = j; found = true; break; }
+                --j;
+            }
+            if (!found) ++i;
+        }
+    }
+    return tokens;
+}
 
 struct Model {
     HParams hp;
@@ -421,6 +454,7 @@ struct Sequence {
 struct Decoder {
     std::vector<float> k, v;  // self KV: [L][n_text_ctx][d]
     Sequence sequence;
+    std::vector<int> sampled;   // test hook: every id sampled in the current attempt, before the truncation to result_len
     int seek_delta = 0; bool failed = false, completed = false, has_ts = false;
     std::vector<float> probs, logits, logprobs;
 };
@@ -433,7 +467,11 @@ struct FullParams {  // wcpp: whisper_full_params (fields the reference sets, wh
     int32_t no_context = 0, single_segment = 0, no_timestamps = 0, suppress_blank = 1, tdrz_enable = 0, print_special = 0;
     int32_t max_tokens = 0, n_max_text_ctx = 16384, audio_ctx = 0, translate = 0;
     int32_t fixed_steps = 0;   // bench "Mode F" (SURVEY.md §8d): >0 => exactly this many greedy steps, EOT suppressed, no fallback
-    char language[8] = "en";
+    char language[8] = "en";   // "" / "auto": whisper_lang_auto_detect
+    int32_t offset_ms = 0, duration_ms = 0, detect_language = 0;
+    int32_t prompt_n_tokens = 0;
+    const int32_t* prompt_tokens = nullptr;
+    const char* initial_prompt = nullptr;
 };
 
 struct State {
@@ -445,9 +483,16 @@ struct State {
     std::vector<int> prompt_past;
     std::vector<Segment> result_all;
     std::vector<TokenData> all_tokens;    // concatenated accepted tokens over windows (test hook)
+    std::vector<int> sampled_all;         // every id the winning decoder of each window sampled, incl. the tail past result_len (test hook)
     std::vector<float> logits;            // last decode: [n_tokens_out][n_vocab]
     std::mt19937 rng{0};
     int n_fail = 0, n_encode = 0, n_decode = 0;
+    int lang_id = -1;                     // wcpp: whisper_full_lang_id
+    // Test hook (not whisper.cpp): forced replay.  Greedy sampling step g takes forced[g] instead of the argmax and records
+    // forced_gap[g] = logprob[argmax] - logprob[forced[g]] (0 when they coincide, +inf when a rule had suppressed the forced token).
+    // A second implementation's token stream is thereby checked step by step against this one ON ITS OWN TRAJECTORY: every pick must be
+    // the oracle's best or within numerical noise of it, across all windows (seek / prompt_past / segments follow from the tokens).
+    std::vector<int> forced; size_t forced_pos = 0; std::vector<float> forced_gap; std::vector<int> forced_best;
 };
 
 void cross_kv(State& s, int max_layers = -1) {
@@ -597,6 +642,13 @@ TokenData sample_token(State& s, Decoder& dec, bool best) {
     }
     if (best) {
         for (int i = 0; i < n_logits; i++) if (r.p < probs[i]) { r.id = i; r.p = probs[i]; r.plog = logprobs[i]; }
+        if (s.forced_pos < s.forced.size()) {
+            const int f = s.forced[s.forced_pos++];
+            float gap = INFINITY;
+            if (f >= 0 && f < n_logits && probs[f] > 0.0f) gap = r.plog - logprobs[f];
+            s.forced_gap.push_back(gap); s.forced_best.push_back(r.id);
+            if (f >= 0 && f < n_logits) { r.id = f; r.p = probs[f]; r.plog = logprobs[f]; }
+        }
     } else {
         std::discrete_distribution<> dist(probs.begin(), probs.end());
         r.id = dist(s.rng); r.p = probs[r.id]; r.plog = logprobs[r.id];
@@ -625,14 +677,34 @@ void sequence_score(const FullParams& P, Sequence& q) {
 // ---------------------------------------------------------------------------------------------
 int full(State& s, const float* samples, int n_samples, const FullParams& P) {
     const Model& m = *s.m; const Vocab& vocab = m.vocab; const HParams& hp = m.hp;
-    s.result_all.clear(); s.all_tokens.clear();
+    s.result_all.clear(); s.all_tokens.clear(); s.sampled_all.clear();
     s.n_encode = s.n_decode = s.n_fail = 0;
     if (n_samples > 0) {
         s.n_len = mel_n_len(n_samples); s.n_len_org = mel_n_len_org(n_samples);
         s.mel.resize((size_t)m.filt_n_mel * s.n_len);
         log_mel(m, samples, n_samples, s.mel.data(), s.n_len);
     }
-    const int seek_start = 0, seek_end = s.n_len_org;
+    s.lang_id = -1;
+    std::string language = P.language;
+    const bool auto_lang = language.empty() || language == "auto" || P.detect_language;
+    s.enc.resize((size_t)hp.n_audio_ctx * hp.n_audio_state);
+    if (auto_lang && vocab.is_multilingual()) {   // wcpp: whisper_lang_auto_detect_with_state(ctx, state, 0, ...): window at offset 0, prompt [sot], argmax over the language tokens
+        if (s.n_len_org <= 0) return -3;
+        encode(m, s.mel.data(), s.n_len, 0, s.o, s.enc.data());
+        cross_kv(s);
+        std::vector<float> lgd(hp.n_vocab);
+        s.decoders.resize(std::max<size_t>(1, s.decoders.size()));
+        const int sot = vocab.token_sot;
+        decode(s, s.decoders[0], &sot, 1, 0, lgd.data());
+        int best = 0;
+        for (int i = 1; i < k_n_lang && sot + 1 + i < hp.n_vocab; i++) if (lgd[sot + 1 + i] > lgd[sot + 1 + best]) best = i;
+        s.lang_id = best; language = k_lang[best];
+        s.n_decode = 0;
+        if (P.detect_language) return 0;
+    } else if (auto_lang) {
+        language = "en";
+    }
+    const int seek_start = P.offset_ms / 10, seek_end = P.duration_ms == 0 ? s.n_len_org : seek_start + P.duration_ms / 10;
     if (seek_end < seek_start + 100) return 0;
     std::vector<float> temperatures;
     if (P.fixed_steps > 0) temperatures.push_back(0.0f);
@@ -641,11 +713,21 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
     const int n_decoders = std::max(1, (int)P.best_of);
     s.decoders.resize(n_decoders);
     if (P.no_context) s.prompt_past.clear();
+    {   // wcpp "prepare prompt": initial_prompt -> tokens unless prompt_tokens is given; prepended to prompt_past (push_back + rotate)
+        std::vector<int> pt;
+        if (P.prompt_tokens && P.prompt_n_tokens > 0) pt.assign(P.prompt_tokens, P.prompt_tokens + P.prompt_n_tokens);
+        else if (P.initial_prompt && *P.initial_prompt) { pt = tokenize(vocab, P.initial_prompt); if (pt.size() > 1024) pt.resize(1024); }
+        if (!pt.empty()) {
+            for (int t : pt) s.prompt_past.push_back(t);
+            std::rotate(s.prompt_past.begin(), s.prompt_past.end() - pt.size(), s.prompt_past.end());
+        }
+    }
     if (P.audio_ctx > hp.n_audio_ctx) return -5;
     std::vector<int> prompt_init = {vocab.token_sot};
     if (vocab.is_multilingual()) {
-        const int lid = lang_id(P.language);
+        const int lid = lang_id(language.c_str());
         if (lid < 0) return -3;
+        s.lang_id = lid;
         prompt_init.push_back(vocab.token_sot + 1 + lid);
         prompt_init.push_back(P.translate ? vocab.token_translate : vocab.token_transcribe);
     }
@@ -653,7 +735,6 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
     int seek = seek_start;
     std::vector<int> prompt;
     std::vector<float> lg(hp.n_vocab);
-    s.enc.resize((size_t)hp.n_audio_ctx * hp.n_audio_state);
     while (true) {
         if (seek + 100 >= seek_end) break;
         encode(m, s.mel.data(), s.n_len, seek, s.o, s.enc.data());
@@ -737,6 +818,8 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
                 for (int j = 0; j < n_cur; j++) {
                     Decoder& d = s.decoders[j];
                     if (d.failed) continue;
+                    d.sampled.clear();
+                    for (auto& t : d.sequence.tokens) d.sampled.push_back(t.id);
                     d.sequence.tokens.resize(d.sequence.result_len);
                     sequence_score(P, d.sequence);
                     if (P.fixed_steps == 0 && d.sequence.result_len > 32 && d.sequence.entropy < P.entropy_thold) { d.failed = true; continue; }
@@ -758,6 +841,7 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
             if (!prompt.empty() && prompt.front() == vocab.token_prev) s.prompt_past.insert(s.prompt_past.end(), prompt.begin() + 1, prompt.end() - prompt_init.size());
             for (int i = 0; i < result_len && i < (int)tokens_cur.size(); i++) s.prompt_past.push_back(tokens_cur[i].id);
             for (auto& t : tokens_cur) s.all_tokens.push_back(t);
+            s.sampled_all.insert(s.sampled_all.end(), bd.sampled.begin(), bd.sampled.end());
             if (!tokens_cur.empty()) {
                 int i0 = 0;
                 int64_t t0 = seek + 2 * (tokens_cur.front().tid - vocab.token_beg);
@@ -847,6 +931,26 @@ int orc_process_logits(void* sp, const float* raw, const int32_t* hist, int n_hi
 }
 void orc_full_default_params(FullParams* p) { *p = FullParams(); }
 int orc_full(void* sp, const float* pcm, int n, const FullParams* P) { return full(*(State*)sp, pcm, n, *P); }
+// forced replay (see State::forced): returns orc_full's code; gaps_out / best_out get one entry per consumed forced token, *n_used their count
+int orc_full_forced(void* sp, const float* pcm, int n, const FullParams* P, const int32_t* ids, int n_ids, float* gaps_out, int32_t* best_out, int32_t* n_used) {
+    State& s = *(State*)sp;
+    s.forced.assign(ids, ids + n_ids); s.forced_pos = 0; s.forced_gap.clear(); s.forced_best.clear();
+    const int rc = full(s, pcm, n, *P);
+    const int k = (int)s.forced_gap.size();
+    for (int i = 0; i < k; i++) { gaps_out[i] = s.forced_gap[i]; best_out[i] = s.forced_best[i]; }
+    *n_used = k;
+    s.forced.clear(); s.forced_pos = 0;
+    return rc;
+}
+int orc_lang_id(void* sp) { return ((State*)sp)->lang_id; }
+int orc_tokenize(void* mp, const char* text, int32_t* ids, int n_max) {
+    const std::vector<int> t = tokenize(((Model*)mp)->vocab, text);
+    if ((int)t.size() > n_max) return -(int)t.size();
+    for (size_t i = 0; i < t.size(); i++) ids[i] = t[i];
+    return (int)t.size();
+}
+int orc_n_sampled(void* sp) { return (int)((State*)sp)->sampled_all.size(); }
+void orc_sampled(void* sp, int32_t* ids) { State* s = (State*)sp; for (size_t i = 0; i < s->sampled_all.size(); i++) ids[i] = s->sampled_all[i]; }
 int orc_n_segments(void* sp) { return (int)((State*)sp)->result_all.size(); }
 const char* orc_segment_text(void* sp, int i) { return ((State*)sp)->result_all[i].text.c_str(); }
 int64_t orc_segment_t0(void* sp, int i) { return ((State*)sp)->result_all[i].t0; }

@@ -24,7 +24,9 @@ class Params(C.Structure):
                 ("logprob_thold", C.c_float), ("max_initial_ts", C.c_float), ("length_penalty", C.c_float), ("no_context", C.c_int32),
                 ("single_segment", C.c_int32), ("no_timestamps", C.c_int32), ("suppress_blank", C.c_int32), ("tdrz_enable", C.c_int32),
                 ("print_special", C.c_int32), ("max_tokens", C.c_int32), ("audio_ctx", C.c_int32), ("translate", C.c_int32),
-                ("fixed_steps", C.c_int32), ("language", C.c_char * 8)]
+                ("fixed_steps", C.c_int32), ("language", C.c_char * 8),
+                ("n_max_text_ctx", C.c_int32), ("offset_ms", C.c_int32), ("duration_ms", C.c_int32), ("detect_language", C.c_int32),
+                ("prompt_tokens", C.c_void_p), ("prompt_n_tokens", C.c_int32), ("reserved0", C.c_int32), ("initial_prompt", C.c_char_p)]
 
 
 class DenoiseConfig(C.Structure):   # DenoiseConfig, /root/reference/src/audio/mod.rs:41-61
@@ -70,7 +72,12 @@ def lib():
         L.ss_result_segment_speaker_turn_next.argtypes = [vp, i32]
         L.ss_result_n_tokens.argtypes = [vp]
         L.ss_result_tokens.argtypes = [vp, vp, vp]
+        L.ss_result_n_sampled_tokens.argtypes = [vp]
+        L.ss_result_sampled_tokens.argtypes = [vp, vp]
         L.ss_result_counters.argtypes = [vp, vp]
+        L.ss_result_lang_id.argtypes = [vp]
+        L.ss_engine_tokenize.argtypes = [vp, C.c_char_p, vp, i32]
+        L.ss_model_tokenize.argtypes = [C.c_char_p, C.c_char_p, vp, i32]
         L.ss_session_rng_draws.argtypes = [vp]
         L.ss_session_rng_draws.restype = C.c_int64
         L.ss_session_rng_discard.argtypes = [vp, C.c_int64]
@@ -108,10 +115,36 @@ def default_params(**kw) -> Params:
     p = Params()
     lib().ss_default_params(C.byref(p))
     for k, v in kw.items():
-        if k == "language" and isinstance(v, str):
+        if k in ("language", "initial_prompt") and isinstance(v, str):
             v = v.encode()
+        if k == "prompt_tokens":
+            arr = np.ascontiguousarray(v, np.int32)
+            p._keep = arr                      # the struct holds a raw pointer; the library copies the tokens during the call
+            p.prompt_tokens = arr.ctypes.data
+            p.prompt_n_tokens = len(arr)
+            continue
         setattr(p, k, v)
     return p
+
+
+_LANGS = ("en zh de es ru ko fr ja pt tr pl ca nl ar sv it id hi fi vi he uk el ms cs ro da hu ta no th ur hr bg lt la mi ml cy sk te fa lv bn sr az "
+          "sl kn et mk br eu is hy ne mn bs kk sq sw gl mr pa si km sn yo so af oc ka be tg sd gu am yi lo uz fo ht ps tk nn mt sa lb my bo tl mg as tt "
+          "haw ln ha ba jw su yue").split()
+
+
+def lang_code(lang_id: int) -> str:
+    """whisper_lang_str"""
+    return _LANGS[lang_id]
+
+
+def model_tokenize(model_path: str, text) -> list:
+    """whisper_tokenize with only the file's vocabulary loaded (host only, no GPU)."""
+    b = text.encode("utf-8") if isinstance(text, str) else text
+    ids = np.zeros(max(16, 2 * len(b)), np.int32)
+    n = lib().ss_model_tokenize(model_path.encode(), b, _p(ids), len(ids))
+    if n < 0:
+        raise SpeakSenseError(n, lib().ss_last_error().decode(errors="replace"))
+    return [int(x) for x in ids[:n]]
 
 
 class Engine:
@@ -145,6 +178,14 @@ class Engine:
 
     def token_str(self, i: int) -> bytes:
         return self.L.ss_engine_token_str(self.h, i)
+
+    def tokenize(self, text) -> list:
+        b = text.encode("utf-8") if isinstance(text, str) else text
+        ids = np.zeros(max(16, 2 * len(b)), np.int32)
+        n = self.L.ss_engine_tokenize(self.h, b, _p(ids), len(ids))
+        if n < 0:
+            raise SpeakSenseError(n, "tokenize: buffer too small")
+        return [int(x) for x in ids[:n]]
 
     def new_session(self) -> "Session":
         return Session(self)
@@ -275,9 +316,14 @@ class Session:
         plog = np.zeros(n, np.float32)
         if n:
             self.L.ss_result_tokens(self.h, _p(ids), _p(plog))
+        ns = self.L.ss_result_n_sampled_tokens(self.h)
+        sampled = np.zeros(ns, np.int32)
+        if ns:
+            self.L.ss_result_sampled_tokens(self.h, _p(sampled))
         c = np.zeros(4, np.int32)
         self.L.ss_result_counters(self.h, _p(c))
-        return dict(segments=segs, tokens=ids, plog=plog, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]), n_windows=int(c[3]))
+        return dict(segments=segs, tokens=ids, plog=plog, sampled=sampled, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]),
+                    n_windows=int(c[3]), lang_id=int(self.L.ss_result_lang_id(self.h)))
 
     def rng_draws(self) -> int:
         """Invocations of the session's std::mt19937 so far (whisper_state::rng, consumed only by temperature-fallback sampling)."""

@@ -14,7 +14,22 @@ static int fail(int code, const std::string& msg) { g_err = msg; return code; }
 #define SS_TRY try {
 #define SS_CATCH                                                          \
     } catch (const ss::Error& e) { return fail(e.code, e.what()); }        \
-    catch (const std::exception& e) { return fail(SS_ERR_DEVICE, e.what()); }
+    catch (const std::exception& e) { return fail(SS_ERR_DEVICE, e.what()); }  \
+    catch (...) { return fail(SS_ERR_DEVICE, "unknown exception"); }
+
+// whisper_full_with_state "prepare prompt": initial_prompt is tokenised unless prompt_tokens is given; the job keeps its own copy
+static void capture_prompt(Job& j, const EngineBase* e) {
+    j.prompt_tokens.clear();
+    if (j.P.prompt_tokens && j.P.prompt_n_tokens > 0) j.prompt_tokens.assign(j.P.prompt_tokens, j.P.prompt_tokens + j.P.prompt_n_tokens);
+    else if (j.P.initial_prompt && *j.P.initial_prompt) j.prompt_tokens = tokenize(e->hm.vocab, j.P.initial_prompt);
+    if (j.prompt_tokens.size() > 1024) j.prompt_tokens.resize(1024);   // whisper.cpp tokenises the initial prompt into a 1024-token buffer
+    j.P.prompt_tokens = nullptr; j.P.prompt_n_tokens = 0; j.P.initial_prompt = nullptr;
+}
+static int bad_prompt(const ss_params& P, const EngineBase* e) {
+    if (P.prompt_n_tokens < 0 || (P.prompt_n_tokens > 0 && !P.prompt_tokens)) return 1;
+    for (int i = 0; i < P.prompt_n_tokens; i++) if (P.prompt_tokens[i] < 0 || P.prompt_tokens[i] >= e->hm.hp.n_vocab) return 1;
+    return 0;
+}
 
 extern "C" {
 
@@ -28,6 +43,8 @@ void ss_default_params(ss_params* p) {
     p->suppress_blank = 1; p->tdrz_enable = 0; p->print_special = 0; p->max_tokens = 0; p->audio_ctx = 0; p->translate = 0;
     p->fixed_steps = 0;
     strcpy(p->language, "en");
+    p->n_max_text_ctx = 16384; p->offset_ms = 0; p->duration_ms = 0; p->detect_language = 0;
+    p->prompt_tokens = nullptr; p->prompt_n_tokens = 0; p->initial_prompt = nullptr;
 }
 
 int ss_engine_create(const char* path, const ss_engine_opts* opts, ss_engine** out) {
@@ -67,6 +84,26 @@ const char* ss_engine_token_str(const ss_engine* e, int32_t id) {
     return e->e->hm.vocab.id_to_token[id].c_str();
 }
 
+int ss_engine_tokenize(const ss_engine* e, const char* text, int32_t* ids, int32_t n_max) {
+    if (!e || !text || (n_max > 0 && !ids)) return fail(SS_ERR_ARG, "ss_engine_tokenize: bad argument");
+    const std::vector<int> t = tokenize(e->e->hm.vocab, text);
+    if ((int)t.size() > n_max) return -(int)t.size();
+    for (size_t i = 0; i < t.size(); i++) ids[i] = t[i];
+    return (int)t.size();
+}
+
+int ss_model_tokenize(const char* path, const char* text, int32_t* ids, int32_t n_max) {
+    if (!path || !text || (n_max > 0 && !ids)) return fail(SS_ERR_ARG, "ss_model_tokenize: bad argument");
+    SS_TRY
+    HostModel m;
+    load_ggml_model(path, m, true);
+    const std::vector<int> t = tokenize(m.vocab, text);
+    if ((int)t.size() > n_max) return fail(SS_ERR_ARG, "ss_model_tokenize: buffer too small");
+    for (size_t i = 0; i < t.size(); i++) ids[i] = t[i];
+    return (int)t.size();
+    SS_CATCH
+}
+
 ss_session* ss_session_create(ss_engine* e) {
     if (!e) return nullptr;
     ss_session* s = new ss_session();
@@ -80,6 +117,7 @@ int ss_transcribe_batch(ss_engine* e, ss_session* const* sessions, const float* 
     if (!e || !sessions || !pcm || !n_samples || n <= 0) return fail(SS_ERR_ARG, "ss_transcribe_batch: bad argument");
     ss_params P;
     if (params) P = *params; else ss_default_params(&P);
+    if (bad_prompt(P, e->e)) return fail(SS_ERR_ARG, "ss_transcribe_batch: bad prompt_tokens");
     std::vector<Job> jobs(n);
     std::vector<Job*> jp(n);
     for (int i = 0; i < n; i++) {
@@ -87,11 +125,13 @@ int ss_transcribe_batch(ss_engine* e, ss_session* const* sessions, const float* 
         for (int k = 0; k < i; k++) if (sessions[k] == sessions[i]) return fail(SS_ERR_ARG, "ss_transcribe_batch: sessions must be distinct");
         jobs[i].sess = &sessions[i]->s; jobs[i].pcm = pcm[i]; jobs[i].n_samples = n_samples[i]; jobs[i].pcm_on_device = pcm_on_device != 0;
         jobs[i].P = P;
+        capture_prompt(jobs[i], e->e);
         jp[i] = &jobs[i];
     }
     SS_TRY
     e->e->run_jobs(jp);
-    for (int i = 0; i < n; i++) if (jobs[i].status != 0) return fail(jobs[i].status, "chunk " + std::to_string(i) + " failed");
+    for (int i = 0; i < n; i++)
+        if (jobs[i].status != 0) return fail(jobs[i].status, "chunk " + std::to_string(i) + " failed" + (jobs[i].err.empty() ? "" : ": " + jobs[i].err));
     return SS_OK;
     SS_CATCH
 }
@@ -110,6 +150,8 @@ int ss_submit(ss_session* s, const float* pcm, int32_t n_samples, const ss_param
     t->job.owned.assign(pcm, pcm + n_samples);
     t->job.pcm = t->job.owned.data(); t->job.n_samples = n_samples;
     if (params) t->job.P = *params; else ss_default_params(&t->job.P);
+    if (bad_prompt(t->job.P, s->s.eng)) { delete t; return fail(SS_ERR_ARG, "ss_submit: bad prompt_tokens"); }
+    capture_prompt(t->job, s->s.eng);
     s->s.eng->submit(&t->job);
     *out = t;
     return SS_OK;
@@ -118,8 +160,9 @@ int ss_wait(ss_ticket* t) {
     if (!t) return fail(SS_ERR_ARG, "ss_wait: null ticket");
     t->job.sess->eng->wait(&t->job);
     const int st = t->job.status;
+    const std::string why = t->job.err.empty() ? std::string("chunk failed") : t->job.err;
     delete t;
-    return st == 0 ? SS_OK : fail(st, "chunk failed");
+    return st == 0 ? SS_OK : fail(st, why);
 }
 
 int32_t ss_result_n_segments(const ss_session* s) { return s ? (int32_t)s->s.segments.size() : 0; }
@@ -138,6 +181,13 @@ int ss_result_tokens(const ss_session* s, int32_t* ids, float* plog) {
     for (size_t i = 0; i < s->s.tokens.size(); i++) { ids[i] = s->s.tokens[i].id; if (plog) plog[i] = s->s.tokens[i].plog; }
     return SS_OK;
 }
+int32_t ss_result_n_sampled_tokens(const ss_session* s) { return s ? (int32_t)s->s.sampled.size() : 0; }
+int ss_result_sampled_tokens(const ss_session* s, int32_t* ids) {
+    if (!s || !ids) return fail(SS_ERR_ARG, "null argument");
+    for (size_t i = 0; i < s->s.sampled.size(); i++) ids[i] = s->s.sampled[i];
+    return SS_OK;
+}
+int32_t ss_result_lang_id(const ss_session* s) { return s ? s->s.lang_id : -1; }
 int ss_result_counters(const ss_session* s, int32_t out4[4]) {
     if (!s || !out4) return fail(SS_ERR_ARG, "null argument");
     out4[0] = s->s.n_encode; out4[1] = s->s.n_decode; out4[2] = s->s.n_fail; out4[3] = s->s.n_windows;

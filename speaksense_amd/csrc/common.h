@@ -73,6 +73,8 @@ struct Vocab {
     int num_languages() const { return n_vocab - 51765 - (is_multilingual() ? 1 : 0); }
 };
 int lang_id(const char* code);  // -1 if unknown
+const char* lang_code(int id);   // nullptr if out of range
+std::vector<int> tokenize(const Vocab& vocab, const std::string& text);   // whisper.cpp's tokenize(): GPT-2 pre-split + greedy longest match
 
 // Host-side tensor as read from the file: f32 copy + the raw f16 payload when the file stored f16
 struct HostTensor {
@@ -90,7 +92,7 @@ struct HostModel {
     std::map<std::string, HostTensor> t;
     const HostTensor& get(const std::string& name) const;
 };
-void load_ggml_model(const char* path, HostModel& m);  // throws ss::Error(-2,...)
+void load_ggml_model(const char* path, HostModel& m, bool vocab_only = false);  // throws ss::Error(-2,...)
 
 // audio constants (whisper.cpp: WHISPER_SAMPLE_RATE / N_FFT / HOP_LENGTH / CHUNK_SIZE)
 constexpr int kSampleRate = 16000, kNFft = 400, kHop = 160, kChunkSec = 30, kNBins = 201;

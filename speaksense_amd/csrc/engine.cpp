@@ -66,7 +66,6 @@ struct DBuf {
     template <typename U> U* as() const { return (U*)p; }
 };
 
-constexpr int kNMaxTextCtx = 16384;  // whisper_full_default_params: n_max_text_ctx
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // per-decoder state (whisper_decoder + whisper_sequence)
@@ -80,6 +79,7 @@ struct Dec {
     int i = 0;       // index of the next token to sample
     bool active = false;
     int slot = 0;
+    std::vector<int> sampled;   // every id this decoder sampled, before the truncation to result_len (ss_result_sampled_tokens)
 };
 struct Window {
     Job* job = nullptr;
@@ -90,10 +90,12 @@ struct Window {
     std::vector<int> prompt;
     std::vector<Dec> decs;
     int best = 0;
+    bool skip = false;     // detect_language only: the window is not decoded
 };
 struct JobState {
-    Job* job; int slot; int n_len = 0, n_len_org = 0, seek = 0, seek_end = 0; bool alive = false;
+    Job* job; int slot; int n_len = 0, n_len_org = 0, seek = 0, seek_start = 0, seek_end = 0; bool alive = false;
     std::vector<int> prompt_init;
+    bool need_detect = false;   // language "auto": resolved after the first window's encoder pass
 };
 
 static void sequence_score(const ss_params& P, Dec& q) {  // whisper_sequence_score
@@ -136,13 +138,30 @@ struct EngineT : EngineBase {
     std::vector<DBuf> pcm_d, mel_d, fmax_d;  // per batch slot
     DBuf x0, h1, x, ln, qk, vT, att, ff, encT, encF, cross, kself, vself;
     DBuf xd, lnd, qd, attd, ffd, logits, probs, cscratch, ctl_d;
-    RowCtl* ctl_h = nullptr;       // pinned, mapped
-    int* rowidx_h = nullptr;       // pinned
+    // Host staging for one decoder launch: control blocks, sampling-row indices and the uniform draws.  H2D copies from pinned memory read
+    // their source when the copy EXECUTES, and the stream may be backlogged (encoder pass, earlier launches of the same round), so every
+    // launch fills its own block of a ring and a block is only rewritten after the event recorded behind its copies has completed.
+    struct Stage { RowCtl ctl[128]; int rowidx[64]; double u[64]; };
+    static constexpr int kStageRing = 16;
+    Stage* stage_h = nullptr;      // pinned ring
+    hipEvent_t stage_ev[kStageRing];
+    bool stage_busy[kStageRing] = {};
+    int stage_cur = 0;
+    RowCtl* ctl_h = nullptr;       // = stage_h[stage_cur].ctl  ([0,64) rows, [64,128) sampling rows)
+    int* rowidx_h = nullptr;       // = stage_h[stage_cur].rowidx
+    void stage_acquire() {         // next free block of the ring becomes ctl_h / rowidx_h / u_h
+        stage_cur = (stage_cur + 1) % kStageRing;
+        if (stage_busy[stage_cur]) { SS_HIP(hipEventSynchronize(stage_ev[stage_cur])); stage_busy[stage_cur] = false; }
+        ctl_h = stage_h[stage_cur].ctl; rowidx_h = stage_h[stage_cur].rowidx; u_h = stage_h[stage_cur].u;
+    }
+    void stage_release() {         // call after the last H2D copy of the launch has been enqueued
+        SS_HIP(hipEventRecord(stage_ev[stage_cur], st)); stage_busy[stage_cur] = true;
+    }
     SampleOut* samp_h = nullptr;   // pinned, mapped
     SampleOut* samp_hb[2] = {nullptr, nullptr};   // fused steps alternate between two result buffers (a chained step may be in flight)
     hipEvent_t ev_step[2];
     int step_parity = 0;
-    double* u_h = nullptr;         // pinned: one uniform draw per sampled row (t > 0)
+    double* u_h = nullptr;         // = stage_h[stage_cur].u: one uniform draw per sampled row (t > 0)
     DBuf u_d;
     hipEvent_t ev[4];
 
@@ -186,11 +205,10 @@ struct EngineT : EngineBase {
         if (step_timing && tm_n > 1)
             fprintf(stderr, "[ss] decode steps %ld: launch call %.1f us, wait for samples %.1f us, host between steps %.1f us (averages)\n", tm_n, tm_launch / tm_n,
                     tm_wait / tm_n, tm_host / (tm_n - 1));
-        if (ctl_h) (void)hipHostFree(ctl_h);
-        if (rowidx_h) (void)hipHostFree(rowidx_h);
+        if (stage_h) (void)hipHostFree(stage_h);
+        for (auto& e : stage_ev) (void)hipEventDestroy(e);
         for (auto& kv : step_graphs) { if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph); }
         if (samp_h) (void)hipHostFree(samp_h);
-        if (u_h) (void)hipHostFree(u_h);
         for (auto& e : ev) (void)hipEventDestroy(e);
         if (st) (void)hipStreamDestroy(st);
     }
@@ -317,11 +335,12 @@ struct EngineT : EngineBase {
         ffd.alloc((size_t)R * 4 * d * 2); logits.alloc((size_t)R * n_vocab_pad * 4); probs.alloc((size_t)R * n_vocab_pad * 4);
         cscratch.alloc((size_t)R * H * 4 * 66 * 4); ctl_d.alloc(2 * R * sizeof(RowCtl));
         samp_d.alloc(R * sizeof(SampleOut)); rowidx_d.alloc(R * 4); rules_scratch.alloc((size_t)R * 64 * 8 * 4);
-        SS_HIP(hipHostMalloc((void**)&ctl_h, 2 * R * sizeof(RowCtl), hipHostMallocDefault));
+        SS_HIP(hipHostMalloc((void**)&stage_h, kStageRing * sizeof(Stage), hipHostMallocDefault));
+        memset(stage_h, 0, kStageRing * sizeof(Stage));
+        for (auto& e : stage_ev) SS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        stage_acquire();
         SS_HIP(hipHostMalloc((void**)&samp_h, 2 * R * sizeof(SampleOut), hipHostMallocDefault));
         samp_hb[0] = samp_h; samp_hb[1] = samp_h + R;
-        SS_HIP(hipHostMalloc((void**)&rowidx_h, R * sizeof(int), hipHostMallocDefault));
-        SS_HIP(hipHostMalloc((void**)&u_h, (size_t)R * sizeof(double), hipHostMallocDefault));
         u_d.alloc((size_t)R * sizeof(double));
     }
 
@@ -666,7 +685,7 @@ struct EngineT : EngineBase {
             try {
                 run_group(grp);
             } catch (const Error& e) {
-                for (Job* j : grp) if (j->status == 0) j->status = e.code;
+                for (Job* j : grp) if (j->status == 0) { j->status = e.code; j->err = e.what(); }
                 throw;
             }
         }
@@ -679,21 +698,39 @@ struct EngineT : EngineBase {
         for (size_t i = 0; i < grp.size(); i++) {
             Job* j = grp[i];
             Session* s = j->sess;
-            s->segments.clear(); s->tokens.clear(); s->n_encode = s->n_decode = s->n_fail = s->n_windows = 0;
+            s->segments.clear(); s->tokens.clear(); s->sampled.clear(); s->n_encode = s->n_decode = s->n_fail = s->n_windows = 0;
             if (j->P.no_context) s->prompt_past.clear();
+            if (!j->prompt_tokens.empty()) {   // "prepend the prompt tokens to the prompt_past"
+                s->prompt_past.insert(s->prompt_past.end(), j->prompt_tokens.begin(), j->prompt_tokens.end());
+                std::rotate(s->prompt_past.begin(), s->prompt_past.end() - j->prompt_tokens.size(), s->prompt_past.end());
+            }
             JobState q; q.job = j; q.slot = (int)i;
             j->status = 0;
             const ss_params& P = j->P;
-            if (P.audio_ctx > n_ctx) { j->status = SS_ERR_AUDIO_CTX; js.push_back(q); continue; }
-            if (P.best_of > ND) { j->status = SS_ERR_ARG; js.push_back(q); continue; }
-            q.prompt_init = {vocab.token_sot};
-            if (vocab.is_multilingual()) {
-                const int lid = lang_id(P.language);
-                if (lid < 0 || lid >= vocab.num_languages()) { j->status = SS_ERR_LANG; js.push_back(q); continue; }
-                q.prompt_init.push_back(vocab.token_sot + 1 + lid);
-                q.prompt_init.push_back(P.translate ? vocab.token_translate : vocab.token_transcribe);
+            if (P.audio_ctx > n_ctx) { j->status = SS_ERR_AUDIO_CTX; j->err = "audio_ctx larger than the model's n_audio_ctx"; js.push_back(q); continue; }
+            if (P.audio_ctx != 0 && P.audio_ctx != n_ctx) {   // the reference only ever passes 1500 or 0 (whisper.rs:144,68); a shortened encoder context is not built
+                j->status = SS_ERR_UNSUPPORTED; j->err = "audio_ctx must be 0 or the model's n_audio_ctx"; js.push_back(q); continue;
             }
-            if (P.no_timestamps) q.prompt_init.push_back(vocab.token_not);
+            if (P.best_of > ND) { j->status = SS_ERR_ARG; j->err = "best_of exceeds the engine's max_decoders"; js.push_back(q); continue; }
+            if (P.offset_ms < 0 || P.duration_ms < 0) { j->status = SS_ERR_ARG; j->err = "negative offset_ms / duration_ms"; js.push_back(q); continue; }
+            // "auto-detect language if not specified": language nullptr / "" / "auto" or detect_language (whisper_full_with_state)
+            const bool auto_lang = P.language[0] == 0 || !strcmp(P.language, "auto") || P.detect_language;
+            s->lang_id = -1;
+            if (vocab.is_multilingual()) {
+                if (auto_lang) {
+                    // whisper_lang_auto_detect looks at the window at offset 0; here it shares the first window's encoder pass
+                    if (P.offset_ms != 0) { j->status = SS_ERR_UNSUPPORTED; j->err = "language detection together with offset_ms"; js.push_back(q); continue; }
+                    q.need_detect = true;
+                } else {
+                    const int lid = lang_id(P.language);
+                    if (lid < 0 || lid >= vocab.num_languages()) { j->status = SS_ERR_LANG; j->err = std::string("unknown language '") + P.language + "'"; js.push_back(q); continue; }
+                    s->lang_id = lid;
+                    set_prompt_init(q, lid);
+                }
+            } else {
+                if (P.detect_language) { j->status = SS_ERR_LANG; j->err = "detect_language on an English-only model"; js.push_back(q); continue; }
+                set_prompt_init(q, 0);   // .en models: [sot] only, whatever the language says
+            }
             if (j->n_samples > 0) {
                 q.n_len = mel_n_len(j->n_samples); q.n_len_org = mel_n_len_org(j->n_samples);
                 const float* dp;
@@ -706,8 +743,9 @@ struct EngineT : EngineBase {
                 mel_d[i].ensure((size_t)n_mel * q.n_len * 4);
                 fmax_d[i].ensure((size_t)q.n_len * 4);
                 launch_log_mel(mt, dp, j->n_samples, mel_d[i].as<float>(), q.n_len, fmax_d[i].as<float>(), st);
-                q.seek = 0; q.seek_end = q.n_len_org;
-                q.alive = q.seek_end >= 100;  // "if length of spectrogram is less than 1.0s, return"
+                q.seek_start = P.offset_ms / 10;
+                q.seek = q.seek_start; q.seek_end = P.duration_ms == 0 ? q.n_len_org : q.seek_start + P.duration_ms / 10;
+                q.alive = q.seek_end >= q.seek_start + 100;  // "if length of spectrogram is less than 1.0s, return"
             }
             js.push_back(q);
         }
@@ -724,7 +762,7 @@ struct EngineT : EngineBase {
                 else if (P.temperature_inc > 0.0f) for (float t = P.temperature; t < 1.0f + 1e-6f; t += P.temperature_inc) w.temperatures.push_back(t);
                 else w.temperatures = {P.temperature};
                 // "if there is a very short audio segment left to process, we remove any past prompt"
-                if (q.seek > 0 && q.seek + 500 >= q.seek_end) q.job->sess->prompt_past.clear();
+                if (q.seek > q.seek_start && q.seek + 500 >= q.seek_end) q.job->sess->prompt_past.clear();
                 launch_mel_window<T>(mel_d[q.slot].template as<float>(), n_mel, q.n_len, q.seek, 2 * n_ctx,
                                      x0.as<T>() + (size_t)w.cross * (2 * n_ctx + 2) * n_mel, st);
                 wins.push_back(std::move(w));
@@ -738,8 +776,11 @@ struct EngineT : EngineBase {
             cross_kv_pass(Wn);
             SS_HIP(hipEventRecord(e1, st));
             for (auto& w : wins) { w.job->sess->n_encode++; w.job->sess->n_windows++; }
+            detect_languages(wins, js);
+            for (auto& w : wins) if (w.skip) w.pending = false;
             // temperature ladder
-            int n_pending = Wn;
+            int n_pending = 0;
+            for (auto& w : wins) n_pending += w.pending;
             for (int it = 0; n_pending > 0; it++) {
                 std::vector<Window*> run;
                 for (auto& w : wins) if (w.pending) { w.it = it; run.push_back(&w); }
@@ -751,6 +792,8 @@ struct EngineT : EngineBase {
                     for (size_t j = 0; j < w->decs.size(); j++) {
                         Dec& dq = w->decs[j];
                         if (dq.failed) continue;
+                        dq.sampled.resize(dq.tokens.size());
+                        for (size_t k = 0; k < dq.tokens.size(); k++) dq.sampled[k] = dq.tokens[k].id;
                         dq.tokens.resize(dq.result_len);
                         sequence_score(P, dq);
                         if (P.fixed_steps == 0 && dq.result_len > 32 && dq.entropy < P.entropy_thold) { dq.failed = true; continue; }
@@ -771,7 +814,7 @@ struct EngineT : EngineBase {
             ms_enc += a; ms_dec += b;
             (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
             // emit segments, advance seek
-            for (auto& w : wins) finalize_window(w, js);
+            for (auto& w : wins) if (!w.skip) finalize_window(w, js);
         }
         SS_HIP(hipEventRecord(ev[2], st));
         SS_HIP(hipEventSynchronize(ev[2]));
@@ -779,6 +822,56 @@ struct EngineT : EngineBase {
         SS_HIP(hipEventElapsedTime(&ms_mel, ev[0], ev[1]));
         SS_HIP(hipEventElapsedTime(&ms_tot, ev[0], ev[2]));
         last_ms[0] = ms_mel; last_ms[1] = ms_enc; last_ms[2] = ms_dec; last_ms[3] = ms_tot;
+    }
+
+    // "these tokens determine the task that will be performed": [sot, lang, task] (multilingual) or [sot], + [notimestamps]
+    void set_prompt_init(JobState& q, int lid) {
+        const Vocab& vocab = hm.vocab;
+        const ss_params& P = q.job->P;
+        q.prompt_init = {vocab.token_sot};
+        if (vocab.is_multilingual()) {
+            q.prompt_init.push_back(vocab.token_sot + 1 + lid);
+            q.prompt_init.push_back(P.translate ? vocab.token_translate : vocab.token_transcribe);
+        }
+        if (P.no_timestamps) q.prompt_init.push_back(vocab.token_not);
+    }
+    // whisper_lang_auto_detect for the windows whose job asked for it: one decoder row [sot] at position 0 per window on the cross-KV just
+    // computed, language = argmax of the raw logits over the language tokens sot+1+id, id in [0, 100) (softmax is monotonic)
+    void detect_languages(std::vector<Window>& wins, std::vector<JobState>& js) {
+        const Vocab& vocab = hm.vocab;
+        std::vector<Window*> need;
+        for (auto& w : wins) if (state_of(js, w.job).need_detect) need.push_back(&w);
+        if (need.empty()) return;
+        spec.valid = false;
+        ss_params P0; memset(&P0, 0, sizeof(P0));
+        const RuleConsts rc = rule_consts(P0);
+        constexpr int kLangs = 100;   // g_lang: 100 entries whatever the model's vocabulary holds
+        std::vector<float> lg((size_t)kLangs);
+        for (size_t r0 = 0; r0 < need.size(); r0 += 16) {
+            const int M = (int)std::min<size_t>(16, need.size() - r0);
+            stage_acquire();
+            std::vector<int> sr;
+            for (int m = 0; m < M; m++) {
+                RowCtl c{};
+                c.token = vocab.token_sot; c.pos = 0; c.slot = m; c.cross = need[r0 + m]->cross; c.n_hist = 1;
+                ctl_h[m] = c; ctl_h[64 + m] = c;
+                sr.push_back(m);
+            }
+            decoder_step(M, rc, sr, false);
+            stage_release();
+            SS_HIP(hipStreamSynchronize(st));
+            for (int m = 0; m < M; m++) {
+                const int first = vocab.token_sot + 1, n = std::min(kLangs, n_vocab - first);
+                SS_HIP(hipMemcpy(lg.data(), logits.as<float>() + (size_t)m * n_vocab_pad + first, (size_t)n * 4, hipMemcpyDeviceToHost));
+                int best = 0;
+                for (int i = 1; i < n; i++) if (lg[i] > lg[best]) best = i;
+                JobState& q = state_of(js, need[r0 + m]->job);
+                q.need_detect = false;
+                q.job->sess->lang_id = best;
+                if (q.job->P.detect_language) { q.alive = false; need[r0 + m]->skip = true; }   // "if (params.detect_language) return 0"
+                else set_prompt_init(q, best);
+            }
+        }
     }
 
     JobState& state_of(std::vector<JobState>& js, Job* j) { for (auto& q : js) if (q.job == j) return q; throw Error(-1, "internal: job state"); }
@@ -799,8 +892,8 @@ struct EngineT : EngineBase {
             Session* s = w->job->sess;
             JobState& jq = state_of(js, w->job);
             w->prompt.clear();
-            if (!s->prompt_past.empty() && t_cur < 0.5f && kNMaxTextCtx > 0) {
-                const int n_take = std::min(std::min(kNMaxTextCtx, n_tctx / 2), (int)s->prompt_past.size());
+            if (!s->prompt_past.empty() && t_cur < 0.5f && P.n_max_text_ctx > 0) {
+                const int n_take = std::min(std::min((int)P.n_max_text_ctx, n_tctx / 2), (int)s->prompt_past.size());
                 w->prompt.push_back(hm.vocab.token_prev);
                 w->prompt.insert(w->prompt.end(), s->prompt_past.end() - n_take, s->prompt_past.end());
             }
@@ -907,6 +1000,7 @@ struct EngineT : EngineBase {
             const int M = (int)std::min<size_t>(64, rows.size() - r0);
             std::vector<int> samp_rows;
             bool any_probs = false;
+            stage_acquire();   // this launch's own pinned block (ctl_h / rowidx_h / u_h)
             for (int m = 0; m < M; m++) {
                 ctl_h[m] = rows[r0 + m];
                 if (refs[r0 + m].sample) {
@@ -920,6 +1014,7 @@ struct EngineT : EngineBase {
             }
             const auto tt0 = std::chrono::steady_clock::now();
             const int par = decoder_step(M, rc, samp_rows, any_probs);
+            stage_release();
             const auto tt1 = std::chrono::steady_clock::now();
             if (samp_rows.empty()) continue;
             if (simple && par >= 0 && may_continue()) launch_chained();
@@ -992,6 +1087,7 @@ struct EngineT : EngineBase {
         const int seek = jq.seek, seek_delta = bd.seek_delta;
         const std::vector<TokenData>& tk = bd.tokens;
         for (auto& t : tk) s->tokens.push_back(t);
+        s->sampled.insert(s->sampled.end(), bd.sampled.begin(), bd.sampled.end());
         // update prompt_past: the past context that was fed (without [prev] and the task tokens) + this window's text
         {
             std::vector<int> np;
@@ -1062,10 +1158,12 @@ struct EngineT : EngineBase {
         for (int i = 0; i < n; i++) {
             RowCtl c{};
             c.token = tokens[i]; c.pos = n_past + i; c.slot = 0; c.cross = 0; c.n_hist = 1;
+            stage_acquire();
             ctl_h[0] = c; ctl_h[64] = c;
             std::vector<int> sr;
             if (i == n - 1) sr.push_back(0);
             decoder_step(1, rc, sr, false);
+            stage_release();
             SS_HIP(hipStreamSynchronize(st));
         }
         SS_HIP(hipMemcpy(logits_out, logits.p, (size_t)n_vocab * 4, hipMemcpyDeviceToHost));
@@ -1080,8 +1178,10 @@ struct EngineT : EngineBase {
         c.last_ts = n_hist > 0 && hist[n_hist - 1] >= vocab.token_beg;
         c.penult_ts = n_hist < 2 || hist[n_hist - 2] >= vocab.token_beg;
         c.has_ts = has_ts; c.ts_min = seek_delta / 2; c.temperature = 0.0f;
+        stage_acquire();
         ctl_h[0] = c;
         SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, sizeof(RowCtl), hipMemcpyHostToDevice, st));
+        stage_release();
         launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl_d.as<RowCtl>(), 1, rule_consts(P), samp_d.as<SampleOut>(), nullptr, rules_scratch.as<float>(), st);
         SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, sizeof(SampleOut), hipMemcpyDeviceToHost, st));
         SS_HIP(hipStreamSynchronize(st));
@@ -1180,7 +1280,7 @@ struct EngineT : EngineBase {
         float* gain = sub + 2 * n_frames;
         long* d_off = nullptr;
         if (!off.empty()) {
-            d_off = (long*)(gain + n_frames + (n_frames & 1));
+            d_off = (long*)(gain + n_frames);   // 16 * n_frames bytes into an allocation aligned to 256: 8-byte aligned
             SS_HIP(hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, st));
         }
         SS_HIP(hipMemcpyAsync(dn_in.p, pcm, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1304,10 +1404,25 @@ void EngineBase::start_worker() {
                 const int maxb = opts.max_batch > 0 ? opts.max_batch : 8;
                 if ((int)queue.size() < maxb && opts.batch_wait_us > 0)
                     qcv.wait_for(lk, std::chrono::microseconds(opts.batch_wait_us), [&] { return stop || (int)queue.size() >= maxb; });
-                while (!queue.empty() && (int)batch.size() < maxb) { batch.push_back(queue.front()); queue.pop_front(); }
+                // one chunk per session per batch (run_group writes the session's results): a second ticket of a session already in this
+                // batch stays queued, in order, for the next one
+                for (auto it = queue.begin(); it != queue.end() && (int)batch.size() < maxb;) {
+                    bool dup = false;
+                    for (Job* b : batch) if (b->sess == (*it)->sess) { dup = true; break; }
+                    if (dup) { ++it; continue; }
+                    batch.push_back(*it);
+                    it = queue.erase(it);
+                }
             }
             if (batch.empty()) continue;
-            try { run_jobs(batch); } catch (const Error& e) { for (Job* j : batch) if (j->status == 0) j->status = e.code; }
+            // nothing may escape this thread (std::terminate would take the host service down) and every job must be marked done
+            auto fail_all = [&](int code, const char* what) {
+                for (Job* j : batch) if (j->status == 0) { j->status = code; j->err = what; }
+            };
+            try { run_jobs(batch); }
+            catch (const Error& e) { fail_all(e.code, e.what()); }
+            catch (const std::exception& e) { fail_all(SS_ERR_DEVICE, e.what()); }
+            catch (...) { fail_all(SS_ERR_DEVICE, "unknown exception in the batch former"); }
             {
                 std::lock_guard<std::mutex> lk(qmu);
                 for (Job* j : batch) j->done = true;

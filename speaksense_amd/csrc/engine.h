@@ -33,8 +33,10 @@ struct Session {
     struct EngineBase* eng = nullptr;
     std::vector<Segment> segments;
     std::vector<TokenData> tokens;
+    std::vector<int> sampled;      // every id the winning decoder of each window sampled (incl. the tail past result_len that `tokens` drops)
     int n_encode = 0, n_decode = 0, n_fail = 0, n_windows = 0;
     std::vector<int> prompt_past;  // whisper_state::prompt_past: text context carried between windows (and calls, unless no_context)
+    int lang_id = -1;              // whisper_full_lang_id: language of the last chunk (given or detected)
     CountingRng rng;  // whisper_state::rng (std::mt19937 seeded with 0 once per state, never reseeded per call)
 };
 
@@ -45,7 +47,9 @@ struct Job {  // one chunk handed to transcribe (== one whisper_full_with_state 
     bool pcm_on_device = false;
     ss_params P{};
     int status = 0;
+    std::string err;           // what failed (travels on the ticket: the worker's thread-local message would be lost)
     std::vector<float> owned;  // async submit keeps its own copy
+    std::vector<int> prompt_tokens;   // P.prompt_tokens / tokenised P.initial_prompt, captured at the API boundary (P's pointers are not kept)
     // async completion
     bool done = false;
 };

@@ -21,6 +21,62 @@ int lang_id(const char* code) {
     return -1;
 }
 
+const char* lang_code(int id) { return id >= 0 && id < kNLang ? kLang[id] : nullptr; }
+
+// whisper.cpp `tokenize(vocab, text)` (what whisper_tokenize / initial_prompt use): words = successive matches of the GPT-2 pattern
+//   's|'t|'re|'ve|'m|'ll|'d| ?[[:alpha:]]+| ?[[:digit:]]+| ?[^\s[:alpha:][:digit:]]+|\s+(?!\S)|\s+
+// (std::regex, classic locale: alpha/digit/space are ASCII classes, every byte >= 0x80 is "other"), then each word is cut greedily into the
+// longest vocabulary entries; a byte no entry starts with is skipped.  Written out by hand: the alternatives are tried in order at each position.
+static inline bool is_alpha_c(unsigned char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+static inline bool is_digit_c(unsigned char c) { return c >= '0' && c <= '9'; }
+static inline bool is_space_c(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }
+static inline bool is_other_c(unsigned char c) { return !is_alpha_c(c) && !is_digit_c(c) && !is_space_c(c); }
+std::vector<int> tokenize(const Vocab& vocab, const std::string& text) {
+    std::vector<std::string> words;
+    const size_t n = text.size();
+    size_t i = 0;
+    auto run = [&](size_t from, bool (*cls)(unsigned char)) { size_t j = from; while (j < n && cls((unsigned char)text[j])) j++; return j; };
+    while (i < n) {
+        size_t e = 0;   // end of the match starting at i (0 = none yet)
+        if (text[i] == '\'') {
+            static const char* const suf[] = {"'s", "'t", "'re", "'ve", "'m", "'ll", "'d"};
+            for (const char* sfx : suf) { const size_t l = strlen(sfx); if (text.compare(i, l, sfx) == 0) { e = i + l; break; } }
+        }
+        if (!e) {
+            const size_t b = (text[i] == ' ' && i + 1 < n) ? i + 1 : i;   // " ?": with the space first, then (backtracking) without it
+            bool (*const classes[3])(unsigned char) = {is_alpha_c, is_digit_c, is_other_c};
+            for (auto cls : classes) {
+                size_t j = run(b, cls);
+                if (j > b) { e = j; break; }
+                if (b != i) { j = run(i, cls); if (j > i) { e = j; break; } }
+            }
+        }
+        if (!e) {   // \s+(?!\S) | \s+
+            const size_t j = run(i, is_space_c);
+            if (j > i) e = (j < n && j - i >= 2) ? j - 1 : j;
+        }
+        if (!e) e = i + 1;   // unreachable: every byte is in one of the classes
+        words.push_back(text.substr(i, e - i));
+        i = e;
+    }
+    std::vector<int> tokens;
+    for (const std::string& word : words) {
+        size_t a = 0;
+        const size_t m = word.size();
+        while (a < m) {
+            size_t j = m;
+            bool found = false;
+            while (j > a) {
+                auto it = vocab.token_to_id.find(word.substr(a, j - a));
+                if (it != vocab.token_to_id.end()) { tokens.push_back(it->second); a = j; found = true; break; }
+                --j;
+            }
+            if (!found) ++a;
+        }
+    }
+    return tokens;
+}
+
 const HostTensor& HostModel::get(const std::string& name) const {
     auto it = t.find(name);
     if (it == t.end()) throw Error(-2, "model: missing tensor " + name);
@@ -50,7 +106,7 @@ struct File {
 };
 }  // namespace
 
-void load_ggml_model(const char* path, HostModel& m) {
+void load_ggml_model(const char* path, HostModel& m, bool vocab_only) {
     File F(path);
     if (!F.f) throw Error(-2, std::string("model: cannot open ") + path);
     uint32_t magic = 0;
@@ -58,7 +114,14 @@ void load_ggml_model(const char* path, HostModel& m) {
     if (!F.rd(&m.hp, sizeof(HParams))) throw Error(-2, "model: truncated header");
     const HParams& hp = m.hp;
     if (hp.ftype != 0 && hp.ftype != 1) throw Error(-2, "model: quantised ftype " + std::to_string(hp.ftype) + " not supported (f32/f16 only)");
-    if (hp.n_audio_state % hp.n_audio_head || hp.n_audio_state / hp.n_audio_head != 64 || hp.n_text_state / hp.n_text_head != 64)
+    // a malformed header must come back as SS_ERR_MODEL, never as SIGFPE: check every field before dividing by any of them
+    const int32_t* hv = &hp.n_vocab;
+    for (int i = 0; i < 10; i++) if (hv[i] <= 0) throw Error(-2, "model: non-positive hyper-parameter in the header");
+    if (hp.n_vocab > (1 << 20) || hp.n_audio_ctx > 1500 || hp.n_text_ctx > 448 || hp.n_mels > 128 || hp.n_audio_layer > 256 || hp.n_text_layer > 256 ||
+        hp.n_audio_state > 8192 || hp.n_text_state > 8192)
+        throw Error(-2, "model: hyper-parameter out of range");
+    if (hp.n_audio_state % hp.n_audio_head || hp.n_text_state % hp.n_text_head || hp.n_audio_state / hp.n_audio_head != 64 ||
+        hp.n_text_state / hp.n_text_head != 64)
         throw Error(-2, "model: head dim must be 64");
     int32_t nm = 0, nf = 0;
     if (!F.rd(&nm, 4) || !F.rd(&nf, 4) || nf != kNBins || nm != hp.n_mels) throw Error(-2, "model: bad mel filterbank header");
@@ -105,6 +168,7 @@ void load_ggml_model(const char* path, HostModel& m) {
             v.token_to_id[w] = i;
         }
     }
+    if (vocab_only) return;
     while (true) {
         int32_t nd = 0, nl = 0, tt = 0;
         if (!F.rd(&nd, 4)) break;  // clean EOF

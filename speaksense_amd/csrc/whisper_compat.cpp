@@ -95,11 +95,13 @@ int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* s
                             int n_samples) {
     if (!ctx || !state) return -1;
     // features of whisper_full this path does not implement are refused, never silently ignored
-    if (params.strategy != WHISPER_SAMPLING_GREEDY || params.speed_up || params.detect_language || params.offset_ms != 0 ||
-        params.duration_ms != 0 || params.initial_prompt || params.prompt_n_tokens > 0 || params.suppress_non_speech_tokens ||
-        params.n_grammar_rules > 0 || params.logits_filter_callback || params.max_len > 0)
+    if (params.strategy != WHISPER_SAMPLING_GREEDY || params.speed_up || params.suppress_non_speech_tokens || params.n_grammar_rules > 0 ||
+        params.logits_filter_callback || params.max_len > 0)
         return SS_ERR_UNSUPPORTED;
-    if (!params.language || !*params.language || !strcmp(params.language, "auto")) return SS_ERR_UNSUPPORTED;
+    // callbacks would have to fire from inside the device batch.  token_timestamps / split_on_word (the reference sets both, whisper.rs:160-161)
+    // only act together with max_len > 0, refused above.
+    if (params.new_segment_callback || params.progress_callback || params.encoder_begin_callback || params.abort_callback) return SS_ERR_UNSUPPORTED;
+    if (params.audio_ctx != 0 && params.audio_ctx != whisper_n_audio_ctx(ctx)) return SS_ERR_UNSUPPORTED;
     ss_params p;
     ss_default_params(&p);
     p.best_of = params.greedy.best_of > 0 ? params.greedy.best_of : 1;
@@ -108,8 +110,11 @@ int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* s
     p.no_context = params.no_context; p.single_segment = params.single_segment; p.no_timestamps = params.no_timestamps;
     p.suppress_blank = params.suppress_blank; p.tdrz_enable = params.tdrz_enable; p.print_special = params.print_special;
     p.max_tokens = params.max_tokens; p.audio_ctx = params.audio_ctx; p.translate = params.translate;
-    strncpy(p.language, params.language, sizeof(p.language) - 1);
-    p.language[sizeof(p.language) - 1] = 0;
+    if (params.language) { strncpy(p.language, params.language, sizeof(p.language) - 1); p.language[sizeof(p.language) - 1] = 0; }
+    else p.language[0] = 0;   // nullptr / "" / "auto": detect
+    p.n_max_text_ctx = params.n_max_text_ctx; p.offset_ms = params.offset_ms; p.duration_ms = params.duration_ms;
+    p.detect_language = params.detect_language;
+    p.prompt_tokens = params.prompt_tokens; p.prompt_n_tokens = params.prompt_n_tokens; p.initial_prompt = params.initial_prompt;
     ss_ticket* t = nullptr;
     int rc = ss_submit(state->ses, samples, n_samples, &p, &t);
     if (rc != SS_OK) return rc;

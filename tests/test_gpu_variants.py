@@ -237,10 +237,10 @@ def test_whisper_asr_mirror_end_to_end(toy_ml_path, om, orc):
     p2 = asr.AsrParams(language="zh", stream_mode=False)
     res2 = eng.transcribe(pcm, p2)
     ref = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(language="zh", no_context=0))
-    if ref["n_fail"] == 0:
-        kept = [s for s in ref["segments"] if not asr.is_promotional_text(s["text"].decode())]
-        assert [s.text for s in res2.segments] == [asr.add_punctuation(s["text"].decode()) for s in kept]
-        assert [(s.start, s.end) for s in res2.segments] == [(float(s["t0"]), float(s["t1"])) for s in kept]
+    assert ref["n_fail"] == 0, "fixture drifted: the oracle fell back to sampling; re-pick the seed with tools/find_nofallback_seeds.py"
+    kept = [s for s in ref["segments"] if not asr.is_promotional_text(s["text"].decode())]
+    assert [s.text for s in res2.segments] == [asr.add_punctuation(s["text"].decode()) for s in kept]
+    assert [(s.start, s.end) for s in res2.segments] == [(float(s["t0"]), float(s["t1"])) for s in kept]
     assert res2.full_text == "".join(s.text for s in res2.segments)
     assert res.segments[0].text == res.full_text
     # batched form: identical per-chunk results

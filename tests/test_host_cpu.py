@@ -104,11 +104,38 @@ def test_no_cpu_fallback(toy_ml_path):
     assert e.value.code == -4
 
 
-def test_params_struct_layout_matches_header():
+def _abi_layout(tmp_path):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "layout")
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+                        os.path.join(root, "tests", "c_harness", "layout.c"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe], capture_output=True, text=True).stdout
+    return out, {(a, b): (int(c), int(d)) for a, b, c, d in (l.split() for l in out.strip().splitlines())}
+
+
+def test_params_struct_layout_matches_header(tmp_path):
+    """Both by-value parameter structs, field by field: what a C11 compiler makes of the public headers == the committed table
+    (tests/golden/abi_layout.txt; the whisper_full_params part was derived by hand from whisper.h v1.5.4 for LP64 -- a maintainer diffs it
+    against bindgen's layout test of the vendored header) == the ctypes mirror the Python binding passes."""
+    import os
     from speaksense_amd import binding
+    out, lay = _abi_layout(tmp_path)
+    golden = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "abi_layout.txt")).read()
+    assert out == golden, "include/*.h no longer lay out as the committed ABI table"
+    assert lay[("whisper_full_params", "sizeof")][0] == 256 and lay[("whisper_full_params", "language")] == (88, 8)
+    assert lay[("whisper_full_params", "greedy")] == (128, 4) and lay[("whisper_full_params", "grammar_penalty")] == (248, 4)
+    for name, ctype in binding.Params._fields_:
+        f = getattr(binding.Params, name)
+        assert lay[("ss_params", name)] == (f.offset, f.size), name
+    assert lay[("ss_params", "sizeof")][0] == ctypes.sizeof(binding.Params)
+    assert len([k for k in lay if k[0] == "ss_params"]) == len(binding.Params._fields_) + 1
+    for name, ctype in binding.EngineOpts._fields_:
+        f = getattr(binding.EngineOpts, name)
+        assert lay[("ss_engine_opts", name)] == (f.offset, f.size), name
     p = binding.default_params()
-    assert ctypes.sizeof(binding.Params) == 17 * 4 + 8
-    assert (p.best_of, p.no_context, p.suppress_blank, p.language) == (5, 1, 1, b"en")
+    assert (p.best_of, p.no_context, p.suppress_blank, p.language, p.n_max_text_ctx, p.offset_ms, p.prompt_n_tokens) == (5, 1, 1, b"en", 16384, 0, 0)
     assert abs(p.temperature_inc - 0.2) < 1e-7 and abs(p.entropy_thold - 2.4) < 1e-6 and p.logprob_thold == -1.0
     assert ctypes.sizeof(binding.EngineOpts) == 32
 
@@ -133,3 +160,30 @@ def test_public_headers_compile_as_c_and_link(tmp_path):
     exe = _build_c_harness(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 2 and "usage" in r.stderr
+
+
+def test_tokenizer_matches_regex_restatement(tmp_path):
+    """whisper_tokenize (initial_prompt): the product's hand-written GPT-2 pre-split (csrc/model.cpp) against the oracle, which restates
+    whisper.cpp's tokenize() with the same std::regex pattern -- two independent implementations, host only."""
+    import random
+    from oracle import binding as orc
+    from speaksense_amd import binding, ggml_io
+    path = str(tmp_path / "toy.bin")
+    ggml_io.write_model(path, "toy", seed=1)
+    om = orc.OracleModel(path)
+    rnd = random.Random(1)
+    texts = [b"", b"  ", b"a  b   c    ", b"'re're 'll x'd", "什么 好 ".encode(), b"it's 12  x\t\n y"]
+    for _ in range(200):
+        t = b"".join(om.token_str(rnd.randint(0, 50000)) for _ in range(rnd.randint(1, 12)))
+        if rnd.random() < 0.3:
+            t = t.replace(b" ", b"  ")
+        if rnd.random() < 0.2:
+            t += b"'s 12 x"
+        texts.append(t)
+    n_long = 0
+    for t in texts:
+        a, b = om.tokenize(t), binding.model_tokenize(path, t)
+        assert a == b, t
+        n_long += len(a) > 2
+    assert n_long > 100
+    om.close()
