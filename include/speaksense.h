@@ -44,7 +44,9 @@ typedef struct ss_engine_opts {
     int32_t max_batch;    /* windows encoded+decoded together on the device (default 8) */
     int32_t max_decoders; /* decoders per window at temperature > 0 (reference: Greedy{best_of:5}, whisper.rs:132) */
     int32_t batch_wait_us;/* how long the batch former waits for more chunks before launching a partial batch */
-    int32_t reserved[3];
+    int32_t n_lanes;      /* device batches in flight at once over one copy of the weights (0 = default 2; env SS_LANES overrides): each lane has
+                             its own stream, workspaces and KV caches, so one group's encoder pass and another's decode chain overlap */
+    int32_t reserved[2];
 } ss_engine_opts;
 
 /* The whisper_full_params fields the reference sets (whisper.rs:131-173) plus its per-request overrides
@@ -98,6 +100,24 @@ int ss_model_tokenize(const char* ggml_model_path, const char* text, int32_t* id
 ss_session* ss_session_create(ss_engine* e);
 void ss_session_free(ss_session* s);
 
+/* ---- one model on several GPUs of a node (wiring it slots under: /root/reference/src/main.rs:38-39,59,71 -- one
+ * WhisperAsr shared by the gRPC handler and the REST worker) ----------------------------------------------------------------------------
+ * Chunks are independent (both reference callers force no_context), so the pool is N engines -- one per listed HIP device, weights replicated,
+ * no collective -- and a router: every submitted chunk goes to the engine with the fewest chunks queued or running, ties round-robin
+ * (north_star: "sharded round-robin across the 8 GPUs").  A session's state (prompt_past, sampler) lives on the host, so its chunks may run
+ * on different GPUs; results come back on the session as usual.  device_ids may repeat (tests: two engines on one GPU). */
+typedef struct ss_pool ss_pool;
+int ss_pool_create(const char* ggml_model_path, const int32_t* device_ids, int32_t n_devices, const ss_engine_opts* opts /* .device ignored */,
+                   ss_pool** out);
+void ss_pool_free(ss_pool* p);
+int32_t ss_pool_n_engines(const ss_pool* p);
+ss_engine* ss_pool_engine(ss_pool* p, int32_t i);              /* borrowed: hparams, tokens, timing of engine i */
+ss_session* ss_pool_session_create(ss_pool* p);               /* freed with ss_session_free */
+int ss_pool_submit(ss_pool* p, ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, ss_ticket** out);   /* ss_wait as usual */
+int32_t ss_pool_last_engine(const ss_session* s);             /* index of the engine that ran (or runs) the session's last chunk */
+/* the routing rule alone (host only): index of the engine a chunk goes to given each engine's load and the round-robin cursor */
+int32_t ss_pool_pick(const int32_t* load, int32_t n_engines, uint32_t cursor);
+
 /* ---- transcription ---------------------------------------------------------------------------------- */
 /* Blocking: n chunks (one per session, sessions distinct) processed as one device batch stream.
  * pcm[i]: n_samples[i] mono f32 samples @16 kHz in [-1,1].  pcm_on_device != 0: pcm[i] are device pointers
@@ -108,6 +128,8 @@ int ss_transcribe_batch(ss_engine* e, ss_session* const* sessions, const float* 
 int ss_transcribe(ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params);
 /* Non-blocking: copies the samples, returns a ticket; the engine batches across sessions. */
 int ss_submit(ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, ss_ticket** out);
+/* The same; pcm_on_device != 0: `pcm` is a device pointer on the engine's GPU, not copied -- it must stay valid until ss_wait returns. */
+int ss_submit_ex(ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, int32_t pcm_on_device, ss_ticket** out);
 int ss_wait(ss_ticket* t);      /* blocks; returns the chunk's status; frees the ticket */
 
 /* ---- results of the session's last chunk (valid until its next transcribe/submit) -------------------- */
@@ -184,6 +206,12 @@ int ss_preprocess_stream(ss_engine* e, const float* pcm, int64_t n_samples, cons
 /* ---- timing hooks for bench.py (HIP events on the engine's own stream) ------------------------------ */
 /* ms spent in the phases of the last ss_transcribe_batch: [0] mel, [1] encoder+cross-KV, [2] decode, [3] total */
 int ss_engine_last_timing(const ss_engine* e, float out_ms[4]);
+/* work of the last device group: [0] decoder passes (each streams the decoder weights once: prompt pass + one per later step),
+ * [1] decoder rows over those passes, [2] encoder windows, [3] 0.  With last_timing[2] this gives the in-pipeline decode-step time. */
+int ss_engine_last_counters(const ss_engine* e, int64_t out4[4]);
+/* Cumulative since engine creation, summed over the lanes: device ms [mel, encoder+cross-KV, decode, total] and work [decoder passes, decoder
+ * rows, encoder windows, 0].  Differences around a timed region give the in-pipeline averages when several groups run concurrently. */
+int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[4], int32_t* n_lanes);
 /* average device time (ms) of `reps` launches of the dominant encoder GEMM (FC1: M=batch*1500, N=4d, K=d) on the
  * engine's stream, and its algorithmic FLOPs per launch: the roofline probe bench.py reports. */
 int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_ms, double* flops_per_launch);

@@ -16,7 +16,7 @@ DTYPE_BF16, DTYPE_F16 = 0, 1
 
 class EngineOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("dtype", C.c_int32), ("max_batch", C.c_int32), ("max_decoders", C.c_int32),
-                ("batch_wait_us", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("batch_wait_us", C.c_int32), ("n_lanes", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class Params(C.Structure):
@@ -96,6 +96,19 @@ def lib():
         L.ss_preprocess_n_out.restype = C.c_int64
         L.ss_preprocess_stream.argtypes = [vp, f32p, C.c_int64, vp, i32, i32, C.POINTER(DenoiseConfig), f32p, f32p, C.POINTER(C.c_float)]
         L.ss_engine_last_timing.argtypes = [vp, f32p]
+        L.ss_engine_last_counters.argtypes = [vp, vp]
+        L.ss_engine_totals.argtypes = [vp, vp, vp, C.POINTER(i32)]
+        L.ss_pool_create.argtypes = [C.c_char_p, vp, i32, C.POINTER(EngineOpts), C.POINTER(vp)]
+        L.ss_pool_free.argtypes = [vp]
+        L.ss_pool_n_engines.argtypes = [vp]
+        L.ss_pool_engine.restype = vp
+        L.ss_pool_engine.argtypes = [vp, i32]
+        L.ss_pool_session_create.restype = vp
+        L.ss_pool_session_create.argtypes = [vp]
+        L.ss_pool_submit.argtypes = [vp, vp, f32p, i32, C.POINTER(Params), C.POINTER(vp)]
+        L.ss_pool_last_engine.argtypes = [vp]
+        L.ss_pool_pick.argtypes = [vp, i32, C.c_uint32]
+        L.ss_submit_ex.argtypes = [vp, f32p, i32, C.POINTER(Params), i32, C.POINTER(vp)]
         L.ss_engine_probe_gemm.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_double)]
         L.ss_engine_selftest_gemm.argtypes = [vp, i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _LIB = L
@@ -149,9 +162,9 @@ def model_tokenize(model_path: str, text) -> list:
 
 class Engine:
     def __init__(self, model_path: str, device: int = 0, dtype: int = DTYPE_F16, max_batch: int = 8, max_decoders: int = 5,
-                 batch_wait_us: int = 2000):
+                 batch_wait_us: int = 2000, n_lanes: int = 0):
         self.L = lib()
-        o = EngineOpts(device, dtype, max_batch, max_decoders, batch_wait_us)
+        o = EngineOpts(device, dtype, max_batch, max_decoders, batch_wait_us, n_lanes)
         h = C.c_void_p()
         self.model_path = model_path
         _check(self.L.ss_engine_create(model_path.encode(), C.byref(o), C.byref(h)))
@@ -269,7 +282,19 @@ class Engine:
     def last_timing(self):
         t = np.zeros(4, np.float32)
         self.L.ss_engine_last_timing(self.h, _p(t))
-        return dict(mel_ms=float(t[0]), encode_ms=float(t[1]), decode_ms=float(t[2]), total_ms=float(t[3]))
+        c = np.zeros(4, np.int64)
+        self.L.ss_engine_last_counters(self.h, _p(c))
+        return dict(mel_ms=float(t[0]), encode_ms=float(t[1]), decode_ms=float(t[2]), total_ms=float(t[3]), decoder_passes=int(c[0]),
+                    decoder_rows=int(c[1]), encoder_windows=int(c[2]))
+
+    def totals(self):
+        """Cumulative device time / work over all lanes since the engine was created (ss_engine_totals)."""
+        ms = np.zeros(4, np.float64)
+        cnt = np.zeros(4, np.int64)
+        nl = C.c_int32()
+        _check(self.L.ss_engine_totals(self.h, _p(ms), _p(cnt), C.byref(nl)))
+        return dict(mel_ms=float(ms[0]), encode_ms=float(ms[1]), decode_ms=float(ms[2]), total_ms=float(ms[3]), decoder_passes=int(cnt[0]),
+                    decoder_rows=int(cnt[1]), encoder_windows=int(cnt[2]), n_lanes=int(nl.value))
 
     def probe_gemm(self, batch: int, reps: int):
         ms, fl = C.c_float(), C.c_double()
@@ -299,6 +324,12 @@ class Session:
         pcm = np.ascontiguousarray(pcm, np.float32)
         t = C.c_void_p()
         _check(self.L.ss_submit(self.h, _p(pcm), len(pcm), C.byref(params) if params is not None else None, C.byref(t)))
+        return t
+
+    def submit_device(self, ptr: int, n: int, params: Params | None = None):
+        """Async submit of PCM already resident on the engine's GPU (device pointer); the buffer must outlive wait()."""
+        t = C.c_void_p()
+        _check(self.L.ss_submit_ex(self.h, C.c_void_p(int(ptr)), int(n), C.byref(params) if params is not None else None, 1, C.byref(t)))
         return t
 
     def wait(self, ticket):
@@ -341,3 +372,52 @@ class Session:
         out = np.empty(self.eng.n_vocab, np.float32)
         _check(self.L.ss_session_decode(self.h, _p(t), len(t), n_past, _p(out)))
         return out
+
+
+class Pool:
+    """One model on several GPUs of a node (ss_pool_*): N engines, chunks routed to the least-loaded one, ties round-robin."""
+
+    def __init__(self, model_path: str, device_ids, dtype: int = DTYPE_F16, max_batch: int = 8, max_decoders: int = 5, batch_wait_us: int = 2000,
+                 n_lanes: int = 0):
+        self.L = lib()
+        ids = np.ascontiguousarray(device_ids, np.int32)
+        o = EngineOpts(0, dtype, max_batch, max_decoders, batch_wait_us, n_lanes)
+        h = C.c_void_p()
+        _check(self.L.ss_pool_create(model_path.encode(), _p(ids), len(ids), C.byref(o), C.byref(h)))
+        self.h = h
+        self.n_engines = int(self.L.ss_pool_n_engines(self.h))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ss_pool_free(self.h)
+            self.h = None
+
+    def new_session(self) -> "PoolSession":
+        return PoolSession(self)
+
+
+class PoolSession(Session):
+    def __init__(self, pool: Pool):
+        self.pool = pool
+        self.L = pool.L
+        self.eng = None
+        self.h = self.L.ss_pool_session_create(pool.h)
+        if not self.h:
+            raise SpeakSenseError(-1, "ss_pool_session_create failed")
+
+    def submit(self, pcm: np.ndarray, params: Params | None = None):
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        t = C.c_void_p()
+        _check(self.L.ss_pool_submit(self.pool.h, self.h, _p(pcm), len(pcm), C.byref(params) if params is not None else None, C.byref(t)))
+        return t
+
+    def transcribe(self, pcm: np.ndarray, params: Params | None = None):
+        return self.wait(self.submit(pcm, params))
+
+    def last_engine(self) -> int:
+        return int(self.L.ss_pool_last_engine(self.h))
+
+
+def pool_pick(load, cursor: int) -> int:
+    a = np.ascontiguousarray(load, np.int32)
+    return int(lib().ss_pool_pick(_p(a), len(a), cursor & 0xFFFFFFFF))

@@ -8,6 +8,7 @@ using namespace ss;
 struct ss_engine { EngineBase* e; };
 struct ss_session { Session s; };
 struct ss_ticket { Job job; };
+struct ss_pool { std::vector<ss_engine*> engines; std::atomic<uint32_t> cursor{0}; };
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -112,6 +113,52 @@ ss_session* ss_session_create(ss_engine* e) {
 }
 void ss_session_free(ss_session* s) { delete s; }
 
+int32_t ss_pool_pick(const int32_t* load, int32_t n, uint32_t cursor) {
+    if (!load || n <= 0) return -1;
+    int best = (int)(cursor % (uint32_t)n);
+    for (int k = 1; k < n; k++) {                       // scan from the cursor: among equally loaded engines the next in turn wins
+        const int i = (int)((cursor + (uint32_t)k) % (uint32_t)n);
+        if (load[i] < load[best]) best = i;
+    }
+    return best;
+}
+int ss_pool_create(const char* path, const int32_t* device_ids, int32_t n, const ss_engine_opts* opts, ss_pool** out) {
+    if (!path || !device_ids || n <= 0 || n > 64 || !out) return fail(SS_ERR_ARG, "ss_pool_create: bad argument");
+    *out = nullptr;
+    ss_pool* p = new ss_pool();
+    for (int i = 0; i < n; i++) {
+        ss_engine_opts o{};
+        o.dtype = SS_DTYPE_F16;
+        if (opts) o = *opts;
+        o.device = device_ids[i];
+        ss_engine* e = nullptr;
+        const int rc = ss_engine_create(path, &o, &e);
+        if (rc != SS_OK) { ss_pool_free(p); return rc; }     // message already set by ss_engine_create
+        p->engines.push_back(e);
+    }
+    *out = p;
+    return SS_OK;
+}
+void ss_pool_free(ss_pool* p) {
+    if (!p) return;
+    for (ss_engine* e : p->engines) ss_engine_free(e);
+    delete p;
+}
+int32_t ss_pool_n_engines(const ss_pool* p) { return p ? (int32_t)p->engines.size() : 0; }
+ss_engine* ss_pool_engine(ss_pool* p, int32_t i) { return (!p || i < 0 || i >= (int)p->engines.size()) ? nullptr : p->engines[i]; }
+ss_session* ss_pool_session_create(ss_pool* p) { return (!p || p->engines.empty()) ? nullptr : ss_session_create(p->engines[0]); }
+int32_t ss_pool_last_engine(const ss_session* s) { return s ? s->s.pool_engine : -1; }
+int ss_pool_submit(ss_pool* p, ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, ss_ticket** out) {
+    if (!p || p->engines.empty() || !s) return fail(SS_ERR_ARG, "ss_pool_submit: bad argument");
+    const int n = (int)p->engines.size();
+    std::vector<int32_t> load(n);
+    for (int i = 0; i < n; i++) load[i] = p->engines[i]->e->load.load();
+    const int k = ss_pool_pick(load.data(), n, p->cursor.fetch_add(1));
+    s->s.eng = p->engines[k]->e;       // the session's state is host-side only: this chunk runs on engine k
+    s->s.pool_engine = k;
+    return ss_submit(s, pcm, n_samples, params, out);
+}
+
 int ss_transcribe_batch(ss_engine* e, ss_session* const* sessions, const float* const* pcm, const int32_t* n_samples, int32_t n,
                         const ss_params* params, int32_t pcm_on_device) {
     if (!e || !sessions || !pcm || !n_samples || n <= 0) return fail(SS_ERR_ARG, "ss_transcribe_batch: bad argument");
@@ -129,7 +176,7 @@ int ss_transcribe_batch(ss_engine* e, ss_session* const* sessions, const float* 
         jp[i] = &jobs[i];
     }
     SS_TRY
-    e->e->run_jobs(jp);
+    e->e->run_jobs_parallel(jp);
     for (int i = 0; i < n; i++)
         if (jobs[i].status != 0) return fail(jobs[i].status, "chunk " + std::to_string(i) + " failed" + (jobs[i].err.empty() ? "" : ": " + jobs[i].err));
     return SS_OK;
@@ -144,11 +191,15 @@ int ss_transcribe(ss_session* s, const float* pcm, int32_t n_samples, const ss_p
     return ss_transcribe_batch(&tmp, ss1, p1, n1, 1, params, 0);
 }
 int ss_submit(ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, ss_ticket** out) {
+    return ss_submit_ex(s, pcm, n_samples, params, 0, out);
+}
+int ss_submit_ex(ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, int32_t pcm_on_device, ss_ticket** out) {
     if (!s || !out || n_samples < 0 || (n_samples > 0 && !pcm)) return fail(SS_ERR_ARG, "ss_submit: bad argument");
     ss_ticket* t = new ss_ticket();
     t->job.sess = &s->s;
-    t->job.owned.assign(pcm, pcm + n_samples);
-    t->job.pcm = t->job.owned.data(); t->job.n_samples = n_samples;
+    if (pcm_on_device) { t->job.pcm = pcm; t->job.pcm_on_device = true; }      // device buffer: the caller keeps it alive until ss_wait
+    else { t->job.owned.assign(pcm, pcm + n_samples); t->job.pcm = t->job.owned.data(); }
+    t->job.n_samples = n_samples;
     if (params) t->job.P = *params; else ss_default_params(&t->job.P);
     if (bad_prompt(t->job.P, s->s.eng)) { delete t; return fail(SS_ERR_ARG, "ss_submit: bad prompt_tokens"); }
     capture_prompt(t->job, s->s.eng);
@@ -229,6 +280,23 @@ int ss_process_logits(ss_engine* e, const float* raw, const int32_t* hist, int32
 int ss_engine_last_timing(const ss_engine* e, float out_ms[4]) {
     if (!e || !out_ms) return fail(SS_ERR_ARG, "null argument");
     memcpy(out_ms, e->e->last_ms, 16);
+    return SS_OK;
+}
+int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[4], int32_t* n_lanes) {
+    if (!e || !out_ms || !out_cnt) return fail(SS_ERR_ARG, "null argument");
+    for (int i = 0; i < 4; i++) { out_ms[i] = 0; out_cnt[i] = 0; }
+    const int n = e->e->n_lanes();
+    for (int l = 0; l < n; l++) {
+        EngineBase* L = e->e->lane(l);
+        std::lock_guard<std::mutex> lk(L->mu);    // a lane updates its totals at the end of a group, under its own lock
+        for (int i = 0; i < 4; i++) { out_ms[i] += L->tot_ms[i]; out_cnt[i] += L->tot_cnt[i]; }
+    }
+    if (n_lanes) *n_lanes = n;
+    return SS_OK;
+}
+int ss_engine_last_counters(const ss_engine* e, int64_t out4[4]) {
+    if (!e || !out4) return fail(SS_ERR_ARG, "null argument");
+    for (int i = 0; i < 4; i++) out4[i] = e->e->last_cnt[i];
     return SS_OK;
 }
 void ss_default_denoise_config(ss_denoise_config* c) {

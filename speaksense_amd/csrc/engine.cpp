@@ -52,13 +52,21 @@ template <typename T> static inline uint16_t to_bits(float x);
 template <> inline uint16_t to_bits<bf16>(float x) { return f32_to_bf16_bits(x); }
 template <> inline uint16_t to_bits<f16>(float x) { return f32_to_f16_bits(x); }
 
+// Every lane works on its own NON-blocking stream and never touches the legacy stream at run time: an operation on the legacy stream would
+// have to synchronise with every blocking stream, which HIP refuses while another lane is capturing its decode graph.  Allocations made while
+// an engine method runs are zeroed on that lane's stream (t_alloc_stream), the ones made at construction on the legacy stream + a device sync.
+static thread_local hipStream_t t_alloc_stream = nullptr;
+struct AllocStreamScope { hipStream_t prev; explicit AllocStreamScope(hipStream_t s) : prev(t_alloc_stream) { t_alloc_stream = s; } ~AllocStreamScope() { t_alloc_stream = prev; } };
 struct DBuf {
     void* p = nullptr; size_t bytes = 0;
     void alloc(size_t n, bool zero = true) {
         free();
         if (n == 0) n = 16;
         SS_HIP(hipMalloc(&p, n)); bytes = n;
-        if (zero) SS_HIP(hipMemset(p, 0, n));
+        if (zero) {
+            if (t_alloc_stream) { SS_HIP(hipMemsetAsync(p, 0, n, t_alloc_stream)); SS_HIP(hipStreamSynchronize(t_alloc_stream)); }
+            else { SS_HIP(hipMemset(p, 0, n)); SS_HIP(hipDeviceSynchronize()); }
+        }
     }
     void ensure(size_t n) { if (n > bytes) alloc(n); }
     void free() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
@@ -165,13 +173,19 @@ struct EngineT : EngineBase {
     DBuf u_d;
     hipEvent_t ev[4];
 
-    EngineT(const char* path, const ss_engine_opts& o) {
+    std::vector<std::unique_ptr<EngineT>> extra_lanes;   // lanes 1.. (lane 0 = this); they borrow this engine's weight arena
+    int n_lanes() const override { return 1 + (int)extra_lanes.size(); }
+    EngineBase* lane(int i) override { return i == 0 ? (EngineBase*)this : (EngineBase*)extra_lanes[i - 1].get(); }
+
+    // donor != nullptr: a lane of `donor` -- same device, same weights (pointers into the donor's arena), own stream / workspaces / caches
+    EngineT(const char* path, const ss_engine_opts& o, EngineT* donor = nullptr) {
         opts = o;
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw Error(SS_ERR_DEVICE, "no HIP device visible: the MI355X path has no CPU fallback");
         if (o.device < 0 || o.device >= ndev) throw Error(SS_ERR_DEVICE, "bad device ordinal");
         SS_HIP(hipSetDevice(o.device));
-        load_ggml_model(path, hm);
+        if (donor) { hm.hp = donor->hm.hp; hm.vocab = donor->hm.vocab; hm.filt_n_mel = donor->hm.filt_n_mel; hm.filt_n_fft = donor->hm.filt_n_fft; }
+        else load_ggml_model(path, hm);
         const HParams& hp = hm.hp;
         B = o.max_batch > 0 ? o.max_batch : 8;
         ND = o.max_decoders > 0 ? o.max_decoders : 5;
@@ -184,10 +198,18 @@ struct EngineT : EngineBase {
         dtype_is_f16 = sizeof(T) == 2 && std::is_same<T, f16>::value;
         if (d % 128 || da % 128) throw Error(SS_ERR_MODEL, "model: state size must be a multiple of 128");
         if (n_ctx % 4 || n_tctx > 448) throw Error(SS_ERR_MODEL, "model: unsupported context sizes");
-        SS_HIP(hipStreamCreate(&st));
+        SS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        AllocStreamScope alloc_scope(st);
         for (auto& e : ev) SS_HIP(hipEventCreate(&e));
         for (auto& e : ev_step) SS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        upload_weights();
+        if (donor) {
+            enc = donor->enc; dec = donor->dec;
+            conv1w = donor->conv1w; conv2w = donor->conv2w; tok_emb = donor->tok_emb; crosskv_w = donor->crosskv_w;
+            conv1b = donor->conv1b; conv2b = donor->conv2b; enc_pos = donor->enc_pos; lnpostw = donor->lnpostw; lnpostb = donor->lnpostb;
+            dec_pos = donor->dec_pos; crosskv_b = donor->crosskv_b; lnw = donor->lnw; lnb = donor->lnb; mt = donor->mt;
+        } else {
+            upload_weights();
+        }
         alloc_workspaces();
         plan_decode();
         use_fused = getenv("SS_DECODE_UNFUSED") == nullptr;
@@ -197,10 +219,18 @@ struct EngineT : EngineBase {
         step_timing = getenv("SS_STEP_TIMING") != nullptr;
         { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }
         ln_fused = getenv("SS_DECODE_LN_FUSED") ? atoi(getenv("SS_DECODE_LN_FUSED")) : 0;   // 1 both seams, 2 self-attention seam only, 3 cross-attention seam only
-        start_worker();
+        decode_v2 = narrow_ok && getenv("SS_DECODE_V2") != nullptr && ln_fused == 0 && combine_separate && !cross_direct;
+        if (!donor) {
+            int nl = o.n_lanes > 0 ? o.n_lanes : 2;
+            if (const char* lv = getenv("SS_LANES")) nl = atoi(lv);
+            nl = std::min(std::max(nl, 1), 8);
+            for (int i = 1; i < nl; i++) extra_lanes.emplace_back(new EngineT(path, o, this));
+            start_worker();
+        }
     }
     ~EngineT() override {
-        stop_worker();
+        stop_worker();          // joins the workers of every lane (they live in lane 0); a lane itself has none
+        extra_lanes.clear();    // before the weight arena goes
         if (st) (void)hipStreamSynchronize(st);   // a chained decode step may still be in flight: it writes into the pinned buffers freed below
         if (step_timing && tm_n > 1)
             fprintf(stderr, "[ss] decode steps %ld: launch call %.1f us, wait for samples %.1f us, host between steps %.1f us (averages)\n", tm_n, tm_launch / tm_n,
@@ -313,7 +343,8 @@ struct EngineT : EngineBase {
         float *dsin, *dcos, *dhann, *dfilt;
         put_f32(dsin, sinv); put_f32(dcos, cosv); put_f32(dhann, hann); put_f32(dfilt, hm.filters);
         w_all.alloc(ar.off + 256, false);
-        SS_HIP(hipMemcpy(w_all.p, ar.host.data(), ar.off, hipMemcpyHostToDevice));
+        SS_HIP(hipMemcpyAsync(w_all.p, ar.host.data(), ar.off, hipMemcpyHostToDevice, st));
+        SS_HIP(hipStreamSynchronize(st));
         for (auto& f : fix) *f.first = (uint8_t*)w_all.p + f.second;
         mt.sin_t = dsin; mt.cos_t = dcos; mt.hann = dhann; mt.filt = dfilt; mt.n_mel = n_mel;
         std::vector<uint8_t>().swap(ar.host);
@@ -420,12 +451,27 @@ struct EngineT : EngineBase {
         dec_gemv_plan(d, 4 * d, &pl_fc2.S, &pl_fc2.NW);
         pl_logits.S = 1; fix_nw(pl_logits, d);
         fix_nw(pl_d1, d);   // d x d projections with the whole K sum in one workgroup (residual epilogue, LayerNorm prologue)
+        pn_qkv = plan_narrow(3 * d, d); pn_dd = plan_narrow(d, d); pn_fc1 = plan_narrow(4 * d, d); pn_fc2 = plan_narrow(d, 4 * d);
+        narrow_ok = pn_qkv.NW && pn_dd.NW && pn_fc1.NW && pn_fc2.NW && d <= 2048;
         const size_t pb = (size_t)8 * 16 * d * 4;
         xa.alloc((size_t)16 * d * 4); xb.alloc((size_t)16 * d * 4); p1.alloc(pb); pq.alloc(pb); p2.alloc(pb); p3.alloc(pb);
     }
     void fix_nw(Plan& p, int K) {  // direct epilogues need S == 1: pick the widest block whose per-wave k is a multiple of 32 and <= 320
         for (int nw = 4; nw >= 1; nw >>= 1) if (K % nw == 0 && (K / nw) % 32 == 0 && K / nw <= 320) { p.NW = nw; p.S = 1; return; }
         throw Error(SS_ERR_MODEL, "model: width not supported by the fused decode step");
+    }
+    // narrow-tile plan (whole K in one workgroup): fewest waves (<= 16) whose per-wave k is a multiple of 32 and <= 320; output columns per
+    // workgroup so that the grid is a whole number of workgroups per CU where the shape allows (N = 1280: 5 columns -> 256 workgroups)
+    struct NPlan { int NW = 0, NT = 16; };
+    NPlan pn_qkv, pn_dd, pn_fc1, pn_fc2;
+    bool narrow_ok = false;
+    NPlan plan_narrow(int N, int K) {
+        NPlan p;
+        for (int nw = 1; nw <= 16; nw <<= 1) if (K % nw == 0 && (K / nw) % 32 == 0 && K / nw <= 320) { p.NW = nw; break; }
+        const int cus = device_cu_count();
+        const int k = (N + cus * 16 - 1) / (cus * 16);
+        p.NT = std::min(16, std::max(1, (N + cus * k - 1) / (cus * k)));
+        return p;
     }
     DecGemvDesc dgd(int pro, int epi, const void* Wt, int M, int N, int K, int S) {
         DecGemvDesc g{};
@@ -439,6 +485,7 @@ struct EngineT : EngineBase {
     // chained = true: the control blocks are already on the device (the previous step's pick kernel advanced them), nothing is uploaded
     void decoder_step_fused(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs, bool chained = false) {
         const int n_samp = (int)samp_rows.size();
+        cnt_passes++; cnt_rows += M;
         if (!chained) {
             SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
             if (n_samp) {
@@ -469,7 +516,71 @@ struct EngineT : EngineBase {
         SS_HIP(hipMemcpyAsync(samp_hb[step_parity], samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
         SS_HIP(hipEventRecord(ev_step[step_parity], st));
     }
+    // ---- decode step, 9 launches per layer: no split-K, no partials, no stand-alone reductions (opt-in, measured slower: see decode_v2) ----------
+    // Every projection runs as narrow tiles (pn_*: the whole K sum inside one workgroup), so its epilogue is the real one and the residual
+    // stream x (f32, xa) is updated IN PLACE by the three d-wide projections; the three LayerNorms are prologues of the GEMVs that consume
+    // them (each workgroup normalises the <= 16 rows itself while its weight fragments are in flight).
+    //   QKV[LN1] -> self-attention -> out-proj(+x) -> cross-q[LNc] -> cross-attention -> combine -> out-proj(+x) -> FC1[LN2]+GELU -> FC2(+x)
+    void fused_body2(int M, int n_samp) {
+        const RowCtl* ctl = ctl_d.as<RowCtl>();
+        const long slot_stride = (long)n_tctx * d, layer_stride = (long)S * slot_stride;
+        const long cb_stride = (long)2 * H * n_ctx * 64, cl_stride = (long)B * cb_stride;
+        float* x = xa.as<float>();
+        for (int il = 0; il < L; il++) {
+            const DecL& e = dec[il];
+            {   // LN1 -> QKV; q scaled, K/V appended to the cache.  Layer 0: x = token + positional embedding, written back by workgroup 0
+                DecGemvDesc g = dgd(PRO_LN, DEPI_QKV, e.wqkv, M, 3 * d, d, 1);
+                g.NT = pn_qkv.NT;
+                if (il == 0) { g.ctl = ctl; g.tok_emb = tok_emb; g.pos_emb = dec_pos; g.x_out = x; }
+                else g.x_in = x;
+                g.ln_w = e.ln1w; g.ln_b = e.ln1b; g.bias = e.bqkv; g.out = qd.p; g.ldo = d; g.scale = qscale;
+                g.ctl_rows = ctl; g.kcache = kself.as<T>() + il * layer_stride; g.vcache = vself.as<T>() + il * layer_stride; g.slot_stride = slot_stride;
+                launch_dec_gemv<T>(g, pn_qkv.NW, st);
+            }
+            launch_dec_self_attention<T>(qd.as<T>(), kself.as<T>() + il * layer_stride, vself.as<T>() + il * layer_stride, slot_stride, d, H, ctl, M,
+                                         attd.as<T>(), st);
+            {   // x += bo + Wo a
+                DecGemvDesc g = dgd(PRO_T, DEPI_RES, e.wo, M, d, d, 1);
+                g.NT = pn_dd.NT; g.Xt = attd.p; g.ldx = d; g.bias = e.bo; g.x_in = x; g.x_out = x;
+                launch_dec_gemv<T>(g, pn_dd.NW, st);
+            }
+            {   // LNc -> cross query (raw sums; bias, scale and rounding happen where it is consumed)
+                DecGemvDesc g = dgd(PRO_LN, DEPI_PART, e.wcq, M, d, d, 1);
+                g.NT = pn_dd.NT; g.x_in = x; g.ln_w = e.lncw; g.ln_b = e.lncb; g.part_out = pq.as<float>();
+                launch_dec_gemv<T>(g, pn_dd.NW, st);
+            }
+            const T* kc = cross.as<T>() + il * cl_stride;
+            launch_dec_cross_attention_q<T>(pq.as<float>(), 1, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
+                                            cscratch.as<float>(), st);
+            launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
+            {   // x += bco + Wco a
+                DecGemvDesc g = dgd(PRO_T, DEPI_RES, e.wco, M, d, d, 1);
+                g.NT = pn_dd.NT; g.Xt = attd.p; g.ldx = d; g.bias = e.bco; g.x_in = x; g.x_out = x;
+                launch_dec_gemv<T>(g, pn_dd.NW, st);
+            }
+            {   // LN2 -> FC1 + GELU
+                DecGemvDesc g = dgd(PRO_LN, DEPI_GELU_T, e.w1, M, 4 * d, d, 1);
+                g.NT = pn_fc1.NT; g.x_in = x; g.ln_w = e.ln2w; g.ln_b = e.ln2b; g.bias = e.b1; g.out = ffd.p; g.ldo = 4 * d;
+                launch_dec_gemv<T>(g, pn_fc1.NW, st);
+            }
+            {   // x += b2 + W2 f
+                DecGemvDesc g = dgd(PRO_T, DEPI_RES, e.w2, M, d, 4 * d, 1);
+                g.NT = pn_fc2.NT; g.Xt = ffd.p; g.ldx = 4 * d; g.bias = e.b2; g.x_in = x; g.x_out = x;
+                launch_dec_gemv<T>(g, pn_fc2.NW, st);
+            }
+        }
+        if (n_samp == 0) return;
+        {   // final LayerNorm once (gathering the sampling rows), then logits = x . tok_emb^T
+            DecGemvDesc g = dgd(PRO_LN, DEPI_LOGITS, tok_emb, n_samp, n_vocab_pad, d, 1);
+            g.x_in = x; g.ln_w = lnw; g.ln_b = lnb; g.row_idx = rowidx_d.as<int>();
+            launch_dec_reduce_ln<T>(g, lnd.as<T>(), st);
+            DecGemvDesc q = dgd(PRO_T, DEPI_LOGITS, tok_emb, n_samp, n_vocab_pad, d, 1);
+            q.Xt = lnd.p; q.ldx = d; q.out = logits.p; q.ldo = n_vocab_pad; q.n_valid = n_vocab;
+            launch_dec_gemv<T>(q, pl_logits.NW, st);
+        }
+    }
     void fused_body(int M, int n_samp) {
+        if (decode_v2) { fused_body2(M, n_samp); return; }
         const RowCtl* ctl = ctl_d.as<RowCtl>();
         const long slot_stride = (long)n_tctx * d, layer_stride = (long)S * slot_stride;
         const long cb_stride = (long)2 * H * n_ctx * 64, cl_stride = (long)B * cb_stride;
@@ -585,6 +696,7 @@ struct EngineT : EngineBase {
     int decoder_step(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
         if (M <= 16 && use_fused) { decoder_step_fused(M, rc, samp_rows, any_probs); return step_parity; }
         const int n_samp = (int)samp_rows.size();
+        cnt_passes++; cnt_rows += M;
         SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
         if (n_samp) {
             memcpy(rowidx_h, samp_rows.data(), (size_t)n_samp * 4);
@@ -651,9 +763,12 @@ struct EngineT : EngineBase {
         }
     }
     DBuf samp_d, rowidx_d, rules_scratch;
+    long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
     bool use_fused = true, cross_direct = false, combine_separate = true, use_graph = true;
     int ln_fused = 0;
     bool chain_steps = true;
+    bool decode_v2 = false;  // SS_DECODE_V2=1: the 9-launch step below (narrow tiles, LayerNorm prologues); measured SLOWER than the 12-launch step
+                             // (2.39 vs 2.18 ms per pass alone, 1304 vs 1533 xRT with two lanes): kept for A/B runs only
     bool step_timing = false; double tm_launch = 0, tm_wait = 0, tm_host = 0; long tm_n = 0; std::chrono::steady_clock::time_point tm_prev;
 
     RuleConsts rule_consts(const ss_params& P) {
@@ -679,7 +794,11 @@ struct EngineT : EngineBase {
     // ------------------------------------------------------------------------------------------
     void run_jobs(std::vector<Job*>& jobs) override {
         std::lock_guard<std::mutex> lk(mu);
+        run_jobs_locked(jobs);
+    }
+    void run_jobs_locked(std::vector<Job*>& jobs) override {
         SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
         for (size_t i = 0; i < jobs.size(); i += B) {
             std::vector<Job*> grp(jobs.begin() + i, jobs.begin() + std::min(jobs.size(), i + (size_t)B));
             try {
@@ -750,6 +869,7 @@ struct EngineT : EngineBase {
             js.push_back(q);
         }
         SS_HIP(hipEventRecord(ev[1], st));
+        cnt_passes = cnt_rows = cnt_windows = 0;
         float ms_enc = 0.f, ms_dec = 0.f;
         while (true) {
             std::vector<Window> wins;
@@ -776,6 +896,7 @@ struct EngineT : EngineBase {
             cross_kv_pass(Wn);
             SS_HIP(hipEventRecord(e1, st));
             for (auto& w : wins) { w.job->sess->n_encode++; w.job->sess->n_windows++; }
+            cnt_windows += Wn;
             detect_languages(wins, js);
             for (auto& w : wins) if (w.skip) w.pending = false;
             // temperature ladder
@@ -822,6 +943,8 @@ struct EngineT : EngineBase {
         SS_HIP(hipEventElapsedTime(&ms_mel, ev[0], ev[1]));
         SS_HIP(hipEventElapsedTime(&ms_tot, ev[0], ev[2]));
         last_ms[0] = ms_mel; last_ms[1] = ms_enc; last_ms[2] = ms_dec; last_ms[3] = ms_tot;
+        last_cnt[0] = cnt_passes; last_cnt[1] = cnt_rows; last_cnt[2] = cnt_windows; last_cnt[3] = 0;
+        for (int i = 0; i < 4; i++) { tot_ms[i] += last_ms[i]; tot_cnt[i] += last_cnt[i]; }
     }
 
     // "these tokens determine the task that will be performed": [sot, lang, task] (multilingual) or [sot], + [notimestamps]
@@ -862,7 +985,8 @@ struct EngineT : EngineBase {
             SS_HIP(hipStreamSynchronize(st));
             for (int m = 0; m < M; m++) {
                 const int first = vocab.token_sot + 1, n = std::min(kLangs, n_vocab - first);
-                SS_HIP(hipMemcpy(lg.data(), logits.as<float>() + (size_t)m * n_vocab_pad + first, (size_t)n * 4, hipMemcpyDeviceToHost));
+                SS_HIP(hipMemcpyAsync(lg.data(), logits.as<float>() + (size_t)m * n_vocab_pad + first, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+                SS_HIP(hipStreamSynchronize(st));
                 int best = 0;
                 for (int i = 1; i < n; i++) if (lg[i] > lg[best]) best = i;
                 JobState& q = state_of(js, need[r0 + m]->job);
@@ -1124,6 +1248,7 @@ struct EngineT : EngineBase {
     void log_mel_host(const float* pcm, int n, float* out, int n_len) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
         if (n_len != mel_n_len(n)) throw Error(SS_ERR_ARG, "log_mel: n_len mismatch");
         pcm_d[0].ensure((size_t)std::max(n, 1) * 4);
         SS_HIP(hipMemcpyAsync(pcm_d[0].p, pcm, (size_t)n * 4, hipMemcpyHostToDevice, st));
@@ -1135,6 +1260,7 @@ struct EngineT : EngineBase {
     void encode_host(const float* mel, int n_len, int seek, float* enc_out) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
         mel_d[0].ensure((size_t)n_mel * n_len * 4);
         SS_HIP(hipMemcpyAsync(mel_d[0].p, mel, (size_t)n_mel * n_len * 4, hipMemcpyHostToDevice, st));
         launch_mel_window<T>(mel_d[0].as<float>(), n_mel, n_len, seek, 2 * n_ctx, x0.as<T>(), st);
@@ -1145,6 +1271,7 @@ struct EngineT : EngineBase {
     void set_encoder_host(const float* encv) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
         SS_HIP(hipMemcpyAsync(encF.p, encv, (size_t)n_ctx * da * 4, hipMemcpyHostToDevice, st));
         launch_f32_to_T<T>(encF.as<float>(), encT.as<T>(), (size_t)n_ctx * da, st);
         cross_kv_pass(1);
@@ -1153,6 +1280,7 @@ struct EngineT : EngineBase {
     void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
         ss_params P; ss_default_params(&P);
         const RuleConsts rc = rule_consts(P);
         for (int i = 0; i < n; i++) {
@@ -1166,11 +1294,13 @@ struct EngineT : EngineBase {
             stage_release();
             SS_HIP(hipStreamSynchronize(st));
         }
-        SS_HIP(hipMemcpy(logits_out, logits.p, (size_t)n_vocab * 4, hipMemcpyDeviceToHost));
+        SS_HIP(hipMemcpyAsync(logits_out, logits.p, (size_t)n_vocab * 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(hipStreamSynchronize(st));
     }
     void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6]) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
         const Vocab& vocab = hm.vocab;
         SS_HIP(hipMemcpyAsync(logits.p, raw, (size_t)n_vocab * 4, hipMemcpyHostToDevice, st));
         RowCtl c{};
@@ -1214,6 +1344,7 @@ struct EngineT : EngineBase {
     void denoise_host(const float* pcm, int n, const ss_denoise_config& cfg, int force_type, float* out, int* noise_type, float* norm_var, float* ms) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
         if (cfg.frame_size != 2048) throw Error(SS_ERR_UNSUPPORTED, "denoise: only frame_size 2048 (the reference default) is implemented");
         if (n < 2048) throw Error(SS_ERR_ARG, "denoise: fewer samples than one frame (the reference panics in overlap_add)");
         const int step = (int)(2048.0f * (1.0f - cfg.overlap));
@@ -1250,13 +1381,15 @@ struct EngineT : EngineBase {
         std::vector<float> tw(2048);
         for (int k = 0; k < 1024; k++) { tw[2 * k] = (float)cos(-2.0 * M_PI * k / 2048.0); tw[2 * k + 1] = (float)sin(-2.0 * M_PI * k / 2048.0); }
         dn_tw.alloc(2048 * 4);
-        SS_HIP(hipMemcpy(dn_tw.p, tw.data(), 2048 * 4, hipMemcpyHostToDevice));
+        SS_HIP(hipMemcpyAsync(dn_tw.p, tw.data(), 2048 * 4, hipMemcpyHostToDevice, st));
+        SS_HIP(hipStreamSynchronize(st));
     }
     // StreamAudioProcessor over a whole stream (src/audio/mod.rs:67-155): see kernels_denoise.hip
     void preprocess_stream_host(const float* pcm, int64_t n, const int32_t* chunk_lens, int n_chunks, int chunk_len, const ss_denoise_config& cfg, float* out,
                                 float* gains_out, float* ms) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
         if (cfg.frame_size != 2048) throw Error(SS_ERR_UNSUPPORTED, "preprocess: only frame_size 2048 (the reference default) is implemented");
         dn_twiddles();
         std::vector<long> off;
@@ -1317,13 +1450,15 @@ struct EngineT : EngineBase {
     void resample_stream_host(const float* pcm, int64_t n, int from_rate, float* out, int64_t out_cap, int64_t* n_out, int32_t* chunk_lens, float* ms) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
         if (from_rate <= 0 || from_rate == 16000) throw Error(SS_ERR_ARG, "resample: from_rate must be positive and different from 16000");
         const double ratio = 16000.0 / (double)from_rate;
         if (rs_rate != from_rate) {
             std::vector<float> sincs;
             rs_make_sincs(ratio >= 1.0 ? 0.95f : 0.95f * (float)ratio, sincs);
             rs_sincs.ensure(sincs.size() * 4);
-            SS_HIP(hipMemcpy(rs_sincs.p, sincs.data(), sincs.size() * 4, hipMemcpyHostToDevice));
+            SS_HIP(hipMemcpyAsync(rs_sincs.p, sincs.data(), sincs.size() * 4, hipMemcpyHostToDevice, st));
+            SS_HIP(hipStreamSynchronize(st));
             rs_rate = from_rate;
         }
         // the output instants: process_into_buffer's `while idx < end_idx { idx += t_ratio; ... }`, last_index carried between chunks
@@ -1368,6 +1503,7 @@ struct EngineT : EngineBase {
     void selftest_gemm(int M, int N, int K, int kind, float* max_err, float* max_ref) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
         if (M < 1 || N % 128 || K % 64 || N < 128 || K < 64) throw Error(SS_ERR_ARG, "selftest_gemm: N must be a multiple of 128 and K of 64");
         gemm_selftest<T>(M, N, K, kind, max_err, max_ref, st);
     }
@@ -1375,6 +1511,7 @@ struct EngineT : EngineBase {
     void probe_gemm(int batch, int reps, float* avg_ms, double* flops) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
         if (batch < 1 || batch > B) throw Error(SS_ERR_ARG, "probe_gemm: batch out of range");
         const int M = batch * n_ctx;
         GemmDesc g = gd(ln.p, da, enc[0].w1, M, 4 * da, da, EPI_GELU_T, enc[0].b1, ff.p, 4 * da);
@@ -1393,43 +1530,96 @@ struct EngineT : EngineBase {
 // ------------------------------------------------------------------------------------------------
 // async batch former
 // ------------------------------------------------------------------------------------------------
-void EngineBase::start_worker() {
-    worker = std::thread([this] {
-        while (true) {
-            std::vector<Job*> batch;
-            {
-                std::unique_lock<std::mutex> lk(qmu);
-                qcv.wait(lk, [this] { return stop || !queue.empty(); });
-                if (stop && queue.empty()) return;
-                const int maxb = opts.max_batch > 0 ? opts.max_batch : 8;
-                if ((int)queue.size() < maxb && opts.batch_wait_us > 0)
-                    qcv.wait_for(lk, std::chrono::microseconds(opts.batch_wait_us), [&] { return stop || (int)queue.size() >= maxb; });
-                // one chunk per session per batch (run_group writes the session's results): a second ticket of a session already in this
-                // batch stays queued, in order, for the next one
-                for (auto it = queue.begin(); it != queue.end() && (int)batch.size() < maxb;) {
-                    bool dup = false;
-                    for (Job* b : batch) if (b->sess == (*it)->sess) { dup = true; break; }
-                    if (dup) { ++it; continue; }
-                    batch.push_back(*it);
-                    it = queue.erase(it);
-                }
-            }
-            if (batch.empty()) continue;
-            // nothing may escape this thread (std::terminate would take the host service down) and every job must be marked done
-            auto fail_all = [&](int code, const char* what) {
-                for (Job* j : batch) if (j->status == 0) { j->status = code; j->err = what; }
-            };
-            try { run_jobs(batch); }
-            catch (const Error& e) { fail_all(e.code, e.what()); }
-            catch (const std::exception& e) { fail_all(SS_ERR_DEVICE, e.what()); }
-            catch (...) { fail_all(SS_ERR_DEVICE, "unknown exception in the batch former"); }
-            {
-                std::lock_guard<std::mutex> lk(qmu);
-                for (Job* j : batch) j->done = true;
-            }
-            donecv.notify_all();
+void EngineBase::run_jobs_any(std::vector<Job*>& jobs) {
+    const int n = n_lanes();
+    for (int i = 0; i < n; i++) {
+        EngineBase* l = lane(i);
+        if (l->mu.try_lock()) {
+            std::lock_guard<std::mutex> lk(l->mu, std::adopt_lock);
+            l->run_jobs_locked(jobs);
+            return;
         }
-    });
+    }
+    lane((int)(rr.fetch_add(1) % (unsigned)n))->run_jobs(jobs);
+}
+
+void EngineBase::run_jobs_parallel(std::vector<Job*>& jobs) {
+    const size_t B = (size_t)(opts.max_batch > 0 ? opts.max_batch : 8);
+    const int nl = n_lanes();
+    if (jobs.size() <= B || nl == 1) { run_jobs_any(jobs); return; }
+    std::vector<std::vector<Job*>> groups;
+    for (size_t i = 0; i < jobs.size(); i += B) groups.emplace_back(jobs.begin() + i, jobs.begin() + std::min(jobs.size(), i + B));
+    std::atomic<size_t> next{0};
+    std::mutex emu;
+    std::exception_ptr first;
+    auto body = [&](int li) {
+        for (size_t g; (g = next.fetch_add(1)) < groups.size();) {
+            try { lane(li)->run_jobs(groups[g]); }
+            catch (...) { std::lock_guard<std::mutex> lk(emu); if (!first) first = std::current_exception(); }
+        }
+    };
+    std::vector<std::thread> th;
+    const int nt = (int)std::min<size_t>(nl, groups.size());
+    for (int i = 1; i < nt; i++) th.emplace_back(body, i);
+    body(0);
+    for (auto& t : th) t.join();
+    if (first) std::rethrow_exception(first);
+}
+
+void EngineBase::start_worker() {
+    const int n = n_lanes();
+    for (int li = 0; li < n; li++) {
+        workers.emplace_back([this, li] {
+            EngineBase* L = lane(li);
+            while (true) {
+                std::vector<Job*> batch;
+                {
+                    // one worker at a time forms a batch (otherwise two idle workers would split a trickle of chunks between them); the
+                    // others queue up behind form_mu and form the NEXT batch while this one runs
+                    std::lock_guard<std::mutex> fl(form_mu);
+                    std::unique_lock<std::mutex> lk(qmu);
+                    qcv.wait(lk, [this] { return stop || !queue.empty(); });
+                    if (stop && queue.empty()) return;
+                    const int maxb = opts.max_batch > 0 ? opts.max_batch : 8;
+                    if ((int)queue.size() < maxb && opts.batch_wait_us > 0)
+                        qcv.wait_for(lk, std::chrono::microseconds(opts.batch_wait_us), [&] { return stop || (int)queue.size() >= maxb; });
+                    // one chunk per session per batch (run_group writes the session's results): a second ticket of a session already in this
+                    // batch stays queued, in order, for the next one
+                    for (auto it = queue.begin(); it != queue.end() && (int)batch.size() < maxb;) {
+                        bool dup = false;
+                        for (Job* b : batch) if (b->sess == (*it)->sess) { dup = true; break; }
+                        if (!dup) for (Job* b : running) if (b->sess == (*it)->sess) { dup = true; break; }   // ... or still running on another lane
+                        if (dup) { ++it; continue; }
+                        batch.push_back(*it);
+                        it = queue.erase(it);
+                    }
+                    for (Job* b : batch) running.push_back(b);
+                    if (batch.empty()) {   // only tickets of busy sessions are queued: wait for a completion instead of spinning
+                        donecv.wait_for(lk, std::chrono::milliseconds(2));
+                        continue;
+                    }
+                }
+                // nothing may escape this thread (std::terminate would take the host service down) and every job must be marked done
+                auto fail_all = [&](int code, const char* what) {
+                    for (Job* j : batch) if (j->status == 0) { j->status = code; j->err = what; }
+                };
+                try { L->run_jobs(batch); }
+                catch (const Error& e) { fail_all(e.code, e.what()); }
+                catch (const std::exception& e) { fail_all(SS_ERR_DEVICE, e.what()); }
+                catch (...) { fail_all(SS_ERR_DEVICE, "unknown exception in the batch former"); }
+                {
+                    std::lock_guard<std::mutex> lk(qmu);
+                    load.fetch_sub((int)batch.size());
+                    for (Job* j : batch) {
+                        j->done = true;
+                        running.erase(std::find(running.begin(), running.end(), j));
+                    }
+                }
+                donecv.notify_all();
+                qcv.notify_all();
+            }
+        });
+    }
 }
 void EngineBase::stop_worker() {
     {
@@ -1437,9 +1627,11 @@ void EngineBase::stop_worker() {
         stop = true;
     }
     qcv.notify_all();
-    if (worker.joinable()) worker.join();
+    for (auto& w : workers) if (w.joinable()) w.join();
+    workers.clear();
 }
 void EngineBase::submit(Job* j) {
+    load.fetch_add(1);
     {
         std::lock_guard<std::mutex> lk(qmu);
         queue.push_back(j);
@@ -1451,7 +1643,7 @@ void EngineBase::wait(Job* j) {
     donecv.wait(lk, [&] { return j->done; });
 }
 
-EngineBase* make_engine_bf16(const char* path, const ss_engine_opts& o) { return new EngineT<bf16>(path, o); }
-EngineBase* make_engine_f16(const char* path, const ss_engine_opts& o) { return new EngineT<f16>(path, o); }
+EngineBase* make_engine_bf16(const char* path, const ss_engine_opts& o) { return new EngineT<bf16>(path, o, nullptr); }
+EngineBase* make_engine_f16(const char* path, const ss_engine_opts& o) { return new EngineT<f16>(path, o, nullptr); }
 
 }  // namespace ss

@@ -7,6 +7,8 @@
 #include <mutex>
 #include <random>
 #include <thread>
+#include <algorithm>
+#include <atomic>
 
 #include "../../include/speaksense.h"
 #include "common.h"
@@ -36,6 +38,7 @@ struct Session {
     std::vector<int> sampled;      // every id the winning decoder of each window sampled (incl. the tail past result_len that `tokens` drops)
     int n_encode = 0, n_decode = 0, n_fail = 0, n_windows = 0;
     std::vector<int> prompt_past;  // whisper_state::prompt_past: text context carried between windows (and calls, unless no_context)
+    int pool_engine = -1;          // ss_pool: engine index of the last chunk
     int lang_id = -1;              // whisper_full_lang_id: language of the last chunk (given or detected)
     CountingRng rng;  // whisper_state::rng (std::mt19937 seeded with 0 once per state, never reseeded per call)
 };
@@ -59,8 +62,10 @@ struct EngineBase {
     ss_engine_opts opts{};
     std::mutex mu;  // serialises device work
     float last_ms[4] = {0, 0, 0, 0};
+    long last_cnt[4] = {0, 0, 0, 0};   // last group: decoder passes, decoder rows, encoder windows
     virtual ~EngineBase() {}
-    virtual void run_jobs(std::vector<Job*>& jobs) = 0;  // blocking, any count (grouped by max_batch)
+    virtual void run_jobs(std::vector<Job*>& jobs) = 0;  // blocking, any count (grouped by max_batch); takes this lane's `mu`
+    virtual void run_jobs_locked(std::vector<Job*>& jobs) = 0;   // caller holds `mu`
     virtual void log_mel_host(const float* pcm, int n, float* out, int n_len) = 0;
     virtual void encode_host(const float* mel, int n_len, int seek, float* enc_out) = 0;
     virtual void set_encoder_host(const float* enc) = 0;
@@ -73,12 +78,27 @@ struct EngineBase {
     virtual void preprocess_stream_host(const float* pcm, int64_t n, const int32_t* chunk_lens, int n_chunks, int chunk_len, const ss_denoise_config& cfg,
                                         float* out, float* gains_out, float* ms) = 0;
 
-    // async batch former
-    std::thread worker;
-    std::mutex qmu;
+    // Lanes: independent (stream, workspaces, KV caches, staging) contexts over ONE resident copy of the weights.  A decode step is a chain of
+    // ~400 short dependent launches that leaves most of the chip idle, and the encoder pass of the next group is MFMA-bound while a decode is
+    // latency-bound: groups running on different lanes overlap both.  lane(0) is this engine.
+    virtual int n_lanes() const { return 1; }
+    virtual EngineBase* lane(int) { return this; }
+    void run_jobs_any(std::vector<Job*>& jobs);   // blocking: on a lane that is free right now, else round-robin
+    void run_jobs_parallel(std::vector<Job*>& jobs);   // blocking: groups of max_batch spread over the lanes (one thread per lane in use)
+    // cumulative device time (ms: mel, encoder+cross-KV, decode, total) and work (decoder passes, decoder rows, encoder windows) of this lane since
+    // creation; ss_engine_totals sums over the lanes
+    double tot_ms[4] = {0, 0, 0, 0};
+    long tot_cnt[4] = {0, 0, 0, 0};
+
+    // async batch former: one worker thread per lane; one of them at a time forms the next batch from the queue
+    std::vector<std::thread> workers;
+    std::mutex qmu, form_mu;
     std::condition_variable qcv, donecv;
+    std::atomic<int> load{0};      // chunks queued or running (ss_pool routing)
     std::deque<Job*> queue;
+    std::vector<Job*> running;     // popped, not yet done (a session has at most one chunk in flight across all lanes)
     bool stop = false;
+    std::atomic<unsigned> rr{0};
     void start_worker();
     void stop_worker();
     void submit(Job* j);

@@ -104,6 +104,7 @@ struct DecGemvDesc {
     const void* Xt; long ldx;               // PRO_T: T [M][ldx]
     const float* cross_parts;               // PRO_COMBINE: [M][H][4][66]
     const void* W; int M, N, K, S;          // W: T [N][K]
+    int NT;                                 // output columns per workgroup, 1..16 (0 = 16): narrow tiles fill the chip without split-K
     const float* bias; void* out; long ldo; float scale; int n_valid;
     float* part_out;                        // DEPI_PART: [S][16][N]
     const RowCtl* ctl_rows; void* kcache; void* vcache; long slot_stride; int d;   // DEPI_QKV

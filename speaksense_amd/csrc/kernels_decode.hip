@@ -143,13 +143,17 @@ __global__ __launch_bounds__(64) void dec_reduce_ln_kernel(DecGemvDesc g, T* out
     ln_row<T, NI>(g, blockIdx.x, threadIdx.x, true, 0, g.K, out + (long)blockIdx.x * g.K);
 }
 
-template <typename T, int PRO, int EPI, int NI>
-__global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
+// NT = g.NT output columns per workgroup (1..16; the MFMA tile is 16 wide, rows >= NT are never loaded nor stored).  Narrow tiles are how a
+// projection with few outputs (N = d) still fills the chip WITHOUT split-K: N / NT >= 256 workgroups each own the whole K sum, so the epilogue
+// can be the real one (residual update, q scaling, GELU) and no partials / reduce launch exists.  MAXT = 1024 carries K = 4d in 16 waves.
+template <typename T, int PRO, int EPI, int NI, int MAXT>
+__global__ __launch_bounds__(MAXT) void dec_gemv_kernel(DecGemvDesc g) {
     typedef typename MfmaD<T>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
     const int frow = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * 16, s = blockIdx.y;
+    const int NT = g.NT;
+    const int n0 = blockIdx.x * NT, s = blockIdx.y;
     const int kslice = g.K / g.S, kbeg = s * kslice, kw = kslice / NW, kwb = wave * kw;   // kw % 32 == 0, kw <= 320
     const int nfr = kw / 32, npair = nfr / 2;
     T* xs = (T*)smem_d;                                   // [16][kslice + pad]
@@ -157,17 +161,19 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     float* red = (float*)(smem_d + (PRO == PRO_T ? (size_t)0 : (size_t)16 * xld * sizeof(T)));  // [NW][16][17]
 
     // ---- weight prefetch: lane loads 32 contiguous bytes of its row per MFMA pair ----
-    const T* wp = (const T*)g.W + (long)(n0 + frow) * g.K + kbeg + kwb;
+    const bool wrow = frow < NT && n0 + frow < g.N;          // this lane's weight row exists
+    const T* wp = (const T*)g.W + (long)(wrow ? n0 + frow : 0) * g.K + kbeg + kwb;
     V8 wf[kMaxFrag];
 #pragma unroll
     for (int j = 0; j < kMaxFrag / 2; j++) {
-        if (j < npair) {
+        wf[2 * j] = V8{}; wf[2 * j + 1] = V8{};
+        if (j < npair && wrow) {
             wf[2 * j] = SS_LDW((const V8*)(wp + j * 64 + fg * 16));
             wf[2 * j + 1] = SS_LDW((const V8*)(wp + j * 64 + fg * 16 + 8));
         }
     }
     V8 wtail = {};
-    if (nfr & 1) wtail = SS_LDW((const V8*)(wp + npair * 64 + fg * 8));
+    if ((nfr & 1) && wrow) wtail = SS_LDW((const V8*)(wp + npair * 64 + fg * 8));
 
     // ---- prologue: build the operand tile xs[m][0..kslice) ----
     if constexpr (PRO == PRO_LN) {
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     // ---- epilogue: 16 m x 16 n outputs ----
     for (int idx = tid; idx < 256; idx += blockDim.x) {
         const int m = idx >> 4, nn = idx & 15, n = n0 + nn;
-        if (m < g.M) {
+        if (m < g.M && nn < NT && n < g.N) {
             float v = 0.f;
             for (int w = 0; w < NW; w++) v += red[(w * 16 + m) * 17 + nn];
             if constexpr (EPI == DEPI_PART) {
@@ -282,15 +288,20 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     }
 }
 
-template <typename T, int PRO, int EPI, int NI>
-static void launch_dg2(const DecGemvDesc& g, int NW, hipStream_t st) {
+template <typename T, int PRO, int EPI, int NI, int MAXT>
+static void launch_dg3(const DecGemvDesc& g, int NW, hipStream_t st) {
     const int kslice = g.K / g.S;
     size_t red_f = (size_t)NW * 16 * 17, wtab_f = (size_t)16 * (kslice / 64 + 1) * 5;
     const size_t lds = (PRO == PRO_T ? 0 : (size_t)16 * (kslice + kXsPad) * sizeof(T)) + (red_f > wtab_f ? red_f : wtab_f) * 4;
     static std::atomic<uint64_t> attr{0};
-    once_per_device(attr, [] { SS_HIP(hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
-    dim3 grid((g.N + 15) / 16, g.S);
-    dec_gemv_kernel<T, PRO, EPI, NI><<<grid, NW * 64, lds, st>>>(g); SS_LAUNCH_CHECK();
+    once_per_device(attr, [] { SS_HIP(hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, NI, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+    dim3 grid((g.N + g.NT - 1) / g.NT, g.S);
+    dec_gemv_kernel<T, PRO, EPI, NI, MAXT><<<grid, NW * 64, lds, st>>>(g); SS_LAUNCH_CHECK();
+}
+template <typename T, int PRO, int EPI, int NI>
+static void launch_dg2(const DecGemvDesc& g, int NW, hipStream_t st) {
+    if (NW <= 4) launch_dg3<T, PRO, EPI, NI, 256>(g, NW, st);
+    else launch_dg3<T, PRO, EPI, NI, 1024>(g, NW, st);
 }
 template <typename T, int PRO, int EPI>
 static void launch_dg(const DecGemvDesc& g, int NW, hipStream_t st) {
@@ -334,7 +345,10 @@ template void launch_dec_reduce_ln<bf16>(const DecGemvDesc&, bf16*, hipStream_t)
 template void launch_dec_reduce_ln<f16>(const DecGemvDesc&, f16*, hipStream_t);
 
 template <typename T>
-void launch_dec_gemv(const DecGemvDesc& g, int NW, hipStream_t st) {
+void launch_dec_gemv(const DecGemvDesc& g0, int NW, hipStream_t st) {
+    DecGemvDesc g = g0;
+    if (g.NT <= 0) g.NT = 16;
+    if (g.NT > 16 || NW < 1 || NW > 16 || (NW & (NW - 1))) throw Error(-1, "dec_gemv: bad tile / wave count");
     if (g.n_parts > 4) throw Error(-1, "dec_gemv: at most 4 split-K partials");
     if (g.pro == PRO_COMBINE && (g.K / g.S) % 64) throw Error(-1, "dec_gemv: combine prologue needs K slices of whole heads");
     if (g.M < 1 || g.M > 16 || g.K % g.S || (g.K / g.S) % NW || ((g.K / g.S) / NW) % 32 || (g.K / g.S) / NW > 320)

@@ -53,3 +53,15 @@ def base_en_path(model_dir):
 @pytest.fixture(scope="session")
 def wide2_path(model_dir):
     return _model(model_dir, "wide2")
+
+
+def report(msg: str):
+    """Parity numbers worth keeping (margins, flip counts, stage errors): printed and, on the GPU box, appended to gpurun_out/parity_report.txt."""
+    print(msg)
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_report.txt"), "a") as f:
+            f.write(msg + "\n")
+    except OSError:
+        pass

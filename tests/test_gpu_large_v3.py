@@ -14,6 +14,7 @@ import numpy as np
 import pytest
 
 from speaksense_amd import synth
+from conftest import report
 
 pytestmark = pytest.mark.gpu
 
@@ -56,7 +57,7 @@ def test_large_v3_full_depth_stages_vs_oracle(large_v3_path, eng8):
         ref = om.encode(mel, 0, orc.MODE_GGML_F16)
         got = eng8.encode(mel, 0)
         rel = np.abs(got - ref).max() / np.abs(ref).max()
-        print(f"large-v3 encoder (32 layers): max|gpu - oracle| / max|oracle| = {rel:.2e}")
+        report(f"large-v3 encoder (32 layers): max|gpu - oracle| / max|oracle| = {rel:.2e}")
         assert rel < 4e-3, rel                                              # same bound as the 2-layer models (test_encoder_matches_oracle)
         # decoder: both sides start from the SAME encoder output (the oracle's), so this isolates the 32 decoder layers + cross-KV
         ost = om.new_state(orc.MODE_GGML_F16)
@@ -78,7 +79,7 @@ def test_large_v3_full_depth_stages_vs_oracle(large_v3_path, eng8):
             top2 = np.sort(r)[-2:]
             if top2[1] - top2[0] > 6e-3 * sd * 2:                           # argmax must agree unless the oracle's own top-2 is inside the noise
                 assert int(g.argmax()) == int(r.argmax()), f"step {i}"
-        print(f"large-v3 decoder (32 layers, 8 cached steps): worst max|logits - oracle| / std = {worst:.2e}")
+        report(f"large-v3 decoder (32 layers, 8 cached steps): worst max|logits - oracle| / std = {worst:.2e}")
         om.close()
     finally:
         orc.set_thread_cap(16)
@@ -99,7 +100,9 @@ def test_large_v3_batch8_properties(eng8):
     for i in (0, 3, 7):                                                      # a row of the batch == the chunk alone
         s = eng8.new_session().transcribe(pcms[i], P)
         assert list(s["tokens"]) == list(a[i]["tokens"]), f"chunk {i}: batch of 8 differs from the single run"
-        np.testing.assert_allclose(s["plog"], a[i]["plog"], atol=1e-5)
+        # the 3-token prompt pass runs as 3 rows of the fused step alone and as 24 rows of the 17..64-row kernels in the batch: other
+        # accumulation orders in the K/V of the prompt positions, so log-probabilities agree to f16-noise, ids exactly
+        np.testing.assert_allclose(s["plog"], a[i]["plog"], atol=2e-2)
     # chunks differ from one another (the audio matters: the cross-attention path is live at full depth)
     assert len({tuple(r["tokens"]) for r in a}) > 1
 

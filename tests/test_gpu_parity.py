@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from speaksense_amd import synth
+from conftest import report
 
 pytestmark = pytest.mark.gpu
 
@@ -168,7 +169,7 @@ def check_against_oracle(got, om, orc, mode, pcm, P, ctx, gap_tol, replay_only=F
     assert worst < gap_tol, f"{ctx}: device pick outside the noise of the oracle's argmax: (step, device id, oracle id, logprob gap) = {flips}"
     _same_result(got, rep, ctx + " (forced replay)")
     if flips:
-        print(f"{ctx}: {len(flips)} near-tie flip(s) of {len(gaps)} steps, largest oracle margin {worst:.4f} < {gap_tol:.3f}: {flips}")
+        report(f"{ctx}: {len(flips)} near-tie flip(s) of {len(gaps)} steps, largest oracle margin {worst:.4f} < {gap_tol:.3f}: {flips}")
     return len(flips) == 0, worst
 
 
@@ -222,7 +223,7 @@ def test_full_path_real_widths_f16(tiny_en_path, base_en_path, wide2_path, orc, 
         ok, _ = check_against_oracle(got, om, orc, orc.MODE_GGML_F16, pcm, orc.default_params(language="en", temperature_inc=0.0),
                                      f"{which} seed {seed}", GAP_TOL_F16)
         same += ok
-    print(f"{which}: {same}/{len(cases)} chunks token-identical to the free-running oracle, the rest proven near ties")
+    report(f"{which}: {same}/{len(cases)} chunks token-identical to the free-running oracle, the rest proven near ties")
     assert same >= 1, "no chunk at all matched the free-running oracle"
     eng.close(); om.close()
 
@@ -255,7 +256,7 @@ def test_full_path_default_ladder_f16(toy_en_path, toy_ml_path, orc, which):
                 _same_result(got, ref, f"{which} seed {seed} (fallback, same draws)")
                 assert got["n_fail"] == ref["n_fail"]
             assert got["n_encode"] >= 1 and len(got["tokens"]) > 0
-    print(f"{which}: {n_exact} chunks without fallback identical; {n_fb_same}/{n_fb} fallback chunks identical")
+    report(f"{which}: {n_exact} chunks without fallback identical; {n_fb_same}/{n_fb} fallback chunks identical")
     assert n_exact >= 1, "fixture drifted: no chunk stays at temperature 0"
     assert n_fb == 0 or n_fb_same * 2 >= n_fb
     eng.close(); om.close()
@@ -280,7 +281,7 @@ def test_full_path_bf16_vs_oracle(toy_ml_path, base_en_path, orc, which):
                                        f"bf16 {which} seed {seed}", GAP_TOL_BF16)
         same += ok
         worst = max(worst, gap)
-    print(f"bf16 {which}: {same}/{len(cases)} chunks token-identical, largest proven near-tie margin {worst:.4f}")
+    report(f"bf16 {which}: {same}/{len(cases)} chunks token-identical, largest proven near-tie margin {worst:.4f}")
     eng.close(); om.close()
 
 

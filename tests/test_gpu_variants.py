@@ -299,3 +299,33 @@ def test_c_harness_matches_python_binding(toy_ml_path, eng, tmp_path):
     assert len(py) == len(nat)      # sinf in C vs numpy may differ in the last bit of a few samples: compare structure, then text when equal
     if py != nat:
         assert [p.split(" ")[:2] for p in py] == [q.split(" ")[:2] for q in nat]
+
+
+def test_pool_two_engines_on_one_gpu(toy_ml_path):
+    """ss_pool_*: the multi-GPU router with a device list that names GPU 0 twice (the box has one GPU; on a node it would be [0..7]).  Chunks of one
+    session alternate between the engines (its state is host-side), every result equals the single-engine result, and a burst spreads evenly."""
+    from speaksense_amd import binding
+    single = binding.Engine(toy_ml_path, max_batch=4)
+    pool = binding.Pool(toy_ml_path, [0, 0], max_batch=4)
+    assert pool.n_engines == 2
+    P = binding.default_params(language="en", temperature_inc=0.0, no_context=0)       # context carried from chunk to chunk ACROSS engines
+    s_ref, s_pool = single.new_session(), pool.new_session()
+    used = []
+    for seed in (61, 62, 63, 64):
+        pcm = synth.speech_like(seed, 16000 * 9)
+        a = s_ref.transcribe(pcm, P)
+        b = s_pool.transcribe(pcm, P)
+        assert list(a["tokens"]) == list(b["tokens"]) and [s["text"] for s in a["segments"]] == [s["text"] for s in b["segments"]]
+        used.append(s_pool.last_engine())
+    assert used == [0, 1, 0, 1]
+    # burst: 8 sessions at once -> 4 chunks per engine, results as from one engine
+    pcms = [synth.speech_like(70 + k, 16000 * 8) for k in range(8)]
+    P1 = binding.default_params(language="en", temperature_inc=0.0)
+    want = [single.new_session().transcribe(x, P1) for x in pcms]
+    ses = [pool.new_session() for _ in pcms]
+    tickets = [s.submit(x, P1) for s, x in zip(ses, pcms)]
+    got = [s.wait(t) for s, t in zip(ses, tickets)]
+    for a, b in zip(want, got):
+        assert list(a["tokens"]) == list(b["tokens"])
+    assert sorted(s.last_engine() for s in ses) == [0] * 4 + [1] * 4
+    pool.close(); single.close()

@@ -187,3 +187,22 @@ def test_tokenizer_matches_regex_restatement(tmp_path):
         n_long += len(a) > 2
     assert n_long > 100
     om.close()
+
+
+def test_pool_routing_rule():
+    """ss_pool_pick: least-loaded engine, ties go round-robin from the cursor (north_star: chunks 'sharded round-robin across the 8 GPUs')."""
+    from speaksense_amd import binding
+    n = 8
+    # idle pool: pure round-robin
+    assert [binding.pool_pick([0] * n, c) for c in range(2 * n)] == [c % n for c in range(2 * n)]
+    # 64 chunks arriving at once (BASELINE configs[3]: 64 concurrent streams over 8 GPUs): every engine ends up with exactly 8
+    load = [0] * n
+    for c in range(64):
+        k = binding.pool_pick(load, c)
+        load[k] += 1
+    assert load == [8] * n
+    # a busy engine is skipped even when it is next in turn; the least-loaded one wins wherever the cursor stands
+    assert binding.pool_pick([5, 0, 0, 0], 0) == 1
+    assert binding.pool_pick([3, 2, 1, 2], 0) == 2 and binding.pool_pick([3, 2, 1, 2], 3) == 2
+    assert binding.pool_pick([1, 1, 0, 0], 3) == 3 and binding.pool_pick([1, 1, 0, 0], 0) == 2
+    assert binding.pool_pick([7], 123) == 0
