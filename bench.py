@@ -161,9 +161,9 @@ def main():
     ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
     ap.add_argument("--fixed-steps", type=int, default=96, help="Mode F decode steps per chunk; 0 = Mode N (natural EOT, full whisper.cpp rules)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2, help="steps (device batches of --batch chunks) in flight at once: step i is submitted before step "
+    ap.add_argument("--inflight", type=int, default=8, help="steps (device batches of --batch chunks) in flight at once: step i is submitted before step "
                     "i-1 is collected, so one batch's encoder pass overlaps the other's decode chain on the engine's lanes; 1 = strictly one batch at a time")
-    ap.add_argument("--device-batch", type=int, default=0, help="engine max_batch: chunks the batch former may put into ONE device batch (0 = --batch). "
+    ap.add_argument("--device-batch", type=int, default=32, help="engine max_batch: chunks the batch former may put into ONE device batch (0 = --batch). "
                     "Larger than --batch with --inflight > 1 lets it merge queued steps into one decode chain (more rows per weight pass)")
     ap.add_argument("--host-pcm", action="store_true", help="headline steps take host f32 PCM (H2D inside the timed region) instead of HBM-resident PCM")
     ap.add_argument("--dry-run", action="store_true", help="CPU test of the sharding/timing plumbing: stub workload, gloo backend")
@@ -290,6 +290,14 @@ def main():
     dt_alt, _ = timed_steps(step, n_alt, 1, dist, torch.cuda.synchronize, drain)
     value_alt = n_gpus * args.batch * n_alt * CHUNK_SEC / dt_alt
 
+    # latency without queueing: one step at a time (submit 8 chunks, wait), the other end of the throughput/latency trade the headline makes
+    state["host"] = args.host_pcm
+    del latencies[:]
+    for _ in range(3):
+        step()
+        drain()
+    lat_unloaded = list(latencies)[1:]
+
     if rank == 0:
         n_steps_dec = args.fixed_steps if args.fixed_steps > 0 else int(np.mean(tok_counts[args.warmup:args.warmup + args.steps]) / max(1, len(my_chunks)))
         work = algorithmic_work(hp, args.batch, n_steps_dec, n_prompt)
@@ -302,8 +310,11 @@ def main():
         # different lanes overlap, so the chip-level rate is all passes' bytes over the wall time of the timed region (conservative: that wall
         # time also holds the encoder phases), not bytes / one pass's duration.
         pass_ms = dec_ms / max(1.0, passes)
-        self_kv_bytes = 2.0 * 2 * hp.n_text_layer * hp.n_text_state * (n_prompt + n_steps_dec / 2.0) * args.batch   # f16 K and V, average history
-        pass_bytes = work["dec_bytes_step"] + self_kv_bytes
+        rows_per_pass = rows / max(1.0, passes)      # the batch former may merge queued steps into one device batch: more rows per weight pass
+        dec_weight_bytes = work["dec_bytes_step"] - args.batch * 2.0 * hp.n_text_layer * 2 * hp.n_audio_ctx * hp.n_text_state
+        cross_kv_row = 2.0 * hp.n_text_layer * 2 * hp.n_audio_ctx * hp.n_text_state
+        self_kv_row = 2.0 * 2 * hp.n_text_layer * hp.n_text_state * (n_prompt + n_steps_dec / 2.0)       # f16 K and V, average history
+        pass_bytes = dec_weight_bytes + rows_per_pass * (cross_kv_row + self_kv_row)
         hbm_gbs = pass_bytes * passes * args.steps / dt / 1e9
         hbm_gbs_single = pass_bytes / (pass_ms * 1e-3) / 1e9
         conc = dd["decode_ms"] * 1e-3 / dt          # average number of decoder passes running at once
@@ -324,6 +335,7 @@ def main():
                        "steps_in_flight": inflight, "engine_lanes": tot1["n_lanes"], "engine_max_batch": eng.max_batch,
                        "validated": "every timed step: tokens per chunk == fixed_steps, >= 1 encoder window per chunk, ids identical to the first step"},
             "p50_chunk_latency_ms": round(1e3 * float(np.median(lat_main)), 2),
+            "p50_chunk_latency_unloaded_ms": round(1e3 * float(np.median(lat_unloaded)), 2),
             ("value_from_host_pcm" if not args.host_pcm else "value_hbm_resident_pcm"): round(value_alt, 2),
             "phase_ms": {"mel": round(dd["mel_ms"] / args.steps, 3), "encode_cross_kv": round(enc_ms, 2), "decode": round(dec_ms, 2),
                          "note": "device time per step on the lane that ran it; with steps_in_flight > 1 phases of different steps overlap"},
@@ -334,7 +346,7 @@ def main():
                          "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
                          "achieved_one_pass_alone": round(hbm_gbs_single, 1), "passes_overlapping": round(conc, 2),
                          "traffic": pmc_traffic(args.model, args.batch, args.dtype, "decoder_pass"),
-                         "algorithmic_bytes": pass_bytes, "avg_launch_ms": round(pass_ms, 5), "launches_per_step": passes, "rows_per_launch": round(rows / max(1.0, passes), 2)},
+                         "algorithmic_bytes": pass_bytes, "avg_launch_ms": round(pass_ms, 5), "launches_per_step": round(passes, 2), "rows_per_launch": round(rows_per_pass, 2)},
             "phase_roofline": {
                 "encoder_phase_tflops": round(args.batch * work["enc_flops"] / (enc_ms * 1e-3) / 1e12, 1),
                 "encoder_phase_frac_mfma": round(args.batch * work["enc_flops"] / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),

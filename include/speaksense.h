@@ -138,6 +138,10 @@ const char* ss_result_segment_text(const ss_session* s, int32_t i);   /* bytes f
 int64_t ss_result_segment_t0(const ss_session* s, int32_t i);         /* centiseconds, as whisper.cpp reports */
 int64_t ss_result_segment_t1(const ss_session* s, int32_t i);
 int32_t ss_result_segment_speaker_turn_next(const ss_session* s, int32_t i);
+int32_t ss_result_segment_n_tokens(const ss_session* s, int32_t i);     /* whisper_full_n_tokens: tokens of segment i (timestamp tokens included) */
+int ss_result_segment_token(const ss_session* s, int32_t i, int32_t k, int32_t* id, int32_t* tid, float out4[4] /* p, plog, pt, ptsum */);
+/* append src's segments to dst shifted by t_offset centiseconds, start times clamped to the previous end (the merge step of whisper_full_parallel) */
+int ss_result_append(ss_session* dst, const ss_session* src, int64_t t_offset);
 int32_t ss_result_n_tokens(const ss_session* s);                      /* accepted tokens over all windows */
 int ss_result_tokens(const ss_session* s, int32_t* ids, float* plog); /* plog may be NULL */
 /* every id the winning decoder of each window SAMPLED, in order, including the tail past result_len that whisper.cpp (and ss_result_tokens)

@@ -99,37 +99,149 @@ struct whisper_full_params {
     float grammar_penalty;
 };
 
+typedef struct whisper_token_data {
+    whisper_token id;   /* token id */
+    whisper_token tid;  /* forced timestamp token id */
+    float p;            /* probability of the token */
+    float plog;         /* log probability of the token */
+    float pt;           /* probability of the timestamp token */
+    float ptsum;        /* sum of probabilities of all timestamp tokens */
+    int64_t t0;         /* token-level timestamps: not computed here (-1) */
+    int64_t t1;
+    float vlen;         /* voice length of the token: not computed (0) */
+} whisper_token_data;
+
+typedef struct whisper_model_loader {
+    void* context;
+    size_t (*read)(void* ctx, void* output, size_t read_size);
+    bool (*eof)(void* ctx);
+    void (*close)(void* ctx);
+} whisper_model_loader;
+
+typedef void (*ggml_log_callback)(int level, const char* text, void* user_data);
+
+/* ---- the complete function list of whisper.h v1.5.4 ------------------------------------------------------------------------------------
+ * Every symbol whisper-rs-sys 0.9.0's bindings can reference resolves against libspeaksense_hip.so.  What the reference calls (listed at the
+ * top of this file) is implemented; so are the helpers that need no new device code.  Entry points of whisper.cpp's LOW-LEVEL API that
+ * this engine has no per-state equivalent for (whisper_encode / whisper_decode / whisper_get_logits, the phase-vocoder mel, OpenVINO,
+ * benchmarks) return an error code (or NULL) and log one line -- they never abort and never pretend to have worked. */
 struct whisper_context_params whisper_context_default_params(void);
-struct whisper_context* whisper_init_from_file_with_params_no_state(const char* path_model, struct whisper_context_params params);
+struct whisper_context_params* whisper_context_default_params_by_ref(void);
 struct whisper_context* whisper_init_from_file_with_params(const char* path_model, struct whisper_context_params params);
+struct whisper_context* whisper_init_from_buffer_with_params(void* buffer, size_t buffer_size, struct whisper_context_params params);
+struct whisper_context* whisper_init_with_params(struct whisper_model_loader* loader, struct whisper_context_params params);
+struct whisper_context* whisper_init_from_file_with_params_no_state(const char* path_model, struct whisper_context_params params);
+struct whisper_context* whisper_init_from_buffer_with_params_no_state(void* buffer, size_t buffer_size, struct whisper_context_params params);
+struct whisper_context* whisper_init_with_params_no_state(struct whisper_model_loader* loader, struct whisper_context_params params);
+struct whisper_context* whisper_init_from_file(const char* path_model);                 /* deprecated forms: default context params */
+struct whisper_context* whisper_init_from_buffer(void* buffer, size_t buffer_size);
+struct whisper_context* whisper_init(struct whisper_model_loader* loader);
+struct whisper_context* whisper_init_from_file_no_state(const char* path_model);
+struct whisper_context* whisper_init_from_buffer_no_state(void* buffer, size_t buffer_size);
+struct whisper_context* whisper_init_no_state(struct whisper_model_loader* loader);
 struct whisper_state* whisper_init_state(struct whisper_context* ctx);
+int whisper_ctx_init_openvino_encoder(struct whisper_context* ctx, const char* model_path, const char* device, const char* cache_dir);   /* 1: not built (as whisper.cpp without OpenVINO) */
 void whisper_free_state(struct whisper_state* state);
 void whisper_free(struct whisper_context* ctx);
+void whisper_free_params(struct whisper_full_params* params);
+void whisper_free_context_params(struct whisper_context_params* params);
 
-struct whisper_full_params whisper_full_default_params(enum whisper_sampling_strategy strategy);
-int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* state, struct whisper_full_params params,
-                            const float* samples, int n_samples);
-int whisper_full(struct whisper_context* ctx, struct whisper_full_params params, const float* samples, int n_samples);
+/* mel: computed on the device, kept in the state (whisper_n_len reports it); the spectrogram only feeds whisper_encode, which is unsupported */
+int whisper_pcm_to_mel(struct whisper_context* ctx, const float* samples, int n_samples, int n_threads);
+int whisper_pcm_to_mel_with_state(struct whisper_context* ctx, struct whisper_state* state, const float* samples, int n_samples, int n_threads);
+int whisper_pcm_to_mel_phase_vocoder(struct whisper_context* ctx, const float* samples, int n_samples, int n_threads);               /* -1 */
+int whisper_pcm_to_mel_phase_vocoder_with_state(struct whisper_context* ctx, struct whisper_state* state, const float* samples, int n_samples, int n_threads);
+int whisper_set_mel(struct whisper_context* ctx, const float* data, int n_len, int n_mel);
+int whisper_set_mel_with_state(struct whisper_context* ctx, struct whisper_state* state, const float* data, int n_len, int n_mel);
+int whisper_encode(struct whisper_context* ctx, int offset, int n_threads);                                                           /* -1 */
+int whisper_encode_with_state(struct whisper_context* ctx, struct whisper_state* state, int offset, int n_threads);                   /* -1 */
+int whisper_decode(struct whisper_context* ctx, const whisper_token* tokens, int n_tokens, int n_past, int n_threads);                /* -1 */
+int whisper_decode_with_state(struct whisper_context* ctx, struct whisper_state* state, const whisper_token* tokens, int n_tokens, int n_past, int n_threads);
+float* whisper_get_logits(struct whisper_context* ctx);                                                                               /* NULL */
+float* whisper_get_logits_from_state(struct whisper_state* state);                                                                    /* NULL */
 
-int whisper_full_n_segments_from_state(struct whisper_state* state);
-const char* whisper_full_get_segment_text_from_state(struct whisper_state* state, int i_segment);
-int64_t whisper_full_get_segment_t0_from_state(struct whisper_state* state, int i_segment);
-int64_t whisper_full_get_segment_t1_from_state(struct whisper_state* state, int i_segment);
-bool whisper_full_get_segment_speaker_turn_next_from_state(struct whisper_state* state, int i_segment);
-int whisper_full_n_segments(struct whisper_context* ctx);
-const char* whisper_full_get_segment_text(struct whisper_context* ctx, int i_segment);
-int64_t whisper_full_get_segment_t0(struct whisper_context* ctx, int i_segment);
-int64_t whisper_full_get_segment_t1(struct whisper_context* ctx, int i_segment);
+int whisper_tokenize(struct whisper_context* ctx, const char* text, whisper_token* tokens, int n_max_tokens);   /* count, or -needed */
+int whisper_lang_max_id(void);
+int whisper_lang_id(const char* lang);
+const char* whisper_lang_str(int id);
+const char* whisper_lang_str_full(int id);
+/* runs the engine's detection on the samples last given to whisper_pcm_to_mel*; lang_probs (optional, whisper_lang_max_id()+1 floats): 1.0 at
+ * the detected id, 0 elsewhere (the device path keeps the argmax only) */
+int whisper_lang_auto_detect(struct whisper_context* ctx, int offset_ms, int n_threads, float* lang_probs);
+int whisper_lang_auto_detect_with_state(struct whisper_context* ctx, struct whisper_state* state, int offset_ms, int n_threads, float* lang_probs);
 
+int whisper_n_len(struct whisper_context* ctx);
+int whisper_n_len_from_state(struct whisper_state* state);
 int whisper_n_vocab(struct whisper_context* ctx);
 int whisper_n_text_ctx(struct whisper_context* ctx);
 int whisper_n_audio_ctx(struct whisper_context* ctx);
 int whisper_is_multilingual(struct whisper_context* ctx);
+int whisper_model_n_vocab(struct whisper_context* ctx);
+int whisper_model_n_audio_ctx(struct whisper_context* ctx);
+int whisper_model_n_audio_state(struct whisper_context* ctx);
+int whisper_model_n_audio_head(struct whisper_context* ctx);
+int whisper_model_n_audio_layer(struct whisper_context* ctx);
+int whisper_model_n_text_ctx(struct whisper_context* ctx);
+int whisper_model_n_text_state(struct whisper_context* ctx);
+int whisper_model_n_text_head(struct whisper_context* ctx);
+int whisper_model_n_text_layer(struct whisper_context* ctx);
+int whisper_model_n_mels(struct whisper_context* ctx);
+int whisper_model_ftype(struct whisper_context* ctx);
+int whisper_model_type(struct whisper_context* ctx);
+const char* whisper_model_type_readable(struct whisper_context* ctx);
+
+const char* whisper_token_to_str(struct whisper_context* ctx, whisper_token token);
 whisper_token whisper_token_eot(struct whisper_context* ctx);
 whisper_token whisper_token_sot(struct whisper_context* ctx);
+whisper_token whisper_token_solm(struct whisper_context* ctx);
+whisper_token whisper_token_prev(struct whisper_context* ctx);
+whisper_token whisper_token_nosp(struct whisper_context* ctx);
+whisper_token whisper_token_not(struct whisper_context* ctx);
 whisper_token whisper_token_beg(struct whisper_context* ctx);
-const char* whisper_token_to_str(struct whisper_context* ctx, whisper_token token);
-int whisper_lang_id(const char* lang);
+whisper_token whisper_token_lang(struct whisper_context* ctx, int lang_id);
+whisper_token whisper_token_translate(struct whisper_context* ctx);
+whisper_token whisper_token_transcribe(struct whisper_context* ctx);
+
+void whisper_print_timings(struct whisper_context* ctx);
+void whisper_reset_timings(struct whisper_context* ctx);
+const char* whisper_print_system_info(void);
+void whisper_log_set(ggml_log_callback log_callback, void* user_data);
+
+struct whisper_full_params* whisper_full_default_params_by_ref(enum whisper_sampling_strategy strategy);
+struct whisper_full_params whisper_full_default_params(enum whisper_sampling_strategy strategy);
+int whisper_full(struct whisper_context* ctx, struct whisper_full_params params, const float* samples, int n_samples);
+int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* state, struct whisper_full_params params,
+                            const float* samples, int n_samples);
+/* splits the audio into n_processors chunks that run as ONE device batch (whisper.cpp: one thread + state each), merged with its offset rule */
+int whisper_full_parallel(struct whisper_context* ctx, struct whisper_full_params params, const float* samples, int n_samples, int n_processors);
+
+int whisper_full_n_segments(struct whisper_context* ctx);
+int whisper_full_n_segments_from_state(struct whisper_state* state);
+int whisper_full_lang_id(struct whisper_context* ctx);
+int whisper_full_lang_id_from_state(struct whisper_state* state);
+int64_t whisper_full_get_segment_t0(struct whisper_context* ctx, int i_segment);
+int64_t whisper_full_get_segment_t0_from_state(struct whisper_state* state, int i_segment);
+int64_t whisper_full_get_segment_t1(struct whisper_context* ctx, int i_segment);
+int64_t whisper_full_get_segment_t1_from_state(struct whisper_state* state, int i_segment);
+bool whisper_full_get_segment_speaker_turn_next(struct whisper_context* ctx, int i_segment);
+bool whisper_full_get_segment_speaker_turn_next_from_state(struct whisper_state* state, int i_segment);
+const char* whisper_full_get_segment_text(struct whisper_context* ctx, int i_segment);
+const char* whisper_full_get_segment_text_from_state(struct whisper_state* state, int i_segment);
+int whisper_full_n_tokens(struct whisper_context* ctx, int i_segment);
+int whisper_full_n_tokens_from_state(struct whisper_state* state, int i_segment);
+const char* whisper_full_get_token_text(struct whisper_context* ctx, int i_segment, int i_token);
+const char* whisper_full_get_token_text_from_state(struct whisper_context* ctx, struct whisper_state* state, int i_segment, int i_token);
+whisper_token whisper_full_get_token_id(struct whisper_context* ctx, int i_segment, int i_token);
+whisper_token whisper_full_get_token_id_from_state(struct whisper_state* state, int i_segment, int i_token);
+whisper_token_data whisper_full_get_token_data(struct whisper_context* ctx, int i_segment, int i_token);
+whisper_token_data whisper_full_get_token_data_from_state(struct whisper_state* state, int i_segment, int i_token);
+float whisper_full_get_token_p(struct whisper_context* ctx, int i_segment, int i_token);
+float whisper_full_get_token_p_from_state(struct whisper_state* state, int i_segment, int i_token);
+
+int whisper_bench_memcpy(int n_threads);                       /* CPU micro-benchmarks of ggml: nothing to run here */
+const char* whisper_bench_memcpy_str(int n_threads);
+int whisper_bench_ggml_mul_mat(int n_threads);
+const char* whisper_bench_ggml_mul_mat_str(int n_threads);
 
 #ifdef __cplusplus
 }

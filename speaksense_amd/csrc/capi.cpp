@@ -226,6 +226,29 @@ int64_t ss_result_segment_t1(const ss_session* s, int32_t i) { return (!s || i <
 int32_t ss_result_segment_speaker_turn_next(const ss_session* s, int32_t i) {
     return (!s || i < 0 || i >= (int)s->s.segments.size()) ? 0 : (int32_t)s->s.segments[i].speaker_turn_next;
 }
+int32_t ss_result_segment_n_tokens(const ss_session* s, int32_t i) {
+    return (!s || i < 0 || i >= (int)s->s.segments.size()) ? 0 : (int32_t)s->s.segments[i].tokens.size();
+}
+int ss_result_segment_token(const ss_session* s, int32_t i, int32_t k, int32_t* id, int32_t* tid, float out4[4]) {
+    if (!s || i < 0 || i >= (int)s->s.segments.size() || k < 0 || k >= (int)s->s.segments[i].tokens.size()) return fail(SS_ERR_ARG, "segment token: out of range");
+    const TokenData& t = s->s.segments[i].tokens[k];
+    if (id) *id = t.id;
+    if (tid) *tid = t.tid;
+    if (out4) { out4[0] = t.p; out4[1] = t.plog; out4[2] = t.pt; out4[3] = t.ptsum; }
+    return SS_OK;
+}
+// whisper_full_parallel's merge: append src's segments to dst shifted by t_offset centiseconds, "make sure that segments are not overlapping"
+int ss_result_append(ss_session* dst, const ss_session* src, int64_t t_offset) {
+    if (!dst || !src || dst == src) return fail(SS_ERR_ARG, "ss_result_append: bad argument");
+    for (const Segment& g : src->s.segments) {
+        Segment r = g;
+        r.t0 += t_offset; r.t1 += t_offset;
+        if (!dst->s.segments.empty()) r.t0 = std::max(r.t0, dst->s.segments.back().t1);
+        dst->s.segments.push_back(r);
+    }
+    dst->s.tokens.insert(dst->s.tokens.end(), src->s.tokens.begin(), src->s.tokens.end());
+    return SS_OK;
+}
 int32_t ss_result_n_tokens(const ss_session* s) { return s ? (int32_t)s->s.tokens.size() : 0; }
 int ss_result_tokens(const ss_session* s, int32_t* ids, float* plog) {
     if (!s || !ids) return fail(SS_ERR_ARG, "null argument");

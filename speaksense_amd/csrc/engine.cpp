@@ -219,7 +219,10 @@ struct EngineT : EngineBase {
         step_timing = getenv("SS_STEP_TIMING") != nullptr;
         { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }
         ln_fused = getenv("SS_DECODE_LN_FUSED") ? atoi(getenv("SS_DECODE_LN_FUSED")) : 0;   // 1 both seams, 2 self-attention seam only, 3 cross-attention seam only
+        wide_ok = getenv("SS_DECODE_WIDE") ? atoi(getenv("SS_DECODE_WIDE")) != 0 : true;   // 17..64 rows through the fused step (0: the older per-op kernels)
+        wide_ok = wide_ok && ln_fused == 0 && combine_separate && !cross_direct && pl_qkv.NW <= 4 && pl_dd.NW <= 4 && pl_fc1.NW <= 4 && pl_fc2.NW <= 4 && pl_logits.NW <= 4;
         decode_v2 = narrow_ok && getenv("SS_DECODE_V2") != nullptr && ln_fused == 0 && combine_separate && !cross_direct;
+        if (decode_v2) wide_ok = false;
         if (!donor) {
             int nl = o.n_lanes > 0 ? o.n_lanes : 2;
             if (const char* lv = getenv("SS_LANES")) nl = atoi(lv);
@@ -453,8 +456,8 @@ struct EngineT : EngineBase {
         fix_nw(pl_d1, d);   // d x d projections with the whole K sum in one workgroup (residual epilogue, LayerNorm prologue)
         pn_qkv = plan_narrow(3 * d, d); pn_dd = plan_narrow(d, d); pn_fc1 = plan_narrow(4 * d, d); pn_fc2 = plan_narrow(d, 4 * d);
         narrow_ok = pn_qkv.NW && pn_dd.NW && pn_fc1.NW && pn_fc2.NW && d <= 2048;
-        const size_t pb = (size_t)8 * 16 * d * 4;
-        xa.alloc((size_t)16 * d * 4); xb.alloc((size_t)16 * d * 4); p1.alloc(pb); pq.alloc(pb); p2.alloc(pb); p3.alloc(pb);
+        const size_t pb = (size_t)4 * kPartRows * d * 4;   // <= 4 split-K slots of kPartRows token rows
+        xa.alloc((size_t)kPartRows * d * 4); xb.alloc((size_t)kPartRows * d * 4); p1.alloc(pb); pq.alloc(pb); p2.alloc(pb); p3.alloc(pb);
     }
     void fix_nw(Plan& p, int K) {  // direct epilogues need S == 1: pick the widest block whose per-wave k is a multiple of 32 and <= 320
         for (int nw = 4; nw >= 1; nw >>= 1) if (K % nw == 0 && (K / nw) % 32 == 0 && K / nw <= 320) { p.NW = nw; p.S = 1; return; }
@@ -694,7 +697,8 @@ struct EngineT : EngineBase {
     }
     // returns the parity of the result buffer / event to wait on for a fused step, -1 for the skinny path (samp_h after a stream sync)
     int decoder_step(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
-        if (M <= 16 && use_fused) { decoder_step_fused(M, rc, samp_rows, any_probs); return step_parity; }
+        // the fused step carries up to 16 rows in every variant and up to 64 (multi-tile GEMVs) in its default form
+        if (use_fused && (M <= 16 || (wide_ok && M <= kPartRows))) { decoder_step_fused(M, rc, samp_rows, any_probs); return step_parity; }
         const int n_samp = (int)samp_rows.size();
         cnt_passes++; cnt_rows += M;
         SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
@@ -767,6 +771,7 @@ struct EngineT : EngineBase {
     bool use_fused = true, cross_direct = false, combine_separate = true, use_graph = true;
     int ln_fused = 0;
     bool chain_steps = true;
+    bool wide_ok = true;
     bool decode_v2 = false;  // SS_DECODE_V2=1: the 9-launch step below (narrow tiles, LayerNorm prologues); measured SLOWER than the 12-launch step
                              // (2.39 vs 2.18 ms per pass alone, 1304 vs 1533 xRT with two lanes): kept for A/B runs only
     bool step_timing = false; double tm_launch = 0, tm_wait = 0, tm_host = 0; long tm_n = 0; std::chrono::steady_clock::time_point tm_prev;
@@ -1083,7 +1088,7 @@ struct EngineT : EngineBase {
         // of step t has already written the control blocks of step t+1.  Such a step is enqueued BEFORE the host waits for step t, so
         // the GPU never idles through the sample -> host -> upload -> launch turnaround.  The host still accepts every sample with the
         // same rules one step behind; decoders that end simply ignore their row of the step that was already in flight.
-        const bool simple = chain_steps && use_fused && rows.size() == decs_in.size() && rows.size() <= 16 &&
+        const bool simple = chain_steps && use_fused && rows.size() == decs_in.size() && rows.size() <= (size_t)(wide_ok ? kPartRows : 16) &&
                             std::all_of(rows.begin(), rows.end(), [](const RowCtl& c) { return c.temperature <= 0.0f; });
         auto may_continue = [&]() {   // is there a decoder that will still be running after the step that is in flight?
             for (auto& dr : decs_in) {
@@ -1224,20 +1229,28 @@ struct EngineT : EngineBase {
             int64_t t0 = seek + 2 * (tk.front().tid - vocab.token_beg);
             std::string text;
             bool speaker_turn_next = false;
+            int i0 = 0;   // first token of the segment being built ("for (int j = i0; j <= i; j++) result_all.back().tokens.push_back(tokens_cur[j])")
             for (int i = 0; i < (int)tk.size(); i++) {
                 if (P.print_special || tk[i].id < vocab.token_eot) text += vocab.id_to_token[tk[i].id];
                 if (P.tdrz_enable && tk[i].id == vocab.token_solm) speaker_turn_next = true;
                 if (tk[i].id > vocab.token_beg && !P.single_segment) {
                     const int64_t t1 = seek + 2 * (tk[i].tid - vocab.token_beg);
-                    if (!text.empty()) s->segments.push_back({t0, t1, text, speaker_turn_next});
+                    if (!text.empty()) {
+                        s->segments.push_back({t0, t1, text, speaker_turn_next, {}});
+                        s->segments.back().tokens.assign(tk.begin() + i0, tk.begin() + i + 1);
+                    }
                     text.clear();
                     while (i < (int)tk.size() && tk[i].id > vocab.token_beg) i++;
                     i--;
                     t0 = t1;
+                    i0 = i + 1;
                     speaker_turn_next = false;
                 }
             }
-            if (!text.empty()) s->segments.push_back({t0, (int64_t)(seek + seek_delta), text, speaker_turn_next});
+            if (!text.empty()) {
+                s->segments.push_back({t0, (int64_t)(seek + seek_delta), text, speaker_turn_next, {}});
+                s->segments.back().tokens.assign(tk.begin() + i0, tk.end());
+            }
         }
         jq.seek += seek_delta;
     }

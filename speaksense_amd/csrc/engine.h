@@ -17,7 +17,7 @@
 namespace ss {
 
 struct TokenData { int id = 0, tid = 0; float p = 0, plog = 0, pt = 0, ptsum = 0; };
-struct Segment { int64_t t0, t1; std::string text; bool speaker_turn_next; };
+struct Segment { int64_t t0, t1; std::string text; bool speaker_turn_next; std::vector<TokenData> tokens; };   // tokens: whisper_full_get_token_*
 
 // std::mt19937 that counts how often it was invoked: a session's sampling history is then summarised by one number, and a fresh session
 // can be put into the state an older one had (`discard`), which is what lets independent chunks of one reference state run as a batch.

@@ -90,13 +90,14 @@ struct SkinnyDesc {
 template <typename T> void launch_skinny(const SkinnyDesc& g, hipStream_t st);
 
 // Fused decode-step GEMV for M <= 16 rows (kernels_decode.hip): prologue + 16-row weight tiles x split-K + epilogue
+constexpr int kPartRows = 64;   // row stride of the split-K partial buffers [S][kPartRows][N]: a decoder pass carries up to 64 token rows
 enum DecPro { PRO_LN = 0, PRO_T = 1, PRO_COMBINE = 2 };
 enum DecEpi { DEPI_PART = 0, DEPI_QKV = 1, DEPI_GELU_T = 2, DEPI_LOGITS = 3, DEPI_RES = 4 };
 struct DecGemvDesc {
     int pro, epi;
     // PRO_LN: x = x_in (or tok/pos embedding when ctl != null) + bias_prev + sum_p parts[p]; optional write-back; LayerNorm
     const float* x_in; float* x_out;
-    const float* parts; int n_parts;        // [n_parts][16][K] f32 split-K partials of the previous projection
+    const float* parts; int n_parts;        // [n_parts][kPartRows][K] f32 split-K partials of the previous projection
     const float* bias_prev;                 // [K] or null
     const float* ln_w; const float* ln_b;
     const RowCtl* ctl; const void* tok_emb; const float* pos_emb;   // embedding prologue (layer 0)
@@ -106,7 +107,7 @@ struct DecGemvDesc {
     const void* W; int M, N, K, S;          // W: T [N][K]
     int NT;                                 // output columns per workgroup, 1..16 (0 = 16): narrow tiles fill the chip without split-K
     const float* bias; void* out; long ldo; float scale; int n_valid;
-    float* part_out;                        // DEPI_PART: [S][16][N]
+    float* part_out;                        // DEPI_PART: [S][kPartRows][N]
     const RowCtl* ctl_rows; void* kcache; void* vcache; long slot_stride; int d;   // DEPI_QKV
     int gelu_f16_in;
 };

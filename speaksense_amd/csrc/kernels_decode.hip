@@ -89,7 +89,7 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
         const float wgt[4] = {g.n_parts > 0 ? 1.f : 0.f, g.n_parts > 1 ? 1.f : 0.f, g.n_parts > 2 ? 1.f : 0.f, g.n_parts > 3 ? 1.f : 0.f};
         const float* pp[4];
 #pragma unroll
-        for (int p = 0; p < 4; p++) pp[p] = g.n_parts > 0 ? g.parts + ((long)(p < g.n_parts ? p : 0) * 16 + r) * d : xr;
+        for (int p = 0; p < 4; p++) pp[p] = g.n_parts > 0 ? g.parts + ((long)(p < g.n_parts ? p : 0) * kPartRows + r) * d : xr;
         const float bw = g.bias_prev ? 1.f : 0.f;
         const float* bp = g.bias_prev ? g.bias_prev : xr;
         f32x4 a[NI], b[NI], q0[NI], q1[NI];
@@ -141,6 +141,32 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
 template <typename T, int NI>
 __global__ __launch_bounds__(64) void dec_reduce_ln_kernel(DecGemvDesc g, T* out) {
     ln_row<T, NI>(g, blockIdx.x, threadIdx.x, true, 0, g.K, out + (long)blockIdx.x * g.K);
+}
+
+// one output (token row m, output column n, whole-slice sum v) of a decode GEMV
+template <typename T, int EPI>
+__device__ __forceinline__ void dec_epilogue(const DecGemvDesc& g, int s, int m, int n, float v) {
+    if constexpr (EPI == DEPI_PART) {
+        g.part_out[((long)s * kPartRows + m) * g.N + n] = v;
+    } else if constexpr (EPI == DEPI_RES) {   // residual stream: x_out = x_in + bias + W a  (S == 1: the whole K sum is here)
+        g.x_out[(long)m * g.N + n] = (g.x_in[(long)m * g.N + n] + g.bias[n]) + v;
+    } else {
+        if (g.bias) v += g.bias[n];
+        if constexpr (EPI == DEPI_GELU_T) {
+            ((T*)g.out)[(long)m * g.ldo + n] = (T)gelu_tanh_d(gelu_in_round_d<T>(v, g.gelu_f16_in));
+        } else if constexpr (EPI == DEPI_LOGITS) {
+            if (n < g.n_valid) ((float*)g.out)[(long)m * g.ldo + n] = v;
+        } else if constexpr (EPI == DEPI_QKV) {
+            const int d = g.d;
+            if (n < d) ((T*)g.out)[(long)m * g.ldo + n] = (T)(v * g.scale);
+            else {
+                const RowCtl c = g.ctl_rows[m];
+                const long off = (long)c.slot * g.slot_stride + (long)c.pos * d;
+                if (n < 2 * d) ((T*)g.kcache)[off + (n - d)] = (T)(v * g.scale);
+                else ((T*)g.vcache)[off + (n - 2 * d)] = (T)v;
+            }
+        }
+    }
 }
 
 // NT = g.NT output columns per workgroup (1..16; the MFMA tile is 16 wide, rows >= NT are never loaded nor stored).  Narrow tiles are how a
@@ -263,27 +289,7 @@ __global__ __launch_bounds__(MAXT) void dec_gemv_kernel(DecGemvDesc g) {
         if (m < g.M && nn < NT && n < g.N) {
             float v = 0.f;
             for (int w = 0; w < NW; w++) v += red[(w * 16 + m) * 17 + nn];
-            if constexpr (EPI == DEPI_PART) {
-                g.part_out[((long)s * 16 + m) * g.N + n] = v;
-            } else if constexpr (EPI == DEPI_RES) {   // residual stream: x_out = x_in + bias + W a  (S == 1: the whole K sum is here)
-                g.x_out[(long)m * g.N + n] = (g.x_in[(long)m * g.N + n] + g.bias[n]) + v;
-            } else {
-                if (g.bias) v += g.bias[n];
-                if constexpr (EPI == DEPI_GELU_T) {
-                    ((T*)g.out)[(long)m * g.ldo + n] = (T)gelu_tanh_d(gelu_in_round_d<T>(v, g.gelu_f16_in));
-                } else if constexpr (EPI == DEPI_LOGITS) {
-                    if (n < g.n_valid) ((float*)g.out)[(long)m * g.ldo + n] = v;
-                } else if constexpr (EPI == DEPI_QKV) {
-                    const int d = g.d;
-                    if (n < d) ((T*)g.out)[(long)m * g.ldo + n] = (T)(v * g.scale);
-                    else {
-                        const RowCtl c = g.ctl_rows[m];
-                        const long off = (long)c.slot * g.slot_stride + (long)c.pos * d;
-                        if (n < 2 * d) ((T*)g.kcache)[off + (n - d)] = (T)(v * g.scale);
-                        else ((T*)g.vcache)[off + (n - 2 * d)] = (T)v;
-                    }
-                }
-            }
+            dec_epilogue<T, EPI>(g, s, m, n, v);
         }
     }
 }
@@ -312,6 +318,84 @@ static void launch_dg(const DecGemvDesc& g, int NW, hipStream_t st) {
     } else {
         launch_dg2<T, PRO, EPI, 1>(g, NW, st);
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The same GEMV for 17..64 token rows (CT = 2 or 4 column tiles of 16): the weight fragments are fetched ONCE and used by CT MFMAs each, so
+// a decoder pass over up to 64 rows (several device batches merged, best_of = 5 sampled decoders, long prompts) still streams the decoder
+// weights once.  Activations straight from L2 (PRO_T); epilogues as above.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int EPI, int CT>
+__global__ __launch_bounds__(256) void dec_gemv_wide_kernel(DecGemvDesc g) {
+    typedef typename MfmaD<T>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem_d[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16, s = blockIdx.y;
+    const int kslice = g.K / g.S, kbeg = s * kslice, kw = kslice / NW, kwb = wave * kw;
+    const int nfr = kw / 32, npair = nfr / 2;
+    float* red = (float*)smem_d;   // [NW][CT*16][17]
+    const T* wp = (const T*)g.W + (long)(n0 + frow) * g.K + kbeg + kwb;
+    V8 wf[kMaxFrag];
+#pragma unroll
+    for (int j = 0; j < kMaxFrag / 2; j++) {
+        if (j < npair) {
+            wf[2 * j] = SS_LDW((const V8*)(wp + j * 64 + fg * 16));
+            wf[2 * j + 1] = SS_LDW((const V8*)(wp + j * 64 + fg * 16 + 8));
+        }
+    }
+    V8 wtail = {};
+    if (nfr & 1) wtail = SS_LDW((const V8*)(wp + npair * 64 + fg * 8));
+    f32x4 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++) {
+        acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int m = ct * 16 + frow;
+        const T* xg = (const T*)g.Xt + (long)(m < g.M ? m : 0) * g.ldx + kbeg + kwb;
+        V8 xf[kMaxFrag];
+#pragma unroll
+        for (int j = 0; j < kMaxFrag / 2; j++) {
+            if (j < npair) {
+                xf[2 * j] = *(const V8*)(xg + j * 64 + fg * 16);
+                xf[2 * j + 1] = *(const V8*)(xg + j * 64 + fg * 16 + 8);
+            }
+        }
+        V8 xtail = {};
+        if (nfr & 1) xtail = *(const V8*)(xg + npair * 64 + fg * 8);
+#pragma unroll
+        for (int j = 0; j < kMaxFrag / 2; j++) {
+            if (j < npair) {
+                acc[ct] = MfmaD<T>::mma(wf[2 * j], xf[2 * j], acc[ct]);
+                acc[ct] = MfmaD<T>::mma(wf[2 * j + 1], xf[2 * j + 1], acc[ct]);
+            }
+        }
+        if (nfr & 1) acc[ct] = MfmaD<T>::mma(wtail, xtail, acc[ct]);
+    }
+#pragma unroll
+    for (int ct = 0; ct < CT; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[((wave * CT + ct) * 16 + frow) * 17 + fg * 4 + r] = acc[ct][r];
+    __syncthreads();
+    for (int idx = tid; idx < CT * 256; idx += blockDim.x) {
+        const int m = idx >> 4, nn = idx & 15, n = n0 + nn;
+        if (m < g.M && n < g.N) {
+            float v = 0.f;
+            for (int w = 0; w < NW; w++) v += red[((w * CT + (m >> 4)) * 16 + (m & 15)) * 17 + nn];
+            dec_epilogue<T, EPI>(g, s, m, n, v);
+        }
+    }
+}
+template <typename T, int EPI, int CT>
+static void launch_dgw2(const DecGemvDesc& g, int NW, hipStream_t st) {
+    const size_t lds = (size_t)NW * CT * 16 * 17 * 4;
+    dim3 grid((g.N + 15) / 16, g.S);
+    dec_gemv_wide_kernel<T, EPI, CT><<<grid, NW * 64, lds, st>>>(g); SS_LAUNCH_CHECK();
+}
+template <typename T, int EPI>
+static void launch_dgw(const DecGemvDesc& g, int NW, hipStream_t st) {
+    if (g.M <= 32) launch_dgw2<T, EPI, 2>(g, NW, st);
+    else launch_dgw2<T, EPI, 4>(g, NW, st);
 }
 
 // choose split-K so the grid has >= ~256 workgroups; per-wave k must be a multiple of 32 and <= 320
@@ -349,6 +433,19 @@ void launch_dec_gemv(const DecGemvDesc& g0, int NW, hipStream_t st) {
     DecGemvDesc g = g0;
     if (g.NT <= 0) g.NT = 16;
     if (g.NT > 16 || NW < 1 || NW > 16 || (NW & (NW - 1))) throw Error(-1, "dec_gemv: bad tile / wave count");
+    if (g.M > 16) {   // 17..64 rows: the multi-tile kernel
+        if (g.M > kPartRows || g.pro != PRO_T || NW > 4 || g.NT != 16 || g.K % g.S || (g.K / g.S) % NW || ((g.K / g.S) / NW) % 32 || (g.K / g.S) / NW > 320)
+            throw Error(-1, "dec_gemv: bad shape for the 17..64-row kernel");
+        if (g.epi != DEPI_PART && g.S != 1) throw Error(-1, "dec_gemv: direct epilogues need S == 1");
+        switch (g.epi) {
+            case DEPI_PART: launch_dgw<T, DEPI_PART>(g, NW, st); break;
+            case DEPI_QKV: launch_dgw<T, DEPI_QKV>(g, NW, st); break;
+            case DEPI_GELU_T: launch_dgw<T, DEPI_GELU_T>(g, NW, st); break;
+            case DEPI_LOGITS: launch_dgw<T, DEPI_LOGITS>(g, NW, st); break;
+            default: throw Error(-1, "dec_gemv: unsupported epilogue for the 17..64-row kernel");
+        }
+        return;
+    }
     if (g.n_parts > 4) throw Error(-1, "dec_gemv: at most 4 split-K partials");
     if (g.pro == PRO_COMBINE && (g.K / g.S) % 64) throw Error(-1, "dec_gemv: combine prologue needs K slices of whole heads");
     if (g.M < 1 || g.M > 16 || g.K % g.S || (g.K / g.S) % NW || ((g.K / g.S) / NW) % 32 || (g.K / g.S) / NW > 320)
@@ -400,7 +497,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
         f32x4 t0[4], t1[4];
 #pragma unroll
         for (int p = 0; p < 4; p++) {   // up to 4 partial slots, unused ones re-read slot 0 with weight 0
-            const float* pp = qpart + ((long)(p < n_qpart ? p : 0) * 16 + m) * d + col;
+            const float* pp = qpart + ((long)(p < n_qpart ? p : 0) * kPartRows + m) * d + col;
             t0[p] = *(const f32x4*)pp; t1[p] = *(const f32x4*)(pp + 4);
         }
 #pragma unroll

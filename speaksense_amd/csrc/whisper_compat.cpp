@@ -1,31 +1,78 @@
-// whisper.h-compatible shim over the ss_* API (include/whisper_compat.h).  Each call is one chunk through the batch
+// whisper.h-compatible shim over the ss_* API (include/whisper_compat.h).  Each whisper_full* call is one chunk through the batch
 // former, so states running concurrently on one context share device batches -- which the reference's per-stream
 // states (/root/reference/src/grpc/handlers/asr.rs:164) and per-task states (schedule/processors/transcribe.rs:100) do.
+// The whole function list of whisper.h v1.5.4 is exported; what this engine cannot honour returns an error, never aborts.
+#include <cstdarg>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <unistd.h>
+#include <vector>
 
 #include "../../include/speaksense.h"
 #include "../../include/whisper_compat.h"
 #include "common.h"
 
 struct whisper_context { ss_engine* eng; whisper_state* default_state; };
-struct whisper_state { ss_session* ses; whisper_context* ctx; };
+struct whisper_state {
+    ss_session* ses; whisper_context* ctx;
+    std::vector<float> pcm;      // samples last given to whisper_pcm_to_mel* (language detection runs on them)
+    std::vector<float> mel;      // [n_mel][n_len] from the device log-mel
+    int n_len = 0;
+    std::string token_text;      // whisper_full_get_token_text's return buffer
+};
+
+static ggml_log_callback g_log_cb = nullptr;
+static void* g_log_ud = nullptr;
+static void wlog(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (g_log_cb) g_log_cb(2 /* GGML_LOG_LEVEL_ERROR */, buf, g_log_ud);
+    else fputs(buf, stderr);
+}
+static int unsupported(const char* fn) { wlog("%s: not supported by the MI355X engine (use whisper_full*)\n", fn); return -1; }
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
 }
+static int hp(struct whisper_context* ctx, int idx) {
+    int32_t h[11] = {0};
+    if (!ctx || ss_engine_hparams(ctx->eng, h) != SS_OK) return 0;
+    return h[idx];
+}
+static int sp(struct whisper_context* ctx, int idx) {
+    int32_t t[9] = {0};
+    if (!ctx || ss_engine_special_tokens(ctx->eng, t) != SS_OK) return 0;
+    return t[idx];
+}
+static whisper_state* dstate(struct whisper_context* ctx) {
+    if (!ctx) return nullptr;
+    if (!ctx->default_state) ctx->default_state = whisper_init_state(ctx);
+    return ctx->default_state;
+}
 
 extern "C" {
 
+// ---- context / state lifetime -------------------------------------------------------------------------------------------------------
 struct whisper_context_params whisper_context_default_params(void) {
     whisper_context_params p;
     p.use_gpu = true;
     return p;
 }
+struct whisper_context_params* whisper_context_default_params_by_ref(void) {
+    whisper_context_params* p = (whisper_context_params*)malloc(sizeof(whisper_context_params));
+    *p = whisper_context_default_params();
+    return p;
+}
+void whisper_free_context_params(struct whisper_context_params* params) { free(params); }
+void whisper_free_params(struct whisper_full_params* params) { free(params); }
 
 struct whisper_context* whisper_init_from_file_with_params_no_state(const char* path_model, struct whisper_context_params) {
+    if (!path_model) return nullptr;
     ss_engine_opts o;
     memset(&o, 0, sizeof(o));
     o.device = env_int("SS_DEVICE", 0);
@@ -36,7 +83,7 @@ struct whisper_context* whisper_init_from_file_with_params_no_state(const char* 
     o.batch_wait_us = env_int("SS_BATCH_WAIT_US", 2000);
     ss_engine* e = nullptr;
     if (ss_engine_create(path_model, &o, &e) != SS_OK) {
-        fprintf(stderr, "whisper_init_from_file_with_params_no_state: %s\n", ss_last_error());
+        wlog("whisper_init_from_file_with_params_no_state: %s\n", ss_last_error());
         return nullptr;
     }
     return new whisper_context{e, nullptr};
@@ -46,12 +93,62 @@ struct whisper_context* whisper_init_from_file_with_params(const char* path_mode
     if (ctx) ctx->default_state = whisper_init_state(ctx);
     return ctx;
 }
+// the model loader of this library reads a file: a buffer / custom loader is spooled to a temporary file first
+struct whisper_context* whisper_init_from_buffer_with_params_no_state(void* buffer, size_t buffer_size, struct whisper_context_params params) {
+    if (!buffer || buffer_size == 0) return nullptr;
+    char tmpl[] = "/tmp/ss_model_XXXXXX";
+    const int fd = mkstemp(tmpl);
+    if (fd < 0) { wlog("whisper_init_from_buffer: cannot create a temporary file\n"); return nullptr; }
+    size_t off = 0;
+    while (off < buffer_size) {
+        const ssize_t w = write(fd, (const char*)buffer + off, buffer_size - off);
+        if (w <= 0) break;
+        off += (size_t)w;
+    }
+    close(fd);
+    whisper_context* ctx = off == buffer_size ? whisper_init_from_file_with_params_no_state(tmpl, params) : nullptr;
+    unlink(tmpl);
+    return ctx;
+}
+struct whisper_context* whisper_init_from_buffer_with_params(void* buffer, size_t buffer_size, struct whisper_context_params params) {
+    whisper_context* ctx = whisper_init_from_buffer_with_params_no_state(buffer, buffer_size, params);
+    if (ctx) ctx->default_state = whisper_init_state(ctx);
+    return ctx;
+}
+struct whisper_context* whisper_init_with_params_no_state(struct whisper_model_loader* loader, struct whisper_context_params params) {
+    if (!loader || !loader->read) return nullptr;
+    std::vector<char> buf;
+    char chunk[1 << 16];
+    while (true) {
+        if (loader->eof && loader->eof(loader->context)) break;
+        const size_t n = loader->read(loader->context, chunk, sizeof(chunk));
+        if (n == 0) break;
+        buf.insert(buf.end(), chunk, chunk + n);
+    }
+    if (loader->close) loader->close(loader->context);
+    return whisper_init_from_buffer_with_params_no_state(buf.data(), buf.size(), params);
+}
+struct whisper_context* whisper_init_with_params(struct whisper_model_loader* loader, struct whisper_context_params params) {
+    whisper_context* ctx = whisper_init_with_params_no_state(loader, params);
+    if (ctx) ctx->default_state = whisper_init_state(ctx);
+    return ctx;
+}
+struct whisper_context* whisper_init_from_file(const char* path_model) { return whisper_init_from_file_with_params(path_model, whisper_context_default_params()); }
+struct whisper_context* whisper_init_from_buffer(void* b, size_t n) { return whisper_init_from_buffer_with_params(b, n, whisper_context_default_params()); }
+struct whisper_context* whisper_init(struct whisper_model_loader* l) { return whisper_init_with_params(l, whisper_context_default_params()); }
+struct whisper_context* whisper_init_from_file_no_state(const char* path_model) { return whisper_init_from_file_with_params_no_state(path_model, whisper_context_default_params()); }
+struct whisper_context* whisper_init_from_buffer_no_state(void* b, size_t n) { return whisper_init_from_buffer_with_params_no_state(b, n, whisper_context_default_params()); }
+struct whisper_context* whisper_init_no_state(struct whisper_model_loader* l) { return whisper_init_with_params_no_state(l, whisper_context_default_params()); }
+
 struct whisper_state* whisper_init_state(struct whisper_context* ctx) {
     if (!ctx) return nullptr;
     ss_session* s = ss_session_create(ctx->eng);
     if (!s) return nullptr;
-    return new whisper_state{s, ctx};
+    whisper_state* st = new whisper_state();
+    st->ses = s; st->ctx = ctx;
+    return st;
 }
+int whisper_ctx_init_openvino_encoder(struct whisper_context*, const char*, const char*, const char*) { return 1; }
 void whisper_free_state(struct whisper_state* state) {
     if (!state) return;
     ss_session_free(state->ses);
@@ -64,6 +161,146 @@ void whisper_free(struct whisper_context* ctx) {
     delete ctx;
 }
 
+// ---- low-level API ------------------------------------------------------------------------------------------------------------------
+int whisper_pcm_to_mel_with_state(struct whisper_context* ctx, struct whisper_state* state, const float* samples, int n_samples, int) {
+    if (!ctx || !state || !samples || n_samples <= 0) return -1;
+    const int n_len = ss_mel_n_len(n_samples);
+    state->mel.assign((size_t)hp(ctx, 9) * n_len, 0.0f);
+    if (ss_log_mel(ctx->eng, samples, n_samples, state->mel.data(), n_len) != SS_OK) { wlog("whisper_pcm_to_mel: %s\n", ss_last_error()); return -1; }
+    state->n_len = n_len;
+    state->pcm.assign(samples, samples + n_samples);
+    return 0;
+}
+int whisper_pcm_to_mel(struct whisper_context* ctx, const float* samples, int n_samples, int n_threads) {
+    return whisper_pcm_to_mel_with_state(ctx, dstate(ctx), samples, n_samples, n_threads);
+}
+int whisper_pcm_to_mel_phase_vocoder(struct whisper_context*, const float*, int, int) { return unsupported("whisper_pcm_to_mel_phase_vocoder"); }
+int whisper_pcm_to_mel_phase_vocoder_with_state(struct whisper_context*, struct whisper_state*, const float*, int, int) {
+    return unsupported("whisper_pcm_to_mel_phase_vocoder_with_state");
+}
+int whisper_set_mel_with_state(struct whisper_context* ctx, struct whisper_state* state, const float* data, int n_len, int n_mel) {
+    if (!ctx || !state || !data || n_len <= 0) return -1;
+    if (n_mel != hp(ctx, 9)) { wlog("whisper_set_mel: invalid number of mel bands: %d (expected %d)\n", n_mel, hp(ctx, 9)); return -1; }
+    state->mel.assign(data, data + (size_t)n_len * n_mel);
+    state->n_len = n_len;
+    state->pcm.clear();
+    return 0;
+}
+int whisper_set_mel(struct whisper_context* ctx, const float* data, int n_len, int n_mel) { return whisper_set_mel_with_state(ctx, dstate(ctx), data, n_len, n_mel); }
+int whisper_encode(struct whisper_context*, int, int) { return unsupported("whisper_encode"); }
+int whisper_encode_with_state(struct whisper_context*, struct whisper_state*, int, int) { return unsupported("whisper_encode_with_state"); }
+int whisper_decode(struct whisper_context*, const whisper_token*, int, int, int) { return unsupported("whisper_decode"); }
+int whisper_decode_with_state(struct whisper_context*, struct whisper_state*, const whisper_token*, int, int, int) { return unsupported("whisper_decode_with_state"); }
+float* whisper_get_logits(struct whisper_context*) { unsupported("whisper_get_logits"); return nullptr; }
+float* whisper_get_logits_from_state(struct whisper_state*) { unsupported("whisper_get_logits_from_state"); return nullptr; }
+
+int whisper_tokenize(struct whisper_context* ctx, const char* text, whisper_token* tokens, int n_max_tokens) {
+    if (!ctx || !text) return -1;
+    const int n = ss_engine_tokenize(ctx->eng, text, tokens, n_max_tokens);
+    if (n < 0) wlog("whisper_tokenize: too many resulting tokens: %d (max %d)\n", -n, n_max_tokens);
+    return n;
+}
+int whisper_lang_max_id(void) { return 99; }
+int whisper_lang_id(const char* lang) {
+    if (!lang) return -1;
+    const int id = ss::lang_id(lang);
+    if (id >= 0) return id;
+    static const char* const full[] = {"english","chinese","german","spanish","russian","korean","french","japanese","portuguese","turkish","polish","catalan","dutch",
+        "arabic","swedish","italian","indonesian","hindi","finnish","vietnamese","hebrew","ukrainian","greek","malay","czech","romanian","danish","hungarian","tamil",
+        "norwegian","thai","urdu","croatian","bulgarian","lithuanian","latin","maori","malayalam","welsh","slovak","telugu","persian","latvian","bengali","serbian",
+        "azerbaijani","slovenian","kannada","estonian","macedonian","breton","basque","icelandic","armenian","nepali","mongolian","bosnian","kazakh","albanian",
+        "swahili","galician","marathi","punjabi","sinhala","khmer","shona","yoruba","somali","afrikaans","occitan","georgian","belarusian","tajik","sindhi","gujarati",
+        "amharic","yiddish","lao","uzbek","faroese","haitian creole","pashto","turkmen","nynorsk","maltese","sanskrit","luxembourgish","myanmar","tibetan","tagalog",
+        "malagasy","assamese","tatar","hawaiian","lingala","hausa","bashkir","javanese","sundanese","cantonese"};
+    for (int i = 0; i < 100; i++) if (!strcmp(lang, full[i])) return i;     // whisper_lang_id also accepts the full names
+    wlog("whisper_lang_id: unknown language '%s'\n", lang);
+    return -1;
+}
+const char* whisper_lang_str(int id) {
+    const char* c = ss::lang_code(id);
+    if (!c) wlog("whisper_lang_str: unknown language id %d\n", id);
+    return c;
+}
+const char* whisper_lang_str_full(int id) {
+    static const char* const full[] = {"english","chinese","german","spanish","russian","korean","french","japanese","portuguese","turkish","polish","catalan","dutch",
+        "arabic","swedish","italian","indonesian","hindi","finnish","vietnamese","hebrew","ukrainian","greek","malay","czech","romanian","danish","hungarian","tamil",
+        "norwegian","thai","urdu","croatian","bulgarian","lithuanian","latin","maori","malayalam","welsh","slovak","telugu","persian","latvian","bengali","serbian",
+        "azerbaijani","slovenian","kannada","estonian","macedonian","breton","basque","icelandic","armenian","nepali","mongolian","bosnian","kazakh","albanian",
+        "swahili","galician","marathi","punjabi","sinhala","khmer","shona","yoruba","somali","afrikaans","occitan","georgian","belarusian","tajik","sindhi","gujarati",
+        "amharic","yiddish","lao","uzbek","faroese","haitian creole","pashto","turkmen","nynorsk","maltese","sanskrit","luxembourgish","myanmar","tibetan","tagalog",
+        "malagasy","assamese","tatar","hawaiian","lingala","hausa","bashkir","javanese","sundanese","cantonese"};
+    if (id < 0 || id >= 100) { wlog("whisper_lang_str_full: unknown language id %d\n", id); return nullptr; }
+    return full[id];
+}
+int whisper_lang_auto_detect_with_state(struct whisper_context* ctx, struct whisper_state* state, int offset_ms, int, float* lang_probs) {
+    if (!ctx || !state) return -1;
+    if (offset_ms < 0) { wlog("whisper_lang_auto_detect: offset %dms is before the start of the audio\n", offset_ms); return -1; }
+    if (state->pcm.empty()) { wlog("whisper_lang_auto_detect: no samples (call whisper_pcm_to_mel first; a mel set with whisper_set_mel cannot be used)\n"); return -2; }
+    if (offset_ms != 0) { wlog("whisper_lang_auto_detect: only offset_ms = 0 is supported\n"); return -2; }
+    ss_params p;
+    ss_default_params(&p);
+    p.detect_language = 1;
+    const int rc = ss_transcribe(state->ses, state->pcm.data(), (int)state->pcm.size(), &p);
+    if (rc != SS_OK) { wlog("whisper_lang_auto_detect: %s\n", ss_last_error()); return rc == SS_ERR_LANG ? -2 : -6; }
+    const int id = ss_result_lang_id(state->ses);
+    if (lang_probs) { for (int i = 0; i <= whisper_lang_max_id(); i++) lang_probs[i] = 0.0f; if (id >= 0) lang_probs[id] = 1.0f; }
+    return id;
+}
+int whisper_lang_auto_detect(struct whisper_context* ctx, int offset_ms, int n_threads, float* lang_probs) {
+    return whisper_lang_auto_detect_with_state(ctx, dstate(ctx), offset_ms, n_threads, lang_probs);
+}
+
+int whisper_n_len_from_state(struct whisper_state* state) { return state ? state->n_len : 0; }
+int whisper_n_len(struct whisper_context* ctx) { return ctx && ctx->default_state ? ctx->default_state->n_len : 0; }
+int whisper_n_vocab(struct whisper_context* ctx) { return hp(ctx, 0); }
+int whisper_n_audio_ctx(struct whisper_context* ctx) { return hp(ctx, 1); }
+int whisper_n_text_ctx(struct whisper_context* ctx) { return hp(ctx, 5); }
+int whisper_is_multilingual(struct whisper_context* ctx) { return hp(ctx, 0) >= 51865; }
+int whisper_model_n_vocab(struct whisper_context* ctx) { return hp(ctx, 0); }
+int whisper_model_n_audio_ctx(struct whisper_context* ctx) { return hp(ctx, 1); }
+int whisper_model_n_audio_state(struct whisper_context* ctx) { return hp(ctx, 2); }
+int whisper_model_n_audio_head(struct whisper_context* ctx) { return hp(ctx, 3); }
+int whisper_model_n_audio_layer(struct whisper_context* ctx) { return hp(ctx, 4); }
+int whisper_model_n_text_ctx(struct whisper_context* ctx) { return hp(ctx, 5); }
+int whisper_model_n_text_state(struct whisper_context* ctx) { return hp(ctx, 6); }
+int whisper_model_n_text_head(struct whisper_context* ctx) { return hp(ctx, 7); }
+int whisper_model_n_text_layer(struct whisper_context* ctx) { return hp(ctx, 8); }
+int whisper_model_n_mels(struct whisper_context* ctx) { return hp(ctx, 9); }
+int whisper_model_ftype(struct whisper_context* ctx) { return hp(ctx, 10); }
+int whisper_model_type(struct whisper_context* ctx) {   // e_model: by n_audio_layer, as whisper_model_load does
+    switch (hp(ctx, 4)) { case 4: return 1; case 6: return 2; case 12: return 3; case 24: return 4; case 32: return 5; default: return 0; }
+}
+const char* whisper_model_type_readable(struct whisper_context* ctx) {
+    static const char* const names[] = {"unknown", "tiny", "base", "small", "medium", "large"};
+    return names[whisper_model_type(ctx)];
+}
+
+const char* whisper_token_to_str(struct whisper_context* ctx, whisper_token token) { return ctx ? ss_engine_token_str(ctx->eng, token) : nullptr; }
+whisper_token whisper_token_eot(struct whisper_context* ctx) { return sp(ctx, 0); }
+whisper_token whisper_token_sot(struct whisper_context* ctx) { return sp(ctx, 1); }
+whisper_token whisper_token_translate(struct whisper_context* ctx) { return sp(ctx, 2); }
+whisper_token whisper_token_transcribe(struct whisper_context* ctx) { return sp(ctx, 3); }
+whisper_token whisper_token_solm(struct whisper_context* ctx) { return sp(ctx, 4); }
+whisper_token whisper_token_prev(struct whisper_context* ctx) { return sp(ctx, 5); }
+whisper_token whisper_token_nosp(struct whisper_context* ctx) { return sp(ctx, 6); }
+whisper_token whisper_token_not(struct whisper_context* ctx) { return sp(ctx, 7); }
+whisper_token whisper_token_beg(struct whisper_context* ctx) { return sp(ctx, 8); }
+whisper_token whisper_token_lang(struct whisper_context* ctx, int lang_id) { return sp(ctx, 1) + 1 + lang_id; }
+
+void whisper_print_timings(struct whisper_context* ctx) {
+    if (!ctx) return;
+    double ms[4] = {0, 0, 0, 0};
+    int64_t cnt[4] = {0, 0, 0, 0};
+    int32_t nl = 0;
+    if (ss_engine_totals(ctx->eng, ms, cnt, &nl) != SS_OK) return;
+    wlog("whisper_print_timings: device time since load over %d lane(s): mel %.2f ms, encode %.2f ms (%lld windows), decode %.2f ms (%lld passes, %lld rows)\n",
+         nl, ms[0], ms[1], (long long)cnt[2], ms[2], (long long)cnt[0], (long long)cnt[1]);
+}
+void whisper_reset_timings(struct whisper_context*) {}   // the totals are cumulative; callers take differences
+const char* whisper_print_system_info(void) { return "HIP = 1 | MI355X (gfx950) = 1 | MFMA f16/bf16 = 1 | CPU fallback = 0 | "; }
+void whisper_log_set(ggml_log_callback log_callback, void* user_data) { g_log_cb = log_callback; g_log_ud = user_data; }
+
+// ---- whisper_full ---------------------------------------------------------------------------------------------------------------------
 struct whisper_full_params whisper_full_default_params(enum whisper_sampling_strategy strategy) {
     whisper_full_params p;
     memset(&p, 0, sizeof(p));
@@ -90,10 +327,14 @@ struct whisper_full_params whisper_full_default_params(enum whisper_sampling_str
     p.grammar_penalty = 100.0f;
     return p;
 }
+struct whisper_full_params* whisper_full_default_params_by_ref(enum whisper_sampling_strategy strategy) {
+    whisper_full_params* p = (whisper_full_params*)malloc(sizeof(whisper_full_params));
+    *p = whisper_full_default_params(strategy);
+    return p;
+}
 
-int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* state, struct whisper_full_params params, const float* samples,
-                            int n_samples) {
-    if (!ctx || !state) return -1;
+// whisper_full_params -> ss_params; returns SS_OK or the refusal
+static int map_params(struct whisper_context* ctx, const struct whisper_full_params& params, ss_params& p) {
     // features of whisper_full this path does not implement are refused, never silently ignored
     if (params.strategy != WHISPER_SAMPLING_GREEDY || params.speed_up || params.suppress_non_speech_tokens || params.n_grammar_rules > 0 ||
         params.logits_filter_callback || params.max_len > 0)
@@ -102,7 +343,6 @@ int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* s
     // only act together with max_len > 0, refused above.
     if (params.new_segment_callback || params.progress_callback || params.encoder_begin_callback || params.abort_callback) return SS_ERR_UNSUPPORTED;
     if (params.audio_ctx != 0 && params.audio_ctx != whisper_n_audio_ctx(ctx)) return SS_ERR_UNSUPPORTED;
-    ss_params p;
     ss_default_params(&p);
     p.best_of = params.greedy.best_of > 0 ? params.greedy.best_of : 1;
     p.temperature = params.temperature; p.temperature_inc = params.temperature_inc; p.entropy_thold = params.entropy_thold;
@@ -115,15 +355,57 @@ int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* s
     p.n_max_text_ctx = params.n_max_text_ctx; p.offset_ms = params.offset_ms; p.duration_ms = params.duration_ms;
     p.detect_language = params.detect_language;
     p.prompt_tokens = params.prompt_tokens; p.prompt_n_tokens = params.prompt_n_tokens; p.initial_prompt = params.initial_prompt;
+    return SS_OK;
+}
+
+int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* state, struct whisper_full_params params, const float* samples,
+                            int n_samples) {
+    if (!ctx || !state) return -1;
+    ss_params p;
+    int rc = map_params(ctx, params, p);
+    if (rc != SS_OK) return rc;
     ss_ticket* t = nullptr;
-    int rc = ss_submit(state->ses, samples, n_samples, &p, &t);
+    rc = ss_submit(state->ses, samples, n_samples, &p, &t);
     if (rc != SS_OK) return rc;
     return ss_wait(t);
 }
 int whisper_full(struct whisper_context* ctx, struct whisper_full_params params, const float* samples, int n_samples) {
     if (!ctx) return -1;
-    if (!ctx->default_state) ctx->default_state = whisper_init_state(ctx);
-    return whisper_full_with_state(ctx, ctx->default_state, params, samples, n_samples);
+    return whisper_full_with_state(ctx, dstate(ctx), params, samples, n_samples);
+}
+int whisper_full_parallel(struct whisper_context* ctx, struct whisper_full_params params, const float* samples, int n_samples, int n_processors) {
+    if (!ctx) return -1;
+    if (n_processors <= 1) return whisper_full(ctx, params, samples, n_samples);
+    // whisper.cpp: chunk 0 = [0, offset + per) on the context's own state with the caller's offset, chunks 1.. = per samples each on fresh
+    // states with offset 0, the last one taking the remainder; results appended with their time offset, start times clamped to the previous end
+    const int offset_samples = (16000 * params.offset_ms) / 1000;
+    const int per = (n_samples - offset_samples) / n_processors;
+    if (per <= 0) return whisper_full(ctx, params, samples, n_samples);
+    ss_params p0;
+    int rc = map_params(ctx, params, p0);
+    if (rc != SS_OK) return rc;
+    ss_params pi = p0;
+    pi.offset_ms = 0;
+    whisper_state* st0 = dstate(ctx);
+    std::vector<ss_session*> extra;
+    std::vector<ss_ticket*> tickets(n_processors, nullptr);
+    rc = ss_submit(st0->ses, samples, offset_samples + per, &p0, &tickets[0]);
+    for (int i = 0; rc == SS_OK && i < n_processors - 1; i++) {
+        const int start = offset_samples + (i + 1) * per;
+        const int n_cur = (i + 1 == n_processors - 1) ? n_samples - start : per;
+        ss_session* s = ss_session_create(ctx->eng);
+        extra.push_back(s);
+        rc = s ? ss_submit(s, samples + start, n_cur, &pi, &tickets[i + 1]) : SS_ERR_ARG;
+    }
+    int ret = rc;
+    for (int i = 0; i < n_processors; i++) if (tickets[i]) { const int r = ss_wait(tickets[i]); if (r != SS_OK && ret == SS_OK) ret = r; }
+    if (ret == SS_OK) {
+        const int64_t offset_t = (int64_t)params.offset_ms / 10;
+        for (size_t i = 0; i < extra.size(); i++)
+            ss_result_append(st0->ses, extra[i], 100 * ((int64_t)(i + 1) * per) / 16000 + offset_t);
+    }
+    for (ss_session* s : extra) ss_session_free(s);
+    return ret;
 }
 
 int whisper_full_n_segments_from_state(struct whisper_state* state) { return state ? ss_result_n_segments(state->ses) : 0; }
@@ -133,31 +415,48 @@ int64_t whisper_full_get_segment_t1_from_state(struct whisper_state* state, int 
 bool whisper_full_get_segment_speaker_turn_next_from_state(struct whisper_state* state, int i) {
     return state ? ss_result_segment_speaker_turn_next(state->ses, i) != 0 : false;
 }
+int whisper_full_lang_id_from_state(struct whisper_state* state) { return state ? ss_result_lang_id(state->ses) : -1; }
+int whisper_full_n_tokens_from_state(struct whisper_state* state, int i) { return state ? ss_result_segment_n_tokens(state->ses, i) : 0; }
+whisper_token_data whisper_full_get_token_data_from_state(struct whisper_state* state, int i, int k) {
+    whisper_token_data d;
+    memset(&d, 0, sizeof(d));
+    d.t0 = d.t1 = -1;
+    float f[4] = {0, 0, 0, 0};
+    if (state && ss_result_segment_token(state->ses, i, k, &d.id, &d.tid, f) == SS_OK) { d.p = f[0]; d.plog = f[1]; d.pt = f[2]; d.ptsum = f[3]; }
+    return d;
+}
+whisper_token whisper_full_get_token_id_from_state(struct whisper_state* state, int i, int k) { return whisper_full_get_token_data_from_state(state, i, k).id; }
+float whisper_full_get_token_p_from_state(struct whisper_state* state, int i, int k) { return whisper_full_get_token_data_from_state(state, i, k).p; }
+const char* whisper_full_get_token_text_from_state(struct whisper_context* ctx, struct whisper_state* state, int i, int k) {
+    if (!ctx || !state) return nullptr;
+    return ss_engine_token_str(ctx->eng, whisper_full_get_token_id_from_state(state, i, k));
+}
+
 int whisper_full_n_segments(struct whisper_context* ctx) { return ctx && ctx->default_state ? whisper_full_n_segments_from_state(ctx->default_state) : 0; }
+int whisper_full_lang_id(struct whisper_context* ctx) { return ctx && ctx->default_state ? whisper_full_lang_id_from_state(ctx->default_state) : -1; }
 const char* whisper_full_get_segment_text(struct whisper_context* ctx, int i) {
     return ctx && ctx->default_state ? whisper_full_get_segment_text_from_state(ctx->default_state, i) : nullptr;
 }
 int64_t whisper_full_get_segment_t0(struct whisper_context* ctx, int i) { return ctx && ctx->default_state ? whisper_full_get_segment_t0_from_state(ctx->default_state, i) : 0; }
 int64_t whisper_full_get_segment_t1(struct whisper_context* ctx, int i) { return ctx && ctx->default_state ? whisper_full_get_segment_t1_from_state(ctx->default_state, i) : 0; }
+bool whisper_full_get_segment_speaker_turn_next(struct whisper_context* ctx, int i) {
+    return ctx && ctx->default_state ? whisper_full_get_segment_speaker_turn_next_from_state(ctx->default_state, i) : false;
+}
+int whisper_full_n_tokens(struct whisper_context* ctx, int i) { return ctx && ctx->default_state ? whisper_full_n_tokens_from_state(ctx->default_state, i) : 0; }
+const char* whisper_full_get_token_text(struct whisper_context* ctx, int i, int k) {
+    return ctx && ctx->default_state ? whisper_full_get_token_text_from_state(ctx, ctx->default_state, i, k) : nullptr;
+}
+whisper_token whisper_full_get_token_id(struct whisper_context* ctx, int i, int k) {
+    return ctx && ctx->default_state ? whisper_full_get_token_id_from_state(ctx->default_state, i, k) : 0;
+}
+whisper_token_data whisper_full_get_token_data(struct whisper_context* ctx, int i, int k) {
+    return whisper_full_get_token_data_from_state(ctx ? ctx->default_state : nullptr, i, k);
+}
+float whisper_full_get_token_p(struct whisper_context* ctx, int i, int k) { return ctx && ctx->default_state ? whisper_full_get_token_p_from_state(ctx->default_state, i, k) : 0.0f; }
 
-static int hp(struct whisper_context* ctx, int idx) {
-    int32_t h[11] = {0};
-    if (!ctx || ss_engine_hparams(ctx->eng, h) != SS_OK) return 0;
-    return h[idx];
-}
-static int sp(struct whisper_context* ctx, int idx) {
-    int32_t t[9] = {0};
-    if (!ctx || ss_engine_special_tokens(ctx->eng, t) != SS_OK) return 0;
-    return t[idx];
-}
-int whisper_n_vocab(struct whisper_context* ctx) { return hp(ctx, 0); }
-int whisper_n_audio_ctx(struct whisper_context* ctx) { return hp(ctx, 1); }
-int whisper_n_text_ctx(struct whisper_context* ctx) { return hp(ctx, 5); }
-int whisper_is_multilingual(struct whisper_context* ctx) { return hp(ctx, 0) >= 51865; }
-whisper_token whisper_token_eot(struct whisper_context* ctx) { return sp(ctx, 0); }
-whisper_token whisper_token_sot(struct whisper_context* ctx) { return sp(ctx, 1); }
-whisper_token whisper_token_beg(struct whisper_context* ctx) { return sp(ctx, 8); }
-const char* whisper_token_to_str(struct whisper_context* ctx, whisper_token token) { return ctx ? ss_engine_token_str(ctx->eng, token) : nullptr; }
-int whisper_lang_id(const char* lang) { return lang ? ss::lang_id(lang) : -1; }
+int whisper_bench_memcpy(int) { return unsupported("whisper_bench_memcpy"); }
+const char* whisper_bench_memcpy_str(int) { return "whisper_bench_memcpy: ggml CPU benchmark, not part of the MI355X engine\n"; }
+int whisper_bench_ggml_mul_mat(int) { return unsupported("whisper_bench_ggml_mul_mat"); }
+const char* whisper_bench_ggml_mul_mat_str(int) { return "whisper_bench_ggml_mul_mat: ggml CPU benchmark, not part of the MI355X engine\n"; }
 
 }  // extern "C"

@@ -1,9 +1,17 @@
 //! `src/asr/hip.rs` -- SOURCE ONLY (the build image has no Rust toolchain).
 //! A native `AsrEngine` over libspeaksense_hip.so that replaces `WhisperAsr` (/root/reference/src/asr/whisper.rs)
 //! keeping its parameter mapping (whisper.rs:131-173, 60-71) and post-processing (whisper.rs:41-43, 77-128, 175-201).
-use crate::asr::{AsrParams, TranscribeResult, TranscribeSegment};
+//!
+//! Wiring (three one-line edits, the ones SURVEY.md section 8b names):
+//!   src/asr/mod.rs:4                         `use whisper_rs::WhisperState;`  ->  `use crate::asr::hip::WhisperState;`   (+ `pub mod hip;`)
+//!   src/schedule/processors/transcribe.rs:8  the same import; `:23,27` `Arc<WhisperAsr>` -> `Arc<HipAsr>`
+//!   src/main.rs:38-39                        `WhisperAsr::new(path)` -> `HipAsr::new(path)`
+//! `WhisperState<'a>` below keeps the NAME and lifetime parameter of whisper_rs::WhisperState, so the trait in mod.rs:58-73 and every
+//! `Arc<Mutex<Box<WhisperState<'static>>>>` in the gRPC handler (grpc/handlers/asr.rs:20-22,164) compile unchanged.
+use crate::asr::{AsrEngine, AsrParams, TranscribeResult, TranscribeSegment};
 use anyhow::{anyhow, Result};
 use std::ffi::{CStr, CString};
+use std::marker::PhantomData;
 use std::os::raw::{c_char, c_int};
 use std::sync::{Arc, Mutex};
 
@@ -11,14 +19,17 @@ use std::sync::{Arc, Mutex};
 #[repr(C)] pub struct ss_session { _p: [u8; 0] }
 #[repr(C)] pub struct ss_ticket { _p: [u8; 0] }
 #[repr(C)] #[derive(Default)]
-pub struct ss_engine_opts { pub device: i32, pub dtype: i32, pub max_batch: i32, pub max_decoders: i32, pub batch_wait_us: i32, pub reserved: [i32; 3] }
+pub struct ss_engine_opts { pub device: i32, pub dtype: i32, pub max_batch: i32, pub max_decoders: i32, pub batch_wait_us: i32, pub n_lanes: i32, pub reserved: [i32; 2] }
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct ss_params {
     pub best_of: i32, pub temperature: f32, pub temperature_inc: f32, pub entropy_thold: f32, pub logprob_thold: f32,
     pub max_initial_ts: f32, pub length_penalty: f32, pub no_context: i32, pub single_segment: i32, pub no_timestamps: i32,
     pub suppress_blank: i32, pub tdrz_enable: i32, pub print_special: i32, pub max_tokens: i32, pub audio_ctx: i32,
     pub translate: i32, pub fixed_steps: i32, pub language: [u8; 8],
-}
+    pub n_max_text_ctx: i32, pub offset_ms: i32, pub duration_ms: i32, pub detect_language: i32,
+    pub prompt_tokens: *const i32, pub prompt_n_tokens: i32, pub reserved0: i32, pub initial_prompt: *const c_char,
+}   // layout: tests/golden/abi_layout.txt (offsets checked against the C header by tests/test_host_cpu.py)
+unsafe impl Send for ss_params {}
 
 #[link(name = "speaksense_hip")]
 extern "C" {
@@ -39,9 +50,11 @@ extern "C" {
 
 fn last_error() -> String { unsafe { CStr::from_ptr(ss_last_error()).to_string_lossy().into_owned() } }
 
-pub struct HipSession(*mut ss_session);
-unsafe impl Send for HipSession {}
-impl Drop for HipSession { fn drop(&mut self) { unsafe { ss_session_free(self.0) } } }
+/// Stands where `whisper_rs::WhisperState<'a>` stood (the trait leaks that type, mod.rs:4,60,64): a session of the HIP engine.
+pub struct WhisperState<'a> { raw: *mut ss_session, _ctx: PhantomData<&'a ()> }
+unsafe impl<'a> Send for WhisperState<'a> {}
+impl<'a> Drop for WhisperState<'a> { fn drop(&mut self) { unsafe { ss_session_free(self.raw) } } }
+pub type HipSession = WhisperState<'static>;
 
 struct EnginePtr(*mut ss_engine);
 unsafe impl Send for EnginePtr {}
@@ -60,7 +73,7 @@ pub struct HipAsr { engine: Arc<EnginePtr> }
 impl HipAsr {
     pub fn new(model_path: String) -> Result<Self> {
         let path = CString::new(model_path)?;
-        let opts = ss_engine_opts { device: 0, dtype: 1 /* f16 */, max_batch: 8, max_decoders: 5, batch_wait_us: 2000, reserved: [0; 3] };
+        let opts = ss_engine_opts { device: 0, dtype: 1 /* f16 */, max_batch: 8, max_decoders: 5, batch_wait_us: 2000, n_lanes: 2, reserved: [0; 2] };
         let mut e: *mut ss_engine = std::ptr::null_mut();
         let rc = unsafe { ss_engine_create(path.as_ptr(), &opts, &mut e) };
         if rc != 0 { return Err(anyhow!("failed to open whisper model: {}", last_error())); }
@@ -70,7 +83,7 @@ impl HipAsr {
     pub fn create_state(&self) -> Result<Arc<Mutex<Box<HipSession>>>> {
         let s = unsafe { ss_session_create(self.engine.0) };
         if s.is_null() { return Err(anyhow!("Failed to create whisper state")); }
-        Ok(Arc::new(Mutex::new(Box::new(HipSession(s)))))
+        Ok(Arc::new(Mutex::new(Box::new(WhisperState { raw: s, _ctx: PhantomData }))))
     }
 
     fn build_params(&self, ap: &AsrParams) -> ss_params {
@@ -105,7 +118,7 @@ impl HipAsr {
         // the GPU call never runs on a tokio worker: submit is non-blocking, wait happens on the blocking pool
         tokio::task::spawn_blocking(move || -> Result<TranscribeResult> {
             let guard = state.lock().map_err(|e| anyhow!("Failed to lock state: {}", e))?;
-            let s = guard.0;
+            let s = guard.raw;
             let mut t: *mut ss_ticket = std::ptr::null_mut();
             let rc = unsafe { ss_submit(s, audio.as_ptr(), audio.len() as i32, &p, &mut t) };
             if rc != 0 { return Err(anyhow!("submit failed: {}", last_error())); }
@@ -125,5 +138,27 @@ impl HipAsr {
             }
             Ok(TranscribeResult { segments, full_text })
         }).await?
+    }
+}
+
+// The trait the callers hold (`Arc<dyn AsrEngine>`, grpc/handlers/asr.rs:20-22,63-66): same three methods, same defaults (mod.rs:58-73).
+#[async_trait::async_trait]
+impl AsrEngine for HipAsr {
+    fn create_state(&self) -> Result<Arc<Mutex<Box<WhisperState<'static>>>>> {
+        HipAsr::create_state(self)
+    }
+
+    async fn transcribe_with_state(
+        &self,
+        state: Arc<Mutex<Box<WhisperState<'static>>>>,
+        audio: Vec<f32>,
+        params: AsrParams,
+    ) -> Result<TranscribeResult> {
+        HipAsr::transcribe_with_state(self, state, audio, params).await
+    }
+
+    async fn transcribe(&self, audio: Vec<f32>, params: AsrParams) -> Result<TranscribeResult> {
+        let state = HipAsr::create_state(self)?;
+        HipAsr::transcribe_with_state(self, state, audio, params).await
     }
 }

@@ -100,5 +100,121 @@ def main():
     print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# round 2: more shapes (128 mels + multilingual vocabulary, the real tiny.en, large-v3's width) and the logits RULES
+# ------------------------------------------------------------------------------------------------------------------------------------
+SHAPES = {"toy": 11, "tiny.en": 12, "wide2": 13}        # preset -> model seed
+
+
+def hf_model_for(hp, tensors):
+    cfg = WhisperConfig(vocab_size=hp.n_vocab, num_mel_bins=hp.n_mels, d_model=hp.n_audio_state, encoder_layers=hp.n_audio_layer,
+                        encoder_attention_heads=hp.n_audio_head, decoder_layers=hp.n_text_layer, decoder_attention_heads=hp.n_text_head,
+                        encoder_ffn_dim=4 * hp.n_audio_state, decoder_ffn_dim=4 * hp.n_text_state, max_source_positions=hp.n_audio_ctx,
+                        max_target_positions=hp.n_text_ctx, activation_function="gelu", dropout=0.0, attention_dropout=0.0,
+                        activation_dropout=0.0)
+    model = WhisperForConditionalGeneration(cfg).eval()
+    missing, unexpected = model.load_state_dict(ggml_to_hf_state(hp, tensors), strict=False)
+    assert not unexpected, unexpected
+    assert all("k_proj.bias" in m for m in missing) or not missing, missing
+    return model
+
+
+def shapes_fixture():
+    """Encoder rows + per-step top-16 logits of HF Whisper on the seeded `toy` / `tiny.en` / `wide2` models.  The encoder input is the
+    ORACLE's own whisper.cpp-style log-mel of the seeded audio (frames [0, 3000)), rounded to f16 so both sides see the same numbers; the
+    test recomputes it, nothing but the outputs is stored.  For the 128-bin filterbank the HF feature extractor's mel is stored too."""
+    from oracle import binding as orc
+    out = {}
+    tmp = tempfile.mkdtemp()
+    for name, seed in SHAPES.items():
+        path = os.path.join(tmp, f"{name}.bin")
+        ggml_io.write_model(path, name, seed=seed)
+        hp, filt, vocab, tensors = ggml_io.read_model(path)
+        model = hf_model_for(hp, tensors)
+        om = orc.OracleModel(path)
+        pcm = synth.speech_like(SEED_AUDIO + 1)
+        mel = om.log_mel(pcm)[:, :3000].astype(np.float16).astype(np.float32)
+        multilingual = hp.n_vocab >= 51865
+        sot = 50258 if multilingual else 50257
+        beg = om.beg
+        toks = ([sot, sot + 1 + 3, om.transcribe] if multilingual else [sot]) + [beg + 2, 1234, 777, 31000, 42, beg + 40, beg + 40, 9]
+        with torch.no_grad():
+            enc = model.model.encoder(torch.from_numpy(mel)[None]).last_hidden_state[0].numpy()
+            logits = model(encoder_outputs=(torch.from_numpy(enc)[None],), decoder_input_ids=torch.tensor([toks])).logits[0].numpy()
+        topk = np.argsort(-logits, axis=1)[:, :16].astype(np.int32)
+        k = name.replace(".", "_")
+        out[f"{k}_seed"] = seed
+        out[f"{k}_tokens"] = np.array(toks, np.int32)
+        out[f"{k}_n_prompt"] = 3 if multilingual else 1
+        out[f"{k}_enc"] = enc[ENC_ROWS].astype(np.float32)
+        out[f"{k}_enc_absmax"] = np.float32(np.abs(enc).max())
+        out[f"{k}_topk"] = topk
+        out[f"{k}_topv"] = np.take_along_axis(logits, topk, axis=1).astype(np.float32)
+        out[f"{k}_logit_std"] = np.float32(logits.std())
+        if name == "toy":     # 128 mel bins: the HF feature extractor on the same audio, sampled columns
+            fe = WhisperFeatureExtractor(feature_size=hp.n_mels)
+            hf_mel = fe(pcm, sampling_rate=16000, return_tensors="np")["input_features"][0].astype(np.float32)
+            out["toy_mel_cols"] = np.arange(0, 2990, 13)
+            out["toy_hf_mel"] = hf_mel[:, 0:2990:13].astype(np.float32)
+        om.close()
+        print(name, "enc absmax", float(np.abs(enc).max()), "logit std", float(logits.std()))
+    out["seed_audio"] = SEED_AUDIO + 1
+    out["enc_rows"] = np.array(ENC_ROWS)
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_shapes_golden.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from tests_golden_cases import rule_cases, rule_logits  # noqa: E402  (the same seeded cases the test replays)
+
+
+def rules_fixture():
+    """OpenAI's decoding rules as HF transformers implements them (SuppressTokens*, WhisperTimeStampLogitsProcessor) on seeded logits x token
+    histories, for both vocabularies.  Stored per case: the -inf mask (packed bits) and the processed scores' log-softmax at the 24 most
+    likely surviving tokens.  whisper.cpp restates the same rules with three documented differences (tests/test_oracle_golden.py)."""
+    from transformers import GenerationConfig
+    from transformers.generation.logits_process import SuppressTokensAtBeginLogitsProcessor, SuppressTokensLogitsProcessor, WhisperTimeStampLogitsProcessor
+    out = {}
+    for tag, n_vocab in (("en", 51864), ("ml", 51866)):
+        multilingual = n_vocab >= 51865
+        eot = 50257 if multilingual else 50256
+        sot = eot + 1
+        n_lang = n_vocab - 51765 - (1 if multilingual else 0)
+        dt = n_lang - 98 if multilingual else 0
+        translate, transcribe, solm, prev, nosp, not_, beg = [x + dt for x in (50357, 50358, 50359, 50360, 50361, 50362, 50363)]   # whisper.cpp's vocab offsets
+        prompt = [sot, sot + 1, transcribe] if multilingual else [sot]
+        gc = GenerationConfig(eos_token_id=eot, no_timestamps_token_id=not_, max_initial_timestamp_index=50)
+        procs = [SuppressTokensLogitsProcessor([sot, nosp, solm, translate, transcribe, prev] + [sot + 1 + i for i in range(n_lang)]),
+                 SuppressTokensAtBeginLogitsProcessor([220, eot], len(prompt)),
+                 WhisperTimeStampLogitsProcessor(gc, len(prompt), _detect_timestamp_from_logprob=True)]
+        rng = np.random.default_rng(1234 + n_vocab)
+        masks, tops, topv = [], [], []
+        for hist, trial in rule_cases(beg, eot):
+            raw = rule_logits(rng, n_vocab, beg, eot, trial)
+            ids = torch.tensor([prompt + hist])
+            sc = torch.from_numpy(raw)[None].clone()
+            for pr in procs:
+                sc = pr(ids, sc)
+            lp = torch.log_softmax(sc.float(), dim=-1)[0].numpy()
+            masks.append(np.packbits(np.isinf(lp)))
+            order = np.argsort(-lp)[:24].astype(np.int32)
+            tops.append(order)
+            topv.append(lp[order].astype(np.float32))
+        out[f"{tag}_mask"] = np.stack(masks)
+        out[f"{tag}_top"] = np.stack(tops)
+        out[f"{tag}_topv"] = np.stack(topv)
+        out[f"{tag}_n_vocab"] = n_vocab
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_rules_golden.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    which = sys.argv[1:] or ["toy", "shapes", "rules"]
+    if "toy" in which:
+        main()
+    if "shapes" in which:
+        shapes_fixture()
+    if "rules" in which:
+        rules_fixture()

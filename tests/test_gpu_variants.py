@@ -329,3 +329,117 @@ def test_pool_two_engines_on_one_gpu(toy_ml_path):
         assert list(a["tokens"]) == list(b["tokens"])
     assert sorted(s.last_engine() for s in ses) == [0] * 4 + [1] * 4
     pool.close(); single.close()
+
+
+class WTokenData(C.Structure):
+    _fields_ = [("id", C.c_int32), ("tid", C.c_int32), ("p", C.c_float), ("plog", C.c_float), ("pt", C.c_float), ("ptsum", C.c_float),
+                ("t0", C.c_int64), ("t1", C.c_int64), ("vlen", C.c_float)]
+
+
+def test_whisper_h_full_surface(toy_ml_path, eng, monkeypatch):
+    """The rest of whisper.h v1.5.4 (what whisper-rs can reach beyond the reference's call sites): model / token getters, whisper_tokenize,
+    language helpers and detection, per-token results, whisper_full_parallel; the low-level encode/decode entry points refuse with an error
+    code instead of aborting."""
+    from speaksense_amd import binding
+    monkeypatch.setenv("SS_DTYPE", "f16")
+    monkeypatch.setenv("SS_MAX_BATCH", "4")
+    L = C.CDLL(binding.LIB_PATH)
+    vp = C.c_void_p
+    L.whisper_init_from_file.restype = vp
+    L.whisper_init_from_file.argtypes = [C.c_char_p]
+    L.whisper_init_state.restype = vp
+    L.whisper_init_state.argtypes = [vp]
+    L.whisper_full_default_params.restype = WFullParams
+    L.whisper_full_default_params.argtypes = [C.c_int]
+    L.whisper_full_with_state.argtypes = [vp, vp, WFullParams, vp, C.c_int]
+    L.whisper_full_parallel.argtypes = [vp, WFullParams, vp, C.c_int, C.c_int]
+    L.whisper_full.argtypes = [vp, WFullParams, vp, C.c_int]
+    for f in ("whisper_model_n_vocab", "whisper_model_n_mels", "whisper_model_n_audio_layer", "whisper_model_n_text_state", "whisper_model_type", "whisper_n_len",
+              "whisper_token_transcribe", "whisper_token_solm", "whisper_token_not", "whisper_full_n_segments", "whisper_full_lang_id"):
+        getattr(L, f).argtypes = [vp]
+    L.whisper_token_lang.argtypes = [vp, C.c_int]
+    L.whisper_model_type_readable.restype = C.c_char_p
+    L.whisper_model_type_readable.argtypes = [vp]
+    L.whisper_lang_id.argtypes = [C.c_char_p]
+    L.whisper_lang_str.restype = C.c_char_p
+    L.whisper_lang_str_full.restype = C.c_char_p
+    L.whisper_tokenize.argtypes = [vp, C.c_char_p, vp, C.c_int]
+    L.whisper_full_n_segments_from_state.argtypes = [vp]
+    L.whisper_full_n_tokens_from_state.argtypes = [vp, C.c_int]
+    L.whisper_full_get_token_id_from_state.argtypes = [vp, C.c_int, C.c_int]
+    L.whisper_full_get_token_data_from_state.restype = WTokenData
+    L.whisper_full_get_token_data_from_state.argtypes = [vp, C.c_int, C.c_int]
+    L.whisper_full_get_token_text_from_state.restype = C.c_char_p
+    L.whisper_full_get_token_text_from_state.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.whisper_full_lang_id_from_state.argtypes = [vp]
+    L.whisper_full_get_segment_t0.restype = C.c_int64
+    L.whisper_full_get_segment_t0.argtypes = [vp, C.c_int]
+    L.whisper_full_get_segment_t1.restype = C.c_int64
+    L.whisper_full_get_segment_t1.argtypes = [vp, C.c_int]
+    L.whisper_full_get_segment_text.restype = C.c_char_p
+    L.whisper_full_get_segment_text.argtypes = [vp, C.c_int]
+    L.whisper_pcm_to_mel_with_state.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+    L.whisper_n_len_from_state.argtypes = [vp]
+    L.whisper_lang_auto_detect_with_state.argtypes = [vp, vp, C.c_int, C.c_int, vp]
+    L.whisper_encode_with_state.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.whisper_get_logits_from_state.restype = vp
+    L.whisper_get_logits_from_state.argtypes = [vp]
+    L.whisper_free_state.argtypes = [vp]
+    L.whisper_free.argtypes = [vp]
+
+    ctx = L.whisper_init_from_file(toy_ml_path.encode())          # with a default state
+    assert ctx
+    assert (L.whisper_model_n_vocab(ctx), L.whisper_model_n_mels(ctx), L.whisper_model_n_audio_layer(ctx), L.whisper_model_n_text_state(ctx)) == (eng.n_vocab, 128, 2, 128)
+    assert L.whisper_token_transcribe(ctx) == eng.transcribe and L.whisper_token_solm(ctx) == eng.solm and L.whisper_token_not(ctx) == eng.not_
+    assert L.whisper_token_lang(ctx, 1) == eng.sot + 2
+    assert L.whisper_lang_id(b"zh") == 1 and L.whisper_lang_id(b"chinese") == 1 and L.whisper_lang_id(b"klingon") == -1
+    assert L.whisper_lang_str(7) == b"ja" and L.whisper_lang_str_full(7) == b"japanese" and L.whisper_lang_max_id() == 99
+    text = b" " + eng.token_str(1300) + eng.token_str(2222)
+    buf = (C.c_int32 * 64)()
+    n = L.whisper_tokenize(ctx, text, buf, 64)
+    assert list(buf[:n]) == eng.tokenize(text) and L.whisper_tokenize(ctx, text, buf, 1) == -n
+
+    st = L.whisper_init_state(ctx)
+    pcm = synth.speech_like(23, 16000 * 12)
+    p = L.whisper_full_default_params(0)
+    p.language = b"auto"; p.temperature_inc = 0.0
+    assert L.whisper_full_with_state(ctx, st, p, pcm.ctypes.data_as(vp), len(pcm)) == 0
+    ref = eng.new_session().transcribe(pcm, binding.default_params(language="auto", temperature_inc=0.0))
+    assert L.whisper_full_lang_id_from_state(st) == ref["lang_id"]
+    n_seg = L.whisper_full_n_segments_from_state(st)
+    assert n_seg == len(ref["segments"]) and n_seg > 0
+    ids = []
+    for i in range(n_seg):
+        for k in range(L.whisper_full_n_tokens_from_state(st, i)):
+            d = L.whisper_full_get_token_data_from_state(st, i, k)
+            assert d.id == L.whisper_full_get_token_id_from_state(st, i, k) and 0.0 < d.p <= 1.0 and d.t0 == -1
+            assert L.whisper_full_get_token_text_from_state(ctx, st, i, k) == eng.token_str(d.id)
+            ids.append(d.id)
+    assert ids == [int(t) for t in ref["tokens"]][:len(ids)] and len(ids) > 0      # segment tokens = the accepted stream (minus a trailing text-less tail)
+
+    # language detection alone, on the samples given to pcm_to_mel
+    assert L.whisper_pcm_to_mel_with_state(ctx, st, pcm.ctypes.data_as(vp), len(pcm), 4) == 0
+    assert L.whisper_n_len_from_state(st) == (len(pcm) + 480000) // 160
+    probs = (C.c_float * 100)()
+    assert L.whisper_lang_auto_detect_with_state(ctx, st, 0, 4, probs) == ref["lang_id"] and probs[ref["lang_id"]] == 1.0
+    # the ggml-graph-level API is refused, not faked
+    assert L.whisper_encode_with_state(ctx, st, 0, 4) == -1 and not L.whisper_get_logits_from_state(st)
+
+    # whisper_full_parallel: two halves as one device batch, merged on the context's default state with whisper.cpp's offset rule
+    long_pcm = synth.speech_like(24, 16000 * 24)
+    q = L.whisper_full_default_params(0)
+    q.language = b"en"; q.temperature_inc = 0.0
+    assert L.whisper_full_parallel(ctx, q, long_pcm.ctypes.data_as(vp), len(long_pcm), 2) == 0
+    half = len(long_pcm) // 2
+    P = binding.default_params(language="en", temperature_inc=0.0)
+    a = eng.new_session().transcribe(long_pcm[:half], P)
+    b = eng.new_session().transcribe(long_pcm[half:], P)
+    want = [(s["t0"], s["t1"], s["text"]) for s in a["segments"]]
+    off = 100 * half // 16000
+    for s in b["segments"]:
+        t0 = max(s["t0"] + off, want[-1][1]) if want else s["t0"] + off
+        want.append((t0, s["t1"] + off, s["text"]))
+    got = [(L.whisper_full_get_segment_t0(ctx, i), L.whisper_full_get_segment_t1(ctx, i), L.whisper_full_get_segment_text(ctx, i)) for i in range(L.whisper_full_n_segments(ctx))]
+    assert got == want and len(got) > len(a["segments"])
+    L.whisper_free_state(st)
+    L.whisper_free(ctx)

@@ -80,3 +80,98 @@ def test_mel_closed_form_cases(gold_model):
     # n_len follows whisper.cpp: (n + 480000 + 400 - 400) / 160
     for n in (16000, 80000, 480000, 481280):
         assert gold_model.log_mel(synth.speech_like(1, n)).shape[1] == (n + 480000) // 160
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# round 2 fixtures: more shapes, and the decoding rules
+# ------------------------------------------------------------------------------------------------------------------------------------
+SHAPES_GOLD = os.path.join(os.path.dirname(__file__), "golden", "hf_shapes_golden.npz")
+RULES_GOLD = os.path.join(os.path.dirname(__file__), "golden", "hf_rules_golden.npz")
+
+
+@pytest.mark.parametrize("name", ["toy", "tiny.en", "wide2"])
+def test_oracle_matches_hf_on_more_shapes(name, model_dir):
+    """128 mel bins + multilingual vocabulary/prompt (toy), the real tiny.en shape, and large-v3's width, head count and vocabulary (wide2):
+    encoder rows and KV-cached decoder logits of the oracle (exact-f32 mode, erf GELU as HF) against HF transformers' Whisper."""
+    g = np.load(SHAPES_GOLD)
+    k = name.replace(".", "_")
+    path = os.path.join(model_dir, f"gold-{name}.bin")
+    ggml_io.write_model(path, name, seed=int(g[f"{k}_seed"]))
+    om = orc.OracleModel(path)
+    pcm = synth.speech_like(int(g["seed_audio"]))
+    full = om.log_mel(pcm)
+    if name == "toy":     # 128-bin filterbank against the HF feature extractor (away from the tail, where whisper.cpp zero-pads)
+        assert full.shape[0] == 128
+        a, b = full[:, g["toy_mel_cols"]], g["toy_hf_mel"]
+        # the clamp floor is (global max - 8): HF's maximum sits in the reflect-padded last frames this path zero-pads, so the two floors differ
+        # by ~1e-3; bins resting on a floor are compared to their own floor, everything above to 2e-4
+        above = (a > a.min() + 2e-3) & (b > b.min() + 2e-3)
+        assert above.mean() > 0.9 and np.abs(a - b)[above].max() < 2e-4
+        assert abs(float(a.min()) - (float(full.max()) - 2.0)) < 1e-6
+    mel = np.zeros_like(full)
+    mel[:, :3000] = full[:, :3000].astype(np.float16).astype(np.float32)
+    enc = om.encode(mel, 0, orc.MODE_F32, gelu_erf=1)
+    err = np.abs(enc[g["enc_rows"]] - g[f"{k}_enc"]).max()
+    assert err < 1e-3 * float(g[f"{k}_enc_absmax"]), err
+    st = om.new_state(orc.MODE_F32, gelu_erf=1)
+    st.set_encoder(enc)
+    toks = [int(t) for t in g[f"{k}_tokens"]]
+    n_prompt = int(g[f"{k}_n_prompt"])
+    tol = 2e-3 * float(g[f"{k}_logit_std"])
+    lg = st.decode(toks[:n_prompt], 0)
+    assert np.abs(lg[g[f"{k}_topk"][n_prompt - 1]] - g[f"{k}_topv"][n_prompt - 1]).max() < tol
+    for i in range(n_prompt, len(toks)):
+        lg = st.decode(toks[i:i + 1], i)
+        assert np.abs(lg[g[f"{k}_topk"][i]] - g[f"{k}_topv"][i]).max() < tol, i
+        assert int(lg.argmax()) == int(g[f"{k}_topk"][i][0])
+    st.close(); om.close()
+
+
+@pytest.mark.parametrize("tag,preset", [("en", "toy.en"), ("ml", "toy")])
+def test_process_logits_matches_openai_rules(tag, preset, model_dir):
+    """whisper_process_logits (oracle restatement) against OpenAI's rules as HF transformers implements them (SuppressTokens*,
+    WhisperTimeStampLogitsProcessor) on seeded logits x 12 token histories x 4 logit shapes, both vocabularies.  The two rule sets coincide
+    except for three things, each excluded explicitly here and nowhere else:
+      1. first step: OpenAI forces a timestamp (all text masked); whisper.cpp v1.5 only applies max_initial_ts -> the text region is not compared;
+      2. monotonic timestamps: whisper.cpp masks ids < last timestamp (tid0 = seek_delta / 2); OpenAI masks <= last unless a pair is open
+         -> the single id == last timestamp is not compared when OpenAI's "+1" branch is active;
+      3. whisper.cpp's has_ts needs id > token_beg, so a history whose only timestamp is <|0.00|> masks nothing -- the same single id as in 2."""
+    from tests_golden_cases import rule_cases, rule_logits
+    g = np.load(RULES_GOLD)
+    path = os.path.join(model_dir, f"rules-{preset}.bin")
+    ggml_io.write_model(path, preset, seed=1)
+    om = orc.OracleModel(path)
+    assert om.n_vocab == int(g[f"{tag}_n_vocab"])
+    beg, eot = om.beg, om.eot
+    st = om.new_state(orc.MODE_F32)
+    rng = np.random.default_rng(1234 + om.n_vocab)
+    P = orc.default_params()
+    n_cmp = 0
+    for ci, (hist, trial) in enumerate(rule_cases(beg, eot)):
+        raw = rule_logits(rng, om.n_vocab, beg, eot, trial)
+        ts = [t for t in hist if t > beg]
+        has_ts = bool(ts)
+        seek_delta = 2 * (ts[-1] - beg) if ts else 3000
+        _, lp, _ = st.process_logits(raw, hist, has_ts, seek_delta, P)
+        mine = np.isinf(lp)
+        gold = np.unpackbits(g[f"{tag}_mask"][ci])[:om.n_vocab].astype(bool)
+        skip = np.zeros(om.n_vocab, bool)
+        if not hist:
+            skip[:beg] = True                                             # difference 1
+        all_ts = [t for t in hist if t >= beg]
+        if all_ts:
+            pair_open = hist[-1] >= beg and not (len(hist) < 2 or hist[-2] >= beg)
+            if not pair_open:
+                skip[all_ts[-1]] = True                                   # differences 2 and 3
+        cmp_ = ~skip
+        assert np.array_equal(mine[cmp_], gold[cmp_]), (tag, hist, trial, np.nonzero(mine[cmp_] != gold[cmp_])[0][:8])
+        # log-probabilities: relative to the most likely compared token (the skipped ids may carry mass that shifts the normaliser)
+        top, topv = g[f"{tag}_top"][ci], g[f"{tag}_topv"][ci]
+        keep = [j for j in range(len(top)) if cmp_[top[j]] and np.isfinite(topv[j])]
+        if hist and keep:
+            j0 = keep[0]
+            for j in keep:
+                assert abs((lp[top[j]] - lp[top[j0]]) - (topv[j] - topv[j0])) < 2e-4 * max(1.0, abs(topv[j] - topv[j0])), (tag, hist, trial, int(top[j]))
+            n_cmp += len(keep)
+    assert n_cmp > 400
+    st.close(); om.close()
