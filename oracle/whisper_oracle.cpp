@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <random>
 #include <regex>
 #include <string>
@@ -135,6 +136,39 @@ struct Model {
     }
 };
 
+
+// ggml block quantisation (QK = 32), dequantised at load: the files of script/download-ggml-model.sh:28-51 (`*-q5_0`, `*-q5_1`) and the other
+// block types whisper.cpp's quantize tool writes.  ttype: 2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0; returns bytes per 32-element block (0 = not quantised)
+static size_t q_block_bytes(int tt) { return tt == 2 ? 18 : tt == 3 ? 20 : tt == 6 ? 22 : tt == 7 ? 24 : tt == 8 ? 34 : 0; }
+static void dequant_block(int tt, const uint8_t* b, float* y, float (*h2f)(uint16_t)) {
+    uint16_t dh, mh = 0;
+    memcpy(&dh, b, 2);
+    const float d = h2f(dh);
+    float m = 0.0f;
+    if (tt == 3 || tt == 7) { memcpy(&mh, b + 2, 2); m = h2f(mh); }
+    if (tt == 8) {                       // q8_0: { f16 d; int8 qs[32] }
+        const int8_t* qs = (const int8_t*)(b + 2);
+        for (int j = 0; j < 32; j++) y[j] = qs[j] * d;
+    } else if (tt == 2) {                // q4_0: { f16 d; u8 qs[16] }: (nibble - 8) * d
+        const uint8_t* qs = b + 2;
+        for (int j = 0; j < 16; j++) { y[j] = ((int)(qs[j] & 0x0F) - 8) * d; y[j + 16] = ((int)(qs[j] >> 4) - 8) * d; }
+    } else if (tt == 3) {                // q4_1: { f16 d; f16 m; u8 qs[16] }: nibble * d + m
+        const uint8_t* qs = b + 4;
+        for (int j = 0; j < 16; j++) { y[j] = (qs[j] & 0x0F) * d + m; y[j + 16] = (qs[j] >> 4) * d + m; }
+    } else {                             // q5_0: { f16 d; u8 qh[4]; u8 qs[16] } / q5_1: { f16 d; f16 m; u8 qh[4]; u8 qs[16] }: the fifth bits live in qh
+        const uint8_t* p = b + (tt == 7 ? 4 : 2);
+        uint32_t qh;
+        memcpy(&qh, p, 4);
+        const uint8_t* qs = p + 4;
+        for (int j = 0; j < 16; j++) {
+            const uint8_t xh0 = ((qh >> (j + 0)) << 4) & 0x10, xh1 = (qh >> (j + 12)) & 0x10;
+            const int x0 = (qs[j] & 0x0F) | xh0, x1 = (qs[j] >> 4) | xh1;
+            if (tt == 6) { y[j] = (x0 - 16) * d; y[j + 16] = (x1 - 16) * d; }
+            else { y[j] = x0 * d + m; y[j + 16] = x1 * d + m; }
+        }
+    }
+}
+
 // wcpp: whisper_model_load -- magic, hparams, mel filters, vocab (+ synthesised specials), tensors
 bool load_model(const char* path, Model& m) {
     FILE* f = fopen(path, "rb");
@@ -195,6 +229,14 @@ bool load_model(const char* path, Model& m) {
             std::vector<uint16_t> h(n);
             if (!rd(h.data(), n * 2)) { fclose(f); return false; }
             for (size_t i = 0; i < n; i++) T.data[i] = f16_bits_to_f32(h[i]);
+        } else if (q_block_bytes(tt)) {
+            // wcpp: dequantize_row_q*.  The oracle's "weights" for a quantised file are the dequantised values rounded to f16 -- the arithmetic
+            // this build defines for such files (ggml's own CPU path instead quantises the activations to q8_0 and takes integer dot products)
+            const size_t bb = q_block_bytes(tt);
+            std::vector<uint8_t> raw(n / 32 * bb);
+            if (T.ne[0] % 32 || !rd(raw.data(), raw.size())) { fclose(f); return false; }
+            for (size_t b = 0; b < n / 32; b++) dequant_block(tt, raw.data() + b * bb, T.data.data() + b * 32, f16_bits_to_f32);
+            for (size_t i = 0; i < n; i++) T.data[i] = f16_round(T.data[i]);
         } else { fprintf(stderr, "oracle: unsupported tensor type %d\n", tt); fclose(f); return false; }
         m.t[name] = std::move(T);
     }
@@ -301,7 +343,24 @@ typedef __m256 v8;
 inline float hsum(v8 v) { float t[8]; _mm256_storeu_ps(t, v); float s = 0; for (int i = 0; i < 8; i++) s += t[i]; return s; }
 
 // C[M][N] = A[M][K](lda) * W[N][K]^T + bias[N]; A rounded per `mode` first (ggml converts src1 to the weight type).
+// BF16 mode: the engine converts the file's f16 weights to bf16 when it uploads them, so the oracle multiplies bf16-rounded weights too.
+// Rounded copies are made once per weight matrix (keyed by its address: model tensors never move) and kept for the life of the process.
+static std::map<const float*, std::vector<float>> g_bf16_w;
+static std::mutex g_bf16_mu;
+static const float* bf16_weights(const float* W, size_t n) {
+    std::lock_guard<std::mutex> lk(g_bf16_mu);
+    auto it = g_bf16_w.find(W);
+    if (it == g_bf16_w.end()) {
+        std::vector<float> r(n);
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)n; i++) r[i] = bf16_round(W[i]);
+        it = g_bf16_w.emplace(W, std::move(r)).first;
+    }
+    return it->second.data();
+}
+
 void matmul(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int mode) {
+    if (mode == 2) W = bf16_weights(W, (size_t)N * K);
     std::vector<float> Ar;
     const float* Ap = A; int la = lda;
     if (mode != 0) {
@@ -882,7 +941,7 @@ struct orc_opts { int32_t mode, gelu_erf, n_threads; };
 
 void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 void* orc_load(const char* path) { Model* m = new Model(); if (!load_model(path, *m)) { delete m; return nullptr; } return m; }
-void orc_free(void* m) { delete (Model*)m; }
+void orc_free(void* m) { { std::lock_guard<std::mutex> lk(g_bf16_mu); g_bf16_w.clear(); } delete (Model*)m; }   // the bf16 copies are keyed by tensor addresses
 void orc_hparams(void* m, int32_t* out) { memcpy(out, &((Model*)m)->hp, sizeof(HParams)); }
 void orc_special_tokens(void* mp, int32_t* out) {
     const Vocab& v = ((Model*)mp)->vocab;

@@ -97,6 +97,39 @@ static inline float half_to_float(uint16_t h) {
     float f; memcpy(&f, &u, 4); return f;
 }
 
+
+// ggml block quantisation (QK = 32), dequantised at load: the files of script/download-ggml-model.sh:28-51 (`*-q5_0`, `*-q5_1`) and the other
+// block types whisper.cpp's quantize tool writes.  ttype: 2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0; returns bytes per 32-element block (0 = not quantised)
+static size_t q_block_bytes(int tt) { return tt == 2 ? 18 : tt == 3 ? 20 : tt == 6 ? 22 : tt == 7 ? 24 : tt == 8 ? 34 : 0; }
+static void dequant_block(int tt, const uint8_t* b, float* y, float (*h2f)(uint16_t)) {
+    uint16_t dh, mh = 0;
+    memcpy(&dh, b, 2);
+    const float d = h2f(dh);
+    float m = 0.0f;
+    if (tt == 3 || tt == 7) { memcpy(&mh, b + 2, 2); m = h2f(mh); }
+    if (tt == 8) {                       // q8_0: { f16 d; int8 qs[32] }
+        const int8_t* qs = (const int8_t*)(b + 2);
+        for (int j = 0; j < 32; j++) y[j] = qs[j] * d;
+    } else if (tt == 2) {                // q4_0: { f16 d; u8 qs[16] }: (nibble - 8) * d
+        const uint8_t* qs = b + 2;
+        for (int j = 0; j < 16; j++) { y[j] = ((int)(qs[j] & 0x0F) - 8) * d; y[j + 16] = ((int)(qs[j] >> 4) - 8) * d; }
+    } else if (tt == 3) {                // q4_1: { f16 d; f16 m; u8 qs[16] }: nibble * d + m
+        const uint8_t* qs = b + 4;
+        for (int j = 0; j < 16; j++) { y[j] = (qs[j] & 0x0F) * d + m; y[j + 16] = (qs[j] >> 4) * d + m; }
+    } else {                             // q5_0: { f16 d; u8 qh[4]; u8 qs[16] } / q5_1: { f16 d; f16 m; u8 qh[4]; u8 qs[16] }: the fifth bits live in qh
+        const uint8_t* p = b + (tt == 7 ? 4 : 2);
+        uint32_t qh;
+        memcpy(&qh, p, 4);
+        const uint8_t* qs = p + 4;
+        for (int j = 0; j < 16; j++) {
+            const uint8_t xh0 = ((qh >> (j + 0)) << 4) & 0x10, xh1 = (qh >> (j + 12)) & 0x10;
+            const int x0 = (qs[j] & 0x0F) | xh0, x1 = (qs[j] >> 4) | xh1;
+            if (tt == 6) { y[j] = (x0 - 16) * d; y[j + 16] = (x1 - 16) * d; }
+            else { y[j] = x0 * d + m; y[j + 16] = x1 * d + m; }
+        }
+    }
+}
+
 namespace {
 struct File {
     FILE* f;
@@ -113,7 +146,10 @@ void load_ggml_model(const char* path, HostModel& m, bool vocab_only) {
     if (!F.rd(&magic, 4) || magic != 0x67676d6c) throw Error(-2, "model: bad magic (not a ggml legacy file)");
     if (!F.rd(&m.hp, sizeof(HParams))) throw Error(-2, "model: truncated header");
     const HParams& hp = m.hp;
-    if (hp.ftype != 0 && hp.ftype != 1) throw Error(-2, "model: quantised ftype " + std::to_string(hp.ftype) + " not supported (f32/f16 only)");
+    // whisper_model_load: "qntvr = ftype / GGML_QNT_VERSION_FACTOR; ftype %= GGML_QNT_VERSION_FACTOR"; the tensor records carry their own type
+    const int ftype = hp.ftype % 1000;
+    if (!(ftype == 0 || ftype == 1 || ftype == 2 || ftype == 3 || ftype == 7 || ftype == 8 || ftype == 9))
+        throw Error(-2, "model: ftype " + std::to_string(hp.ftype) + " not supported (f32, f16, q4_0, q4_1, q5_0, q5_1, q8_0)");
     // a malformed header must come back as SS_ERR_MODEL, never as SIGFPE: check every field before dividing by any of them
     const int32_t* hv = &hp.n_vocab;
     for (int i = 0; i < 10; i++) if (hv[i] <= 0) throw Error(-2, "model: non-positive hyper-parameter in the header");
@@ -190,6 +226,13 @@ void load_ggml_model(const char* path, HostModel& m, bool vocab_only) {
             std::vector<uint16_t> h(n);
             if (!F.rd(h.data(), n * 2)) throw Error(-2, "model: truncated tensor " + name);
             for (size_t i = 0; i < n; i++) T.f32[i] = half_to_float(h[i]);
+        } else if (q_block_bytes(tt)) {
+            // dequantised here, converted to the engine's operand type (f16 / bf16) at upload: the decoder streams 2-byte weights
+            const size_t bb = q_block_bytes(tt);
+            if (T.ne[0] % 32) throw Error(-2, "model: quantised tensor " + name + " has a row length that is not a multiple of 32");
+            std::vector<uint8_t> raw(n / 32 * bb);
+            if (!F.rd(raw.data(), raw.size())) throw Error(-2, "model: truncated tensor " + name);
+            for (size_t b = 0; b < n / 32; b++) dequant_block(tt, raw.data() + b * bb, T.f32.data() + b * 32, half_to_float);
         } else {
             throw Error(-2, "model: unsupported tensor type " + std::to_string(tt) + " for " + name);
         }

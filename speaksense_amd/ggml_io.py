@@ -17,6 +17,12 @@ import numpy as np
 GGML_MAGIC = 0x67676D6C
 GGML_TYPE_F32 = 0
 GGML_TYPE_F16 = 1
+GGML_TYPE_Q4_0, GGML_TYPE_Q4_1, GGML_TYPE_Q5_0, GGML_TYPE_Q5_1, GGML_TYPE_Q8_0 = 2, 3, 6, 7, 8
+# whisper.cpp's quantize tool: file ftype -> type of the quantised (2-D) tensors; everything else stays f16 / f32
+FTYPE_TO_QTYPE = {2: GGML_TYPE_Q4_0, 3: GGML_TYPE_Q4_1, 7: GGML_TYPE_Q8_0, 8: GGML_TYPE_Q5_0, 9: GGML_TYPE_Q5_1}
+FTYPE_BY_NAME = {"f32": 0, "f16": 1, "q4_0": 2, "q4_1": 3, "q8_0": 7, "q5_0": 8, "q5_1": 9}
+Q_BLOCK_BYTES = {GGML_TYPE_Q4_0: 18, GGML_TYPE_Q4_1: 20, GGML_TYPE_Q5_0: 22, GGML_TYPE_Q5_1: 24, GGML_TYPE_Q8_0: 34}
+QUANT_SKIP = ("encoder.conv1.bias", "encoder.conv2.bias", "encoder.positional_embedding", "decoder.positional_embedding")
 
 
 @dataclass
@@ -93,6 +99,82 @@ def mel_filters(n_mels: int, n_fft: int = 400, sr: int = 16000) -> np.ndarray:
     enorm = 2.0 / (mel_pts[2 : n_mels + 2] - mel_pts[:n_mels])
     w *= enorm[:, None]
     return w.astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# ggml block quantisation, QK = 32 (the `*-q5_0` / `*-q5_1` files of /root/reference/script/download-ggml-model.sh:28-51 and the other types
+# whisper.cpp's quantize tool writes): numpy restatement of quantize_row_q*_reference / dequantize_row_q*
+# ----------------------------------------------------------------------------------------------
+def quantize_blocks(x: np.ndarray, qtype: int) -> bytes:
+    """x: float32, size a multiple of 32 (rows are multiples of 32 long) -> the ggml block stream."""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, 32)
+    nb = x.shape[0]
+    if qtype == GGML_TYPE_Q8_0:
+        amax = np.abs(x).max(axis=1)
+        d = (amax / 127.0).astype(np.float32)
+        inv = np.where(d != 0, 1.0 / np.where(d != 0, d, 1), 0).astype(np.float32)
+        q = np.round(x * inv[:, None]).astype(np.int8)
+        out = np.zeros((nb, 34), np.uint8)
+        out[:, 0:2] = d.astype("<f2").view(np.uint8).reshape(nb, 2)
+        out[:, 2:] = q.view(np.uint8)
+        return out.tobytes()
+    if qtype in (GGML_TYPE_Q4_0, GGML_TYPE_Q5_0):
+        half, top = (8, 15) if qtype == GGML_TYPE_Q4_0 else (16, 31)
+        idx = np.abs(x).argmax(axis=1)
+        mx = x[np.arange(nb), idx]
+        d = (mx / -float(half)).astype(np.float32)
+        inv = np.where(d != 0, 1.0 / np.where(d != 0, d, 1), 0).astype(np.float32)
+        q = np.minimum(top, (x * inv[:, None] + (half + 0.5)).astype(np.int8)).astype(np.uint8)       # MIN(top, (int8_t)(x*id + half.5))
+        dd, mm = d, None
+    else:
+        top = 15 if qtype == GGML_TYPE_Q4_1 else 31
+        mn, mxv = x.min(axis=1), x.max(axis=1)
+        d = ((mxv - mn) / float(top)).astype(np.float32)
+        inv = np.where(d != 0, 1.0 / np.where(d != 0, d, 1), 0).astype(np.float32)
+        q = ((x - mn[:, None]) * inv[:, None] + 0.5).astype(np.uint8)
+        dd, mm = d, mn.astype(np.float32)
+    lo, hi = q[:, :16], q[:, 16:]
+    qs = ((lo & 0x0F) | ((hi & 0x0F) << 4)).astype(np.uint8)
+    parts = [dd.astype("<f2").view(np.uint8).reshape(nb, 2)]
+    if mm is not None:
+        parts.append(mm.astype("<f2").view(np.uint8).reshape(nb, 2))
+    if qtype in (GGML_TYPE_Q5_0, GGML_TYPE_Q5_1):
+        j = np.arange(16, dtype=np.uint32)
+        qh = (((lo.astype(np.uint32) & 0x10) >> 4) << j[None, :]).sum(axis=1, dtype=np.uint32) | \
+             (((hi.astype(np.uint32) & 0x10) >> 4) << (j[None, :] + 16)).sum(axis=1, dtype=np.uint32)
+        parts.append(qh.astype("<u4").view(np.uint8).reshape(nb, 4))
+    parts.append(qs)
+    return np.concatenate(parts, axis=1).tobytes()
+
+
+def dequantize_blocks(buf, qtype: int, n: int) -> np.ndarray:
+    bb = Q_BLOCK_BYTES[qtype]
+    nb = n // 32
+    b = np.frombuffer(buf, np.uint8, nb * bb).reshape(nb, bb)
+    d = b[:, 0:2].copy().view("<f2").astype(np.float32).reshape(nb, 1)
+    off = 2
+    m = None
+    if qtype in (GGML_TYPE_Q4_1, GGML_TYPE_Q5_1):
+        m = b[:, 2:4].copy().view("<f2").astype(np.float32).reshape(nb, 1)
+        off = 4
+    if qtype == GGML_TYPE_Q8_0:
+        return (b[:, 2:].copy().view(np.int8).astype(np.float32) * d).reshape(-1)
+    if qtype in (GGML_TYPE_Q5_0, GGML_TYPE_Q5_1):
+        qh = b[:, off:off + 4].copy().view("<u4").reshape(nb, 1)
+        off += 4
+        j = np.arange(16, dtype=np.uint32)[None, :]
+        xh0 = ((qh >> j) << 4) & 0x10
+        xh1 = (qh >> (j + 12)) & 0x10
+    else:
+        xh0 = xh1 = 0
+    qs = b[:, off:off + 16].astype(np.uint32)
+    x0 = ((qs & 0x0F) | xh0).astype(np.float32)
+    x1 = ((qs >> 4) | xh1).astype(np.float32)
+    q = np.concatenate([x0, x1], axis=1)
+    if m is not None:
+        return (q * d + m).astype(np.float32).reshape(-1)
+    sub = 8.0 if qtype == GGML_TYPE_Q4_0 else 16.0
+    return ((q - sub) * d).astype(np.float32).reshape(-1)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -253,11 +335,20 @@ def synth_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logit_
 
 
 def write_model(path: str, hp: HParams | str, seed: int = 0, logit_gain: float = 9.0, tensors: dict | None = None,
-                ts_period: int = 12, eot_start: int = 40):
+                ts_period: int = 12, eot_start: int = 40, ftype: int | str | None = None):
     """Write a ggml legacy whisper model. `tensors` (name -> ndarray in PyTorch layout) overrides the
-    synthetic draw -- used by the HF cross-check to export a transformers model's weights."""
+    synthetic draw -- used by the HF cross-check to export a transformers model's weights.
+    `ftype` ("q5_0", "q5_1", "q8_0", "q4_0", "q4_1" or the ggml number): what whisper.cpp's quantize tool produces from the f16 file -- every
+    2-D weight except the positional embeddings becomes block-quantised, the header's ftype says which type (+ 2000: GGML_QNT_VERSION 2)."""
     if isinstance(hp, str):
         hp = PRESETS[hp]
+    if isinstance(ftype, str):
+        ftype = FTYPE_BY_NAME[ftype]
+    qtype = FTYPE_TO_QTYPE.get(ftype) if ftype is not None else None
+    if ftype is not None:
+        hp = HParams(*(hp.astuple()[:10] + ((2000 + ftype) if qtype is not None else ftype,)))
+    base_ftype = 1 if qtype is not None else hp.ftype
+    spec_hp = HParams(*(hp.astuple()[:10] + (base_ftype,)))
     rng = np.random.default_rng(seed)
     ctx = {"ts_period": ts_period, "eot_start": eot_start}
     vocab = synth_vocab(hp.n_vocab)
@@ -271,17 +362,24 @@ def write_model(path: str, hp: HParams | str, seed: int = 0, logit_gain: float =
         for t in vocab:
             f.write(struct.pack("<I", len(t)))
             f.write(t)
-        for name, shape, ttype in tensor_specs(hp):
+        for name, shape, ttype in tensor_specs(spec_hp):
             if tensors is not None and name in tensors:
                 data = np.asarray(tensors[name], dtype=np.float32).reshape(shape)
             else:
                 data = synth_tensor(name, shape, hp, rng, logit_gain, ctx)
             nb = name.encode()
+            quant = qtype is not None and len(shape) == 2 and name.endswith("weight") and name not in QUANT_SKIP and shape[-1] % 32 == 0
+            if quant:       # the tool quantises the f16 file's values
+                data = data.astype(np.float16).astype(np.float32)
+                ttype = qtype
             f.write(struct.pack("<3i", len(shape), len(nb), ttype))
             for i in range(len(shape)):
                 f.write(struct.pack("<i", shape[len(shape) - 1 - i]))  # ggml order: ne[0] fastest
             f.write(nb)
-            f.write(data.astype("<f2" if ttype == GGML_TYPE_F16 else "<f4").tobytes())
+            if quant:
+                f.write(quantize_blocks(data, qtype))
+            else:
+                f.write(data.astype("<f2" if ttype == GGML_TYPE_F16 else "<f4").tobytes())
     return hp
 
 
@@ -323,6 +421,9 @@ def read_model(path: str):
         elif ttype == GGML_TYPE_F32:
             data = np.frombuffer(buf, "<f4", n, off).copy()
             off += 4 * n
+        elif ttype in Q_BLOCK_BYTES:
+            data = dequantize_blocks(buf[off : off + n // 32 * Q_BLOCK_BYTES[ttype]], ttype, n)
+            off += n // 32 * Q_BLOCK_BYTES[ttype]
         else:
             raise ValueError(f"unsupported ggml tensor type {ttype} for {name}")
         tensors[name] = data.reshape(tuple(reversed(ne)))

@@ -443,3 +443,26 @@ def test_whisper_h_full_surface(toy_ml_path, eng, monkeypatch):
     assert got == want and len(got) > len(a["segments"])
     L.whisper_free_state(st)
     L.whisper_free(ctx)
+
+
+@pytest.mark.parametrize("ft", ["q5_0", "q5_1", "q8_0", "q4_0"])
+def test_quantised_ggml_models(tmp_path, ft):
+    """Block-quantised ggml files (script/download-ggml-model.sh:28-51 lists the -q5_0 / -q5_1 variants): dequantised at load into the engine's
+    f16 operands; ids, segments and timestamps identical to the oracle reading the same file, stages within the f16 tolerances."""
+    from oracle import binding as orc
+    from speaksense_amd import binding, ggml_io
+    path = str(tmp_path / f"toy-{ft}.bin")
+    ggml_io.write_model(path, "toy", seed=1, ftype=ft)
+    om = orc.OracleModel(path)
+    e = binding.Engine(path, dtype=binding.DTYPE_F16, max_batch=2)
+    assert e.ftype == 2000 + ggml_io.FTYPE_BY_NAME[ft]
+    pcm = synth.speech_like(5, 16000 * 20)
+    mel = om.log_mel(pcm)
+    ref_enc = om.encode(mel, 0, orc.MODE_GGML_F16)
+    assert np.abs(e.encode(mel, 0) - ref_enc).max() / np.abs(ref_enc).max() < 4e-3
+    P = dict(language="en", temperature_inc=0.0)
+    got = e.new_session().transcribe(pcm, binding.default_params(**P))
+    ref = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(**P))
+    assert list(got["tokens"]) == list(ref["tokens"]) and len(got["tokens"]) > 0
+    assert [(s["t0"], s["t1"], s["text"]) for s in got["segments"]] == [(s["t0"], s["t1"], s["text"]) for s in ref["segments"]]
+    e.close(); om.close()

@@ -206,3 +206,32 @@ def test_pool_routing_rule():
     assert binding.pool_pick([3, 2, 1, 2], 0) == 2 and binding.pool_pick([3, 2, 1, 2], 3) == 2
     assert binding.pool_pick([1, 1, 0, 0], 3) == 3 and binding.pool_pick([1, 1, 0, 0], 0) == 2
     assert binding.pool_pick([7], 123) == 0
+
+
+@pytest.mark.parametrize("ft", ["q5_0", "q5_1", "q8_0"])
+def test_quantised_model_files(tmp_path, ft):
+    """The `*-q5_0` / `*-q5_1` files of script/download-ggml-model.sh:28-51 (and q8_0): ggml block format written by ggml_io (numpy restatement of
+    quantize_row_q*_reference), dequantised by the oracle's C++ loader.  The oracle on the quantised file must equal -- to the bit -- the oracle on
+    an f16 file holding numpy's dequantisation of the same blocks (the product loader shares the dequantiser; its GPU test is test_gpu_variants)."""
+    from oracle import binding as orc
+    from speaksense_amd import synth
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(32 * 257).astype(np.float32)
+    q = ggml_io.FTYPE_TO_QTYPE[ggml_io.FTYPE_BY_NAME[ft]]
+    blocks = ggml_io.quantize_blocks(x, q)
+    assert len(blocks) == 257 * ggml_io.Q_BLOCK_BYTES[q]
+    y = ggml_io.dequantize_blocks(blocks, q, len(x))
+    assert np.abs(x - y).max() < {"q5_0": 0.05, "q5_1": 0.03, "q8_0": 0.005}[ft] * np.abs(x).max()
+    assert ggml_io.quantize_blocks(y, q) == blocks or ft != "q8_0"        # q8_0 is idempotent on its own grid
+    pq, pf = str(tmp_path / "q.bin"), str(tmp_path / "deq.bin")
+    ggml_io.write_model(pq, "toy", seed=1, ftype=ft)
+    hp, filt, vocab, t = ggml_io.read_model(pq)
+    assert hp.ftype == 2000 + ggml_io.FTYPE_BY_NAME[ft]
+    assert os.path.getsize(pq) < 0.62 * 16517 * 1024
+    ggml_io.write_model(pf, "toy", seed=1, tensors=t)
+    a, b = orc.OracleModel(pq), orc.OracleModel(pf)
+    pcm = synth.speech_like(3, 16000 * 10)
+    P = orc.default_params(language="en", temperature_inc=0.0)
+    ra, rb = a.new_state(orc.MODE_GGML_F16).full(pcm, P), b.new_state(orc.MODE_GGML_F16).full(pcm, P)
+    assert list(ra["tokens"]) == list(rb["tokens"]) and np.array_equal(ra["plog"], rb["plog"]) and len(ra["tokens"]) > 0
+    a.close(); b.close()

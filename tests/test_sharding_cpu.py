@@ -29,3 +29,24 @@ def test_two_rank_dry_run_gloo():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["chunks_rank0"] == [0, 2, 4, 6]
     assert 0 < j["value"] < 2 * 4 * 30 / 0.04 * 1.01   # 8 chunks per 40 ms step at most
+
+
+def test_two_ranks_transcribe_disjoint_shards_gloo(toy_ml_path, tmp_path):
+    """The data path across ranks with a real transcriber in place of the GPU engine (the CPU oracle; tests/shard_worker.py): two ranks, 7 chunks
+    (ragged), every chunk transcribed exactly once, results gathered in chunk order and identical to a single-process run."""
+    from oracle import binding as orc
+    from speaksense_amd import synth
+    out = str(tmp_path / "gathered.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "tests", "shard_worker.py"), toy_ml_path, "7", out]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.load(open(out))
+    assert j["shards"] == [[0, 2, 4, 6], [1, 3, 5]] and sorted(int(k) for k in j["tokens"]) == list(range(7))
+    om = orc.OracleModel(toy_ml_path)
+    P = orc.default_params(language="en", temperature_inc=0.0)
+    for cid in range(7):
+        ref = om.new_state(orc.MODE_GGML_F16).full(synth.speech_like(100 + cid, 16000 * 3), P)
+        assert j["tokens"][str(cid)] == [int(t) for t in ref["tokens"]], cid
+    assert j["seconds_max_over_ranks"] > 0
+    om.close()
