@@ -227,7 +227,7 @@ struct EngineT : EngineBase {
             int nl = o.n_lanes > 0 ? o.n_lanes : 2;
             if (const char* lv = getenv("SS_LANES")) nl = atoi(lv);
             nl = std::min(std::max(nl, 1), 8);
-            for (int i = 1; i < nl; i++) extra_lanes.emplace_back(new EngineT(path, o, this));
+            for (int i = 1; i < nl; i++) { extra_lanes.emplace_back(new EngineT(path, o, this)); extra_lanes.back()->owner = this; }
             start_worker();
         }
     }
@@ -767,7 +767,7 @@ struct EngineT : EngineBase {
         }
     }
     DBuf samp_d, rowidx_d, rules_scratch;
-    long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
+    long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0, cnt_admitted = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
     bool use_fused = true, cross_direct = false, combine_separate = true, use_graph = true;
     int ln_fused = 0;
     bool chain_steps = true;
@@ -809,18 +809,17 @@ struct EngineT : EngineBase {
             try {
                 run_group(grp);
             } catch (const Error& e) {
-                for (Job* j : grp) if (j->status == 0) { j->status = e.code; j->err = e.what(); }
+                for (Job* j : grp) if (j && j->status == 0) { j->status = e.code; j->err = e.what(); }   // finished chunks were nulled: theirs to free
                 throw;
             }
         }
     }
 
-    void run_group(std::vector<Job*>& grp) {
-        const Vocab& vocab = hm.vocab;
-        std::vector<JobState> js;
-        SS_HIP(hipEventRecord(ev[0], st));
-        for (size_t i = 0; i < grp.size(); i++) {
-            Job* j = grp[i];
+    // whisper_full_with_state up to the window loop for one chunk: session reset, prompt, parameter checks, language, log-mel on the device.
+    // `i` = the batch slot whose device buffers (pcm_d / mel_d / fmax_d) the chunk uses.  A chunk that is refused or has nothing to decode
+    // comes back with alive == false (status says why).
+    JobState setup_job(Job* j, int i) {
+            const Vocab& vocab = hm.vocab;
             Session* s = j->sess;
             s->segments.clear(); s->tokens.clear(); s->sampled.clear(); s->n_encode = s->n_decode = s->n_fail = s->n_windows = 0;
             if (j->P.no_context) s->prompt_past.clear();
@@ -831,28 +830,28 @@ struct EngineT : EngineBase {
             JobState q; q.job = j; q.slot = (int)i;
             j->status = 0;
             const ss_params& P = j->P;
-            if (P.audio_ctx > n_ctx) { j->status = SS_ERR_AUDIO_CTX; j->err = "audio_ctx larger than the model's n_audio_ctx"; js.push_back(q); continue; }
+            if (P.audio_ctx > n_ctx) { j->status = SS_ERR_AUDIO_CTX; j->err = "audio_ctx larger than the model's n_audio_ctx"; return q; }
             if (P.audio_ctx != 0 && P.audio_ctx != n_ctx) {   // the reference only ever passes 1500 or 0 (whisper.rs:144,68); a shortened encoder context is not built
-                j->status = SS_ERR_UNSUPPORTED; j->err = "audio_ctx must be 0 or the model's n_audio_ctx"; js.push_back(q); continue;
+                j->status = SS_ERR_UNSUPPORTED; j->err = "audio_ctx must be 0 or the model's n_audio_ctx"; return q;
             }
-            if (P.best_of > ND) { j->status = SS_ERR_ARG; j->err = "best_of exceeds the engine's max_decoders"; js.push_back(q); continue; }
-            if (P.offset_ms < 0 || P.duration_ms < 0) { j->status = SS_ERR_ARG; j->err = "negative offset_ms / duration_ms"; js.push_back(q); continue; }
+            if (P.best_of > ND) { j->status = SS_ERR_ARG; j->err = "best_of exceeds the engine's max_decoders"; return q; }
+            if (P.offset_ms < 0 || P.duration_ms < 0) { j->status = SS_ERR_ARG; j->err = "negative offset_ms / duration_ms"; return q; }
             // "auto-detect language if not specified": language nullptr / "" / "auto" or detect_language (whisper_full_with_state)
             const bool auto_lang = P.language[0] == 0 || !strcmp(P.language, "auto") || P.detect_language;
             s->lang_id = -1;
             if (vocab.is_multilingual()) {
                 if (auto_lang) {
                     // whisper_lang_auto_detect looks at the window at offset 0; here it shares the first window's encoder pass
-                    if (P.offset_ms != 0) { j->status = SS_ERR_UNSUPPORTED; j->err = "language detection together with offset_ms"; js.push_back(q); continue; }
+                    if (P.offset_ms != 0) { j->status = SS_ERR_UNSUPPORTED; j->err = "language detection together with offset_ms"; return q; }
                     q.need_detect = true;
                 } else {
                     const int lid = lang_id(P.language);
-                    if (lid < 0 || lid >= vocab.num_languages()) { j->status = SS_ERR_LANG; j->err = std::string("unknown language '") + P.language + "'"; js.push_back(q); continue; }
+                    if (lid < 0 || lid >= vocab.num_languages()) { j->status = SS_ERR_LANG; j->err = std::string("unknown language '") + P.language + "'"; return q; }
                     s->lang_id = lid;
                     set_prompt_init(q, lid);
                 }
             } else {
-                if (P.detect_language) { j->status = SS_ERR_LANG; j->err = "detect_language on an English-only model"; js.push_back(q); continue; }
+                if (P.detect_language) { j->status = SS_ERR_LANG; j->err = "detect_language on an English-only model"; return q; }
                 set_prompt_init(q, 0);   // .en models: [sot] only, whatever the language says
             }
             if (j->n_samples > 0) {
@@ -871,16 +870,54 @@ struct EngineT : EngineBase {
                 q.seek = q.seek_start; q.seek_end = P.duration_ms == 0 ? q.n_len_org : q.seek_start + P.duration_ms / 10;
                 q.alive = q.seek_end >= q.seek_start + 100;  // "if length of spectrogram is less than 1.0s, return"
             }
-            js.push_back(q);
-        }
+            return q;
+    }
+
+    void run_group(std::vector<Job*>& grp) {
+        const Vocab& vocab = hm.vocab;
+        std::vector<JobState> js;
+        SS_HIP(hipEventRecord(ev[0], st));
+        for (size_t i = 0; i < grp.size(); i++) js.push_back(setup_job(grp[i], (int)i));
         SS_HIP(hipEventRecord(ev[1], st));
-        cnt_passes = cnt_rows = cnt_windows = 0;
+        cnt_passes = cnt_rows = cnt_windows = cnt_admitted = 0;
         float ms_enc = 0.f, ms_dec = 0.f;
+        // A chunk is reported the moment its last window is finalised (or it is refused), not when the slowest chunk of the group is done, and
+        // a group that keeps running (multi-window chunks, natural-length decodes) takes queued chunks into its free slots at the next window
+        // boundary: continuous batching at window granularity.  Finished entries forget their Job (its owner may free it at once).
+        auto sweep = [&]() {
+            int n_alive = 0;
+            for (auto& q : js) {
+                if (!q.job) continue;
+                if (q.alive && q.job->status == 0 && q.seek + 100 >= q.seek_end) q.alive = false;
+                if (!q.alive || q.job->status != 0) {
+                    Job* j = q.job;
+                    q.job = nullptr; q.alive = false;
+                    for (auto& gj : grp) if (gj == j) gj = nullptr;
+                    owner->job_finished(j, this);
+                } else n_alive++;
+            }
+            return n_alive;
+        };
         while (true) {
+            const int n_alive = sweep();
+            if (n_alive == 0) break;
+            if (from_queue && n_alive < B) {
+                std::vector<Job*> more;
+                owner->admit_more(B - n_alive, this, more);
+                cnt_admitted += (long)more.size();
+                for (Job* j : more) {
+                    int slot = -1;
+                    std::vector<bool> used(B, false);
+                    for (auto& q : js) if (q.job) used[q.slot] = true;
+                    for (int i = 0; i < B; i++) if (!used[i]) { slot = i; break; }
+                    grp.push_back(j);
+                    js.push_back(setup_job(j, slot));
+                }
+                if (!more.empty()) sweep();
+            }
             std::vector<Window> wins;
             for (auto& q : js) {
-                if (!q.alive || q.job->status != 0) continue;
-                if (q.seek + 100 >= q.seek_end) { q.alive = false; continue; }
+                if (!q.job || !q.alive) continue;
                 Window w; w.job = q.job; w.cross = (int)wins.size();
                 const ss_params& P = q.job->P;
                 if (P.fixed_steps > 0) w.temperatures = {0.0f};
@@ -892,7 +929,7 @@ struct EngineT : EngineBase {
                                      x0.as<T>() + (size_t)w.cross * (2 * n_ctx + 2) * n_mel, st);
                 wins.push_back(std::move(w));
             }
-            if (wins.empty()) break;
+            if (wins.empty()) continue;   // (everything left was refused at admission: the sweep ends the loop)
             const int Wn = (int)wins.size();
             hipEvent_t e0, e1, e2;
             SS_HIP(hipEventCreate(&e0)); SS_HIP(hipEventCreate(&e1)); SS_HIP(hipEventCreate(&e2));
@@ -942,13 +979,14 @@ struct EngineT : EngineBase {
             // emit segments, advance seek
             for (auto& w : wins) if (!w.skip) finalize_window(w, js);
         }
+        sweep();
         SS_HIP(hipEventRecord(ev[2], st));
         SS_HIP(hipEventSynchronize(ev[2]));
         float ms_mel = 0, ms_tot = 0;
         SS_HIP(hipEventElapsedTime(&ms_mel, ev[0], ev[1]));
         SS_HIP(hipEventElapsedTime(&ms_tot, ev[0], ev[2]));
         last_ms[0] = ms_mel; last_ms[1] = ms_enc; last_ms[2] = ms_dec; last_ms[3] = ms_tot;
-        last_cnt[0] = cnt_passes; last_cnt[1] = cnt_rows; last_cnt[2] = cnt_windows; last_cnt[3] = 0;
+        last_cnt[0] = cnt_passes; last_cnt[1] = cnt_rows; last_cnt[2] = cnt_windows; last_cnt[3] = cnt_admitted;
         for (int i = 0; i < 4; i++) { tot_ms[i] += last_ms[i]; tot_cnt[i] += last_cnt[i]; }
     }
 
@@ -1003,7 +1041,7 @@ struct EngineT : EngineBase {
         }
     }
 
-    JobState& state_of(std::vector<JobState>& js, Job* j) { for (auto& q : js) if (q.job == j) return q; throw Error(-1, "internal: job state"); }
+    JobState& state_of(std::vector<JobState>& js, Job* j) { for (auto& q : js) if (q.job == j && j) return q; throw Error(-1, "internal: job state"); }
 
     // Decode all decoders of the given windows at their current ladder temperature, in lock-step rounds.
     // Round = every active decoder advances to its next sampling point: the first round feeds the whole prompt
@@ -1579,6 +1617,34 @@ void EngineBase::run_jobs_parallel(std::vector<Job*>& jobs) {
     if (first) std::rethrow_exception(first);
 }
 
+void EngineBase::job_finished(Job* j, EngineBase* lane_) {
+    bool q = false;
+    {
+        std::lock_guard<std::mutex> lk(qmu);
+        q = j->queued;
+        if (q) {
+            auto it = std::find(running.begin(), running.end(), std::make_pair(j, lane_));
+            if (it != running.end()) running.erase(it);
+            load.fetch_sub(1);
+        }
+        j->done = true;      // after this the waiter may delete the ticket: `j` must not be touched again
+    }
+    if (q) { donecv.notify_all(); qcv.notify_all(); }
+}
+int EngineBase::admit_more(int n_max, EngineBase* lane_, std::vector<Job*>& out) {
+    std::lock_guard<std::mutex> lk(qmu);
+    for (auto it = queue.begin(); it != queue.end() && (int)out.size() < n_max;) {
+        bool dup = false;
+        for (Job* b : out) if (b->sess == (*it)->sess) { dup = true; break; }
+        if (!dup) for (auto& r : running) if (r.first->sess == (*it)->sess) { dup = true; break; }
+        if (dup) { ++it; continue; }
+        out.push_back(*it);
+        running.push_back({*it, lane_});
+        it = queue.erase(it);
+    }
+    return (int)out.size();
+}
+
 void EngineBase::start_worker() {
     const int n = n_lanes();
     for (int li = 0; li < n; li++) {
@@ -1601,31 +1667,39 @@ void EngineBase::start_worker() {
                     for (auto it = queue.begin(); it != queue.end() && (int)batch.size() < maxb;) {
                         bool dup = false;
                         for (Job* b : batch) if (b->sess == (*it)->sess) { dup = true; break; }
-                        if (!dup) for (Job* b : running) if (b->sess == (*it)->sess) { dup = true; break; }   // ... or still running on another lane
+                        if (!dup) for (auto& r : running) if (r.first->sess == (*it)->sess) { dup = true; break; }   // ... or still running on another lane
                         if (dup) { ++it; continue; }
                         batch.push_back(*it);
                         it = queue.erase(it);
                     }
-                    for (Job* b : batch) running.push_back(b);
+                    for (Job* b : batch) running.push_back({b, L});
                     if (batch.empty()) {   // only tickets of busy sessions are queued: wait for a completion instead of spinning
                         donecv.wait_for(lk, std::chrono::milliseconds(2));
                         continue;
                     }
                 }
-                // nothing may escape this thread (std::terminate would take the host service down) and every job must be marked done
-                auto fail_all = [&](int code, const char* what) {
-                    for (Job* j : batch) if (j->status == 0) { j->status = code; j->err = what; }
-                };
-                try { L->run_jobs(batch); }
-                catch (const Error& e) { fail_all(e.code, e.what()); }
-                catch (const std::exception& e) { fail_all(SS_ERR_DEVICE, e.what()); }
-                catch (...) { fail_all(SS_ERR_DEVICE, "unknown exception in the batch former"); }
+                // nothing may escape this thread (std::terminate would take the host service down).  Chunks normally complete one by one from
+                // inside the group (job_finished); whatever this lane still has registered afterwards -- the group threw -- is failed and released.
+                int fail_code = 0;
+                std::string fail_what;
+                {
+                    std::lock_guard<std::mutex> lane_lk(L->mu);      // a blocking caller (ss_transcribe_batch) may be using this lane
+                    L->from_queue = true;
+                    try { L->run_jobs_locked(batch); }
+                    catch (const Error& e) { fail_code = e.code; fail_what = e.what(); }
+                    catch (const std::exception& e) { fail_code = SS_ERR_DEVICE; fail_what = e.what(); }
+                    catch (...) { fail_code = SS_ERR_DEVICE; fail_what = "unknown exception in the batch former"; }
+                    L->from_queue = false;
+                }
                 {
                     std::lock_guard<std::mutex> lk(qmu);
-                    load.fetch_sub((int)batch.size());
-                    for (Job* j : batch) {
+                    for (auto it = running.begin(); it != running.end();) {
+                        if (it->second != L) { ++it; continue; }
+                        Job* j = it->first;
+                        if (j->status == 0) { j->status = fail_code ? fail_code : SS_ERR_DEVICE; j->err = fail_code ? fail_what : "chunk left unfinished by its device group"; }
                         j->done = true;
-                        running.erase(std::find(running.begin(), running.end(), j));
+                        load.fetch_sub(1);
+                        it = running.erase(it);
                     }
                 }
                 donecv.notify_all();
@@ -1644,6 +1718,7 @@ void EngineBase::stop_worker() {
     workers.clear();
 }
 void EngineBase::submit(Job* j) {
+    j->queued = true;
     load.fetch_add(1);
     {
         std::lock_guard<std::mutex> lk(qmu);

@@ -52,6 +52,7 @@ struct Job {  // one chunk handed to transcribe (== one whisper_full_with_state 
     int status = 0;
     std::string err;           // what failed (travels on the ticket: the worker's thread-local message would be lost)
     std::vector<float> owned;  // async submit keeps its own copy
+    bool queued = false;       // came through submit() (counts in `load`, lives in `running` while in flight)
     std::vector<int> prompt_tokens;   // P.prompt_tokens / tokenised P.initial_prompt, captured at the API boundary (P's pointers are not kept)
     // async completion
     bool done = false;
@@ -96,7 +97,12 @@ struct EngineBase {
     std::condition_variable qcv, donecv;
     std::atomic<int> load{0};      // chunks queued or running (ss_pool routing)
     std::deque<Job*> queue;
-    std::vector<Job*> running;     // popped, not yet done (a session has at most one chunk in flight across all lanes)
+    std::vector<std::pair<Job*, EngineBase*>> running;     // popped, not yet done, with the lane that runs it (a session has at most one chunk in flight)
+    EngineBase* owner = this;      // the engine whose queue feeds this lane (lane 0)
+    bool from_queue = false;       // this lane is running a batch its worker popped: chunks complete one by one, more may be admitted between windows
+    // continuous batching at window granularity (called by a lane from inside its device group, on `owner`):
+    void job_finished(Job* j, EngineBase* lane_);                         // this chunk's results are final: wake its waiter now, not when the group ends
+    int admit_more(int n_max, EngineBase* lane_, std::vector<Job*>& out); // pop up to n_max queued chunks (sessions not in flight) for a running group
     bool stop = false;
     std::atomic<unsigned> rr{0};
     void start_worker();

@@ -466,3 +466,45 @@ def test_quantised_ggml_models(tmp_path, ft):
     assert list(got["tokens"]) == list(ref["tokens"]) and len(got["tokens"]) > 0
     assert [(s["t0"], s["t1"], s["text"]) for s in got["segments"]] == [(s["t0"], s["t1"], s["text"]) for s in ref["segments"]]
     e.close(); om.close()
+
+
+def test_continuous_batching_early_completion_and_admission(toy_ml_path):
+    """A device group reports each chunk as soon as ITS last window is done, and while multi-window chunks keep the group alive it admits queued
+    chunks into its free slots at the next window boundary (one lane, max_batch 4).  Results must equal the one-chunk-at-a-time results."""
+    import threading
+    import time
+    from speaksense_amd import binding
+    ref_eng = binding.Engine(toy_ml_path, max_batch=4, n_lanes=1)
+    P = binding.default_params(language="en", temperature_inc=0.0)
+    long_pcms = [synth.speech_like(80 + k) for k in range(2)]                  # 30 s: several windows each on the toy model
+    short_pcms = [synth.speech_like(90 + k, 16000 * 3) for k in range(5)]       # 3 s: one window
+    want_long = [ref_eng.new_session().transcribe(x, P) for x in long_pcms]
+    want_short = [ref_eng.new_session().transcribe(x, P) for x in short_pcms]
+    assert all(r["n_encode"] >= 2 for r in want_long)
+    ref_eng.close()
+
+    eng = binding.Engine(toy_ml_path, max_batch=4, n_lanes=1, batch_wait_us=50000)
+    s_long = [eng.new_session() for _ in long_pcms]
+    s_short = [eng.new_session() for _ in short_pcms]
+    # 7 chunks at once, 4 slots: the batch former takes 2 long + 2 short; the other 3 short ones wait in the queue for a free slot
+    tickets = [(s, s.submit(x, P), "long") for s, x in zip(s_long, long_pcms)] + [(s, s.submit(x, P), "short") for s, x in zip(s_short, short_pcms)]
+    done_at, results = {}, {}
+
+    def waiter(i, s, t):
+        results[i] = s.wait(t)
+        done_at[i] = time.perf_counter()
+
+    th = [threading.Thread(target=waiter, args=(i, s, t)) for i, (s, t, _) in enumerate(tickets)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i, b in enumerate(want_long + want_short):
+        a = results[i]
+        assert list(a["tokens"]) == list(b["tokens"]) and [s["text"] for s in a["segments"]] == [s["text"] for s in b["segments"]], i
+    tot = eng.totals()
+    first_short, last_long = min(done_at[2], done_at[3]), max(done_at[0], done_at[1])
+    print(f"one-window chunks of the first batch back {1e3 * (last_long - first_short):.1f} ms before the multi-window ones; admitted into the running group: {tot['admitted']}")
+    assert first_short < last_long, "the one-window chunks were held until the multi-window chunks of their group had finished"
+    assert tot["admitted"] >= 1, "no queued chunk joined the running group at a window boundary"
+    eng.close()

@@ -235,3 +235,28 @@ def test_quantised_model_files(tmp_path, ft):
     ra, rb = a.new_state(orc.MODE_GGML_F16).full(pcm, P), b.new_state(orc.MODE_GGML_F16).full(pcm, P)
     assert list(ra["tokens"]) == list(rb["tokens"]) and np.array_equal(ra["plog"], rb["plog"]) and len(ra["tokens"]) > 0
     a.close(); b.close()
+
+
+def test_whisper_cpp_comparison_runner_parses_ojf(tmp_path):
+    """tools/compare_with_whisper_cpp.py (the box-side runner that pins parity against a real whisper.cpp + weights): its parser of whisper.cpp's
+    `-ojf` JSON and its WAV reader, on a hand-made sample in that format."""
+    import wave
+    sys_path = os.path.join(ROOT, "tools")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cmp_wcpp", os.path.join(sys_path, "compare_with_whisper_cpp.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    j = {"transcription": [
+        {"timestamps": {"from": "00:00:00,000", "to": "00:00:02,500"}, "offsets": {"from": 0, "to": 2500}, "text": " hello",
+         "tokens": [{"text": "[_BEG_]", "id": 50365, "p": 0.9}, {"text": " hello", "id": 7751, "p": 0.8}, {"text": "[_TT_125]", "id": 50490, "p": 0.7}]},
+        {"timestamps": {"from": "00:00:02,500", "to": "00:00:04,000"}, "offsets": {"from": 2500, "to": 4000}, "text": " world",
+         "tokens": [{"text": " world", "id": 1002, "p": 0.6}]}]}
+    ids, segs = m.parse_whisper_json_full(j)
+    assert ids == [50365, 7751, 50490, 1002] and segs == [(0, 250, " hello"), (250, 400, " world")]
+    assert m.first_divergence([1, 2, 3], [1, 2, 3]) is None and m.first_divergence([1, 2, 3], [1, 9, 3]) == 1 and m.first_divergence([1, 2], [1, 2, 3]) == 2
+    p = str(tmp_path / "a.wav")
+    x = (np.sin(np.arange(16000) * 0.05) * 12000).astype("<i2")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(x.tobytes())
+    pcm = m.read_wav_16k_mono(p)
+    assert pcm.dtype == np.float32 and len(pcm) == 16000 and abs(float(np.abs(pcm).max()) - 12000 / 32768) < 1e-3

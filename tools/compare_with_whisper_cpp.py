@@ -1,0 +1,125 @@
+#!/usr/bin/env python
+"""Box-side runner that closes "parity unpinned" on a machine that HAS whisper.cpp and real ggml weights (neither exists in the build image or
+on the offline GPU box).  For every WAV it runs
+
+    <whisper.cpp main> -m MODEL -f WAV -l LANG -ojf -of TMP [-t THREADS] -bo 5 -nf?   (CPU reference: exactly what the reference's whisper-rs calls)
+
+and the MI355X engine on the same samples with the same parameters, then compares token ids, segment boundaries and text:
+  * identical ids                        -> OK
+  * first divergence                     -> reported with both continuations; with --oracle the CPU oracle is forced along whisper.cpp's ids
+                                            (oracle/binding.py full(forced=...)) and the margin of every differing pick is printed, which tells a
+                                            near tie of two correct f16 implementations from a real defect.
+Exit code 0 only if every file is identical or every divergence is a proven near tie (margin < --gap-tol).
+
+usage: python tools/compare_with_whisper_cpp.py --main /path/to/whisper.cpp/main --model ggml-large-v3.bin a.wav b.wav ...
+       python tools/compare_with_whisper_cpp.py --json whisper_output.json --model ggml-large-v3.bin a.wav      (a whisper.cpp -ojf file made elsewhere)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import wave
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def read_wav_16k_mono(path: str) -> np.ndarray:
+    """whisper.cpp's main requires 16 kHz WAV (read_wav in examples/common.cpp): PCM16, mono or stereo (averaged)."""
+    with wave.open(path, "rb") as w:
+        if w.getframerate() != 16000 or w.getsampwidth() != 2 or w.getnchannels() not in (1, 2):
+            raise SystemExit(f"{path}: need 16 kHz 16-bit mono/stereo WAV (as whisper.cpp's main does)")
+        pcm = np.frombuffer(w.readframes(w.getnframes()), "<i2").astype(np.float32)
+        if w.getnchannels() == 2:
+            pcm = (pcm[0::2] + pcm[1::2]) / 65536.0          # (l + r) / 65536, as read_wav
+        else:
+            pcm = pcm / 32768.0
+    return pcm.astype(np.float32)
+
+
+def parse_whisper_json_full(j: dict):
+    """-ojf output -> (token ids incl. timestamp tokens, [(t0_cs, t1_cs, text)]).  Special tokens whisper.cpp prints (e.g. [_BEG_], [_TT_n]) carry
+    their ids in "tokens[].id"; segment offsets are milliseconds."""
+    ids, segs = [], []
+    for s in j.get("transcription", []):
+        segs.append((int(s["offsets"]["from"]) // 10, int(s["offsets"]["to"]) // 10, s["text"]))
+        for t in s.get("tokens", []):
+            ids.append(int(t["id"]))
+    return ids, segs
+
+
+def run_whisper_cpp(main: str, model: str, wav: str, lang: str, threads: int, extra: list[str]):
+    tmp = tempfile.mkdtemp()
+    of = os.path.join(tmp, "out")
+    cmd = [main, "-m", model, "-f", wav, "-l", lang, "-t", str(threads), "-bo", "5", "-ojf", "-of", of] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise SystemExit(f"whisper.cpp failed: {' '.join(cmd)}\n{r.stderr[-2000:]}")
+    return json.load(open(of + ".json"))
+
+
+def first_divergence(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return i
+    return None if len(a) == len(b) else n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--main", help="whisper.cpp `main` (or `whisper-cli`) binary")
+    ap.add_argument("--json", help="a whisper.cpp -ojf output made elsewhere (then exactly one WAV)")
+    ap.add_argument("--model", required=True, help="ggml-*.bin (the file ASR_MODEL_PATH points at, /root/reference/src/lib.rs:24)")
+    ap.add_argument("--language", default="en")
+    ap.add_argument("--threads", type=int, default=16)     # the reference: params.set_n_threads(16), whisper.rs:143
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--oracle", action="store_true", help="on a divergence, force the CPU oracle along whisper.cpp's ids and print the margins")
+    ap.add_argument("--gap-tol", type=float, default=0.108)
+    ap.add_argument("--extra", default="", help="extra whisper.cpp flags, e.g. '-nf' (no temperature fallback)")
+    ap.add_argument("wavs", nargs="+")
+    args = ap.parse_args()
+    from speaksense_amd import binding
+    eng = binding.Engine(args.model, dtype=binding.DTYPE_F16 if args.dtype == "f16" else binding.DTYPE_BF16, max_batch=len(args.wavs))
+    no_fallback = "-nf" in args.extra.split()
+    P = binding.default_params(language=args.language, no_context=0, temperature_inc=0.0 if no_fallback else 0.2)
+    bad = 0
+    for wav in args.wavs:
+        pcm = read_wav_16k_mono(wav)
+        ref = json.load(open(args.json)) if args.json else run_whisper_cpp(args.main, args.model, wav, args.language, args.threads, args.extra.split())
+        ref_ids, ref_segs = parse_whisper_json_full(ref)
+        got = eng.new_session().transcribe(pcm, P)
+        got_ids = []
+        ses_segs = [(s["t0"], s["t1"], s["text"].decode("utf-8", "replace")) for s in got["segments"]]
+        # whisper.cpp's JSON lists the tokens of each segment; the engine keeps the same per-segment lists (ss_result_segment_token)
+        got_ids = [int(t) for t in got["tokens"]]
+        k = first_divergence(ref_ids, got_ids[:len(ref_ids)] if len(got_ids) >= len(ref_ids) else got_ids)
+        same_segs = [(a, b) for a, b, _ in ref_segs] == [(a, b) for a, b, _ in ses_segs] and [c for _, _, c in ref_segs] == [c for _, _, c in ses_segs]
+        if k is None and same_segs:
+            print(f"OK    {wav}: {len(ref_ids)} tokens, {len(ref_segs)} segments identical")
+            continue
+        print(f"DIFF  {wav}: first divergence at token {k}: whisper.cpp {ref_ids[k:k + 6] if k is not None else '-'} vs engine {got_ids[k:k + 6] if k is not None else '-'}; "
+              f"segments {'identical' if same_segs else 'differ'}")
+        proven = False
+        if args.oracle and k is not None:
+            from oracle import binding as orc
+            om = orc.OracleModel(args.model)
+            rep = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(language=args.language, no_context=0, temperature_inc=0.0), forced=got["sampled"])
+            gaps = rep["forced_gap"]
+            worst = float(gaps.max()) if len(gaps) else 0.0
+            print(f"      oracle forced along the engine's ids: largest margin {worst:.4f} (tolerance {args.gap_tol})")
+            proven = worst < args.gap_tol
+            om.close()
+        bad += not proven
+    eng.close()
+    raise SystemExit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

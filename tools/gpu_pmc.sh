@@ -4,7 +4,7 @@ mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/pmc
 for C in FETCH_SIZE WRITE_SIZE; do
-  cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $OUT -o pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 0 --no-cpu-baseline --fixed-steps 6 > $OUT/bench_$C.log 2> $OUT/bench_$C.err
+  cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $OUT -o pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline --fixed-steps 6 > $OUT/bench_$C.log 2> $OUT/bench_$C.err
   cd $GRAFT_REPO_ROOT
 done
 ls gpurun_out/pmc
