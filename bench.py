@@ -136,7 +136,9 @@ def cpu_baseline(path: str, hp, n_steps: int, n_prompt: int):
         ncpu = os.cpu_count() or 1
     cores = max(1, min(64, ncpu))
     om = orc.OracleModel(path)
-    n_enc, n_cross, n_dec = 2, 2, 6
+    # full depth for the encoder and the cross-KV precompute (nothing extrapolated there); the decoder steps are identical in cost up to the
+    # growing self-KV, so 8 timed steps stand for the prompt + n_steps positions
+    n_enc, n_cross, n_dec = hp.n_audio_layer, hp.n_text_layer, 8
     os.environ.setdefault("OMP_PROC_BIND", "close")   # read when the OpenMP runtime starts: threads stay on their cores
     runs = []
     for _ in range(2):      # two timed repeats of the same sample, the faster one is reported (the first also pages the 6 GB f32 model in)

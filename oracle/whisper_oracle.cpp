@@ -359,8 +359,17 @@ static const float* bf16_weights(const float* W, size_t n) {
     return it->second.data();
 }
 
-void matmul(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int mode) {
-    if (mode == 2) W = bf16_weights(W, (size_t)N * K);
+// w_is_model_tensor = false: W is a temporary (the re-ordered conv kernels), rounded here and not cached (its address will be reused)
+void matmul(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int mode, bool w_is_model_tensor = true) {
+    std::vector<float> Wr;
+    if (mode == 2) {
+        if (w_is_model_tensor) W = bf16_weights(W, (size_t)N * K);
+        else {
+            Wr.resize((size_t)N * K);
+            for (size_t i = 0; i < Wr.size(); i++) Wr[i] = bf16_round(W[i]);
+            W = Wr.data();
+        }
+    }
     std::vector<float> Ar;
     const float* Ap = A; int la = lda;
     if (mode != 0) {
@@ -461,11 +470,11 @@ void encode(const Model& m, const float* mel, int n_len, int seek, const Opts& o
     };
     std::vector<float> w1 = reorder(m.w("encoder.conv1.weight"), d, n_mel);
     std::vector<float> h1((size_t)(T2 + 2) * d, 0.0f);
-    matmul(x0.data(), n_mel, w1.data(), m.w("encoder.conv1.bias").data(), h1.data() + d, d, T2, d, 3 * n_mel, o.mode);
+    matmul(x0.data(), n_mel, w1.data(), m.w("encoder.conv1.bias").data(), h1.data() + d, d, T2, d, 3 * n_mel, o.mode, false);
     for (size_t i = d; i < (size_t)(T2 + 1) * d; i++) h1[i] = gelu_op(h1[i], o);
     std::vector<float> w2 = reorder(m.w("encoder.conv2.weight"), d, d);
     std::vector<float> x((size_t)n_ctx * d);
-    matmul(h1.data(), 2 * d, w2.data(), m.w("encoder.conv2.bias").data(), x.data(), d, n_ctx, d, 3 * d, o.mode);
+    matmul(h1.data(), 2 * d, w2.data(), m.w("encoder.conv2.bias").data(), x.data(), d, n_ctx, d, 3 * d, o.mode, false);
     const std::vector<float>& pe = m.w("encoder.positional_embedding");
     for (size_t i = 0; i < x.size(); i++) x[i] = gelu_op(x[i], o) + pe[i];
 

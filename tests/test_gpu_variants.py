@@ -508,3 +508,53 @@ def test_continuous_batching_early_completion_and_admission(toy_ml_path):
     assert first_short < last_long, "the one-window chunks were held until the multi-window chunks of their group had finished"
     assert tot["admitted"] >= 1, "no queued chunk joined the running group at a window boundary"
     eng.close()
+
+
+def test_lanes_under_concurrent_callers(toy_ml_path):
+    """Two lanes, three kinds of callers at once: threads in blocking ss_transcribe_batch calls (groups spread over the lanes), async tickets
+    through the batch former, and a session reused for consecutive chunks.  Every result equals the serial single-lane result; nothing hangs."""
+    import threading
+    from speaksense_amd import binding
+    serial = binding.Engine(toy_ml_path, max_batch=4, n_lanes=1)
+    P = binding.default_params(language="en", temperature_inc=0.0)
+    pcms = [synth.speech_like(200 + k, 16000 * (5 + k % 4)) for k in range(18)]
+    want = [serial.new_session().transcribe(x, P) for x in pcms]
+    serial.close()
+    eng = binding.Engine(toy_ml_path, max_batch=4, n_lanes=2, batch_wait_us=1000)
+    got = [None] * len(pcms)
+    errors = []
+
+    def blocking(idx):
+        try:
+            ses = [eng.new_session() for _ in idx]
+            res = eng.transcribe_batch(ses, [pcms[i] for i in idx], P)
+            for i, r in zip(idx, res):
+                got[i] = r
+        except Exception as e:   # pragma: no cover
+            errors.append(e)
+
+    def reused(idx):
+        try:
+            s = eng.new_session()
+            for i in idx:
+                got[i] = s.transcribe(pcms[i], P)
+        except Exception as e:   # pragma: no cover
+            errors.append(e)
+
+    th = [threading.Thread(target=blocking, args=(list(range(0, 6)),)), threading.Thread(target=blocking, args=(list(range(6, 9)),)),
+          threading.Thread(target=reused, args=(list(range(9, 12)),))]
+    for t in th:
+        t.start()
+    ses = [eng.new_session() for _ in range(12, 18)]
+    tickets = [s.submit(pcms[i], P) for s, i in zip(ses, range(12, 18))]
+    for s, t, i in zip(ses, tickets, range(12, 18)):
+        got[i] = s.wait(t)
+    for t in th:
+        t.join(timeout=120)
+        assert not t.is_alive(), "a caller is stuck"
+    assert not errors, errors
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert a is not None and list(a["tokens"]) == list(b["tokens"]), i
+    tot = eng.totals()
+    assert tot["n_lanes"] == 2 and tot["encoder_windows"] >= len(pcms)
+    eng.close()
