@@ -148,7 +148,7 @@ def cpu_baseline(path: str, hp, n_steps: int, n_prompt: int):
     chunk_s = min(runs)
     return {"value": round(CHUNK_SEC / chunk_s, 4), "unit": "audio-sec/s", "cores": cores, "kind": "port",
             "sample": f"1 chunk: log-mel + conv stem + {n_enc}/{hp.n_audio_layer} encoder layers + {n_cross}/{hp.n_text_layer} cross-KV layers + "
-                      f"{n_dec} decode steps timed, extrapolated to {hp.n_audio_layer} layers and {n_steps + n_prompt} decoder positions "
+                      f"{n_dec} decode steps timed (nothing extrapolated in the encoder; the decoder steps stand for {n_steps + n_prompt} positions) "
                       f"(est. {chunk_s:.1f} s per 30 s chunk; two repeats: {runs[0]:.1f} / {runs[1]:.1f} s, faster one reported); "
                       f"oracle/whisper_oracle.cpp ggml-f16 mode, {cores} OpenMP threads"}
 

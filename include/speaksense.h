@@ -214,8 +214,8 @@ int ss_engine_last_timing(const ss_engine* e, float out_ms[4]);
  * [1] decoder rows over those passes, [2] encoder windows, [3] 0.  With last_timing[2] this gives the in-pipeline decode-step time. */
 int ss_engine_last_counters(const ss_engine* e, int64_t out4[4]);
 /* Cumulative since engine creation, summed over the lanes: device ms [mel, encoder+cross-KV, decode, total] and work [decoder passes, decoder
- * rows, encoder windows, chunks admitted into a running group].  Differences around a timed region give the in-pipeline averages when several groups run concurrently. */
-int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[4], int32_t* n_lanes);
+ * rows, encoder windows, chunks admitted into a running group, windows started while other windows of their group were decoding, 0].  Differences around a timed region give the in-pipeline averages when several groups run concurrently. */
+int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[6], int32_t* n_lanes);
 /* average device time (ms) of `reps` launches of the dominant encoder GEMM (FC1: M=batch*1500, N=4d, K=d) on the
  * engine's stream, and its algorithmic FLOPs per launch: the roofline probe bench.py reports. */
 int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_ms, double* flops_per_launch);

@@ -290,11 +290,11 @@ class Engine:
     def totals(self):
         """Cumulative device time / work over all lanes since the engine was created (ss_engine_totals)."""
         ms = np.zeros(4, np.float64)
-        cnt = np.zeros(4, np.int64)
+        cnt = np.zeros(6, np.int64)
         nl = C.c_int32()
         _check(self.L.ss_engine_totals(self.h, _p(ms), _p(cnt), C.byref(nl)))
         return dict(mel_ms=float(ms[0]), encode_ms=float(ms[1]), decode_ms=float(ms[2]), total_ms=float(ms[3]), decoder_passes=int(cnt[0]),
-                    decoder_rows=int(cnt[1]), encoder_windows=int(cnt[2]), admitted=int(cnt[3]), n_lanes=int(nl.value))
+                    decoder_rows=int(cnt[1]), encoder_windows=int(cnt[2]), admitted=int(cnt[3]), started_midway=int(cnt[4]), n_lanes=int(nl.value))
 
     def probe_gemm(self, batch: int, reps: int):
         ms, fl = C.c_float(), C.c_double()

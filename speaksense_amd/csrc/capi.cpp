@@ -305,14 +305,16 @@ int ss_engine_last_timing(const ss_engine* e, float out_ms[4]) {
     memcpy(out_ms, e->e->last_ms, 16);
     return SS_OK;
 }
-int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[4], int32_t* n_lanes) {
+int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[6], int32_t* n_lanes) {
     if (!e || !out_ms || !out_cnt) return fail(SS_ERR_ARG, "null argument");
-    for (int i = 0; i < 4; i++) { out_ms[i] = 0; out_cnt[i] = 0; }
+    for (int i = 0; i < 4; i++) out_ms[i] = 0;
+    for (int i = 0; i < 6; i++) out_cnt[i] = 0;
     const int n = e->e->n_lanes();
     for (int l = 0; l < n; l++) {
         EngineBase* L = e->e->lane(l);
         std::lock_guard<std::mutex> lk(L->mu);    // a lane updates its totals at the end of a group, under its own lock
-        for (int i = 0; i < 4; i++) { out_ms[i] += L->tot_ms[i]; out_cnt[i] += L->tot_cnt[i]; }
+        for (int i = 0; i < 4; i++) out_ms[i] += L->tot_ms[i];
+        for (int i = 0; i < 6; i++) out_cnt[i] += L->tot_cnt[i];
     }
     if (n_lanes) *n_lanes = n;
     return SS_OK;

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <list>
 
 namespace ss {
 
@@ -99,11 +100,13 @@ struct Window {
     std::vector<Dec> decs;
     int best = 0;
     bool skip = false;     // detect_language only: the window is not decoded
+    bool done = false;     // accepted attempt, ready to be finalised
 };
 struct JobState {
     Job* job; int slot; int n_len = 0, n_len_org = 0, seek = 0, seek_start = 0, seek_end = 0; bool alive = false;
     std::vector<int> prompt_init;
     bool need_detect = false;   // language "auto": resolved after the first window's encoder pass
+    bool has_window = false;    // a window of this chunk is encoded and decoding right now
 };
 
 static void sequence_score(const ss_params& P, Dec& q) {  // whisper_sequence_score
@@ -219,6 +222,8 @@ struct EngineT : EngineBase {
         step_timing = getenv("SS_STEP_TIMING") != nullptr;
         { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }
         ln_fused = getenv("SS_DECODE_LN_FUSED") ? atoi(getenv("SS_DECODE_LN_FUSED")) : 0;   // 1 both seams, 2 self-attention seam only, 3 cross-attention seam only
+        if (const char* dp = getenv("SS_CROSS_DIRECT_PAIRS")) direct_pairs = atoi(dp);
+        if (const char* sm = getenv("SS_CB_START_MIN")) cb_start_min = std::max(1, atoi(sm));
         wide_ok = getenv("SS_DECODE_WIDE") ? atoi(getenv("SS_DECODE_WIDE")) != 0 : true;   // 17..64 rows through the fused step (0: the older per-op kernels)
         wide_ok = wide_ok && ln_fused == 0 && combine_separate && !cross_direct && pl_qkv.NW <= 4 && pl_dd.NW <= 4 && pl_fc1.NW <= 4 && pl_fc2.NW <= 4 && pl_logits.NW <= 4;
         decode_v2 = narrow_ok && getenv("SS_DECODE_V2") != nullptr && ln_fused == 0 && combine_separate && !cross_direct;
@@ -431,9 +436,15 @@ struct EngineT : EngineBase {
         if (want_f32) launch_layernorm_f32out<T>(x.as<float>(), lnpostw, lnpostb, encF.as<float>(), M, da, st);
     }
     // cross K/V of every decoder layer for Wn windows: one GEMM, N = L*2d, written straight into the cache layout
-    void cross_kv_pass(int Wn) {
+    // cmap (optional): window k of this pass writes the cross-KV cache slot cmap[k] (windows of a running group keep their slots)
+    void cross_kv_pass(int Wn, const int* cmap = nullptr) {
         GemmDesc g = gd(encT.p, da, crosskv_w, Wn * n_ctx, L * 2 * d, da, EPI_CROSS_KV, crosskv_b, cross.p, 0);
         g.scale = qscale; g.d = d; g.rows_per_batch = n_ctx; g.n_batch = B;
+        if (cmap) {
+            if (Wn > (int)sizeof(g.batch_map)) throw Error(-1, "internal: cross-KV slot map too small");
+            g.use_batch_map = 1;
+            for (int i = 0; i < Wn; i++) g.batch_map[i] = (unsigned char)cmap[i];
+        }
         launch_gemm<T>(g, st);
     }
 
@@ -633,7 +644,10 @@ struct EngineT : EngineBase {
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
             }
             const T* kc = cross.as<T>() + il * cl_stride;
-            if (cross_direct) {
+            // key splits exist to fill the chip when there are few (row, head) pairs; from M * H >= direct_pairs on, one workgroup per pair
+            // streams all 1500 keys and writes the normalised output itself: no partials, no combine launch
+            const bool direct = cross_direct || (ln_fused == 0 && M * H >= direct_pairs);
+            if (direct) {
                 launch_dec_cross_attention_direct<T>(pq.as<float>(), n_qpart, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
                                                      attd.as<T>(), st);
             } else {
@@ -641,7 +655,7 @@ struct EngineT : EngineBase {
                                                 cscratch.as<float>(), st);
                 if (combine_separate) launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
             }
-            if (!cross_direct && !combine_separate) {   // cross out-projection partials; the split-key combine is this GEMV's prologue
+            if (!direct && !combine_separate) {   // cross out-projection partials; the split-key combine is this GEMV's prologue
                 DecGemvDesc g = dgd(PRO_COMBINE, DEPI_PART, e.wco, M, d, d, pl_dd.S);
                 g.cross_parts = cscratch.as<float>(); g.part_out = p2.as<float>();
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
@@ -655,7 +669,7 @@ struct EngineT : EngineBase {
                 g.Xt = attd.p; g.ldx = d; g.part_out = p2.as<float>();
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
             }
-            if ((ln_fused == 1 || ln_fused == 3) && !cross_direct && combine_separate) {   // LN2 is FC1's prologue
+            if ((ln_fused == 1 || ln_fused == 3) && !direct && combine_separate) {   // LN2 is FC1's prologue
                 DecGemvDesc g = dgd(PRO_LN, DEPI_GELU_T, e.w1, M, 4 * d, d, 1);
                 g.x_in = xcur; g.ln_w = e.ln2w; g.ln_b = e.ln2b; g.bias = e.b1; g.out = ffd.p; g.ldo = 4 * d;
                 launch_dec_gemv<T>(g, pl_fc1.NW, st);
@@ -767,11 +781,13 @@ struct EngineT : EngineBase {
         }
     }
     DBuf samp_d, rowidx_d, rules_scratch;
-    long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0, cnt_admitted = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
+    long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0, cnt_admitted = 0, cnt_midstart = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
     bool use_fused = true, cross_direct = false, combine_separate = true, use_graph = true;
     int ln_fused = 0;
     bool chain_steps = true;
     bool wide_ok = true;
+    int cb_start_min = 4;     // SS_CB_START_MIN: windows that must be waiting before a running group pauses its decoders for their encoder pass
+    int direct_pairs = 320;   // SS_CROSS_DIRECT_PAIRS: (rows x heads) from which the cross-attention runs unsplit (large-v3: 16 rows)
     bool decode_v2 = false;  // SS_DECODE_V2=1: the 9-launch step below (narrow tiles, LayerNorm prologues); measured SLOWER than the 12-launch step
                              // (2.39 vs 2.18 ms per pass alone, 1304 vs 1533 xRT with two lanes): kept for A/B runs only
     bool step_timing = false; double tm_launch = 0, tm_wait = 0, tm_host = 0; long tm_n = 0; std::chrono::steady_clock::time_point tm_prev;
@@ -879,8 +895,7 @@ struct EngineT : EngineBase {
         SS_HIP(hipEventRecord(ev[0], st));
         for (size_t i = 0; i < grp.size(); i++) js.push_back(setup_job(grp[i], (int)i));
         SS_HIP(hipEventRecord(ev[1], st));
-        cnt_passes = cnt_rows = cnt_windows = cnt_admitted = 0;
-        float ms_enc = 0.f, ms_dec = 0.f;
+        cnt_passes = cnt_rows = cnt_windows = cnt_admitted = cnt_midstart = 0;
         // A chunk is reported the moment its last window is finalised (or it is refused), not when the slowest chunk of the group is done, and
         // a group that keeps running (multi-window chunks, natural-length decodes) takes queued chunks into its free slots at the next window
         // boundary: continuous batching at window granularity.  Finished entries forget their Job (its owner may free it at once).
@@ -898,96 +913,127 @@ struct EngineT : EngineBase {
             }
             return n_alive;
         };
+        // ---- continuous batching at token granularity ------------------------------------------------------------------------------------------
+        // Windows are independent state machines (whisper_full's per-window body: temperature ladder, best_of decoders, segmenting).  Every
+        // iteration of this loop (1) starts windows for chunks that have none -- the next window of a running chunk, or a chunk admitted from
+        // the queue -- with one encoder pass over just those windows, their cross-KV going to free cache slots; (2) advances ALL active
+        // decoders of ALL active windows by one round (one decoder pass); (3) closes the attempts that ended: retry at the next temperature,
+        // or finalise the window, free its slots and report the chunk if that was its last window.  Rows freed by an early EOT are therefore
+        // taken over by new windows after at most `start_min` of them are waiting, not when the slowest window of a group is done.
+        std::list<Window> active;
+        std::vector<int> free_cross, free_dec;
+        for (int i = B - 1; i >= 0; i--) free_cross.push_back(i);
+        for (int i = S - 1; i >= 0; i--) free_dec.push_back(i);
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> enc_events;
+        auto n_jobs_alive = [&]() { int n = 0; for (auto& q : js) n += q.job && q.alive; return n; };
         while (true) {
-            const int n_alive = sweep();
-            if (n_alive == 0) break;
-            if (from_queue && n_alive < B) {
+            sweep();
+            // (1) which chunks need a window?
+            std::vector<JobState*> need;
+            for (auto& q : js) if (q.job && q.alive && !q.has_window) need.push_back(&q);
+            if (from_queue && n_jobs_alive() < B) {
                 std::vector<Job*> more;
-                owner->admit_more(B - n_alive, this, more);
+                owner->admit_more(B - n_jobs_alive(), this, more);
                 cnt_admitted += (long)more.size();
-                for (Job* j : more) {
-                    int slot = -1;
-                    std::vector<bool> used(B, false);
-                    for (auto& q : js) if (q.job) used[q.slot] = true;
-                    for (int i = 0; i < B; i++) if (!used[i]) { slot = i; break; }
-                    grp.push_back(j);
-                    js.push_back(setup_job(j, slot));
-                }
-                if (!more.empty()) sweep();
-            }
-            std::vector<Window> wins;
-            for (auto& q : js) {
-                if (!q.job || !q.alive) continue;
-                Window w; w.job = q.job; w.cross = (int)wins.size();
-                const ss_params& P = q.job->P;
-                if (P.fixed_steps > 0) w.temperatures = {0.0f};
-                else if (P.temperature_inc > 0.0f) for (float t = P.temperature; t < 1.0f + 1e-6f; t += P.temperature_inc) w.temperatures.push_back(t);
-                else w.temperatures = {P.temperature};
-                // "if there is a very short audio segment left to process, we remove any past prompt"
-                if (q.seek > q.seek_start && q.seek + 500 >= q.seek_end) q.job->sess->prompt_past.clear();
-                launch_mel_window<T>(mel_d[q.slot].template as<float>(), n_mel, q.n_len, q.seek, 2 * n_ctx,
-                                     x0.as<T>() + (size_t)w.cross * (2 * n_ctx + 2) * n_mel, st);
-                wins.push_back(std::move(w));
-            }
-            if (wins.empty()) continue;   // (everything left was refused at admission: the sweep ends the loop)
-            const int Wn = (int)wins.size();
-            hipEvent_t e0, e1, e2;
-            SS_HIP(hipEventCreate(&e0)); SS_HIP(hipEventCreate(&e1)); SS_HIP(hipEventCreate(&e2));
-            SS_HIP(hipEventRecord(e0, st));
-            encoder_pass(Wn, false);
-            cross_kv_pass(Wn);
-            SS_HIP(hipEventRecord(e1, st));
-            for (auto& w : wins) { w.job->sess->n_encode++; w.job->sess->n_windows++; }
-            cnt_windows += Wn;
-            detect_languages(wins, js);
-            for (auto& w : wins) if (w.skip) w.pending = false;
-            // temperature ladder
-            int n_pending = 0;
-            for (auto& w : wins) n_pending += w.pending;
-            for (int it = 0; n_pending > 0; it++) {
-                std::vector<Window*> run;
-                for (auto& w : wins) if (w.pending) { w.it = it; run.push_back(&w); }
-                decode_windows(run, js);
-                for (Window* w : run) {
-                    const ss_params& P = w->job->P;
-                    double best_score = -INFINITY;
-                    w->best = 0;
-                    for (size_t j = 0; j < w->decs.size(); j++) {
-                        Dec& dq = w->decs[j];
-                        if (dq.failed) continue;
-                        dq.sampled.resize(dq.tokens.size());
-                        for (size_t k = 0; k < dq.tokens.size(); k++) dq.sampled[k] = dq.tokens[k].id;
-                        dq.tokens.resize(dq.result_len);
-                        sequence_score(P, dq);
-                        if (P.fixed_steps == 0 && dq.result_len > 32 && dq.entropy < P.entropy_thold) { dq.failed = true; continue; }
-                        if (best_score < dq.score) { best_score = dq.score; w->best = (int)j; }
+                if (!more.empty()) {
+                    for (Job* j : more) {
+                        int slot = -1;
+                        std::vector<bool> used(B, false);
+                        for (auto& q : js) if (q.job) used[q.slot] = true;
+                        for (int i = 0; i < B; i++) if (!used[i]) { slot = i; break; }
+                        grp.push_back(j);
+                        js.push_back(setup_job(j, slot));
                     }
-                    bool success = true;
-                    if (it != (int)w->temperatures.size() - 1) {
-                        const Dec& dq = w->decs[w->best];
-                        if (dq.failed || dq.avg_logprobs < P.logprob_thold) { success = false; w->job->sess->n_fail++; }
-                    }
-                    if (success) { w->pending = false; n_pending--; }
+                    sweep();
+                    need.clear();
+                    for (auto& q : js) if (q.job && q.alive && !q.has_window) need.push_back(&q);
                 }
             }
-            SS_HIP(hipEventRecord(e2, st));
-            SS_HIP(hipEventSynchronize(e2));
-            float a = 0, b = 0;
-            SS_HIP(hipEventElapsedTime(&a, e0, e1)); SS_HIP(hipEventElapsedTime(&b, e1, e2));
-            ms_enc += a; ms_dec += b;
-            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
-            // emit segments, advance seek
-            for (auto& w : wins) if (!w.skip) finalize_window(w, js);
+            if (active.empty() && need.empty()) break;
+            // starting windows stalls the decoders that are running for one encoder pass, and an encoder pass over a single window fills
+            // less than half the chip: wait until `start_min` windows can share it unless nothing else is running
+            if (!need.empty() && (active.empty() || (int)need.size() >= std::min(cb_start_min, std::max(1, (n_jobs_alive() + 1) / 2))) && !free_cross.empty()) {
+                spec.valid = false;
+                const bool others_running = !active.empty();
+                std::vector<Window*> fresh;
+                std::vector<int> cmap;
+                for (JobState* qp : need) {
+                    if (free_cross.empty()) break;
+                    JobState& q = *qp;
+                    active.emplace_back();
+                    Window& w = active.back();
+                    w.job = q.job; w.cross = free_cross.back(); free_cross.pop_back();
+                    const ss_params& P = q.job->P;
+                    if (P.fixed_steps > 0) w.temperatures = {0.0f};
+                    else if (P.temperature_inc > 0.0f) for (float t = P.temperature; t < 1.0f + 1e-6f; t += P.temperature_inc) w.temperatures.push_back(t);
+                    else w.temperatures = {P.temperature};
+                    // "if there is a very short audio segment left to process, we remove any past prompt"
+                    if (q.seek > q.seek_start && q.seek + 500 >= q.seek_end) q.job->sess->prompt_past.clear();
+                    launch_mel_window<T>(mel_d[q.slot].template as<float>(), n_mel, q.n_len, q.seek, 2 * n_ctx,
+                                         x0.as<T>() + (size_t)fresh.size() * (2 * n_ctx + 2) * n_mel, st);
+                    q.has_window = true;
+                    cmap.push_back(w.cross);
+                    fresh.push_back(&w);
+                }
+                const int Wn = (int)fresh.size();
+                hipEvent_t e0, e1;
+                SS_HIP(hipEventCreate(&e0)); SS_HIP(hipEventCreate(&e1));
+                SS_HIP(hipEventRecord(e0, st));
+                encoder_pass(Wn, false);
+                cross_kv_pass(Wn, cmap.data());
+                SS_HIP(hipEventRecord(e1, st));
+                enc_events.push_back({e0, e1});
+                for (Window* w : fresh) { w->job->sess->n_encode++; w->job->sess->n_windows++; }
+                cnt_windows += Wn;
+                if (others_running) cnt_midstart += Wn;
+                detect_languages(fresh, js, free_dec);
+                for (Window* w : fresh) {
+                    if (w->skip) { w->done = true; continue; }
+                    w->it = 0;
+                    start_attempt(*w, js, free_dec);
+                }
+            }
+            // (2) one round of every active decoder
+            decode_round(active, js);
+            // (3) attempts that ended
+            for (auto it = active.begin(); it != active.end();) {
+                Window& w = *it;
+                bool running = false;
+                for (auto& dq : w.decs) running |= dq.active;
+                if (!w.done && !running && !w.skip) {
+                    spec.valid = false;
+                    for (auto& dq : w.decs) free_dec.push_back(dq.slot);
+                    if (evaluate_attempt(w)) w.done = true;
+                    else { w.it++; start_attempt(w, js, free_dec); }
+                }
+                if (w.done) {
+                    spec.valid = false;
+                    JobState& jq = state_of(js, w.job);
+                    if (!w.skip) finalize_window(w, js);
+                    jq.has_window = false;
+                    free_cross.push_back(w.cross);
+                    it = active.erase(it);
+                } else ++it;
+            }
         }
+        float ms_enc = 0.f;
         sweep();
         SS_HIP(hipEventRecord(ev[2], st));
         SS_HIP(hipEventSynchronize(ev[2]));
         float ms_mel = 0, ms_tot = 0;
         SS_HIP(hipEventElapsedTime(&ms_mel, ev[0], ev[1]));
         SS_HIP(hipEventElapsedTime(&ms_tot, ev[0], ev[2]));
+        for (auto& ee : enc_events) {   // encoder sections were stamped as they were enqueued; everything has completed by now
+            float a = 0;
+            SS_HIP(hipEventElapsedTime(&a, ee.first, ee.second));
+            ms_enc += a;
+            (void)hipEventDestroy(ee.first); (void)hipEventDestroy(ee.second);
+        }
+        const float ms_dec = std::max(0.0f, ms_tot - ms_mel - ms_enc);   // decoder passes + their host turnarounds: what is left of the group
         last_ms[0] = ms_mel; last_ms[1] = ms_enc; last_ms[2] = ms_dec; last_ms[3] = ms_tot;
         last_cnt[0] = cnt_passes; last_cnt[1] = cnt_rows; last_cnt[2] = cnt_windows; last_cnt[3] = cnt_admitted;
         for (int i = 0; i < 4; i++) { tot_ms[i] += last_ms[i]; tot_cnt[i] += last_cnt[i]; }
+        tot_cnt[4] += cnt_midstart;
     }
 
     // "these tokens determine the task that will be performed": [sot, lang, task] (multilingual) or [sot], + [notimestamps]
@@ -1003,10 +1049,10 @@ struct EngineT : EngineBase {
     }
     // whisper_lang_auto_detect for the windows whose job asked for it: one decoder row [sot] at position 0 per window on the cross-KV just
     // computed, language = argmax of the raw logits over the language tokens sot+1+id, id in [0, 100) (softmax is monotonic)
-    void detect_languages(std::vector<Window>& wins, std::vector<JobState>& js) {
+    void detect_languages(std::vector<Window*>& wins, std::vector<JobState>& js, std::vector<int>& free_dec) {
         const Vocab& vocab = hm.vocab;
         std::vector<Window*> need;
-        for (auto& w : wins) if (state_of(js, w.job).need_detect) need.push_back(&w);
+        for (Window* w : wins) if (state_of(js, w->job).need_detect) need.push_back(w);
         if (need.empty()) return;
         spec.valid = false;
         ss_params P0; memset(&P0, 0, sizeof(P0));
@@ -1014,12 +1060,14 @@ struct EngineT : EngineBase {
         constexpr int kLangs = 100;   // g_lang: 100 entries whatever the model's vocabulary holds
         std::vector<float> lg((size_t)kLangs);
         for (size_t r0 = 0; r0 < need.size(); r0 += 16) {
-            const int M = (int)std::min<size_t>(16, need.size() - r0);
+            const int M = (int)std::min<size_t>(std::min<size_t>(16, free_dec.size()), need.size() - r0);
+            if (M < 1) throw Error(-1, "internal: no decoder slot free for language detection");
             stage_acquire();
             std::vector<int> sr;
             for (int m = 0; m < M; m++) {
                 RowCtl c{};
-                c.token = vocab.token_sot; c.pos = 0; c.slot = m; c.cross = need[r0 + m]->cross; c.n_hist = 1;
+                // a decoder slot is borrowed for this one row (position 0 of a free slot: nothing else uses it until the row has run)
+                c.token = vocab.token_sot; c.pos = 0; c.slot = free_dec[free_dec.size() - 1 - m]; c.cross = need[r0 + m]->cross; c.n_hist = 1;
                 ctl_h[m] = c; ctl_h[64 + m] = c;
                 sr.push_back(m);
             }
@@ -1043,52 +1091,68 @@ struct EngineT : EngineBase {
 
     JobState& state_of(std::vector<JobState>& js, Job* j) { for (auto& q : js) if (q.job == j && j) return q; throw Error(-1, "internal: job state"); }
 
-    // Decode all decoders of the given windows at their current ladder temperature, in lock-step rounds.
-    // Round = every active decoder advances to its next sampling point: the first round feeds the whole prompt
-    // ([prev] + past text + sot/lang/task), later rounds one token each.
+    // "init prompt and kv cache for the current iteration" of one window at its ladder position w.it: the prompt ([prev] + past text + sot/lang/task)
+    // and the decoders (1 at t = 0, best_of at t > 0), each on a free self-KV slot
+    void start_attempt(Window& w, std::vector<JobState>& js, std::vector<int>& free_dec) {
+        const ss_params& P = w.job->P;
+        const float t_cur = w.temperatures[w.it];
+        const int nd = (t_cur > 0.0f) ? std::max(1, (int)P.best_of) : 1;
+        Session* s = w.job->sess;
+        JobState& jq = state_of(js, w.job);
+        w.prompt.clear();
+        if (!s->prompt_past.empty() && t_cur < 0.5f && P.n_max_text_ctx > 0) {
+            const int n_take = std::min(std::min((int)P.n_max_text_ctx, n_tctx / 2), (int)s->prompt_past.size());
+            w.prompt.push_back(hm.vocab.token_prev);
+            w.prompt.insert(w.prompt.end(), s->prompt_past.end() - n_take, s->prompt_past.end());
+        }
+        w.prompt.insert(w.prompt.end(), jq.prompt_init.begin(), jq.prompt_init.end());
+        if ((int)free_dec.size() < nd) throw Error(-1, "internal: decoder slots exceeded");
+        w.decs.assign(nd, Dec());
+        for (int j = 0; j < nd; j++) {
+            Dec& q = w.decs[j];
+            q.seek_delta = 100 * kChunkSec; q.active = true; q.slot = free_dec.back(); free_dec.pop_back();
+        }
+    }
+    // the end of an attempt: score the decoders, pick the best, decide between accepting and falling back to the next temperature
+    bool evaluate_attempt(Window& w) {
+        const ss_params& P = w.job->P;
+        double best_score = -INFINITY;
+        w.best = 0;
+        for (size_t j = 0; j < w.decs.size(); j++) {
+            Dec& dq = w.decs[j];
+            if (dq.failed) continue;
+            dq.sampled.resize(dq.tokens.size());
+            for (size_t k = 0; k < dq.tokens.size(); k++) dq.sampled[k] = dq.tokens[k].id;
+            dq.tokens.resize(dq.result_len);
+            sequence_score(P, dq);
+            if (P.fixed_steps == 0 && dq.result_len > 32 && dq.entropy < P.entropy_thold) { dq.failed = true; continue; }
+            if (best_score < dq.score) { best_score = dq.score; w.best = (int)j; }
+        }
+        bool success = true;
+        if (w.it != (int)w.temperatures.size() - 1) {
+            const Dec& dq = w.decs[w.best];
+            if (dq.failed || dq.avg_logprobs < P.logprob_thold) { success = false; w.job->sess->n_fail++; }
+        }
+        return success;
+    }
+    // One round: every active decoder of every active window advances to its next sampling point (the first round of an attempt feeds the
+    // whole prompt, later rounds one token), as rows of the same decoder pass(es); rows are grouped by rule-constant signature (normally one group).
     struct RowRef { Window* w; int j; bool sample; };
     struct Spec { bool valid = false; int parity = 0; RuleConsts rc; std::vector<std::pair<Window*, int>> decs; } spec;   // a chained step in flight
-    void decode_windows(std::vector<Window*>& run, std::vector<JobState>& js) {
-        spec.valid = false;   // a chained step left in flight by the previous attempt belongs to decoders that no longer exist
-        int slot = 0;
-        for (Window* w : run) {
-            const ss_params& P = w->job->P;
-            const float t_cur = w->temperatures[w->it];
-            const int nd = (t_cur > 0.0f) ? std::max(1, (int)P.best_of) : 1;
-            // prompt for this attempt (whisper_full: "init prompt and kv cache for the current iteration")
-            Session* s = w->job->sess;
-            JobState& jq = state_of(js, w->job);
-            w->prompt.clear();
-            if (!s->prompt_past.empty() && t_cur < 0.5f && P.n_max_text_ctx > 0) {
-                const int n_take = std::min(std::min((int)P.n_max_text_ctx, n_tctx / 2), (int)s->prompt_past.size());
-                w->prompt.push_back(hm.vocab.token_prev);
-                w->prompt.insert(w->prompt.end(), s->prompt_past.end() - n_take, s->prompt_past.end());
-            }
-            w->prompt.insert(w->prompt.end(), jq.prompt_init.begin(), jq.prompt_init.end());
-            w->decs.assign(nd, Dec());
-            for (int j = 0; j < nd; j++) {
-                Dec& q = w->decs[j];
-                q.seek_delta = 100 * kChunkSec; q.active = true; q.slot = slot++;
-            }
-        }
-        if (slot > S) throw Error(-1, "internal: decoder slots exceeded");
-        while (true) {
-            // rows of this round, grouped by rule-constant signature (normally a single group)
-            std::vector<RowRef> all;
-            for (Window* w : run)
-                for (int j = 0; j < (int)w->decs.size(); j++) if (w->decs[j].active) all.push_back({w, j, false});
-            if (all.empty()) break;
-            size_t pos0 = 0;
-            while (pos0 < all.size()) {
-                const ss_params& P0 = all[pos0].w->job->P;
-                auto same = [&](const ss_params& a) {
-                    return a.suppress_blank == P0.suppress_blank && a.no_timestamps == P0.no_timestamps && a.tdrz_enable == P0.tdrz_enable &&
-                           a.max_initial_ts == P0.max_initial_ts && (a.fixed_steps > 0) == (P0.fixed_steps > 0);
-                };
-                std::vector<RowRef> g;
-                while (pos0 < all.size() && same(all[pos0].w->job->P)) g.push_back(all[pos0++]);
-                round_rows(g, js, rule_consts(P0));
-            }
+    void decode_round(std::list<Window>& active, std::vector<JobState>& js) {
+        std::vector<RowRef> all;
+        for (Window& w : active)
+            for (int j = 0; j < (int)w.decs.size(); j++) if (w.decs[j].active) all.push_back({&w, j, false});
+        size_t pos0 = 0;
+        while (pos0 < all.size()) {
+            const ss_params& P0 = all[pos0].w->job->P;
+            auto same = [&](const ss_params& a) {
+                return a.suppress_blank == P0.suppress_blank && a.no_timestamps == P0.no_timestamps && a.tdrz_enable == P0.tdrz_enable &&
+                       a.max_initial_ts == P0.max_initial_ts && (a.fixed_steps > 0) == (P0.fixed_steps > 0);
+            };
+            std::vector<RowRef> g;
+            while (pos0 < all.size() && same(all[pos0].w->job->P)) g.push_back(all[pos0++]);
+            round_rows(g, js, rule_consts(P0));
         }
     }
 

@@ -89,7 +89,7 @@ struct EngineBase {
     // cumulative device time (ms: mel, encoder+cross-KV, decode, total) and work (decoder passes, decoder rows, encoder windows) of this lane since
     // creation; ss_engine_totals sums over the lanes
     double tot_ms[4] = {0, 0, 0, 0};
-    long tot_cnt[4] = {0, 0, 0, 0};
+    long tot_cnt[6] = {0, 0, 0, 0, 0, 0};   // ..., [4] windows started while other windows of the group were decoding
 
     // async batch former: one worker thread per lane; one of them at a time forms the next batch from the queue
     std::vector<std::thread> workers;

@@ -47,6 +47,8 @@ struct GemmDesc {
     int rows_per_batch;       // T (1500) for EPI_VT / EPI_CROSS_KV / EPI_GELU_POS_F32
     int d, Tpad, n_batch;     // EPI_VT / EPI_CROSS_KV geometry
     int gelu_f16_in;          // f16 engines: gelu(f16(x)) like ggml's table (no-op for bf16)
+    int use_batch_map;        // EPI_CROSS_KV: window b of this launch writes cache slot batch_map[b] instead of b
+    unsigned char batch_map[128];
     int stagger_ticks, stagger_groups;   // set by launch_gemm: start-time stagger of the persistent workgroups (see gemm256_kernel)
     long long* trace;         // dev tool (tools/gemm_bench.cpp): per workgroup and tile {start, loop start, loop end, stores issued} s_memtime stamps; null in the product
 };

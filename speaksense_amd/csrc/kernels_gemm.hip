@@ -196,7 +196,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
                     // n = l*2d + kv*d + h*64 + j ; cache [l][b][kv][h][t][64]
                     const int H = g.d / 64;
                     const int l = n / (2 * g.d), rem = n % (2 * g.d), kv = rem / g.d, hj = rem % g.d, h = hj >> 6, j = hj & 63;
-                    const int b = (int)(m / g.rows_per_batch), t = (int)(m % g.rows_per_batch);
+                    int b = (int)(m / g.rows_per_batch);
+                    const int t = (int)(m % g.rows_per_batch);
+                    if (g.use_batch_map) b = g.batch_map[b];
                     const float sc = kv == 0 ? g.scale : 1.0f;
                     V4 o;
 #pragma unroll
@@ -545,7 +547,9 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
                 } else if constexpr (KIND == EPI_CROSS_KV) {
                     const int H = g.d / 64;
                     const int l = n / (2 * g.d), rem = n % (2 * g.d), kv = rem / g.d, hj = rem % g.d, h = hj >> 6, j = hj & 63;
-                    const int b = (int)(m / g.rows_per_batch), t = (int)(m % g.rows_per_batch);
+                    int b = (int)(m / g.rows_per_batch);
+                    const int t = (int)(m % g.rows_per_batch);
+                    if (g.use_batch_map) b = g.batch_map[b];
                     const float sc = kv == 0 ? g.scale : 1.0f;
                     V4 o;
 #pragma unroll

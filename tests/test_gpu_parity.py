@@ -144,9 +144,9 @@ def test_process_logits_matches_oracle(toy_en_path, toy_ml_path, orc):
 # ------------------------------------------------------------------------------------------------
 # Top-2 margins.  f16 operands: the device's logits sit ~3e-3 sigma from the ggml-f16 oracle (max over the vocabulary, tools/stage_check.py),
 # the synthetic models have sigma(logits) = logit_gain = 9, so a pick other than the oracle's argmax is only legitimate when the oracle's own
-# margin for it is below a few times 3e-3 * 9 = 0.027.  bf16 (8-bit mantissa at every mat-mul input): measured ~2e-2 sigma.
+# margin for it is below a few times 3e-3 * 9 = 0.027.  bf16 (8-bit mantissa at every mat-mul input, weights included): measured <= 8e-3 sigma.
 GAP_TOL_F16 = 4 * 3e-3 * 9.0      # 0.108 in log-probability units
-GAP_TOL_BF16 = 4 * 2e-2 * 9.0     # 0.72
+GAP_TOL_BF16 = 0.25               # measured with bf16-rounded weights AND activations in the oracle: every flip below 0.07 (run r02_j)
 
 
 def check_against_oracle(got, om, orc, mode, pcm, P, ctx, gap_tol, replay_only=False):

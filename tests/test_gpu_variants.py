@@ -504,9 +504,11 @@ def test_continuous_batching_early_completion_and_admission(toy_ml_path):
         assert list(a["tokens"]) == list(b["tokens"]) and [s["text"] for s in a["segments"]] == [s["text"] for s in b["segments"]], i
     tot = eng.totals()
     first_short, last_long = min(done_at[2], done_at[3]), max(done_at[0], done_at[1])
-    print(f"one-window chunks of the first batch back {1e3 * (last_long - first_short):.1f} ms before the multi-window ones; admitted into the running group: {tot['admitted']}")
+    print(f"one-window chunks of the first batch back {1e3 * (last_long - first_short):.1f} ms before the multi-window ones; admitted into the running group: {tot['admitted']}, "
+          f"windows started while others were decoding: {tot['started_midway']}")
     assert first_short < last_long, "the one-window chunks were held until the multi-window chunks of their group had finished"
     assert tot["admitted"] >= 1, "no queued chunk joined the running group at a window boundary"
+    assert tot["started_midway"] >= 1, "no window was started while other windows of the group were still decoding (rows freed by an early end were not refilled)"
     eng.close()
 
 
