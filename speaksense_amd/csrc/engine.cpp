@@ -1696,6 +1696,7 @@ void EngineBase::job_finished(Job* j, EngineBase* lane_) {
     if (q) { donecv.notify_all(); qcv.notify_all(); }
 }
 int EngineBase::admit_more(int n_max, EngineBase* lane_, std::vector<Job*>& out) {
+    if (workers_free.load() > 0) return 0;   // a lane with nothing to do starts a chunk sooner than a running group reaches its next window start
     std::lock_guard<std::mutex> lk(qmu);
     for (auto it = queue.begin(); it != queue.end() && (int)out.size() < n_max;) {
         bool dup = false;
@@ -1716,6 +1717,8 @@ void EngineBase::start_worker() {
             EngineBase* L = lane(li);
             while (true) {
                 std::vector<Job*> batch;
+                workers_free.fetch_add(1);
+                struct FreeGuard { std::atomic<int>& c; bool on = true; void off() { if (on) { c.fetch_sub(1); on = false; } } ~FreeGuard() { off(); } } free_guard{workers_free};
                 {
                     // one worker at a time forms a batch (otherwise two idle workers would split a trickle of chunks between them); the
                     // others queue up behind form_mu and form the NEXT batch while this one runs
@@ -1744,6 +1747,7 @@ void EngineBase::start_worker() {
                 }
                 // nothing may escape this thread (std::terminate would take the host service down).  Chunks normally complete one by one from
                 // inside the group (job_finished); whatever this lane still has registered afterwards -- the group threw -- is failed and released.
+                free_guard.off();
                 int fail_code = 0;
                 std::string fail_what;
                 {

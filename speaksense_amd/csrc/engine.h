@@ -105,6 +105,7 @@ struct EngineBase {
     int admit_more(int n_max, EngineBase* lane_, std::vector<Job*>& out); // pop up to n_max queued chunks (sessions not in flight) for a running group
     bool stop = false;
     std::atomic<unsigned> rr{0};
+    std::atomic<int> workers_free{0};   // workers not running a batch right now (waiting for, or forming, one): queued chunks are theirs first
     void start_worker();
     void stop_worker();
     void submit(Job* j);
