@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 
 CHUNK_SEC = 30.0
 MFMA_PEAK_TFLOPS = 2500.0   # dense bf16/f16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP8_PEAK_TFLOPS = 5000.0    # dense MX-scaled fp8 MFMA peak (same guide; the non-scaled fp8 MFMA runs at the bf16 rate)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -160,7 +161,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--batch", type=int, default=8, help="30 s chunks per GPU per step")
-    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "fp8"])
     ap.add_argument("--fixed-steps", type=int, default=96, help="Mode F decode steps per chunk; 0 = Mode N (natural EOT, full whisper.cpp rules)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inflight", type=int, default=8, help="steps (device batches of --batch chunks) in flight at once: step i is submitted before step "
@@ -220,7 +221,7 @@ def main():
     torch.cuda.set_device(local_rank_dev)
     path = ensure_model(args.model, local_rank, dist)
     hp = ggml_io.PRESETS.get(args.model)
-    eng = binding.Engine(path, device=local_rank_dev, dtype=binding.DTYPE_F16 if args.dtype == "f16" else binding.DTYPE_BF16,
+    eng = binding.Engine(path, device=local_rank_dev, dtype={"f16": binding.DTYPE_F16, "bf16": binding.DTYPE_BF16, "fp8": binding.DTYPE_FP8}[args.dtype],
                          max_batch=args.device_batch if args.device_batch > 0 else args.batch)
     if hp is None:
         hp = ggml_io.HParams(eng.n_vocab, eng.n_audio_ctx, eng.n_audio_state, eng.n_audio_head, eng.n_audio_layer, eng.n_text_ctx,
@@ -323,6 +324,9 @@ def main():
         gemm_batch = eng.max_batch                   # the encoder GEMMs run over a whole device batch: M = engine max_batch * 1500 rows
         gemm_ms, gemm_flops = eng.probe_gemm(gemm_batch, 20)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
+        fp8 = args.dtype == "fp8"
+        mfma_peak = FP8_PEAK_TFLOPS if fp8 else MFMA_PEAK_TFLOPS     # the encoder GEMMs of the fp8 engine run on the MX-scaled e4m3 MFMA
+        opb = 1.0 if fp8 else 2.0                                    # bytes per operand / FC1 output element
         out = {
             "metric": "audio-sec/s (xRT) + p50 chunk latency, Whisper large-v3 30s chunks @1/8 GPU",
             "value": round(value, 2), "unit": "audio-sec/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -352,13 +356,15 @@ def main():
                          "algorithmic_bytes": pass_bytes, "avg_launch_ms": round(pass_ms, 5), "launches_per_step": round(passes, 2), "rows_per_launch": round(rows_per_pass, 2)},
             "phase_roofline": {
                 "encoder_phase_tflops": round(args.batch * work["enc_flops"] / (enc_ms * 1e-3) / 1e12, 1),
-                "encoder_phase_frac_mfma": round(args.batch * work["enc_flops"] / (enc_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                "encoder_phase_frac_mfma": round(args.batch * work["enc_flops"] / (enc_ms * 1e-3) / 1e12 / mfma_peak, 4),
                 "encoder_phase_note": "device time of the encoder + cross-KV phases while the other lane's decoder passes share the chip; alone (--inflight 1) the same phase runs at ~0.30",
-                "encoder_fc1_gemm": {"bound": "mfma", "kernel": f"gemm256_kernel<T, EPI_GELU_T> (M={gemm_batch}*1500, N=4d, K=d, bias+GELU fused), "
-                                     "20 back-to-back launches on the engine's stream after the timed region",
-                                     "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "encoder_fc1_gemm": {"bound": "mfma", "kernel": (f"gemm_f8_kernel<T, F8_GELU_F8> (e4m3 operands, MX-scaled 32x32x64 MFMA; M={gemm_batch}*1500, N=4d, K=d, "
+                                                                  "weight scale + bias + GELU + e4m3 quantisation fused), " if fp8 else
+                                                                  f"gemm256_kernel<T, EPI_GELU_T> (M={gemm_batch}*1500, N=4d, K=d, bias+GELU fused), ")
+                                     + "20 back-to-back launches on the engine's stream after the timed region",
+                                     "achieved": round(achieved, 1), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(achieved / mfma_peak, 4),
                                      "traffic": pmc_traffic(args.model, args.batch, args.dtype, "fc1"),
-                                     "algorithmic_bytes": 2.0 * (gemm_batch * hp.n_audio_ctx * hp.n_audio_state + 4 * hp.n_audio_state * hp.n_audio_state + 4 * gemm_batch * hp.n_audio_ctx * hp.n_audio_state),
+                                     "algorithmic_bytes": opb * (gemm_batch * hp.n_audio_ctx * hp.n_audio_state + 4 * hp.n_audio_state * hp.n_audio_state + 4 * gemm_batch * hp.n_audio_ctx * hp.n_audio_state),
                                      "avg_launch_ms": round(gemm_ms, 4)},
                 "decode_pass_ms": round(pass_ms, 4),
                 "whole_chunk_tflops": round(n_gpus * args.batch * work["flops_chunk"] * args.steps / dt / 1e12, 1)},

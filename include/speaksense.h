@@ -27,7 +27,7 @@ typedef struct ss_engine ss_engine;
 typedef struct ss_session ss_session;
 typedef struct ss_ticket ss_ticket;
 
-enum { SS_DTYPE_BF16 = 0, SS_DTYPE_F16 = 1 };
+enum { SS_DTYPE_BF16 = 0, SS_DTYPE_F16 = 1, SS_DTYPE_FP8 = 2 };
 enum {
     SS_OK = 0,
     SS_ERR_ARG = -1,       /* null / out-of-range argument */
@@ -40,7 +40,10 @@ enum {
 
 typedef struct ss_engine_opts {
     int32_t device;       /* HIP device ordinal (one engine per GPU; one process per GPU under torchrun) */
-    int32_t dtype;        /* SS_DTYPE_F16 (ggml's arithmetic type: the parity configuration; used when opts == NULL) | SS_DTYPE_BF16 */
+    int32_t dtype;        /* SS_DTYPE_F16 (ggml's arithmetic type: the parity configuration; used when opts == NULL) | SS_DTYPE_BF16 |
+                             SS_DTYPE_FP8: the f16 engine with the encoder-block and cross-KV projections (98 % of the path's FLOPs) on OCP e4m3
+                             weights and activations, MX-scaled fp8 MFMA; needs n_audio_state % 256 == 0 (base and larger).  No reference
+                             counterpart: whisper.cpp has no fp8; parity is against the oracle's FP8 mode with the same rounding points */
     int32_t max_batch;    /* windows encoded+decoded together on the device (default 8) */
     int32_t max_decoders; /* decoders per window at temperature > 0 (reference: Greedy{best_of:5}, whisper.rs:132) */
     int32_t batch_wait_us;/* how long the batch former waits for more chunks before launching a partial batch */
@@ -224,6 +227,15 @@ int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_m
  * compared on the device with a one-thread-per-output reference.  kind: 0 bias -> T, 1 bias + GELU -> T, 2 bias + f32 residual (in place),
  * 6 bias -> f32.  The parity tests run small models (one tile per workgroup); this reaches the multi-tile paths at the large-v3 shapes. */
 int ss_engine_selftest_gemm(ss_engine* e, int32_t M, int32_t N, int32_t K, int32_t kind, float* max_err, float* max_ref);
+/* The same with two extras.  fp8 != 0: the e4m3 GEMM on the MX-scaled MFMA (N % 256 == 0, K % 256 == 0; seeded e4m3 codes, per-row-block exponent
+ * bytes and per-column weight scales; kind: 0 -> T, 1 GELU -> e4m3 + exponent bytes (max_err then is the excess over the 2^-4 quantisation step),
+ * 2 f32 residual, 5 -> f32).  reps > 0: the launch is then repeated reps times and its average duration returned in *avg_ms (may be NULL). */
+int ss_engine_selftest_gemm_ex(ss_engine* e, int32_t M, int32_t N, int32_t K, int32_t kind, int32_t fp8, int32_t reps, float* max_err, float* max_ref,
+                               float* avg_ms);
+
+/* Host utility (no device needed): the OCP e4m3 code of each float, round to nearest even, saturating at +-448 -- the converter the fp8 engine
+ * quantises its weights with at load (w / scale_n, scale_n = amax_n / 448), identical to gfx950's v_cvt_pk_fp8_f32. */
+int ss_e4m3_from_f32(const float* x, uint8_t* codes, int64_t n);
 
 #ifdef __cplusplus
 }

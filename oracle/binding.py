@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-MODE_F32, MODE_GGML_F16, MODE_BF16 = 0, 1, 2
+MODE_F32, MODE_GGML_F16, MODE_BF16, MODE_FP8 = 0, 1, 2, 3   # FP8: GGML_F16 + e4m3 encoder-block / cross-KV projections (whisper_oracle.cpp header)
 
 
 class OrcOpts(C.Structure):
@@ -62,6 +62,9 @@ def lib():
         L.orc_full.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FullParams)]
         L.orc_full_forced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FullParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_n_sampled.argtypes = [C.c_void_p]
+        L.orc_e4m3_round.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_e8m0_exponent.argtypes = [C.c_float]
+        L.orc_quantize_rows_f8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_lang_id.argtypes = [C.c_void_p]
         L.orc_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
         L.orc_sampled.argtypes = [C.c_void_p, C.c_void_p]
@@ -252,3 +255,23 @@ class OracleState:
         c = np.zeros(3, np.int32)
         self.L.orc_counters(self.h, _p(c))
         return dict(segments=segs, tokens=ids, plog=plog, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]), **extra)
+
+
+def e4m3_round(x: np.ndarray) -> np.ndarray:
+    """FP8 mode primitive: nearest OCP e4m3 value (ties to even code, saturating at 448)."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().orc_e4m3_round(x.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), x.size)
+    return out
+
+
+def e8m0_exponent(amax: float) -> int:
+    return int(lib().orc_e8m0_exponent(C.c_float(amax)))
+
+
+def quantize_rows_f8(a: np.ndarray, f16_first: bool = False) -> np.ndarray:
+    """FP8 mode primitive: per (row, 64-column block) power-of-two scale + e4m3, returned dequantised."""
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.empty_like(a)
+    lib().orc_quantize_rows_f8(a.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], int(f16_first))
+    return out

@@ -16,6 +16,10 @@
 //                 mat-mul input, K/V caches f16, GELU and softmax-exp through f16 tables
 //                 (wcpp: ggml_vec_gelu_f32 / ggml_compute_forward_soft_max_f32 with ggml_table_*_f16)
 //   2  BF16     : as mode 1 but rounding activations / caches to bf16 (what a bf16 MFMA pipeline does)
+//   3  FP8      : mode 1 with the projections of the encoder blocks and the cross-K/V projection in OCP e4m3 (BASELINE configs[4]; no
+//                 whisper.cpp counterpart -- this mode DEFINES the rounding points the fp8 engine must reproduce): weights = e4m3 codes x one
+//                 f32 scale per output channel (amax / 448); activations = e4m3 codes x 2^s per (row, 64-column block), s the smallest
+//                 integer with amax / 2^s <= 448; products accumulated in f32.  Conv stem, attention, residual stream, decoder: mode 1.
 //   gelu_erf=1 switches GELU to the exact erf form (HF cross-check only; whisper.cpp uses tanh).
 #include <algorithm>
 #include <cmath>
@@ -45,7 +49,7 @@ inline float bf16_round(float x) {
     float y; memcpy(&y, &u, 4); return y;
 }
 
-struct Opts { int mode = 0; int gelu_erf = 0; int n_threads = 0; };
+struct Opts { int mode = 0; int gelu_erf = 0; int n_threads = 0; int fp8 = 0; };   // fp8: API mode 3 = mode 1 + e4m3 encoder / cross-KV projections
 inline float act_round(float x, int mode) { return mode == 1 ? f16_round(x) : mode == 2 ? bf16_round(x) : x; }
 
 inline float gelu_tanh(float x) {
@@ -408,6 +412,85 @@ void matmul(const float* A, int lda, const float* W, const float* bias, float* C
     }
 }
 
+// ---- FP8 mode (API mode 3) ----
+// e4m3 by table: the 127 non-negative finite values in code order (code = index), nearest with ties to the even code, saturating at 448.
+// Written independently of the engine's bit-twiddling converter and of the device's v_cvt_pk_fp8_f32; tests compare all three.
+static const float* e4m3_values() {
+    static float t[127];
+    static bool init = false;
+    if (!init) {
+        for (int c = 0; c < 127; c++) {
+            const int e = c >> 3, mnt = c & 7;
+            t[c] = e == 0 ? ldexpf((float)mnt, -9) : ldexpf(1.0f + mnt / 8.0f, e - 7);
+        }
+        init = true;
+    }
+    return t;
+}
+inline float e4m3_round(float x) {
+    const float* t = e4m3_values();
+    const float a = fabsf(x);
+    if (!(a == a)) return x;
+    int c;
+    if (a >= 448.0f) c = 126;
+    else {
+        int lo = 0, hi = 126;                       // t[lo] <= a < t[hi]
+        while (hi - lo > 1) { const int mid = (lo + hi) / 2; if (t[mid] <= a) lo = mid; else hi = mid; }
+        const float dl = a - t[lo], dh = t[hi] - a;   // both exact: neighbours differ in the last few mantissa bits of a
+        c = dl < dh ? lo : dl > dh ? hi : ((lo & 1) ? hi : lo);
+    }
+    return x < 0 ? -t[c] : t[c];
+}
+inline int e8m0_exponent(float amax) {   // biased exponent byte e: scale 2^(e-127), the smallest with amax / scale <= 448; clamped to [1, 253]
+    if (!(amax > 0.0f)) return 1;
+    int ex; const float f = frexpf(amax, &ex);      // amax = f * 2^ex, f in [0.5, 1);  448 = 0.875 * 2^9
+    int sft = ex - 9 + (f > 0.875f ? 1 : 0);
+    int e = sft + 127;
+    return e < 1 ? 1 : e > 253 ? 253 : e;
+}
+// quantise-dequantise a row-major activation matrix in place of a copy: out[m][k] = e4m3(a / 2^s) * 2^s per (row, 64-column block)
+static void quantize_rows_f8(const float* A, int lda, float* out, int M, int K, bool f16_first) {
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < M; i++) {
+        for (int k0 = 0; k0 < K; k0 += 64) {
+            const int kn = std::min(64, K - k0);
+            float v[64], amax = 0.f;
+            for (int k = 0; k < kn; k++) { v[k] = A[(size_t)i * lda + k0 + k]; if (f16_first) v[k] = f16_round(v[k]); amax = std::max(amax, fabsf(v[k])); }
+            const int sft = e8m0_exponent(amax) - 127;
+            for (int k = 0; k < kn; k++) out[(size_t)i * K + k0 + k] = ldexpf(e4m3_round(ldexpf(v[k], -sft)), sft);
+        }
+    }
+}
+struct F8Weight { std::vector<float> q, scale; };   // q: exact e4m3 values (codes dequantised without the scale)
+static std::map<const float*, F8Weight> g_f8_w;
+static const F8Weight& f8_weight(const float* W, int N, int K) {
+    std::lock_guard<std::mutex> lk(g_bf16_mu);
+    auto it = g_f8_w.find(W);
+    if (it == g_f8_w.end()) {
+        F8Weight w; w.q.resize((size_t)N * K); w.scale.resize(N);
+#pragma omp parallel for schedule(static)
+        for (int n = 0; n < N; n++) {
+            float amax = 0.f;
+            for (int k = 0; k < K; k++) amax = std::max(amax, fabsf(W[(size_t)n * K + k]));
+            const float sc = amax > 0.f ? amax / 448.0f : 1.0f;
+            w.scale[n] = sc;
+            for (int k = 0; k < K; k++) w.q[(size_t)n * K + k] = e4m3_round(W[(size_t)n * K + k] / sc);
+        }
+        it = g_f8_w.emplace(W, std::move(w)).first;
+    }
+    return it->second;
+}
+// C = scale[n] * (Aq . Wq) + bias
+static void matmul_f8(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, bool a_f16_first) {
+    const F8Weight& w = f8_weight(W, N, K);
+    std::vector<float> Aq((size_t)M * K);
+    quantize_rows_f8(A, lda, Aq.data(), M, K, a_f16_first);
+    matmul(Aq.data(), K, w.q.data(), nullptr, C, ldc, M, N, K, 0);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < M; i++)
+        for (int n = 0; n < N; n++) C[(size_t)i * ldc + n] = C[(size_t)i * ldc + n] * w.scale[n] + (bias ? bias[n] : 0.0f);
+}
+
 // wcpp: ggml_compute_forward_norm_f32 (double sums) followed by mul(w) + add(b)
 void layer_norm(const float* x, const float* w, const float* b, float* y, int rows, int d, float eps = 1e-5f) {
 #pragma omp parallel for schedule(static)
@@ -486,9 +569,15 @@ void encode(const Model& m, const float* mel, int n_len, int seek, const Opts& o
     for (int il = 0; il < n_layers_run; il++) {
         const std::string p = "encoder.blocks." + std::to_string(il) + ".";
         layer_norm(x.data(), m.w(p + "attn_ln.weight").data(), m.w(p + "attn_ln.bias").data(), ln.data(), n_ctx, d);
-        matmul(ln.data(), d, m.w(p + "attn.query.weight").data(), m.w(p + "attn.query.bias").data(), q.data(), d, n_ctx, d, d, o.mode);
-        matmul(ln.data(), d, m.w(p + "attn.key.weight").data(), nullptr, k.data(), d, n_ctx, d, d, o.mode);
-        matmul(ln.data(), d, m.w(p + "attn.value.weight").data(), m.w(p + "attn.value.bias").data(), v.data(), d, n_ctx, d, d, o.mode);
+        if (o.fp8) {
+            matmul_f8(ln.data(), d, m.w(p + "attn.query.weight").data(), m.w(p + "attn.query.bias").data(), q.data(), d, n_ctx, d, d, false);
+            matmul_f8(ln.data(), d, m.w(p + "attn.key.weight").data(), nullptr, k.data(), d, n_ctx, d, d, false);
+            matmul_f8(ln.data(), d, m.w(p + "attn.value.weight").data(), m.w(p + "attn.value.bias").data(), v.data(), d, n_ctx, d, d, false);
+        } else {
+            matmul(ln.data(), d, m.w(p + "attn.query.weight").data(), m.w(p + "attn.query.bias").data(), q.data(), d, n_ctx, d, d, o.mode);
+            matmul(ln.data(), d, m.w(p + "attn.key.weight").data(), nullptr, k.data(), d, n_ctx, d, d, o.mode);
+            matmul(ln.data(), d, m.w(p + "attn.value.weight").data(), m.w(p + "attn.value.bias").data(), v.data(), d, n_ctx, d, d, o.mode);
+        }
         if (o.mode) for (size_t i = 0; i < k.size(); i++) { k[i] = act_round(k[i], o.mode); v[i] = act_round(v[i], o.mode); }  // K,V stored as itype
 #pragma omp parallel
         {
@@ -497,6 +586,16 @@ void encode(const Model& m, const float* mel, int n_len, int seek, const Opts& o
             for (int h = 0; h < H; h++) for (int t = 0; t < n_ctx; t++)
                 attend_row(q.data() + (size_t)t * d + h * dh, k.data() + h * dh, v.data() + h * dh, d, n_ctx, dh, scale,
                            att.data() + (size_t)t * d + h * dh, o, sc);
+        }
+        if (o.fp8) {   // attention output is stored in f16 by the engine before it is quantised; the GELU output is quantised from f32
+            matmul_f8(att.data(), d, m.w(p + "attn.out.weight").data(), m.w(p + "attn.out.bias").data(), tmp.data(), d, n_ctx, d, d, true);
+            for (size_t i = 0; i < x.size(); i++) x[i] += tmp[i];
+            layer_norm(x.data(), m.w(p + "mlp_ln.weight").data(), m.w(p + "mlp_ln.bias").data(), ln.data(), n_ctx, d);
+            matmul_f8(ln.data(), d, m.w(p + "mlp.0.weight").data(), m.w(p + "mlp.0.bias").data(), ff.data(), 4 * d, n_ctx, 4 * d, d, false);
+            for (size_t i = 0; i < ff.size(); i++) ff[i] = gelu_tanh(f16_round(ff[i]));
+            matmul_f8(ff.data(), 4 * d, m.w(p + "mlp.2.weight").data(), m.w(p + "mlp.2.bias").data(), tmp.data(), d, n_ctx, d, 4 * d, false);
+            for (size_t i = 0; i < x.size(); i++) x[i] += tmp[i];
+            continue;
         }
         matmul(att.data(), d, m.w(p + "attn.out.weight").data(), m.w(p + "attn.out.bias").data(), tmp.data(), d, n_ctx, d, d, o.mode);
         for (size_t i = 0; i < x.size(); i++) x[i] += tmp[i];
@@ -572,8 +671,13 @@ void cross_kv(State& s, int max_layers = -1) {
     for (int il = 0; il < Lrun; il++) {
         const std::string p = "decoder.blocks." + std::to_string(il) + ".cross_attn.";
         float* K = &s.ck[(size_t)il * n_ctx * d]; float* V = &s.cv[(size_t)il * n_ctx * d];
-        matmul(s.enc.data(), hp.n_audio_state, m.w(p + "key.weight").data(), nullptr, K, d, n_ctx, d, hp.n_audio_state, s.o.mode);
-        matmul(s.enc.data(), hp.n_audio_state, m.w(p + "value.weight").data(), m.w(p + "value.bias").data(), V, d, n_ctx, d, hp.n_audio_state, s.o.mode);
+        if (s.o.fp8) {
+            matmul_f8(s.enc.data(), hp.n_audio_state, m.w(p + "key.weight").data(), nullptr, K, d, n_ctx, d, hp.n_audio_state, false);
+            matmul_f8(s.enc.data(), hp.n_audio_state, m.w(p + "value.weight").data(), m.w(p + "value.bias").data(), V, d, n_ctx, d, hp.n_audio_state, false);
+        } else {
+            matmul(s.enc.data(), hp.n_audio_state, m.w(p + "key.weight").data(), nullptr, K, d, n_ctx, d, hp.n_audio_state, s.o.mode);
+            matmul(s.enc.data(), hp.n_audio_state, m.w(p + "value.weight").data(), m.w(p + "value.bias").data(), V, d, n_ctx, d, hp.n_audio_state, s.o.mode);
+        }
         for (size_t i = 0; i < (size_t)n_ctx * d; i++) { K[i] = act_round(K[i] * kscale, s.o.mode); V[i] = act_round(V[i], s.o.mode); }
     }
 }
@@ -950,7 +1054,7 @@ struct orc_opts { int32_t mode, gelu_erf, n_threads; };
 
 void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 void* orc_load(const char* path) { Model* m = new Model(); if (!load_model(path, *m)) { delete m; return nullptr; } return m; }
-void orc_free(void* m) { { std::lock_guard<std::mutex> lk(g_bf16_mu); g_bf16_w.clear(); } delete (Model*)m; }   // the bf16 copies are keyed by tensor addresses
+void orc_free(void* m) { { std::lock_guard<std::mutex> lk(g_bf16_mu); g_bf16_w.clear(); g_f8_w.clear(); } delete (Model*)m; }   // the bf16 copies are keyed by tensor addresses
 void orc_hparams(void* m, int32_t* out) { memcpy(out, &((Model*)m)->hp, sizeof(HParams)); }
 void orc_special_tokens(void* mp, int32_t* out) {
     const Vocab& v = ((Model*)mp)->vocab;
@@ -958,16 +1062,20 @@ void orc_special_tokens(void* mp, int32_t* out) {
     memcpy(out, t, sizeof(t));
 }
 const char* orc_token_str(void* mp, int id) { return ((Model*)mp)->vocab.id_to_token[id].c_str(); }
+// FP8 mode primitives, exposed for the tests that pin them against torch.float8_e4m3fn and against the device kernels
+void orc_e4m3_round(const float* in, float* out, int n) { for (int i = 0; i < n; i++) out[i] = e4m3_round(in[i]); }
+int orc_e8m0_exponent(float amax) { return e8m0_exponent(amax); }
+void orc_quantize_rows_f8(const float* A, float* out, int M, int K, int f16_first) { quantize_rows_f8(A, K, out, M, K, f16_first != 0); }
 int orc_mel_n_len(int n_samples) { return mel_n_len(n_samples); }
 int orc_mel_n_len_org(int n_samples) { return mel_n_len_org(n_samples); }
 int orc_log_mel(void* mp, const float* pcm, int n, float* out, int n_len) { log_mel(*(Model*)mp, pcm, n, out, n_len); return 0; }
 int orc_encode(void* mp, const float* mel, int n_len, int seek, const orc_opts* o, float* enc_out) {
-    Opts op; op.mode = o->mode; op.gelu_erf = o->gelu_erf;
+    Opts op; op.fp8 = o->mode == 3; op.mode = op.fp8 ? 1 : o->mode; op.gelu_erf = o->gelu_erf;
     if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
     encode(*(Model*)mp, mel, n_len, seek, op, enc_out); return 0;
 }
 void* orc_state_new(void* mp, const orc_opts* o) {
-    State* s = new State(); s->m = (Model*)mp; s->o.mode = o->mode; s->o.gelu_erf = o->gelu_erf;
+    State* s = new State(); s->m = (Model*)mp; s->o.fp8 = o->mode == 3; s->o.mode = s->o.fp8 ? 1 : o->mode; s->o.gelu_erf = o->gelu_erf;
     if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
     s->decoders.resize(1); return s;
 }
@@ -1035,7 +1143,7 @@ void orc_counters(void* sp, int32_t* out) { State* s = (State*)sp; out[0] = s->n
 int orc_time_sample(void* mp, const float* pcm, int n, int mode, int n_enc_layers, int n_cross_layers, int n_dec_steps, int n_threads, double* out5) {
     Model* m = (Model*)mp;
     if (n_threads > 0) omp_set_num_threads(n_threads);
-    State s; s.m = m; s.o.mode = mode; s.decoders.resize(1);
+    State s; s.m = m; s.o.fp8 = mode == 3; s.o.mode = s.o.fp8 ? 1 : mode; s.decoders.resize(1);
     const HParams& hp = m->hp;
     double t0 = omp_get_wtime();
     s.n_len = mel_n_len(n); s.mel.resize((size_t)m->filt_n_mel * s.n_len);

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libspeaksense_hip.so")
 _LIB = None
 
-DTYPE_BF16, DTYPE_F16 = 0, 1
+DTYPE_BF16, DTYPE_F16, DTYPE_FP8 = 0, 1, 2   # FP8: the f16 engine with e4m3 encoder / cross-KV projections
 
 
 class EngineOpts(C.Structure):
@@ -70,6 +70,8 @@ def lib():
         L.ss_result_segment_t1.restype = C.c_int64
         L.ss_result_segment_t1.argtypes = [vp, i32]
         L.ss_result_segment_speaker_turn_next.argtypes = [vp, i32]
+        L.ss_result_segment_n_tokens.argtypes = [vp, i32]
+        L.ss_result_segment_token.argtypes = [vp, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.ss_result_n_tokens.argtypes = [vp]
         L.ss_result_tokens.argtypes = [vp, vp, vp]
         L.ss_result_n_sampled_tokens.argtypes = [vp]
@@ -111,6 +113,8 @@ def lib():
         L.ss_submit_ex.argtypes = [vp, f32p, i32, C.POINTER(Params), i32, C.POINTER(vp)]
         L.ss_engine_probe_gemm.argtypes = [vp, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_double)]
         L.ss_engine_selftest_gemm.argtypes = [vp, i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.ss_e4m3_from_f32.argtypes = [vp, vp, C.c_int64]
+        L.ss_engine_selftest_gemm_ex.argtypes = [vp, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         _LIB = L
     return _LIB
 
@@ -279,6 +283,13 @@ class Engine:
         _check(self.L.ss_engine_selftest_gemm(self.h, M, N, K, kind, C.byref(err), C.byref(ref)))
         return err.value, ref.value
 
+    def selftest_gemm_ex(self, M: int, N: int, K: int, kind: int, fp8: bool = False, reps: int = 0):
+        """As selftest_gemm, optionally the e4m3 kernel (fp8=True; kinds 0 -> T, 1 GELU -> e4m3, 2 f32 residual, 5 -> f32) and a timing of `reps`
+        back-to-back launches -> (max |diff|, max |ref|, average ms per launch)."""
+        err, ref, ms = C.c_float(), C.c_float(), C.c_float()
+        _check(self.L.ss_engine_selftest_gemm_ex(self.h, M, N, K, kind, int(fp8), reps, C.byref(err), C.byref(ref), C.byref(ms)))
+        return err.value, ref.value, ms.value
+
     def last_timing(self):
         t = np.zeros(4, np.float32)
         self.L.ss_engine_last_timing(self.h, _p(t))
@@ -339,9 +350,13 @@ class Session:
     def result(self):
         segs = []
         for i in range(self.L.ss_result_n_segments(self.h)):
+            first_id, first_tid, o4 = C.c_int32(-1), C.c_int32(-1), (C.c_float * 4)()
+            if self.L.ss_result_segment_n_tokens(self.h, i) > 0:
+                self.L.ss_result_segment_token(self.h, i, 0, C.byref(first_id), C.byref(first_tid), o4)
             segs.append(dict(text=self.L.ss_result_segment_text(self.h, i), t0=self.L.ss_result_segment_t0(self.h, i),
                              t1=self.L.ss_result_segment_t1(self.h, i),
-                             speaker_turn_next=bool(self.L.ss_result_segment_speaker_turn_next(self.h, i))))
+                             speaker_turn_next=bool(self.L.ss_result_segment_speaker_turn_next(self.h, i)),
+                             first_id=int(first_id.value)))   # whisper.cpp derives t0 from the first token's `tid` (argmax over timestamps)
         n = self.L.ss_result_n_tokens(self.h)
         ids = np.zeros(n, np.int32)
         plog = np.zeros(n, np.float32)
@@ -421,3 +436,11 @@ class PoolSession(Session):
 def pool_pick(load, cursor: int) -> int:
     a = np.ascontiguousarray(load, np.int32)
     return int(lib().ss_pool_pick(_p(a), len(a), cursor & 0xFFFFFFFF))
+
+
+def e4m3_from_f32(x: np.ndarray) -> np.ndarray:
+    """OCP e4m3 codes (uint8) of float32 values: the host converter the fp8 engine quantises weights with.  Needs no GPU."""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty(x.shape, np.uint8)
+    _check(lib().ss_e4m3_from_f32(_p(x), _p(out), x.size))
+    return out

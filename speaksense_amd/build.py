@@ -9,8 +9,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspeaksense_hip.so")
-SOURCES = ["model.cpp", "kernels_mel.hip", "kernels_gemm.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_decode.hip", "kernels_denoise.hip", "kernels_resample.hip", "engine.cpp", "capi.cpp"]
-HEADERS = ["common.h", "kernels.h", "wave_ops.h", "engine.h", os.path.join("..", "..", "include", "speaksense.h"), os.path.join("..", "..", "include", "whisper_compat.h")]
+SOURCES = ["model.cpp", "kernels_mel.hip", "kernels_gemm.hip", "kernels_gemm_fp8.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_decode.hip", "kernels_denoise.hip", "kernels_resample.hip", "engine.cpp", "capi.cpp"]
+HEADERS = ["common.h", "kernels.h", "gemm_common.h", "wave_ops.h", "engine.h", os.path.join("..", "..", "include", "speaksense.h"), os.path.join("..", "..", "include", "whisper_compat.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-x", "hip"]
 
 

@@ -58,7 +58,9 @@ int ss_engine_create(const char* path, const ss_engine_opts* opts, ss_engine** o
     if (o.max_decoders <= 0) o.max_decoders = 5;
     if (o.max_batch * o.max_decoders > 64 * 8) return fail(SS_ERR_ARG, "ss_engine_create: max_batch*max_decoders too large");
     SS_TRY
-    EngineBase* e = o.dtype == SS_DTYPE_F16 ? make_engine_f16(path, o) : make_engine_bf16(path, o);
+    if (o.dtype != SS_DTYPE_F16 && o.dtype != SS_DTYPE_BF16 && o.dtype != SS_DTYPE_FP8) return fail(SS_ERR_ARG, "ss_engine_create: unknown dtype");
+    // SS_DTYPE_FP8 = the f16 engine with its encoder and cross-KV projections in e4m3
+    EngineBase* e = o.dtype == SS_DTYPE_BF16 ? make_engine_bf16(path, o) : make_engine_f16(path, o);
     *out = new ss_engine{e};
     return SS_OK;
     SS_CATCH
@@ -360,6 +362,15 @@ int ss_preprocess_stream(ss_engine* e, const float* pcm, int64_t n, const int32_
 int ss_engine_selftest_gemm(ss_engine* e, int32_t M, int32_t N, int32_t K, int32_t kind, float* max_err, float* max_ref) {
     if (!e || !max_err || !max_ref) return fail(SS_ERR_ARG, "bad argument");
     SS_TRY e->e->selftest_gemm(M, N, K, kind, max_err, max_ref); return SS_OK; SS_CATCH
+}
+int ss_e4m3_from_f32(const float* x, uint8_t* codes, int64_t n) {
+    if (!x || !codes || n < 0) return fail(SS_ERR_ARG, "ss_e4m3_from_f32: bad argument");
+    for (int64_t i = 0; i < n; i++) codes[i] = f32_to_e4m3(x[i]);
+    return SS_OK;
+}
+int ss_engine_selftest_gemm_ex(ss_engine* e, int32_t M, int32_t N, int32_t K, int32_t kind, int32_t fp8, int32_t reps, float* max_err, float* max_ref, float* avg_ms) {
+    if (!e || !max_err || !max_ref || reps < 0) return fail(SS_ERR_ARG, "bad argument");
+    SS_TRY e->e->selftest_gemm_ex(M, N, K, kind, fp8, reps, max_err, max_ref, avg_ms); return SS_OK; SS_CATCH
 }
 int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_ms, double* flops) {
     if (!e || !avg_ms || !flops || reps <= 0) return fail(SS_ERR_ARG, "bad argument");

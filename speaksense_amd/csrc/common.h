@@ -4,6 +4,7 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -55,6 +56,33 @@ inline int device_cu_count() {   // cached per device: hipGetDeviceProperties is
         cu[dev & 63].store(v, std::memory_order_relaxed);
     }
     return v;
+}
+
+// OCP e4m3 (1-4-3, bias 7, no infinities, 0x7f = NaN, largest finite 448) of a float, round to nearest even, saturating: the conversion
+// v_cvt_pk_fp8_f32 does on gfx950, used here for the weights of the fp8 engine (quantised once on the host at load)
+inline uint8_t f32_to_e4m3(float x) {
+    uint32_t b; memcpy(&b, &x, 4);
+    const uint8_t sign = (uint8_t)((b >> 24) & 0x80);
+    b &= 0x7fffffffu;
+    float a; memcpy(&a, &b, 4);
+    if (!(a == a)) return (uint8_t)(sign | 0x7f);
+    if (a >= 464.0f) return (uint8_t)(sign | 0x7e);            // beyond the last rounding boundary: saturate to 448
+    if (a < 0.0009765625f) return sign;                         // below half the smallest subnormal (2^-10): zero (ties at exactly 2^-10 go to even = 0)
+    int e = (int)(b >> 23) - 127;                               // unbiased exponent of a
+    uint32_t q;                                                 // magnitude in units of the target step
+    if (e < -6) {                                               // subnormal target: step 2^-9
+        const float t = a * 512.0f;                             // exact
+        q = (uint32_t)t;
+        const float r = t - (float)q;
+        if (r > 0.5f || (r == 0.5f && (q & 1))) q++;
+        return (uint8_t)(sign | q);                             // q == 8 is the smallest normal: the encoding carries over
+    }
+    const uint32_t mant = b & 0x7fffffu;
+    q = mant >> 20;                                             // 3 mantissa bits
+    const uint32_t rest = mant & 0xfffffu;
+    if (rest > 0x80000u || (rest == 0x80000u && (q & 1))) q++;
+    if (q == 8) { q = 0; e++; }
+    return (uint8_t)(sign | ((uint32_t)(e + 7) << 3) | q);
 }
 
 // ggml legacy header; field order is the file order

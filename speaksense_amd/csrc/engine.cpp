@@ -137,17 +137,22 @@ struct EngineT : EngineBase {
 
     // ---- weights ----
     DBuf w_all;  // one arena
-    struct EncL { float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2; T *wqkv, *wo, *w1, *w2; };
+    struct EncL { float *ln1w, *ln1b, *bqkv, *bo, *ln2w, *ln2b, *b1, *b2; T *wqkv, *wo, *w1, *w2;
+                  uint8_t *wqkv8, *wo8, *w18, *w28; float *sqkv, *so, *s1, *s2; };   // fp8 engine: e4m3 codes + one f32 scale per output channel
     struct DecL { float *ln1w, *ln1b, *bqkv, *bo, *lncw, *lncb, *bcq, *bco, *ln2w, *ln2b, *b1, *b2; T *wqkv, *wo, *wcq, *wco, *w1, *w2; };
     std::vector<EncL> enc;
     std::vector<DecL> dec;
     T *conv1w, *conv2w, *tok_emb, *crosskv_w;
+    uint8_t* crosskv_w8 = nullptr; float* crosskv_s = nullptr;
+    bool fp8_enc = false;   // SS_DTYPE_FP8: encoder projections and the cross-KV projection in e4m3 on the MX-scaled MFMA; everything else as the f16 engine
     float *conv1b, *conv2b, *enc_pos, *lnpostw, *lnpostb, *dec_pos, *crosskv_b, *lnw, *lnb;
     MelTables mt{};
 
     // ---- workspaces ----
     std::vector<DBuf> pcm_d, mel_d, fmax_d;  // per batch slot
     DBuf x0, h1, x, ln, qk, vT, att, ff, encT, encF, cross, kself, vself;
+    DBuf ln8, ln_sc, att8, att_sc, ff8, ff_sc;   // fp8 engine: quantised activations + their exponent bytes
+    long Mpad = 0;
     DBuf xd, lnd, qd, attd, ffd, logits, probs, cscratch, ctl_d;
     // Host staging for one decoder launch: control blocks, sampling-row indices and the uniform draws.  H2D copies from pinned memory read
     // their source when the copy EXECUTES, and the stream may be backlogged (encoder pass, earlier launches of the same round), so every
@@ -199,6 +204,8 @@ struct EngineT : EngineBase {
         Tpad = round_up(n_ctx, 64);   // V^T rows padded (zero) to whole 64-key chunks for the LDS-staged attention kernel
         qscale = powf(64.0f, -0.25f);
         dtype_is_f16 = sizeof(T) == 2 && std::is_same<T, f16>::value;
+        fp8_enc = o.dtype == SS_DTYPE_FP8;
+        if (fp8_enc && (da % 256 || d % 64)) throw Error(SS_ERR_UNSUPPORTED, "fp8: n_audio_state must be a multiple of 256 (k-step groups of the e4m3 GEMM)");
         if (d % 128 || da % 128) throw Error(SS_ERR_MODEL, "model: state size must be a multiple of 128");
         if (n_ctx % 4 || n_tctx > 448) throw Error(SS_ERR_MODEL, "model: unsupported context sizes");
         SS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -208,6 +215,7 @@ struct EngineT : EngineBase {
         if (donor) {
             enc = donor->enc; dec = donor->dec;
             conv1w = donor->conv1w; conv2w = donor->conv2w; tok_emb = donor->tok_emb; crosskv_w = donor->crosskv_w;
+            crosskv_w8 = donor->crosskv_w8; crosskv_s = donor->crosskv_s;
             conv1b = donor->conv1b; conv2b = donor->conv2b; enc_pos = donor->enc_pos; lnpostw = donor->lnpostw; lnpostb = donor->lnpostb;
             dec_pos = donor->dec_pos; crosskv_b = donor->crosskv_b; lnw = donor->lnw; lnb = donor->lnb; mt = donor->mt;
         } else {
@@ -271,6 +279,28 @@ struct EngineT : EngineBase {
         for (size_t i = n; i < n_alloc; i++) dst[i] = 0;
         reg(ptr, o);
     }
+    // [N][K] weight -> e4m3 codes + per-output-channel scale (amax_n / 448): w ~ code * scale
+    void put_f8(uint8_t*& ptr, float*& sc, const float* v, size_t N, size_t K) {
+        size_t o = ar.take(N * K);
+        std::vector<float> scales(N);
+        for (size_t n = 0; n < N; n++) {
+            float amax = 0.f;
+            for (size_t k = 0; k < K; k++) amax = std::max(amax, fabsf(v[n * K + k]));
+            scales[n] = amax > 0.f ? amax / 448.0f : 1.0f;
+        }
+        uint8_t* dst = ar.host.data() + o;
+        for (size_t n = 0; n < N; n++) {
+            const float sn = scales[n];
+            for (size_t k = 0; k < K; k++) dst[n * K + k] = f32_to_e4m3(v[n * K + k] / sn);
+        }
+        reg(ptr, o);
+        put_f32(sc, scales);
+    }
+    // a projection weight: T in the f16 / bf16 engines, e4m3 + scales in the fp8 engine (which then carries no T copy of it)
+    void put_proj(T*& ptrT, uint8_t*& ptr8, float*& sc, const float* v, size_t N, size_t K) {
+        if (fp8_enc) { ptrT = nullptr; put_f8(ptr8, sc, v, N, K); }
+        else { ptr8 = nullptr; sc = nullptr; put_T(ptrT, v, N * K); }
+    }
     const std::vector<float>& W(const std::string& n) { return hm.get(n).f32; }
     void expect(const std::string& n, size_t cnt) { if (hm.get(n).f32.size() != cnt) throw Error(SS_ERR_MODEL, "model: bad shape for " + n); }
 
@@ -308,12 +338,13 @@ struct EngineT : EngineBase {
             put_f32(e.ln1w, W(p + "attn_ln.weight")); put_f32(e.ln1b, W(p + "attn_ln.bias"));
             auto wqkv = cat({&W(p + "attn.query.weight"), &W(p + "attn.key.weight"), &W(p + "attn.value.weight")});
             if (wqkv.size() != (size_t)3 * da * da) throw Error(SS_ERR_MODEL, "model: bad attention weight shape");
-            put_T(e.wqkv, wqkv.data(), wqkv.size());
+            put_proj(e.wqkv, e.wqkv8, e.sqkv, wqkv.data(), (size_t)3 * da, da);
             put_f32(e.bqkv, cat({&W(p + "attn.query.bias"), &zeros_da, &W(p + "attn.value.bias")}));
-            put_T(e.wo, W(p + "attn.out.weight").data(), (size_t)da * da); put_f32(e.bo, W(p + "attn.out.bias"));
+            put_proj(e.wo, e.wo8, e.so, W(p + "attn.out.weight").data(), da, da); put_f32(e.bo, W(p + "attn.out.bias"));
             put_f32(e.ln2w, W(p + "mlp_ln.weight")); put_f32(e.ln2b, W(p + "mlp_ln.bias"));
-            put_T(e.w1, W(p + "mlp.0.weight").data(), (size_t)4 * da * da); put_f32(e.b1, W(p + "mlp.0.bias"));
-            put_T(e.w2, W(p + "mlp.2.weight").data(), (size_t)4 * da * da); put_f32(e.b2, W(p + "mlp.2.bias"));
+            if (W(p + "mlp.0.weight").size() != (size_t)4 * da * da || W(p + "mlp.2.weight").size() != (size_t)4 * da * da) throw Error(SS_ERR_MODEL, "model: bad mlp weight shape");
+            put_proj(e.w1, e.w18, e.s1, W(p + "mlp.0.weight").data(), (size_t)4 * da, da); put_f32(e.b1, W(p + "mlp.0.bias"));
+            put_proj(e.w2, e.w28, e.s2, W(p + "mlp.2.weight").data(), da, (size_t)4 * da); put_f32(e.b2, W(p + "mlp.2.bias"));
         }
         put_f32(lnpostw, W("encoder.ln_post.weight")); put_f32(lnpostb, W("encoder.ln_post.bias"));
         put_T(tok_emb, W("decoder.token_embedding.weight").data(), (size_t)n_vocab * d, (size_t)n_vocab_pad * d);
@@ -339,7 +370,8 @@ struct EngineT : EngineBase {
             ckb.insert(ckb.end(), zeros_d.begin(), zeros_d.end());
             const auto& vb = W(p + "cross_attn.value.bias"); ckb.insert(ckb.end(), vb.begin(), vb.end());
         }
-        put_T(crosskv_w, ckw.data(), ckw.size()); put_f32(crosskv_b, ckb);
+        if (ckw.size() != (size_t)L * 2 * d * da) throw Error(SS_ERR_MODEL, "model: bad cross-attention key/value weight shape");
+        put_proj(crosskv_w, crosskv_w8, crosskv_s, ckw.data(), (size_t)L * 2 * d, da); put_f32(crosskv_b, ckb);
         put_f32(lnw, W("decoder.ln.weight")); put_f32(lnb, W("decoder.ln.bias"));
         // mel tables: same libm calls as whisper.cpp's fill_sin_cos_table / hann_window (periodic)
         std::vector<float> sinv(400), cosv(400), hann(400);
@@ -366,7 +398,16 @@ struct EngineT : EngineBase {
         h1.alloc(((size_t)B * (2 * n_ctx + 2) * da + 256) * 2);
         x.alloc(M * da * 4); ln.alloc(M * da * 2); qk.alloc(M * 2 * da * 2);
         vT.alloc((size_t)B * Ha * 64 * Tpad * 2);
-        att.alloc(M * da * 2); ff.alloc(M * 4 * da * 2); encT.alloc(M * da * 2); encF.alloc(M * da * 4);
+        att.alloc(M * da * 2); encT.alloc(M * da * 2); encF.alloc(M * da * 4);
+        if (fp8_enc) {   // the quantised activations replace the T copy of the MLP hidden state; exponent bytes: one per (row, 64 columns), rows padded to 256
+            Mpad = (long)((M + 255) & ~(size_t)255);
+            ln8.alloc(M * da); ln_sc.alloc((size_t)Mpad * (da / 64)); att8.alloc(M * da); att_sc.alloc((size_t)Mpad * (da / 64));
+            ff8.alloc(M * 4 * da); ff_sc.alloc((size_t)Mpad * (4 * da / 64));
+            SS_HIP(hipMemsetAsync(ln_sc.p, 127, (size_t)Mpad * (da / 64), t_alloc_stream)); SS_HIP(hipMemsetAsync(att_sc.p, 127, (size_t)Mpad * (da / 64), t_alloc_stream));
+            SS_HIP(hipMemsetAsync(ff_sc.p, 127, (size_t)Mpad * (4 * da / 64), t_alloc_stream));
+        } else {
+            ff.alloc(M * 4 * da * 2);
+        }
         cross.alloc((size_t)L * B * 2 * H * n_ctx * 64 * 2);
         kself.alloc((size_t)L * S * n_tctx * d * 2); vself.alloc((size_t)L * S * n_tctx * d * 2);
         const int R = 64;  // rows per decode launch
@@ -410,6 +451,7 @@ struct EngineT : EngineBase {
             g.pos = enc_pos;
             launch_gemm<T>(g, st);
         }
+        if (fp8_enc) { encoder_layers_f8(Wn, want_f32); return; }
         for (int il = 0; il < La; il++) {
             const EncL& e = enc[il];
             launch_layernorm<T>(x.as<float>(), e.ln1w, e.ln1b, ln.as<T>(), M, da, nullptr, st);
@@ -435,9 +477,59 @@ struct EngineT : EngineBase {
         launch_layernorm<T>(x.as<float>(), lnpostw, lnpostb, encT.as<T>(), M, da, nullptr, st);
         if (want_f32) launch_layernorm_f32out<T>(x.as<float>(), lnpostw, lnpostb, encF.as<float>(), M, da, st);
     }
+    // fp8 engine: every projection of the encoder blocks on the e4m3 GEMM.  LayerNorm writes e4m3 + exponent bytes directly, FC1's epilogue
+    // quantises its GELU output per (row, 64 columns), the attention output (T) is quantised by one small pass; attention itself, the f32
+    // residual stream and the conv stem are those of the f16 engine.  ln_post leaves its e4m3 output in ln8 / ln_sc for cross_kv_pass.
+    GemmF8Desc gd8(const void* A8, const void* Asc, long lda, const uint8_t* W8, const float* Ws, int M, int N, int K, int kind, const float* bias, void* out, long ldo) {
+        GemmF8Desc g{};
+        g.A = (const unsigned char*)A8; g.lda = lda; g.a_scale = (const unsigned char*)Asc; g.ldsc = Mpad; g.W = W8; g.w_scale = Ws;
+        g.M = M; g.N = N; g.K = K; g.kind = kind; g.bias = bias; g.out = out; g.ldo = ldo; g.scale = 1.0f;
+        g.rows_per_batch = n_ctx; g.d = da; g.Tpad = Tpad; g.n_batch = B; g.gelu_f16_in = dtype_is_f16;
+        return g;
+    }
+    void encoder_layers_f8(int Wn, bool want_f32) {
+        const int M = Wn * n_ctx;
+        for (int il = 0; il < La; il++) {
+            const EncL& e = enc[il];
+            launch_layernorm_f8(x.as<float>(), e.ln1w, e.ln1b, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, M, da, st);
+            launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8, e.sqkv, M, 2 * da, da, F8_STORE_T, e.bqkv, qk.p, 2 * da), st);
+            launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8 + (size_t)2 * da * da, e.sqkv + 2 * da, M, da, da, F8_VT, e.bqkv + 2 * da, vT.p, 0), st);
+            launch_enc_attention<T>(qk.as<T>(), qk.as<T>() + da, 2 * da, vT.as<T>(), Tpad, att.as<T>(), da, Wn, Ha, n_ctx, st);
+            launch_quantize_f8<T>(att.as<T>(), da, att8.as<unsigned char>(), att_sc.as<unsigned char>(), Mpad, M, da, st);
+            {
+                GemmF8Desc g = gd8(att8.p, att_sc.p, da, e.wo8, e.so, M, da, da, F8_RES_F32, e.bo, x.p, da);
+                g.res = x.as<float>();
+                launch_gemm_f8<T>(g, st);
+            }
+            launch_layernorm_f8(x.as<float>(), e.ln2w, e.ln2b, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, M, da, st);
+            {
+                GemmF8Desc g = gd8(ln8.p, ln_sc.p, da, e.w18, e.s1, M, 4 * da, da, F8_GELU_F8, e.b1, ff8.p, 4 * da);
+                g.out_scale = ff_sc.as<unsigned char>(); g.ld_osc = Mpad;
+                launch_gemm_f8<T>(g, st);
+            }
+            {
+                GemmF8Desc g = gd8(ff8.p, ff_sc.p, 4 * da, e.w28, e.s2, M, da, 4 * da, F8_RES_F32, e.b2, x.p, da);
+                g.res = x.as<float>();
+                launch_gemm_f8<T>(g, st);
+            }
+        }
+        launch_layernorm_f8(x.as<float>(), lnpostw, lnpostb, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, M, da, st);
+        if (want_f32) launch_layernorm_f32out<T>(x.as<float>(), lnpostw, lnpostb, encF.as<float>(), M, da, st);
+    }
     // cross K/V of every decoder layer for Wn windows: one GEMM, N = L*2d, written straight into the cache layout
     // cmap (optional): window k of this pass writes the cross-KV cache slot cmap[k] (windows of a running group keep their slots)
     void cross_kv_pass(int Wn, const int* cmap = nullptr) {
+        if (fp8_enc) {
+            GemmF8Desc g = gd8(ln8.p, ln_sc.p, da, crosskv_w8, crosskv_s, Wn * n_ctx, L * 2 * d, da, F8_CROSS_KV, crosskv_b, cross.p, 0);
+            g.scale = qscale; g.d = d; g.rows_per_batch = n_ctx; g.n_batch = B;
+            if (cmap) {
+                if (Wn > (int)sizeof(g.batch_map)) throw Error(-1, "internal: cross-KV slot map too small");
+                g.use_batch_map = 1;
+                for (int i = 0; i < Wn; i++) g.batch_map[i] = (unsigned char)cmap[i];
+            }
+            launch_gemm_f8<T>(g, st);
+            return;
+        }
         GemmDesc g = gd(encT.p, da, crosskv_w, Wn * n_ctx, L * 2 * d, da, EPI_CROSS_KV, crosskv_b, cross.p, 0);
         g.scale = qscale; g.d = d; g.rows_per_batch = n_ctx; g.n_batch = B;
         if (cmap) {
@@ -1389,6 +1481,7 @@ struct EngineT : EngineBase {
         AllocStreamScope alloc_scope(st);
         SS_HIP(hipMemcpyAsync(encF.p, encv, (size_t)n_ctx * da * 4, hipMemcpyHostToDevice, st));
         launch_f32_to_T<T>(encF.as<float>(), encT.as<T>(), (size_t)n_ctx * da, st);
+        if (fp8_enc) launch_quantize_f8<T>(encT.as<T>(), da, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, n_ctx, da, st);
         cross_kv_pass(1);
         SS_HIP(hipStreamSynchronize(st));
     }
@@ -1623,16 +1716,38 @@ struct EngineT : EngineBase {
         gemm_selftest<T>(M, N, K, kind, max_err, max_ref, st);
     }
 
+    void selftest_gemm_ex(int M, int N, int K, int kind, int fp8, int reps, float* max_err, float* max_ref, float* avg_ms) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
+        if (avg_ms) *avg_ms = 0.f;
+        if (fp8) {
+            if (M < 1 || N < 256 || N % 256 || K < 256 || K % 256) throw Error(SS_ERR_ARG, "selftest_gemm (fp8): N and K must be multiples of 256");
+            gemm_f8_selftest<T>(M, N, K, kind, max_err, max_ref, st, reps, avg_ms);
+        } else {
+            if (M < 1 || N % 128 || K % 64 || N < 128 || K < 64) throw Error(SS_ERR_ARG, "selftest_gemm: N must be a multiple of 128 and K of 64");
+            gemm_selftest<T>(M, N, K, kind, max_err, max_ref, st, reps, avg_ms);
+        }
+    }
+
     void probe_gemm(int batch, int reps, float* avg_ms, double* flops) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
         if (batch < 1 || batch > B) throw Error(SS_ERR_ARG, "probe_gemm: batch out of range");
         const int M = batch * n_ctx;
-        GemmDesc g = gd(ln.p, da, enc[0].w1, M, 4 * da, da, EPI_GELU_T, enc[0].b1, ff.p, 4 * da);
-        launch_gemm<T>(g, st);
-        SS_HIP(hipEventRecord(ev[0], st));
-        for (int i = 0; i < reps; i++) launch_gemm<T>(g, st);
+        if (fp8_enc) {   // the same projection on the e4m3 kernel (GELU output quantised in the epilogue)
+            GemmF8Desc g = gd8(ln8.p, ln_sc.p, da, enc[0].w18, enc[0].s1, M, 4 * da, da, F8_GELU_F8, enc[0].b1, ff8.p, 4 * da);
+            g.out_scale = ff_sc.as<unsigned char>(); g.ld_osc = Mpad;
+            launch_gemm_f8<T>(g, st);
+            SS_HIP(hipEventRecord(ev[0], st));
+            for (int i = 0; i < reps; i++) launch_gemm_f8<T>(g, st);
+        } else {
+            GemmDesc g = gd(ln.p, da, enc[0].w1, M, 4 * da, da, EPI_GELU_T, enc[0].b1, ff.p, 4 * da);
+            launch_gemm<T>(g, st);
+            SS_HIP(hipEventRecord(ev[0], st));
+            for (int i = 0; i < reps; i++) launch_gemm<T>(g, st);
+        }
         SS_HIP(hipEventRecord(ev[1], st));
         SS_HIP(hipEventSynchronize(ev[1]));
         float ms = 0;

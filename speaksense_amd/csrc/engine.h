@@ -75,6 +75,7 @@ struct EngineBase {
     virtual void probe_gemm(int batch, int reps, float* avg_ms, double* flops) = 0;
     virtual void denoise_host(const float* pcm, int n, const ss_denoise_config& cfg, int force_type, float* out, int* noise_type, float* norm_var, float* ms) = 0;
     virtual void selftest_gemm(int M, int N, int K, int kind, float* max_err, float* max_ref) = 0;
+    virtual void selftest_gemm_ex(int M, int N, int K, int kind, int fp8, int reps, float* max_err, float* max_ref, float* avg_ms) = 0;
     virtual void resample_stream_host(const float* pcm, int64_t n, int from_rate, float* out, int64_t out_cap, int64_t* n_out, int32_t* chunk_lens, float* ms) = 0;
     virtual void preprocess_stream_host(const float* pcm, int64_t n, const int32_t* chunk_lens, int n_chunks, int chunk_len, const ss_denoise_config& cfg,
                                         float* out, float* gains_out, float* ms) = 0;

@@ -54,7 +54,53 @@ struct GemmDesc {
 };
 template <typename T> void launch_gemm(const GemmDesc& g, hipStream_t st);
 // self-test: tiled kernel vs a one-thread-per-output reference on seeded operands; kind in {EPI_STORE_T, EPI_GELU_T, EPI_RES_F32, EPI_STORE_F32}
-template <typename T> void gemm_selftest(int M, int N, int K, int kind, float* max_err, float* max_ref, hipStream_t st);
+// reps > 0: afterwards the same launch is repeated `reps` times between two events on `st` and the average duration returned in *avg_ms
+template <typename T> void gemm_selftest(int M, int N, int K, int kind, float* max_err, float* max_ref, hipStream_t st, int reps = 0, float* avg_ms = nullptr);
+
+// ---------------------------------------------------------------------------------------------
+// fp8 GEMM (kernels_gemm_fp8.hip):  OCP e4m3 operands on the MX-scaled 32x32x64 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4)
+//   D[m][n] = w_scale[n] * sum_blk 2^(a_scale[m][blk] - 127) * sum_{k in blk} A8[m][k] * W8[n][k]      (blocks of 64 k)
+// Activations carry one E8M0 exponent byte per (row, 64-column block), the hardware applies it inside the MFMA; weights carry one f32
+// scale per output channel, applied in the epilogue.  The exponent bytes live in a tile-aware layout so that one 256-byte LDS-DMA
+// per k-step brings a 256-row tile's bytes and a lane's four row groups sit in one dword: f8_scale_index().
+// ---------------------------------------------------------------------------------------------
+enum Fp8Epi {
+    F8_STORE_T = 0,   // out T[m][n] = (acc * ws[n] + bias[n]) * scale
+    F8_GELU_F8,       // out e4m3[m][n] = quantised gelu(acc * ws[n] + bias[n]) with its own exponent bytes (out_scale)
+    F8_RES_F32,       // out f32[m][n] = res[m][n] + acc * ws[n] + bias[n]
+    F8_VT,            // as EPI_VT
+    F8_CROSS_KV,      // as EPI_CROSS_KV
+    F8_STORE_F32,     // out f32[m][n] = acc * ws[n] + bias[n]
+};
+__host__ __device__ inline long f8_scale_index(long m, long blk, long ldsc) {
+    return blk * ldsc + (m & ~(long)127) + (m & 31) * 4 + ((m >> 5) & 3);
+}
+struct GemmF8Desc {
+    const unsigned char* A; long lda;           // e4m3 [M][lda]
+    const unsigned char* a_scale; long ldsc;    // E8M0 bytes, f8_scale_index(m, k / 64, ldsc); ldsc = rows padded to a multiple of 256
+    const unsigned char* W;                     // e4m3 [N][K]
+    const float* w_scale;                       // [N]
+    int M, N, K, kind;
+    const float* bias;
+    void* out; long ldo;
+    unsigned char* out_scale; long ld_osc;      // F8_GELU_F8
+    const float* res;
+    float scale;
+    int rows_per_batch, d, Tpad, n_batch, gelu_f16_in;
+    int use_batch_map; unsigned char batch_map[128];
+};
+template <typename T> void launch_gemm_f8(const GemmF8Desc& g, hipStream_t st);
+// LayerNorm with quantised output (one wave per row), and plain quantisation of a T matrix (attention output): e4m3 + exponent bytes
+void launch_layernorm_f8(const float* x, const float* w, const float* b, unsigned char* y8, unsigned char* y_scale, long ldsc, int rows, int d, hipStream_t st);
+template <typename T> void launch_quantize_f8(const T* x, long ldx, unsigned char* y8, unsigned char* y_scale, long ldsc, int rows, int d, hipStream_t st);
+// self-test: the fp8 kernel against a one-thread-per-output reference on seeded e4m3 operands and exponent bytes; kind in Fp8Epi except VT / CROSS_KV
+template <typename T> void gemm_f8_selftest(int M, int N, int K, int kind, float* max_err, float* max_ref, hipStream_t st, int reps = 0, float* avg_ms = nullptr);
+// host + device: exponent byte for a block whose largest magnitude is amax (amax / 2^(e-127) <= 448), and the OCP e4m3 code of a float
+__host__ __device__ inline int e8m0_for_amax(float amax) {
+    unsigned bits; __builtin_memcpy(&bits, &amax, 4);
+    int e = (int)((bits >> 23) & 0xff) - 8 + ((bits & 0x7fffffu) > 0x600000u ? 1 : 0);
+    return e < 1 ? 1 : (e > 253 ? 253 : e);
+}
 
 // Skinny GEMM for decode steps: M <= 64 rows, weights streamed once.  out[m][n] = sum_k X[m][k] W[n][k]
 enum SkinnyEpi {

@@ -8,59 +8,9 @@
 // operands swapped so each lane owns 4 consecutive output features (8/16-byte stores), epilogues fused.
 #include <cstdlib>
 
-#include "kernels.h"
+#include "gemm_common.h"
 
 namespace ss {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef f16 f16x8 __attribute__((ext_vector_type(8)));
-typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef f16 f16x4 __attribute__((ext_vector_type(4)));
-
-template <typename T> struct Mfma;
-template <> struct Mfma<bf16> {
-    typedef bf16x8 V8; typedef bf16x4 V4;
-    static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct Mfma<f16> {
-    typedef f16x8 V8; typedef f16x4 V4;
-    static __device__ __forceinline__ f32x4 mma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-    // 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)));  tanh(u) = 1 - 2/(exp(2u)+1)
-    // == x * sigmoid(2u): one v_exp_f32 + one v_rcp_f32
-    const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
-    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
-}
-template <typename T> __device__ __forceinline__ float gelu_in_round(float x, int on);
-template <> __device__ __forceinline__ float gelu_in_round<bf16>(float x, int) { return x; }
-template <> __device__ __forceinline__ float gelu_in_round<f16>(float x, int on) { return on ? (float)(f16)x : x; }
-
-// Tile rasterisation.  The dispatcher places workgroup b on XCD b % 8 (observed; used for speed only), each XCD has a private
-// 4 MB L2 and runs ~32 tiles at a time.  (1) bijective remap: every XCD gets a contiguous range of logical ids;
-// (2) logical ids walk the grid in column groups of GN n-panels with m fastest inside a group, so the ~32 concurrent tiles of
-// an XCD form a ~GN x (32/GN) patch: fabric traffic per launch ~ A_bytes*nbn/GN + W_bytes*nbm*GN/32, minimal near GN = sqrt(32).
-// With plain n-fastest order an XCD swept all nbn weight panels (13 MB for FC1 >> L2) for every ~1.6 tile rows: rocprofv3
-// FETCH_SIZE showed 460 MB per FC1 launch against 44 MB of operands, and the kernel sat on the ~10 B/clk/CU miss rate.
-__device__ __forceinline__ void tile_of_block(int bid, int nbm, int nbn, int* mb, int* nb) {
-    const int nwg = nbm * nbn;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    int GN = nbn;
-    if (nbn > 8) {
-        GN = 5;
-        if (nbn % 5 != 0) { if (nbn % 6 == 0) GN = 6; else if (nbn % 4 == 0) GN = 4; else if (nbn % 7 == 0) GN = 7; }
-    }
-    const int per_group = nbm * GN, full = nbn / GN;
-    int g = bid / per_group, rem = bid - g * per_group, gn = GN;
-    if (g >= full) { g = full; rem = bid - full * per_group; gn = nbn - full * GN; }
-    *mb = rem / gn;
-    *nb = g * GN + rem % gn;
-}
 
 // ---------------------------------------------------------------------------------------------
 // 128 x 128 x 64 tile, 256 threads = 4 waves (2 n x 2 m), each wave 64 x 64 = 4 x 4 MFMA 16x16x32 tiles.
@@ -72,11 +22,6 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int kTileBytes = BM * BK * 2;       // 16 KB
 constexpr int kGemmLds = 4 * kTileBytes;      // 64 KB
 
-template <typename T>
-__device__ __forceinline__ void glds16(const T* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 template <typename T, int KIND>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
@@ -253,7 +198,6 @@ template <int WM> struct G256 {
     static constexpr int NP = (TM + TN) / RPP;             // DMA instructions per thread per stage: 4 / 6
 };
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // DMA4 (WM = 2 only): waves 0-3 issue ALL the LDS-DMA (two 16-row slots each per pass) and are the only ones that wait on vmcnt; waves 4-7
 // never wait on it inside the main loop, so THEIR output stores of the previous tile drain in the background for a whole tile.
@@ -788,7 +732,7 @@ __global__ void st_diff(const void* out, const float* ref, size_t n, int f32out,
 }  // namespace
 
 template <typename T>
-void gemm_selftest(int M, int N, int K, int kind, float* max_err, float* max_ref, hipStream_t st) {
+void gemm_selftest(int M, int N, int K, int kind, float* max_err, float* max_ref, hipStream_t st, int reps, float* avg_ms) {
     if (kind != EPI_STORE_T && kind != EPI_GELU_T && kind != EPI_RES_F32 && kind != EPI_STORE_F32) throw Error(-1, "gemm selftest: kind not covered");
     T *A, *W; float *bias, *res, *ref, *mx; void* out;
     const bool f32out = kind == EPI_RES_F32 || kind == EPI_STORE_F32;
@@ -810,9 +754,21 @@ void gemm_selftest(int M, int N, int K, int kind, float* max_err, float* max_ref
     SS_HIP(hipMemcpyAsync(h, mx, 8, hipMemcpyDeviceToHost, st));
     SS_HIP(hipStreamSynchronize(st));
     *max_err = h[0]; *max_ref = h[1];
+    if (reps > 0 && avg_ms) {
+        hipEvent_t e0, e1;
+        SS_HIP(hipEventCreate(&e0)); SS_HIP(hipEventCreate(&e1));
+        SS_HIP(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; i++) launch_gemm<T>(g, st);
+        SS_HIP(hipEventRecord(e1, st));
+        SS_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        SS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *avg_ms = ms / reps;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
     (void)hipFree(A); (void)hipFree(W); (void)hipFree(bias); (void)hipFree(res); (void)hipFree(ref); (void)hipFree(out); (void)hipFree(mx);
 }
-template void gemm_selftest<bf16>(int, int, int, int, float*, float*, hipStream_t);
-template void gemm_selftest<f16>(int, int, int, int, float*, float*, hipStream_t);
+template void gemm_selftest<bf16>(int, int, int, int, float*, float*, hipStream_t, int, float*);
+template void gemm_selftest<f16>(int, int, int, int, float*, float*, hipStream_t, int, float*);
 
 }  // namespace ss

@@ -77,7 +77,7 @@ struct whisper_context* whisper_init_from_file_with_params_no_state(const char* 
     memset(&o, 0, sizeof(o));
     o.device = env_int("SS_DEVICE", 0);
     const char* dt = getenv("SS_DTYPE");
-    o.dtype = (dt && !strcmp(dt, "bf16")) ? SS_DTYPE_BF16 : SS_DTYPE_F16;
+    o.dtype = (dt && !strcmp(dt, "bf16")) ? SS_DTYPE_BF16 : (dt && !strcmp(dt, "fp8")) ? SS_DTYPE_FP8 : SS_DTYPE_F16;
     o.max_batch = env_int("SS_MAX_BATCH", 8);
     o.max_decoders = 5;
     o.batch_wait_us = env_int("SS_BATCH_WAIT_US", 2000);

@@ -38,3 +38,32 @@ def test_gemm_matches_reference(eng, M, N, K, kind):
     else:
         tol = (1.2e-3 if eng.dtype_name == "f16" else 9e-3) * ref        # + one rounding of the output to f16 / bf16
     assert err <= tol, f"max |diff| {err} vs max |ref| {ref}"
+
+
+# ---- the e4m3 GEMM on the MX-scaled MFMA (kernels_gemm_fp8.hip) ----
+F8_STORE, F8_GELU, F8_RES, F8_STORE_F32 = 0, 1, 2, 5
+
+
+@pytest.mark.parametrize("M,N,K,kind", [
+    (12000, 5120, 1280, F8_STORE_F32),   # FC1 shape: 940 tiles on 256 workgroups, partial last row tile, every group kind of the k loop
+    (12000, 5120, 1280, F8_GELU),        # e4m3 output + its own exponent bytes
+    (12000, 2560, 1280, F8_STORE),       # QK projection -> T
+    (12000, 1280, 5120, F8_RES),         # FC2: 80 k-steps, f32 residual in place
+    (12000, 1280, 1280, F8_RES),         # attention out-projection
+    (1500, 1280, 1280, F8_STORE),        # one window: fewer tiles than workgroups (no early prologue)
+    (24000, 5120, 1280, F8_GELU),        # batch 16
+    (777, 256, 256, F8_STORE_F32),       # K = 256: the single (last) k group only, ragged rows
+    (3000, 512, 512, F8_RES),            # two k groups
+])
+def test_gemm_fp8_matches_reference(eng, M, N, K, kind):
+    """Operands are exact e4m3 codes with power-of-two block exponents, so the only difference from the one-thread-per-output reference is the
+    f32 accumulation order (and one rounding of the output to T / e4m3)."""
+    err, ref, _ = eng.selftest_gemm_ex(M, N, K, kind, fp8=True)
+    assert ref > 0.5
+    if kind in (F8_RES, F8_STORE_F32):
+        tol = 1e-4 * ref           # f32 accumulation order inside / across the 64-k MFMAs vs the sequential reference
+    elif kind == F8_GELU:
+        tol = 1e-4 * ref          # err is already the excess over the 2^-4 relative quantisation step of an e4m3 output
+    else:
+        tol = (1.2e-3 if eng.dtype_name == "f16" else 9e-3) * ref
+    assert err <= tol, f"max |diff| {err} vs max |ref| {ref}"

@@ -149,7 +149,7 @@ GAP_TOL_F16 = 4 * 3e-3 * 9.0      # 0.108 in log-probability units
 GAP_TOL_BF16 = 0.25               # measured with bf16-rounded weights AND activations in the oracle: every flip below 0.07 (run r02_j)
 
 
-def check_against_oracle(got, om, orc, mode, pcm, P, ctx, gap_tol, replay_only=False):
+def check_against_oracle(got, om, orc, mode, pcm, P, ctx, gap_tol, replay_only=False, tid_slack_beg=None):
     """Token ids identical to the free-running oracle -> full result comparison, returns (True, 0.0).
     Otherwise the device's sampled stream is REPLAYED on the oracle (every greedy step takes the device's token; oracle/binding.py): the test
     fails unless at every step the device's pick is the oracle's argmax or its log-probability is within `gap_tol` of it (a proven near tie
@@ -158,7 +158,7 @@ def check_against_oracle(got, om, orc, mode, pcm, P, ctx, gap_tol, replay_only=F
     if not replay_only:
         ref = om.new_state(mode).full(pcm, P)
         if list(got["tokens"]) == list(ref["tokens"]):
-            _same_result(got, ref, ctx)
+            _same_result(got, ref, ctx, tid_slack_beg)
             return True, 0.0
     rep = om.new_state(mode).full(pcm, P, forced=got["sampled"])
     gaps, best = rep["forced_gap"], rep["forced_best"]
@@ -167,17 +167,25 @@ def check_against_oracle(got, om, orc, mode, pcm, P, ctx, gap_tol, replay_only=F
     flips = [(int(i), int(got["sampled"][i]), int(best[i]), float(gaps[i])) for i in np.nonzero(best != got["sampled"])[0]]
     worst = float(gaps.max()) if len(gaps) else 0.0
     assert worst < gap_tol, f"{ctx}: device pick outside the noise of the oracle's argmax: (step, device id, oracle id, logprob gap) = {flips}"
-    _same_result(got, rep, ctx + " (forced replay)")
+    _same_result(got, rep, ctx + " (forced replay)", tid_slack_beg)
     if flips:
         report(f"{ctx}: {len(flips)} near-tie flip(s) of {len(gaps)} steps, largest oracle margin {worst:.4f} < {gap_tol:.3f}: {flips}")
     return len(flips) == 0, worst
 
 
-def _same_result(got, ref, ctx):
+def _same_result(got, ref, ctx, tid_slack_beg=None):
+    """tid_slack_beg (fp8 tests only) = the first timestamp token id: whisper.cpp takes a segment's t0 from the `tid` of its first token -- the
+    argmax over the timestamp probabilities at that step.  When that token is a TEXT token, tid is a pick among timestamps that all lost, i.e.
+    an argmax over a nearly flat tail which e4m3 noise can move without any sampled id changing; such a t0 is then not compared."""
     assert list(got["tokens"]) == list(ref["tokens"]), f"{ctx}: token ids differ"
     assert len(got["segments"]) == len(ref["segments"]), ctx
     for a, b in zip(got["segments"], ref["segments"]):
-        assert a["text"] == b["text"] and a["t0"] == b["t0"] and a["t1"] == b["t1"] and a["speaker_turn_next"] == b["speaker_turn_next"], ctx
+        assert a["text"] == b["text"] and a["t1"] == b["t1"] and a["speaker_turn_next"] == b["speaker_turn_next"], ctx
+        if tid_slack_beg is not None and 0 <= a.get("first_id", -1) < tid_slack_beg:
+            if a["t0"] != b["t0"]:
+                report(f"{ctx}: t0 {a['t0']} vs {b['t0']} from the tid of a text token (not compared)")
+            continue
+        assert a["t0"] == b["t0"], ctx
     assert got["n_encode"] == ref["n_encode"], ctx
 
 
