@@ -494,8 +494,7 @@ struct EngineT : EngineBase {
             launch_layernorm_f8(x.as<float>(), e.ln1w, e.ln1b, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, M, da, st);
             launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8, e.sqkv, M, 2 * da, da, F8_STORE_T, e.bqkv, qk.p, 2 * da), st);
             launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8 + (size_t)2 * da * da, e.sqkv + 2 * da, M, da, da, F8_VT, e.bqkv + 2 * da, vT.p, 0), st);
-            launch_enc_attention<T>(qk.as<T>(), qk.as<T>() + da, 2 * da, vT.as<T>(), Tpad, att.as<T>(), da, Wn, Ha, n_ctx, st);
-            launch_quantize_f8<T>(att.as<T>(), da, att8.as<unsigned char>(), att_sc.as<unsigned char>(), Mpad, M, da, st);
+            launch_enc_attention_f8<T>(qk.as<T>(), qk.as<T>() + da, 2 * da, vT.as<T>(), Tpad, att8.as<unsigned char>(), da, att_sc.as<unsigned char>(), Mpad, Wn, Ha, n_ctx, st);
             {
                 GemmF8Desc g = gd8(att8.p, att_sc.p, da, e.wo8, e.so, M, da, da, F8_RES_F32, e.bo, x.p, da);
                 g.res = x.as<float>();

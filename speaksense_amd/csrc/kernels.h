@@ -102,6 +102,16 @@ __host__ __device__ inline int e8m0_for_amax(float amax) {
     return e < 1 ? 1 : (e > 253 ? 253 : e);
 }
 
+// device helpers shared by the producers of e4m3 activations (kernels_gemm_fp8.hip, the fp8 epilogue of enc_attn_lds_kernel)
+__device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float d) {
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
+    return (unsigned)p;
+}
+__device__ __forceinline__ float pow2_neg_of_e8m0(int e) {   // 2^-(e - 127), e in [1, 253]
+    return __builtin_bit_cast(float, (unsigned)(254 - e) << 23);
+}
+
 // Skinny GEMM for decode steps: M <= 64 rows, weights streamed once.  out[m][n] = sum_k X[m][k] W[n][k]
 enum SkinnyEpi {
     SK_STORE_T = 0,  // out T[m][ldo] = (acc + bias) * scale
@@ -174,6 +184,9 @@ void launch_dec_cross_attention_q(const float* qpart, int n_qpart, const float* 
 // Encoder self-attention, non-causal.  q,k: T [B*Tn][ld] (head h at column h*64); vT: T [B][H][64][Tpad]; out T [B*Tn][ldo]
 template <typename T>
 void launch_enc_attention(const T* q, const T* k, long ld, const T* vT, int Tpad, T* out, long ldo, int B, int H, int Tn, hipStream_t st);
+// fp8 engine: the same attention with its output rounded to T and then quantised in the epilogue: e4m3 [B*Tn][ldo] + one exponent byte per (row, head)
+template <typename T>
+void launch_enc_attention_f8(const T* q, const T* k, long ld, const T* vT, int Tpad, unsigned char* out8, long ldo, unsigned char* out_scale, long ldsc, int B, int H, int Tn, hipStream_t st);
 // Decoder self-attention for M rows (one new token each): q T [M][d] (pre-scaled), caches [slot][n_ctx][d]; n_kv = pos+1
 template <typename T>
 void launch_dec_self_attention(const T* q, const T* kcache, const T* vcache, long slot_stride, int d, int H, const RowCtl* ctl, int M, T* out, hipStream_t st);

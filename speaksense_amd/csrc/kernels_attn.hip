@@ -186,9 +186,10 @@ __global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int attn_swz(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-template <typename T, int QT>
+template <typename T, int QT, bool F8OUT = false>
 __global__ __launch_bounds__(256, 2) void enc_attn_lds_kernel(const T* __restrict__ q, const T* __restrict__ k, long ld, const T* __restrict__ vT,
-                                                              int Tpad, T* __restrict__ out, long ldo, int H, int Tn) {
+                                                              int Tpad, T* __restrict__ out, long ldo, int H, int Tn,
+                                                              unsigned char* __restrict__ out8 = nullptr, unsigned char* __restrict__ out_sc = nullptr, long ldsc = 0) {
     typedef typename MfmaA<T>::V8 V8;
     typedef typename MfmaA<T>::V4 V4;
     constexpr int NS = 3, kStage = 16384;            // K tile 64 keys x 128 B, then V^T tile 64 dh rows x 128 B
@@ -335,7 +336,24 @@ __global__ __launch_bounds__(256, 2) void enc_attn_lds_kernel(const T* __restric
         const float l = rows_sum(lrun[qi]);
         const float inv = 1.0f / l;
         const int qr = q0 + qi * 16 + frow;
-        if (qr < Tn) {
+        if constexpr (F8OUT) {
+            // fp8 engine: output rounded to T (as the f16 engine stores it), then e4m3 with one exponent byte per (row, head): the 64 columns of
+            // this head's row are this lane's 16 values and those of the lanes frow + 16 / 32 / 48
+            float v[4][4], amax = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) { v[dt][r] = (float)(T)(o[dt][qi][r] * inv); amax = fmaxf(amax, fabsf(v[dt][r])); }
+            amax = rows_max(amax);
+            const int eb = e8m0_for_amax(amax);
+            const float sc = pow2_neg_of_e8m0(eb);
+            if (qr < Tn) {
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++)
+                    *(unsigned*)(out8 + (rowbase + qr) * ldo + h * 64 + dt * 16 + fg * 4) = pack_e4m3x4(v[dt][0] * sc, v[dt][1] * sc, v[dt][2] * sc, v[dt][3] * sc);
+                if (fg == 0) out_sc[f8_scale_index(rowbase + qr, h, ldsc)] = (unsigned char)eb;
+            }
+        } else if (qr < Tn) {
 #pragma unroll
             for (int dt = 0; dt < 4; dt++) {
                 V4 ov;
@@ -374,6 +392,16 @@ void launch_enc_attention(const T* q, const T* k, long ld, const T* vT, int Tpad
         enc_attn_kernel<T, 2><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn); SS_LAUNCH_CHECK();
     }
 }
+template <typename T>
+void launch_enc_attention_f8(const T* q, const T* k, long ld, const T* vT, int Tpad, unsigned char* out8, long ldo, unsigned char* out_scale, long ldsc, int B, int H, int Tn, hipStream_t st) {
+    if (Tpad < (Tn + 63) / 64 * 64) throw Error(-1, "enc_attention: V^T rows must be padded to a multiple of 64 keys");
+    static std::atomic<uint64_t> attr{0};
+    once_per_device(attr, [] { SS_HIP(hipFuncSetAttribute((const void*)enc_attn_lds_kernel<T, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16384)); });
+    dim3 grid(((Tn + 255) / 256) * H * B);
+    enc_attn_lds_kernel<T, 4, true><<<grid, 256, 3 * 16384, st>>>(q, k, ld, vT, Tpad, nullptr, ldo, H, Tn, out8, out_scale, ldsc); SS_LAUNCH_CHECK();
+}
+template void launch_enc_attention_f8<bf16>(const bf16*, const bf16*, long, const bf16*, int, unsigned char*, long, unsigned char*, long, int, int, int, hipStream_t);
+template void launch_enc_attention_f8<f16>(const f16*, const f16*, long, const f16*, int, unsigned char*, long, unsigned char*, long, int, int, int, hipStream_t);
 template void launch_enc_attention<bf16>(const bf16*, const bf16*, long, const bf16*, int, bf16*, long, int, int, int, hipStream_t);
 template void launch_enc_attention<f16>(const f16*, const f16*, long, const f16*, int, f16*, long, int, int, int, hipStream_t);
 

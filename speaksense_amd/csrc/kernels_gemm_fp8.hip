@@ -39,14 +39,6 @@ __device__ __forceinline__ void blds16(Rsrc r, unsigned voff, int soff, char* ld
 __device__ __forceinline__ void blds4(Rsrc r, unsigned voff, int soff, char* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 4, voff, soff, 0, 0);
 }
-__device__ __forceinline__ unsigned pack_e4m3x4(float a, float b, float c, float d) {
-    int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);
-    return (unsigned)p;
-}
-__device__ __forceinline__ float pow2_neg_of_e8m0(int e) {   // 2^-(e - 127), e in [1, 253]
-    return __builtin_bit_cast(float, (unsigned)(254 - e) << 23);
-}
 struct Frag8 { i32x4 lo, hi; };
 __device__ __forceinline__ i32x8 frag_join(const Frag8& f) { return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
