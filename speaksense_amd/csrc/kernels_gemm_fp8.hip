@@ -45,7 +45,9 @@ __device__ __forceinline__ i32x8 frag_join(const Frag8& f) { return __builtin_sh
 // 256 (m) x 256 (n) x 64 tile, 512 threads = 8 waves (4 n x 2 m), each wave 64 n x 128 m = 2 x 4 MFMA 32x32x64; one workgroup per CU, persistent.
 // LDS rows are 64 B; the 16-B chunk c of row r sits at chunk position c ^ ((r >> 2) & 3), which makes the ds_read_b128 of a fragment
 // (32 rows x one chunk per half-wave) conflict-free; the permutation is applied to the per-lane DMA source address.
-template <typename T, int KIND>
+// KO (dev tool, tools/gemm_fp8_bench.py via SS_F8_KO; results are then WRONG): knock-outs that time what the k loop is made of --
+// bit 0 no barriers, bit 1 no vmcnt waits, bit 2 no DMA, bit 3 no LDS fragment reads, bit 4 no MFMAs (all inside the k loop only)
+template <typename T, int KIND, int KO = 0>
 __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(GemmF8Desc g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Mfma<T>::V4 V4;
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(GemmF8Desc g) {
 #define SS_MMA1(WF, SCV, ni, q)                                                                                                       \
     {                                                                                                                                 \
         const int sx = ((SCV) >> (8 * (q))) & 0xff;                                                                                   \
-        if (SWAP) acc[ni][q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag_join(xf[q]), frag_join(WF[ni]), acc[ni][q], 0, 0, 0, sx, 0, 127); \
+        if constexpr (KO & 16) { acc[ni][q][0] += __builtin_bit_cast(float, frag_join(WF[ni])[0] ^ frag_join(xf[q])[(ni)] ^ sx); }          \
+        else if (SWAP) acc[ni][q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag_join(xf[q]), frag_join(WF[ni]), acc[ni][q], 0, 0, 0, sx, 0, 127); \
         else acc[ni][q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag_join(WF[ni]), frag_join(xf[q]), acc[ni][q], 0, 0, 0, 127, 0, sx);      \
     }
     // one quarter of a step: 2 MFMAs on xf[q]; one operand DMA (+ the exponent-byte DMA in the last quarter); then the in-place refresh of
@@ -135,11 +138,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(GemmF8Desc g) {
     {                                                                                                                                 \
         SS_MMA1(WC, SCC, 0, q)                                                                                                        \
         SS_MMA1(WC, SCC, 1, q)                                                                                                        \
-        if constexpr (DMA) {                                                                                                          \
+        if constexpr (DMA && !(KO & 4)) {                                                                                             \
             SS_DMA(q, dma_kt, smem + (((BUF) + NST - 1) % NST) * kQStage + (q) * (RPP * 64) + wave_off);                              \
             if constexpr ((q) == 3) SS_DMA_SC(((BUF) + NST - 1) % NST, dma_kt);                                                       \
         }                                                                                                                             \
-        if constexpr (READ) {                                                                                                         \
+        if constexpr (READ && !(KO & 8)) {                                                                                            \
             constexpr int ro = (((BUF) + 1) % NST) * kQStage;                                                                         \
             xf[q].lo = *(const i32x4*)(xb0 + ro + (q) * 32 * 64);                                                                     \
             xf[q].hi = *(const i32x4*)(xb1 + ro + (q) * 32 * 64);                                                                     \
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(GemmF8Desc g) {
             if constexpr ((q) == 0) SCN = *(const int*)(scb + (((BUF) + 1) % NST) * (8 * 256));                                       \
         }                                                                                                                             \
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                                            \
-        if constexpr (DMA) __builtin_amdgcn_sched_group_barrier(0x020, (q) == 3 ? 2 : 1, 0);                                          \
-        if constexpr (READ) __builtin_amdgcn_sched_group_barrier(0x100, (q) == 0 ? 4 : 3, 0);                                         \
+        if constexpr (DMA && !(KO & 4)) __builtin_amdgcn_sched_group_barrier(0x020, (q) == 3 ? 2 : 1, 0);                             \
+        if constexpr (READ && !(KO & 8)) __builtin_amdgcn_sched_group_barrier(0x100, (q) == 0 ? 4 : 3, 0);                            \
     }
 #define SS_STEP(WC, SCC, WN, SCN, DMA, READ, BUF, dma_kt)                                                                               \
     {                                                                                                                                 \
@@ -173,30 +176,32 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(GemmF8Desc g) {
     // A step must stay ONE basic block: a run-time branch between steps lets LLVM sink the MFMAs (whose results are only read after the
     // loop) below it, which keeps the old fragments alive and spills the new ones.  Hence compile-time wait counts per group kind:
     // CARRY groups (first group of an early-issued tile) leave the previous tile's stores in flight for their first two waits.
+#define SS_SYNC(N) { if constexpr (!(KO & 2)) wait_vmcnt<(N)>(); if constexpr (!(KO & 1)) __builtin_amdgcn_s_barrier(); }
 #define SS_GROUP(CARRY)                                                                                                                \
     {                                                                                                                                 \
-        wait_vmcnt<OPS + ((CARRY) ? kCarry : 0)>(); __builtin_amdgcn_s_barrier();                                                     \
+        SS_SYNC(OPS + ((CARRY) ? kCarry : 0))                                                                                         \
         SS_STEP(wfA, scA, wfB, scB, true, true, 0, kt + 3)                                                                            \
-        wait_vmcnt<OPS + ((CARRY) ? kCarry : 0)>(); __builtin_amdgcn_s_barrier();                                                     \
+        SS_SYNC(OPS + ((CARRY) ? kCarry : 0))                                                                                         \
         SS_STEP(wfB, scB, wfA, scA, true, true, 1, kt + 4)                                                                            \
-        wait_vmcnt<OPS>(); __builtin_amdgcn_s_barrier();                                                                              \
+        SS_SYNC(OPS)                                                                                                                  \
         SS_STEP(wfA, scA, wfB, scB, true, true, 2, kt + 5)                                                                            \
-        wait_vmcnt<OPS>(); __builtin_amdgcn_s_barrier();                                                                              \
+        SS_SYNC(OPS)                                                                                                                  \
         SS_STEP(wfB, scB, wfA, scA, true, true, 3, kt + 6)                                                                            \
     }
     int kt = 0;
     if (carry && nk > 4) { SS_GROUP(true) kt = 4; }
     for (; kt + 4 < nk; kt += 4) SS_GROUP(false)   // steady groups: stage kt+j+3 goes into the buffer step kt+j-1 just finished with
     {   // last group (kt == nk - 4): one more DMA (stage nk-1), then drain.  Its waits never leave stores in flight (only matters when nk == 4)
-        wait_vmcnt<OPS>(); __builtin_amdgcn_s_barrier();
+        SS_SYNC(OPS)
         SS_STEP(wfA, scA, wfB, scB, true, true, 0, kt + 3)
-        wait_vmcnt<OPS>(); __builtin_amdgcn_s_barrier();
+        SS_SYNC(OPS)
         SS_STEP(wfB, scB, wfA, scA, false, true, 1, 0)
-        wait_vmcnt<0>(); __builtin_amdgcn_s_barrier();
+        SS_SYNC(0)
         SS_STEP(wfA, scA, wfB, scB, false, true, 2, 0)
         SS_STEP(wfB, scB, wfA, scA, false, false, 3, 0)
     }
 #undef SS_GROUP
+#undef SS_SYNC
     // the accumulators must exist HERE: otherwise the last group's MFMAs are sunk below the next tile's prologue and the branches of the
     // epilogue (their results are first read there), with every fragment they need spilled on the way
 #pragma unroll
@@ -381,6 +386,13 @@ static void launch_f8_kind(const GemmF8Desc& g, hipStream_t st) {
     int n_cu = device_cu_count() / 8 * 8;
     if (n_cu < 8) n_cu = 8;
     const int nwg = (g.N / QTN) * ((g.M + QTM - 1) / QTM);
+    if constexpr (KIND == F8_STORE_T) {   // dev tool: knock-out variants of the k loop (wrong results, timing only)
+        static const int ko = getenv("SS_F8_KO") ? atoi(getenv("SS_F8_KO")) : 0;
+#define SS_KO_CASE(V) case V: { static std::atomic<uint64_t> a{0}; once_per_device(a, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm_f8_kernel<T, KIND, V>, hipFuncAttributeMaxDynamicSharedMemorySize, kQLds)); }); \
+                                gemm_f8_kernel<T, KIND, V><<<nwg < n_cu ? nwg : n_cu, 512, kQLds, st>>>(g); SS_LAUNCH_CHECK(); return; }
+        switch (ko) { SS_KO_CASE(1) SS_KO_CASE(2) SS_KO_CASE(3) SS_KO_CASE(4) SS_KO_CASE(7) SS_KO_CASE(8) SS_KO_CASE(15) SS_KO_CASE(16) SS_KO_CASE(20) SS_KO_CASE(28) default: break; }
+#undef SS_KO_CASE
+    }
     gemm_f8_kernel<T, KIND><<<nwg < n_cu ? nwg : n_cu, 512, kQLds, st>>>(g); SS_LAUNCH_CHECK();
 }
 
