@@ -89,26 +89,33 @@ def test_rest_pipeline_end_to_end(wasr, tmp_path):
     req = rest.TranscribeRequest.from_json(json.dumps(dict(path=str(p), path_type="Local", callback_url="http://cb/", language="zh",
                                                           speaker_diarization=False, emotion_recognition=False, filter_dirty_words=False)))
     cfg = rest.task_config_from_request(req)
+    # (1) the reference's own parameters (temperature ladder): the batched submission must reproduce the serial order exactly, including the
+    #     generator position of chunks that fall back to sampling (ss_session_rng_draws / _discard)
     batched = rest.TranscribeProcessor(wasr, batched=True).process_audio(cfg)
     serial = rest.TranscribeProcessor(wasr, batched=False).process_audio(cfg)      # the reference's order: one state, chunk after chunk
     assert batched == serial and len(batched.text) > 0 and len(batched.segments) >= 3
     payload = rest.callback_on_complete("task-1", batched)
     assert json.loads(json.dumps(payload))["data"]["result"]["text"] == batched.text
-    # the chunks the engine saw, transcribed by the oracle: same text
     samples, ch, sr = rest.read_wav_i16(str(p))
     frames = rest.TranscribeProcessor(wasr).preprocess(samples, ch, sr)
     chunks = rest.rest_chunks(frames)
     assert [len(c) for c in chunks] == [481280, 481280, ((len(x) + 2047) // 2048 - 470) * 2048]
     ref_frames, _ = ppo.preprocess_stream(samples, 4096)
     assert frames.shape == ref_frames.shape
-    # every transcription done by the CPU oracle on the same chunks: the same task result
+    # (2) every transcription done by the CPU oracle on the same chunks: the same task result.  Pure greedy here (temperature_inc = 0): on the
+    #     random-weight fixture nearly every window of a 65 s file walks the ladder and SAMPLES (the oracle counted 11 fallbacks), and a draw
+    #     within ~1e-3 of a CDF boundary may legitimately pick the neighbour, which would leave nothing exact to compare.  The ladder against
+    #     the oracle: test_full_path_default_ladder_f16.
     from test_gpu_stream import OracleAsr
-    oa = OracleAsr(orc.OracleModel(wasr.engine.model_path), wasr)
-    want = rest.TranscribeProcessor(oa, batched=False).process_audio(cfg)
-    if oa.n_fail == 0:
-        assert batched == want
-    else:   # sampled fallbacks: tokens are drawn from device-computed probabilities (see test_full_path_default_ladder_f16)
-        assert len(batched.text) > 0 and len(want.text) > 0
+    wasr.params_hook = lambda q: setattr(q, "temperature_inc", 0.0)
+    try:
+        got = rest.TranscribeProcessor(wasr, batched=True).process_audio(cfg)
+        oa = OracleAsr(orc.OracleModel(wasr.engine.model_path), wasr)
+        oa.params_hook = wasr.params_hook
+        want = rest.TranscribeProcessor(oa, batched=False).process_audio(cfg)
+    finally:
+        wasr.params_hook = None
+    assert got == want and len(got.segments) >= 3
 
 
 def test_rest_pipeline_resampled_and_failing_inputs(wasr, tmp_path):

@@ -22,7 +22,8 @@ class OracleAsr(asr.WhisperAsr):
 
     def transcribe_with_state(self, state, audio, user_params):
         bp = self.build_params(user_params)
-        p = orc.default_params(language=bp.language, no_context=bp.no_context, tdrz_enable=bp.tdrz_enable, single_segment=bp.single_segment)
+        p = orc.default_params(language=bp.language, no_context=bp.no_context, tdrz_enable=bp.tdrz_enable, single_segment=bp.single_segment,
+                               temperature_inc=bp.temperature_inc)
         res = state.full(np.asarray(audio, np.float32), p)
         self.n_fail += res["n_fail"]
         return self._collect(res, user_params)
