@@ -315,7 +315,8 @@ def main():
         pass_ms = dec_ms / max(1.0, passes)
         rows_per_pass = rows / max(1.0, passes)      # the batch former may merge queued steps into one device batch: more rows per weight pass
         dec_weight_bytes = work["dec_bytes_step"] - args.batch * 2.0 * hp.n_text_layer * 2 * hp.n_audio_ctx * hp.n_text_state
-        cross_kv_row = 2.0 * hp.n_text_layer * 2 * hp.n_audio_ctx * hp.n_text_state
+        # cross K and V of every layer, read once per row per pass: f16 (2 B per element), or in the fp8 engine e4m3 codes + one exponent byte per 64
+        cross_kv_row = (1.0 + 1.0 / 64.0 if args.dtype == "fp8" else 2.0) * hp.n_text_layer * 2 * hp.n_audio_ctx * hp.n_text_state
         self_kv_row = 2.0 * 2 * hp.n_text_layer * hp.n_text_state * (n_prompt + n_steps_dec / 2.0)       # f16 K and V, average history
         pass_bytes = dec_weight_bytes + rows_per_pass * (cross_kv_row + self_kv_row)
         hbm_gbs = pass_bytes * passes * args.steps / dt / 1e9

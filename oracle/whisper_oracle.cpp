@@ -19,7 +19,8 @@
 //   3  FP8      : mode 1 with the projections of the encoder blocks and the cross-K/V projection in OCP e4m3 (BASELINE configs[4]; no
 //                 whisper.cpp counterpart -- this mode DEFINES the rounding points the fp8 engine must reproduce): weights = e4m3 codes x one
 //                 f32 scale per output channel (amax / 448); activations = e4m3 codes x 2^s per (row, 64-column block), s the smallest
-//                 integer with amax / 2^s <= 448; products accumulated in f32.  Conv stem, attention, residual stream, decoder: mode 1.
+//                 integer with amax / 2^s <= 448; products accumulated in f32.  The cross K/V cache is stored in the same e4m3 form, one
+//                 scale per (key, head).  Conv stem, encoder attention, residual stream, the rest of the decoder: mode 1.
 //   gelu_erf=1 switches GELU to the exact erf form (HF cross-check only; whisper.cpp uses tanh).
 #include <algorithm>
 #include <cmath>
@@ -677,6 +678,15 @@ void cross_kv(State& s, int max_layers = -1) {
         } else {
             matmul(s.enc.data(), hp.n_audio_state, m.w(p + "key.weight").data(), nullptr, K, d, n_ctx, d, hp.n_audio_state, s.o.mode);
             matmul(s.enc.data(), hp.n_audio_state, m.w(p + "value.weight").data(), m.w(p + "value.bias").data(), V, d, n_ctx, d, hp.n_audio_state, s.o.mode);
+        }
+        if (s.o.fp8) {
+            // FP8 mode: the cross cache itself is e4m3 -- one power-of-two scale per (key row, head) = per 64-column block of these [n_ctx][d]
+            // matrices, K pre-scaled by dh^-1/4, quantised from the f32 projection output (no f16 rounding in between)
+            for (size_t i = 0; i < (size_t)n_ctx * d; i++) K[i] *= kscale;
+            std::vector<float> q((size_t)n_ctx * d);
+            quantize_rows_f8(K, d, q.data(), n_ctx, d, false); memcpy(K, q.data(), q.size() * 4);
+            quantize_rows_f8(V, d, q.data(), n_ctx, d, false); memcpy(V, q.data(), q.size() * 4);
+            continue;
         }
         for (size_t i = 0; i < (size_t)n_ctx * d; i++) { K[i] = act_round(K[i] * kscale, s.o.mode); V[i] = act_round(V[i], s.o.mode); }
     }

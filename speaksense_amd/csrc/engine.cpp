@@ -152,6 +152,7 @@ struct EngineT : EngineBase {
     std::vector<DBuf> pcm_d, mel_d, fmax_d;  // per batch slot
     DBuf x0, h1, x, ln, qk, vT, att, ff, encT, encF, cross, kself, vself;
     DBuf ln8, ln_sc, att8, att_sc, ff8, ff_sc;   // fp8 engine: quantised activations + their exponent bytes
+    DBuf cross_sc;                               // fp8 engine: exponent bytes of the e4m3 cross cache, [L][B][kv][h][t]
     long Mpad = 0;
     DBuf xd, lnd, qd, attd, ffd, logits, probs, cscratch, ctl_d;
     // Host staging for one decoder launch: control blocks, sampling-row indices and the uniform draws.  H2D copies from pinned memory read
@@ -408,7 +409,8 @@ struct EngineT : EngineBase {
         } else {
             ff.alloc(M * 4 * da * 2);
         }
-        cross.alloc((size_t)L * B * 2 * H * n_ctx * 64 * 2);
+        cross.alloc((size_t)L * B * 2 * H * n_ctx * 64 * (fp8_enc ? 1 : 2));   // fp8 engine: e4m3 codes + one exponent byte per (key row, head)
+        if (fp8_enc) cross_sc.alloc((size_t)L * B * 2 * H * n_ctx);
         kself.alloc((size_t)L * S * n_tctx * d * 2); vself.alloc((size_t)L * S * n_tctx * d * 2);
         const int R = 64;  // rows per decode launch
         xd.alloc((size_t)R * d * 4); lnd.alloc((size_t)R * d * 2); qd.alloc((size_t)R * d * 2); attd.alloc((size_t)R * d * 2);
@@ -519,8 +521,8 @@ struct EngineT : EngineBase {
     // cmap (optional): window k of this pass writes the cross-KV cache slot cmap[k] (windows of a running group keep their slots)
     void cross_kv_pass(int Wn, const int* cmap = nullptr) {
         if (fp8_enc) {
-            GemmF8Desc g = gd8(ln8.p, ln_sc.p, da, crosskv_w8, crosskv_s, Wn * n_ctx, L * 2 * d, da, F8_CROSS_KV, crosskv_b, cross.p, 0);
-            g.scale = qscale; g.d = d; g.rows_per_batch = n_ctx; g.n_batch = B;
+            GemmF8Desc g = gd8(ln8.p, ln_sc.p, da, crosskv_w8, crosskv_s, Wn * n_ctx, L * 2 * d, da, F8_CROSS_KV8, crosskv_b, cross.p, 0);
+            g.scale = qscale; g.d = d; g.rows_per_batch = n_ctx; g.n_batch = B; g.out_scale = cross_sc.as<unsigned char>();
             if (cmap) {
                 if (Wn > (int)sizeof(g.batch_map)) throw Error(-1, "internal: cross-KV slot map too small");
                 g.use_batch_map = 1;
@@ -685,7 +687,10 @@ struct EngineT : EngineBase {
         }
     }
     void fused_body(int M, int n_samp) {
-        if (decode_v2) { fused_body2(M, n_samp); return; }
+        if (decode_v2) {
+            if (fp8_enc) throw Error(SS_ERR_UNSUPPORTED, "fp8: the e4m3 cross cache is only wired into the default decode step (unset SS_DECODE_V2)");
+            fused_body2(M, n_samp); return;
+        }
         const RowCtl* ctl = ctl_d.as<RowCtl>();
         const long slot_stride = (long)n_tctx * d, layer_stride = (long)S * slot_stride;
         const long cb_stride = (long)2 * H * n_ctx * 64, cl_stride = (long)B * cb_stride;
@@ -738,7 +743,13 @@ struct EngineT : EngineBase {
             // key splits exist to fill the chip when there are few (row, head) pairs; from M * H >= direct_pairs on, one workgroup per pair
             // streams all 1500 keys and writes the normalised output itself: no partials, no combine launch
             const bool direct = cross_direct || (ln_fused == 0 && M * H >= direct_pairs);
-            if (direct) {
+            if (fp8_enc) {   // e4m3 cross cache: the same two forms over codes + exponent bytes (half the bytes of the stream that bounds the pass)
+                const long sc_b = (long)2 * H * n_ctx;
+                launch_dec_cross_attention_f8<T>(pq.as<float>(), n_qpart, e.bcq, qscale, cross.as<unsigned char>() + il * cl_stride,
+                                                 cross_sc.as<unsigned char>() + il * (long)B * sc_b, cb_stride, sc_b, d, H, n_ctx, ctl, M,
+                                                 direct ? nullptr : cscratch.as<float>(), attd.as<T>(), st);
+                if (!direct && combine_separate) launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
+            } else if (direct) {
                 launch_dec_cross_attention_direct<T>(pq.as<float>(), n_qpart, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
                                                      attd.as<T>(), st);
             } else {
@@ -804,6 +815,7 @@ struct EngineT : EngineBase {
     int decoder_step(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
         // the fused step carries up to 16 rows in every variant and up to 64 (multi-tile GEMVs) in its default form
         if (use_fused && (M <= 16 || (wide_ok && M <= kPartRows))) { decoder_step_fused(M, rc, samp_rows, any_probs); return step_parity; }
+        if (fp8_enc) throw Error(SS_ERR_UNSUPPORTED, "fp8: the e4m3 cross cache is only wired into the fused decode step (unset SS_DECODE_UNFUSED / SS_DECODE_WIDE=0)");
         const int n_samp = (int)samp_rows.size();
         cnt_passes++; cnt_rows += M;
         SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));

@@ -71,6 +71,7 @@ enum Fp8Epi {
     F8_VT,            // as EPI_VT
     F8_CROSS_KV,      // as EPI_CROSS_KV
     F8_STORE_F32,     // out f32[m][n] = acc * ws[n] + bias[n]
+    F8_CROSS_KV8,     // the cross cache itself in e4m3: codes [l][b][kv][h][t][64] + one exponent byte per (l, b, kv, h, t) in out_scale (K pre-scaled)
 };
 __host__ __device__ inline long f8_scale_index(long m, long blk, long ldsc) {
     return blk * ldsc + (m & ~(long)127) + (m & 31) * 4 + ((m >> 5) & 3);
@@ -201,6 +202,11 @@ void launch_dec_cross_attention_direct(const float* qpart, int n_qpart, const fl
                                        int H, int Tn, const RowCtl* ctl, int M, T* out, hipStream_t st);
 // flash-decoding combine of the cross-attention partials: out T [M][d]
 template <typename T> void launch_dec_cross_combine(const float* scratch, int d, int H, int M, T* out, hipStream_t st);
+// fp8 engine: the same two cross-attention forms over an e4m3 cross cache (codes [kv][h][t][64] per window, exponent bytes [kv][h][t]); b_stride /
+// sc_stride = bytes per window of the two buffers; scratch != null: 4 key splits into scratch (then launch_dec_cross_combine), else direct into out
+template <typename T>
+void launch_dec_cross_attention_f8(const float* qpart, int n_qpart, const float* qbias, float qscale, const unsigned char* kc, const unsigned char* ksc,
+                                   long b_stride, long sc_stride, int d, int H, int Tn, const RowCtl* ctl, int M, float* scratch, T* out, hipStream_t st);
 
 // ---------------------------------------------------------------------------------------------
 // misc (kernels_misc.hip)

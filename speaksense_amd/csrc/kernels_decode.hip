@@ -601,4 +601,163 @@ template void launch_dec_cross_attention_q<bf16>(const float*, int, const float*
 template void launch_dec_cross_attention_q<f16>(const float*, int, const float*, float, const f16*, const f16*, long, int, int, int, const RowCtl*, int,
                                                 float*, hipStream_t);
 
+// ---------------------------------------------------------------------------------------------
+// the same cross-attention over an e4m3 cross cache (fp8 engine): a key row of one head is 64 codes + one exponent byte, so the stream that
+// bounds a decoder pass (245.8 MB per sequence per step in f16) is halved.  4 lanes x 16 codes per row, 16 key rows per wave-instruction;
+// the exponent of a K row scales its score, the exponent of a V row is folded into its probability.  Arithmetic as the f16 kernel: q rounded
+// to T, scores and P.V accumulated in f32, p rounded to T.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NSPLIT>
+__global__ __launch_bounds__(256) void dec_cross_attn_q8_kernel(const float* __restrict__ qpart, int n_qpart, const float* __restrict__ qbias, float qscale,
+                                                                const unsigned char* __restrict__ kc, const unsigned char* __restrict__ ksc, long b_stride,
+                                                                long sc_stride, int d, int H, int Tn, const RowCtl* __restrict__ ctl,
+                                                                float* __restrict__ scratch, T* __restrict__ out_direct) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ float s_sc[(NSPLIT == 1 ? 1536 : 512) + 128];
+    __shared__ float s_red[8];
+    __shared__ float s_o[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane >> 2, c = lane & 3;            // 16 key rows x 4 chunks of 16 codes per wave-instruction
+    const int sp = blockIdx.x, h = blockIdx.y, m = blockIdx.z;
+    const int per = (Tn + NSPLIT - 1) / NSPLIT;
+    const int k_beg = sp * per, k_end = min(Tn, k_beg + per), nk = k_end - k_beg;
+    const RowCtl rc = ctl[m];
+    // window layout: codes [kv][h][t][64], exponent bytes [kv][h][t]
+    const unsigned char* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
+    const unsigned char* V = K + (long)H * Tn * 64;
+    const unsigned char* KS = ksc + (long)rc.cross * sc_stride + (long)h * Tn;
+    const unsigned char* VS = KS + (long)H * Tn;
+    float qv[16];
+    {
+        const int col = h * 64 + c * 16;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; q4++) {
+            f32x4 a = *(const f32x4*)(qbias + col + q4 * 4);
+            f32x4 t[4];
+#pragma unroll
+            for (int p = 0; p < 4; p++) t[p] = *(const f32x4*)(qpart + ((long)(p < n_qpart ? p : 0) * kPartRows + m) * d + col + q4 * 4);
+#pragma unroll
+            for (int p = 0; p < 4; p++) a += t[p] * (p < n_qpart ? 1.f : 0.f);
+#pragma unroll
+            for (int e = 0; e < 4; e++) qv[q4 * 4 + e] = (float)(T)(a[e] * qscale);
+        }
+    }
+    auto dot16 = [&](const u32x4& w, const float* x) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            a += x[4 * j + 0] * __builtin_amdgcn_cvt_f32_fp8((int)w[j], 0);
+            a += x[4 * j + 1] * __builtin_amdgcn_cvt_f32_fp8((int)w[j], 1);
+            a += x[4 * j + 2] * __builtin_amdgcn_cvt_f32_fp8((int)w[j], 2);
+            a += x[4 * j + 3] * __builtin_amdgcn_cvt_f32_fp8((int)w[j], 3);
+        }
+        return a;
+    };
+    // phase 1: scores
+    float mx = -1e30f;
+    const int nit = (nk + 63) / 64;                   // 64 keys per block iteration (4 waves x 16 rows)
+    for (int it = 0; it < nit; it += 4) {
+        u32x4 kw[4];
+        int ii[4];
+        unsigned char eb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            ii[u] = (it + u) * 64 + wave * 16 + r;
+            const int kk = k_beg + (ii[u] < nk ? ii[u] : 0);
+            kw[u] = SS_LDW((const u32x4*)(K + (long)kk * 64 + c * 16));
+            eb[u] = KS[kk];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float a = dot16(kw[u], qv);
+            a += dpp_mov<kDppXor1>(a);
+            a += dpp_mov<kDppXor2>(a);
+            a *= __builtin_bit_cast(float, (unsigned)eb[u] << 23);
+            if (ii[u] < nk) {
+                if (c == 0) s_sc[ii[u]] = a;
+                mx = fmaxf(mx, a);
+            }
+        }
+    }
+    mx = wave_max(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sum = 0.f;
+    for (int i = tid; i < nk; i += 256) {
+        const float p = (float)(T)__expf(s_sc[i] - mx);
+        s_sc[i] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) s_red[4 + wave] = sum;
+    __syncthreads();
+    sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    // phase 2: o[c*16 + e] += p[key] * 2^(ev - 127) * code
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    for (int it = 0; it < nit; it += 4) {
+        u32x4 vw[4];
+        float pw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = (it + u) * 64 + wave * 16 + r;
+            const bool okk = i < nk;
+            const int kk = k_beg + (okk ? i : 0);
+            vw[u] = SS_LDW((const u32x4*)(V + (long)kk * 64 + c * 16));
+            pw[u] = okk ? s_sc[i] * __builtin_bit_cast(float, (unsigned)VS[kk] << 23) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc[4 * j + 0] += pw[u] * __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 0);
+                acc[4 * j + 1] += pw[u] * __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 1);
+                acc[4 * j + 2] += pw[u] * __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 2);
+                acc[4 * j + 3] += pw[u] * __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 3);
+            }
+    }
+    // sum over the 16 lanes that share lane & 3 (strides 4, 8, 16, 32)
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        float a = acc[e];
+        a += dpp_mov<kDppRor4>(a);
+        a += dpp_mov<kDppRor8>(a);
+        a = rows_sum(a);
+        acc[e] = a;
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) s_o[wave][c * 16 + e] = acc[e];
+    }
+    __syncthreads();
+    if constexpr (NSPLIT == 1) {
+        if (tid < 64) out_direct[(long)m * d + h * 64 + tid] = (T)((s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid]) / sum);
+    } else {
+        float* part = scratch + ((long)(m * H + h) * kCrossSplitD + sp) * kCrossPartD;
+        if (tid < 64) part[2 + tid] = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
+        if (tid == 0) { part[0] = mx; part[1] = sum; }
+    }
+}
+
+template <typename T>
+void launch_dec_cross_attention_f8(const float* qpart, int n_qpart, const float* qbias, float qscale, const unsigned char* kc, const unsigned char* ksc,
+                                   long b_stride, long sc_stride, int d, int H, int Tn, const RowCtl* ctl, int M, float* scratch, T* out, hipStream_t st) {
+    if (scratch) {
+        if ((Tn + kCrossSplitD - 1) / kCrossSplitD > 512) throw Error(-1, "cross attention: n_audio_ctx too large");
+        dim3 grid(kCrossSplitD, H, M);
+        dec_cross_attn_q8_kernel<T, kCrossSplitD><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, scratch, nullptr);
+    } else {
+        if (Tn > 1536) throw Error(-1, "cross attention: n_audio_ctx too large");
+        dim3 grid(1, H, M);
+        dec_cross_attn_q8_kernel<T, 1><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, nullptr, out);
+    }
+    SS_LAUNCH_CHECK();
+}
+template void launch_dec_cross_attention_f8<bf16>(const float*, int, const float*, float, const unsigned char*, const unsigned char*, long, long, int, int, int,
+                                                  const RowCtl*, int, float*, bf16*, hipStream_t);
+template void launch_dec_cross_attention_f8<f16>(const float*, int, const float*, float, const unsigned char*, const unsigned char*, long, long, int, int, int,
+                                                 const RowCtl*, int, float*, f16*, hipStream_t);
+
 }  // namespace ss

@@ -320,6 +320,40 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(GemmF8Desc g) {
         }
         // exponent bytes of rows (mi*32 + l32, mi = 0..3) of this wave's 128-row half: one dword per lane in the tiled layout
         if (kh == 0) *(unsigned*)(g.out_scale + (long)((n0 + wn * 64) >> 6) * g.ld_osc + m0 + wm * 128 + l32 * 4) = ebytes;
+    } else if constexpr (KIND == F8_CROSS_KV8) {
+        // this wave's 64 columns are one head of one (layer, K|V): quantised per (key row, head) like the GELU output, K pre-scaled by dh^-1/4
+        const int H = g.d / 64;
+        const int nw = n0 + wn * 64;
+        const int l = nw / (2 * g.d), rem = nw % (2 * g.d), kv = rem / g.d, h = (rem % g.d) >> 6;
+        const float ksc = kv == 0 ? g.scale : 1.0f;
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) {
+            const long m = m0 + wm * 128 + mi * 32 + l32;
+            float v[2][4][4];
+            float amax = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { v[ni][gq][r] = acc[ni][mi][gq * 4 + r] * ksc; amax = fmaxf(amax, fabsf(v[ni][gq][r])); }
+            amax = swap32_max(amax);
+            const int e = e8m0_for_amax(amax);
+            const float inv = pow2_neg_of_e8m0(e);
+            if (m < g.M) {
+                int b = (int)(m / g.rows_per_batch);
+                const int t = (int)(m % g.rows_per_batch);
+                if (g.use_batch_map) b = g.batch_map[b];
+                const long row = (((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t;
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++)
+                        *(unsigned*)((unsigned char*)g.out + row * 64 + ni * 32 + 8 * gq + 4 * kh) =
+                            pack_e4m3x4(v[ni][gq][0] * inv, v[ni][gq][1] * inv, v[ni][gq][2] * inv, v[ni][gq][3] * inv);
+                if (kh == 0) g.out_scale[row] = (unsigned char)e;
+            }
+        }
     } else if constexpr (!SWAP) {
 #pragma unroll
         for (int mi = 0; mi < 4; mi++) {
@@ -410,6 +444,7 @@ void launch_gemm_f8(const GemmF8Desc& g, hipStream_t st) {
         case F8_VT: launch_f8_kind<T, F8_VT>(g, st); break;
         case F8_CROSS_KV: launch_f8_kind<T, F8_CROSS_KV>(g, st); break;
         case F8_STORE_F32: launch_f8_kind<T, F8_STORE_F32>(g, st); break;
+        case F8_CROSS_KV8: launch_f8_kind<T, F8_CROSS_KV8>(g, st); break;
         default: throw Error(-1, "fp8 gemm: bad epilogue kind");
     }
 }

@@ -21,7 +21,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # One e4m3 rounding flip moves a logit by ~1e-2 sigma on these synthetic models (sigma = 9): measured margins are reported by every test
-GAP_TOL_FP8 = 0.25    # as bf16; measured (r02_n): every flip below 0.03
+# Largest log-probability distance between a device pick and the oracle's argmax on the same prefix that still counts as a near tie.  With the
+# e4m3 cross cache an element of K or V that sits within f16 noise of a code boundary lands on the neighbouring code on one side only (a 6 %
+# step of that element); measured (r02_q): real widths <= 0.043 (base.en 3/3 chunks identical, wide2 d = 1280: 0.043), the 256-wide 4-head toy
+# model, where one element is a far larger share of a 64-dim dot product over 1500 keys, up to 0.23.
+GAP_TOL_FP8 = 0.25
+GAP_TOL_FP8_TOY = 0.5
 
 
 @pytest.fixture(scope="module")
@@ -83,10 +88,41 @@ def test_fp8_full_path_vs_oracle(toy256_path, base_en_path, wide2_path, orc, whi
         got = eng.new_session().transcribe(pcm, binding.default_params(language="en", temperature_inc=0.0))
         assert len(got["tokens"]) > 0
         ok, gap = check_against_oracle(got, om, orc, orc.MODE_FP8, pcm, orc.default_params(language="en", temperature_inc=0.0),
-                                       f"fp8 {which} seed {seed}", GAP_TOL_FP8, tid_slack_beg=om.beg)
+                                       f"fp8 {which} seed {seed}", GAP_TOL_FP8_TOY if which == "toy256" else GAP_TOL_FP8, tid_slack_beg=om.beg)
         same += ok
         worst = max(worst, gap)
     report(f"fp8 {which}: {same}/{len(cases)} chunks token-identical to the FP8-mode oracle, largest proven near-tie margin {worst:.4f}")
+    eng.close(); om.close()
+
+
+@pytest.mark.parametrize("which", ["base.en", "wide2"])
+def test_fp8_decoder_logits_vs_oracle(base_en_path, wide2_path, orc, which):
+    """The decoder over the e4m3 cross cache, teacher-forced from the SAME encoder output on both sides: isolates the cross-K/V projection (e4m3
+    GEMM writing the cache in e4m3) and the decoder's cross-attention over codes + exponent bytes.  The device stores the handed-in encoder
+    output in f16 before quantising it, the oracle quantises the f32 values: a handful of code flips, as everywhere in this mode."""
+    from speaksense_amd import binding
+    path = base_en_path if which == "base.en" else wide2_path
+    om = orc.OracleModel(path)
+    eng = binding.Engine(path, dtype=binding.DTYPE_FP8, max_batch=1)
+    mel = om.log_mel(synth.speech_like(6))
+    enc = om.encode(mel, 0, orc.MODE_FP8)
+    ost = om.new_state(orc.MODE_FP8)
+    ost.set_encoder(enc)
+    ses = eng.new_session()
+    ses.set_encoder(enc)
+    toks = [om.sot, om.beg + 3, 1234, 777, 42, om.beg + 50, 9, 31]
+    worst = 0.0
+    for i in range(len(toks)):
+        ref = ost.decode(toks[i:i + 1], i)
+        got = ses.decode(toks[i:i + 1], i)
+        sd = float(ref.std())
+        e = float(np.abs(got - ref).max()) / sd
+        worst = max(worst, e)
+        top2 = np.sort(ref)[-2:]
+        if top2[1] - top2[0] > 0.25:
+            assert int(got.argmax()) == int(ref.argmax()), f"step {i}"
+    report(f"fp8 decoder logits {which} (e4m3 cross cache, 8 teacher-forced steps): worst max|gpu - oracle FP8| / std = {worst:.2e}")
+    assert worst < 5e-2, worst
     eng.close(); om.close()
 
 
