@@ -438,13 +438,16 @@ void launch_gemm_f8(const GemmF8Desc& g, hipStream_t st) {
     switch (g.kind) {
         case F8_STORE_T: launch_f8_kind<T, F8_STORE_T>(g, st); break;
         case F8_GELU_F8:
+            if (!g.out_scale) throw Error(-1, "fp8 gemm: the e4m3 output needs its exponent-byte buffer");
             if (g.ld_osc % 256 || g.ld_osc < ((g.M + 255) & ~255)) throw Error(-1, "fp8 gemm: bad output exponent-byte pitch");
             launch_f8_kind<T, F8_GELU_F8>(g, st); break;
         case F8_RES_F32: launch_f8_kind<T, F8_RES_F32>(g, st); break;
         case F8_VT: launch_f8_kind<T, F8_VT>(g, st); break;
         case F8_CROSS_KV: launch_f8_kind<T, F8_CROSS_KV>(g, st); break;
         case F8_STORE_F32: launch_f8_kind<T, F8_STORE_F32>(g, st); break;
-        case F8_CROSS_KV8: launch_f8_kind<T, F8_CROSS_KV8>(g, st); break;
+        case F8_CROSS_KV8:
+            if (!g.out_scale || g.d % 64 || g.N % (2 * g.d)) throw Error(-1, "fp8 gemm: the e4m3 cross cache needs its exponent-byte buffer and N = layers * 2 * d");
+            launch_f8_kind<T, F8_CROSS_KV8>(g, st); break;
         default: throw Error(-1, "fp8 gemm: bad epilogue kind");
     }
 }
