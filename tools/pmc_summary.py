@@ -1,11 +1,12 @@
 """Summarise the rocprofv3 --pmc passes of the bench command (tools/gpu_pmc.sh): HBM-side bytes per decoder pass and per encoder FC1 launch.
 bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes); the x2 is the gfx950 FETCH_SIZE correction for 16-B/lane streams (MI355X_MICROARCH.md, HBM).
-usage: python tools/pmc_summary.py <dir with pmc_FETCH_SIZE_results.db, pmc_WRITE_SIZE_results.db> <tag> [out.json] [out.md]"""
+usage: python tools/pmc_summary.py <dir with pmc_FETCH_SIZE_results.db, pmc_WRITE_SIZE_results.db> <tag> [out.json] [out.md] [dtype]"""
 import json
 import sqlite3
 import sys
 
 d, tag = sys.argv[1], sys.argv[2]
+dtype = sys.argv[5] if len(sys.argv) > 5 else "f16"
 per = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     db = sqlite3.connect(f"{d}/pmc_{c}_results.db")
@@ -25,7 +26,8 @@ for name, v in per.items():
         n_pass = n
     if any(k in name for k in ("dec_", "logits_rules", "logits_probs", "sample_draw", "skinny", "embed_kernel")) or ("layernorm" in name and n > 400):
         dec_bytes += b
-    if "gemm256_kernel" in name and "Li1E" in name:      # EPI_GELU_T: FC1 (+ conv1): the launch with the most traffic is an FC1
+    is_fc1 = ("gemm_f8_kernel" in name and "Li1E" in name) if dtype == "fp8" else ("gemm256_kernel" in name and "Li1E" in name)
+    if is_fc1:      # EPI_GELU_T / F8_GELU_F8: FC1 (+ conv1 in the f16 engines): the launch with the most traffic is an FC1
         fc1 = (2.0 * f[2] + w[2]) * 1024.0
 rows.sort(reverse=True)
 lines = ["| kernel | launches | FETCH_SIZE KiB/launch | WRITE_SIZE KiB/launch | total (2F+W) MB |", "|---|---|---|---|---|"]
@@ -42,8 +44,8 @@ if len(sys.argv) > 3:
         j = {}
     src = f"profiles/{tag}_pmc.md (tools/gpu_pmc.sh: rocprofv3 --kernel-trace --pmc, one counter per pass of the bench command)"
     if n_pass:
-        j["large-v3/batch8/f16/decoder_pass"] = {"bytes_per_launch": dec_bytes / n_pass, "passes": n_pass, "source": src,
+        j[f"large-v3/batch8/{dtype}/decoder_pass"] = {"bytes_per_launch": dec_bytes / n_pass, "passes": n_pass, "source": src,
                                                  "note": "sum over every decoder-side kernel of (2 x FETCH_SIZE + WRITE_SIZE) / decoder passes; the pass carried the rows the default bench configuration merges (see rows_per_launch)"}
     if fc1:
-        j["large-v3/batch8/f16/fc1"] = {"bytes_per_launch": fc1, "source": src, "note": "max over the launches of gemm256_kernel<EPI_GELU_T>"}
+        j[f"large-v3/batch8/{dtype}/fc1"] = {"bytes_per_launch": fc1, "source": src, "note": "max over the launches of the FC1 GEMM kernel (gemm256_kernel<EPI_GELU_T> / gemm_f8_kernel<F8_GELU_F8>)"}
     json.dump(j, open(sys.argv[3], "w"), indent=1)
