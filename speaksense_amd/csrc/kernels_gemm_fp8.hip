@@ -421,7 +421,11 @@ static void launch_f8_kind(const GemmF8Desc& g, hipStream_t st) {
     if (n_cu < 8) n_cu = 8;
     const int nwg = (g.N / QTN) * ((g.M + QTM - 1) / QTM);
     if constexpr (KIND == F8_STORE_T) {   // dev tool: knock-out variants of the k loop (wrong results, timing only)
-        static const int ko = getenv("SS_F8_KO") ? atoi(getenv("SS_F8_KO")) : 0;
+        static const int ko = [] {
+            const int v = getenv("SS_F8_KO") ? atoi(getenv("SS_F8_KO")) : 0;
+            if (v) fprintf(stderr, "[ss] SS_F8_KO=%d: parts of the e4m3 GEMM's k loop are knocked out -- its results are WRONG by construction (timing tool only)\n", v);
+            return v;
+        }();
 #define SS_KO_CASE(V) case V: { static std::atomic<uint64_t> a{0}; once_per_device(a, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm_f8_kernel<T, KIND, V>, hipFuncAttributeMaxDynamicSharedMemorySize, kQLds)); }); \
                                 gemm_f8_kernel<T, KIND, V><<<nwg < n_cu ? nwg : n_cu, 512, kQLds, st>>>(g); SS_LAUNCH_CHECK(); return; }
         switch (ko) { SS_KO_CASE(1) SS_KO_CASE(2) SS_KO_CASE(3) SS_KO_CASE(4) SS_KO_CASE(7) SS_KO_CASE(8) SS_KO_CASE(15) SS_KO_CASE(16) SS_KO_CASE(20) SS_KO_CASE(28) default: break; }
