@@ -73,7 +73,7 @@ pub struct HipAsr { engine: Arc<EnginePtr> }
 impl HipAsr {
     pub fn new(model_path: String) -> Result<Self> {
         let path = CString::new(model_path)?;
-        let opts = ss_engine_opts { device: 0, dtype: 1 /* f16 */, max_batch: 8, max_decoders: 5, batch_wait_us: 2000, n_lanes: 2, reserved: [0; 2] };
+        let opts = ss_engine_opts { device: 0, dtype: 1 /* SS_DTYPE_F16 (ggml's arithmetic); 0 = bf16, 2 = fp8 (e4m3 encoder / cross-KV projections and cross cache, base and larger models) */, max_batch: 8, max_decoders: 5, batch_wait_us: 2000, n_lanes: 2, reserved: [0; 2] };
         let mut e: *mut ss_engine = std::ptr::null_mut();
         let rc = unsafe { ss_engine_create(path.as_ptr(), &opts, &mut e) };
         if rc != 0 { return Err(anyhow!("failed to open whisper model: {}", last_error())); }
