@@ -20,10 +20,13 @@ def main():
     ap.add_argument("--model", default="large-v3")
     ap.add_argument("--max-batch", type=int, default=8)
     ap.add_argument("--batch-wait-us", type=int, default=3000)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "fp8"])
     ap.add_argument("--fixed-steps", type=int, default=24, help="Mode F decode length per chunk (random weights never reach a natural EOT without walking the fallback ladder); 0 = natural")
     a = ap.parse_args()
     path = bench.ensure_model(a.model, 0, None)
-    eng = asr.WhisperAsr(path, max_batch=a.max_batch, batch_across_callers=True, batch_wait_us=a.batch_wait_us)
+    from speaksense_amd import binding
+    eng = asr.WhisperAsr(path, dtype={"f16": binding.DTYPE_F16, "bf16": binding.DTYPE_BF16, "fp8": binding.DTYPE_FP8}[a.dtype], max_batch=a.max_batch,
+                         batch_across_callers=True, batch_wait_us=a.batch_wait_us)
     if a.fixed_steps > 0:
         eng.params_hook = lambda p: setattr(p, "fixed_steps", a.fixed_steps)
     msgs = [stream.client_messages(synth.speech_like(100 + i, int(16000 * a.seconds))) for i in range(a.streams)]
@@ -50,7 +53,7 @@ def main():
     stream.GrpcStreamSession.feed = orig_feed
     n_resp = sum(len(r) for r in res)
     lat = np.array(sorted(lat)) * 1e3
-    print(json.dumps({"workload": f"{a.streams} concurrent streams x {a.seconds:.0f} s, 5 s chunks + final flush, {a.model}, max_batch {a.max_batch}, " + (f"Mode F {a.fixed_steps} decode steps per chunk" if a.fixed_steps else "natural EOT"),
+    print(json.dumps({"dtype": a.dtype, "workload": f"{a.streams} concurrent streams x {a.seconds:.0f} s, 5 s chunks + final flush, {a.model}, max_batch {a.max_batch}, " + (f"Mode F {a.fixed_steps} decode steps per chunk" if a.fixed_steps else "natural EOT"),
                       "audio_sec_per_sec": round(a.streams * a.seconds / wall, 1), "wall_s": round(wall, 3), "chunks": int(len(lat)), "responses": n_resp,
                       "chunk_latency_ms_p50": round(float(np.percentile(lat, 50)), 1), "chunk_latency_ms_p95": round(float(np.percentile(lat, 95)), 1)}))
     eng.engine.close()
