@@ -129,3 +129,28 @@ def test_large_v3_decode_vs_oracle_forced_replay(large_v3_path, eng8):
         om.close()
     finally:
         orc.set_thread_cap(16)
+
+
+def test_large_v3_bf16_forced_replay(large_v3_path):
+    """The dtype BASELINE.json names (bf16 MFMA) at full depth: one chunk end to end, the device's token stream replayed on the oracle's bf16
+    mode (bf16-rounded weights and activations at every mat-mul input): every pick the oracle's argmax or within GAP_TOL_BF16 of it."""
+    from oracle import binding as orc
+    from speaksense_amd import binding
+    from test_gpu_parity import GAP_TOL_BF16, check_against_oracle
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    orc.set_thread_cap(min(64, ncpu))
+    try:
+        om = orc.OracleModel(large_v3_path)
+        eng = binding.Engine(large_v3_path, dtype=binding.DTYPE_BF16, max_batch=2)
+        pcm = synth.speech_like(2)
+        got = eng.new_session().transcribe(pcm, binding.default_params(language="en", fixed_steps=32))
+        assert len(got["tokens"]) == 32
+        _, gap = check_against_oracle(got, om, orc, orc.MODE_BF16, pcm, orc.default_params(language="en", fixed_steps=32), "large-v3 bf16", GAP_TOL_BF16,
+                                      replay_only=True)
+        report(f"large-v3 bf16 (32 + 32 layers, 32 greedy steps): largest near-tie margin in the forced replay {gap:.4f}")
+        eng.close(); om.close()
+    finally:
+        orc.set_thread_cap(16)
