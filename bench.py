@@ -360,7 +360,7 @@ def main():
             "phase_roofline": {
                 "encoder_phase_tflops": round(args.batch * work["enc_flops"] / (enc_ms * 1e-3) / 1e12, 1),
                 "encoder_phase_frac_mfma": round(args.batch * work["enc_flops"] / (enc_ms * 1e-3) / 1e12 / mfma_peak, 4),
-                "encoder_phase_note": "device time of the encoder + cross-KV phases while the other lane's decoder passes share the chip; alone (--inflight 1) the same phase runs at ~0.30",
+                "encoder_phase_note": "device time of the encoder + cross-KV phases while the other lanes' kernels share the chip (its kernels wait for their turn: the phase holds gaps); alone (--inflight 1 --lanes 1) the same phase runs at ~0.30",
                 "encoder_fc1_gemm": {"bound": "mfma", "kernel": (f"gemm_f8_kernel<T, F8_GELU_F8> (e4m3 operands, MX-scaled 32x32x64 MFMA; M={gemm_batch}*1500, N=4d, K=d, "
                                                                   "weight scale + bias + GELU + e4m3 quantisation fused), " if fp8 else
                                                                   f"gemm256_kernel<T, EPI_GELU_T> (M={gemm_batch}*1500, N=4d, K=d, bias+GELU fused), ")
