@@ -35,6 +35,7 @@ enum {
     SS_ERR_LANG = -3,      /* unknown language for a multilingual model */
     SS_ERR_DEVICE = -4,    /* no HIP device / HIP runtime error (message via ss_last_error) */
     SS_ERR_AUDIO_CTX = -5, /* audio_ctx larger than the model's (whisper_full returns -5) */
+    SS_ERR_BUFFER = -6,    /* caller's output buffer too small (ss_*_tokenize) */
     SS_ERR_UNSUPPORTED = -9
 };
 
@@ -95,7 +96,8 @@ int ss_engine_hparams(const ss_engine* e, int32_t out11[11]);       /* n_vocab .
 int ss_engine_special_tokens(const ss_engine* e, int32_t out9[9]);  /* eot sot translate transcribe solm prev nosp not beg */
 const char* ss_engine_token_str(const ss_engine* e, int32_t id);
 /* whisper_tokenize: text -> ids with whisper.cpp's rule (GPT-2 pre-split, then greedy longest match in the vocabulary).
- * Returns the number of tokens, or -(needed) when n_max is too small. */
+ * Returns the number of tokens (>= 0); SS_ERR_BUFFER when n_max is too small (nothing written).  ids == NULL with n_max == 0 is the size
+ * query: returns the number of tokens the text needs.  Both tokenize entry points follow this one convention. */
 int ss_engine_tokenize(const ss_engine* e, const char* text, int32_t* ids, int32_t n_max);
 /* the same with only the vocabulary of a model file loaded (host only: no GPU, no engine); negative = error */
 int ss_model_tokenize(const char* ggml_model_path, const char* text, int32_t* ids, int32_t n_max);
@@ -116,7 +118,9 @@ void ss_pool_free(ss_pool* p);
 int32_t ss_pool_n_engines(const ss_pool* p);
 ss_engine* ss_pool_engine(ss_pool* p, int32_t i);              /* borrowed: hparams, tokens, timing of engine i */
 ss_session* ss_pool_session_create(ss_pool* p);               /* freed with ss_session_free */
-int ss_pool_submit(ss_pool* p, ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, ss_ticket** out);   /* ss_wait as usual */
+/* ss_wait as usual.  A session may have several tickets outstanding (as on a single engine: its chunks then run one after another in
+ * submission order); while it has, its chunks stay on the engine that holds them -- the router only moves a session between chunks. */
+int ss_pool_submit(ss_pool* p, ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, ss_ticket** out);
 int32_t ss_pool_last_engine(const ss_session* s);             /* index of the engine that ran (or runs) the session's last chunk */
 /* the routing rule alone (host only): index of the engine a chunk goes to given each engine's load and the round-robin cursor */
 int32_t ss_pool_pick(const int32_t* load, int32_t n_engines, uint32_t cursor);
@@ -172,6 +176,14 @@ int ss_encode(ss_engine* e, const float* mel /* [n_mel][n_len] */, int32_t n_len
  * session's self-KV; logits_out: [n_vocab] of the LAST token, before any rule. */
 int ss_session_set_encoder(ss_session* s, const float* enc /* [n_audio_ctx][n_audio_state] */);
 int ss_session_decode(ss_session* s, const int32_t* tokens, int32_t n_tokens, int32_t n_past, float* logits_out);
+/* The decoder PASS the batched engine runs, as a stage hook: cross-KV cache slot `window` (< max_batch, lane 0) is filled from an encoder
+ * output, then ONE launch carries n_rows (1..64) token rows -- row i = token[i] at position pos[i] of self-KV slot slot[i]
+ * (< max_batch * max_decoders) attending to cross-KV window cross[i]; rows of one slot must be at consecutive positions, earlier rows first.
+ * The kernels are selected by the row count exactly as in ss_transcribe_batch (<= 16 rows: fused step; 17..64: multi-tile GEMVs; rows x
+ * heads >= 320: the unsplit cross-attention).  logits_out: [n_sample_rows][n_vocab] raw logits of the listed rows, before any rule. */
+int ss_engine_set_encoder_window(ss_engine* e, int32_t window, const float* enc /* [n_audio_ctx][n_audio_state] */);
+int ss_engine_decode_rows(ss_engine* e, const int32_t* token, const int32_t* pos, const int32_t* slot, const int32_t* cross, int32_t n_rows,
+                          const int32_t* sample_rows, int32_t n_sample_rows, float* logits_out);
 /* Fused logits rules + log-softmax + greedy pick on the device for one row of raw logits.
  * hist: tokens sampled so far in this window.  out6: id, p, plog, tid, pt, ptsum. */
 int ss_process_logits(ss_engine* e, const float* raw_logits, const int32_t* hist, int32_t n_hist, int32_t has_ts,

@@ -88,6 +88,8 @@ def lib():
         L.ss_encode.argtypes = [vp, f32p, i32, i32, f32p]
         L.ss_session_set_encoder.argtypes = [vp, f32p]
         L.ss_session_decode.argtypes = [vp, vp, i32, i32, f32p]
+        L.ss_engine_set_encoder_window.argtypes = [vp, i32, f32p]
+        L.ss_engine_decode_rows.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, f32p]
         L.ss_process_logits.argtypes = [vp, f32p, vp, i32, i32, i32, C.POINTER(Params), f32p]
         L.ss_default_denoise_config.argtypes = [C.POINTER(DenoiseConfig)]
         L.ss_denoise_audio.argtypes = [vp, f32p, i32, C.POINTER(DenoiseConfig), i32, f32p, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -201,7 +203,7 @@ class Engine:
         ids = np.zeros(max(16, 2 * len(b)), np.int32)
         n = self.L.ss_engine_tokenize(self.h, b, _p(ids), len(ids))
         if n < 0:
-            raise SpeakSenseError(n, "tokenize: buffer too small")
+            raise SpeakSenseError(n, lib().ss_last_error().decode(errors="replace"))
         return [int(x) for x in ids[:n]]
 
     def new_session(self) -> "Session":
@@ -219,6 +221,21 @@ class Engine:
         mel = np.ascontiguousarray(mel, np.float32)
         out = np.empty((self.n_audio_ctx, self.n_audio_state), np.float32)
         _check(self.L.ss_encode(self.h, _p(mel), mel.shape[1], seek, _p(out)))
+        return out
+
+    def set_encoder_window(self, window: int, enc: np.ndarray):
+        """Stage hook: fill cross-KV cache slot `window` (< max_batch) from an encoder output [n_audio_ctx][n_audio_state]."""
+        enc = np.ascontiguousarray(enc, np.float32)
+        assert enc.shape == (self.n_audio_ctx, self.n_audio_state)
+        _check(self.L.ss_engine_set_encoder_window(self.h, int(window), _p(enc)))
+
+    def decode_rows(self, token, pos, slot, cross, sample_rows) -> np.ndarray:
+        """Stage hook: ONE decoder pass over len(token) rows (row i = token[i] at position pos[i] of self-KV slot slot[i], attending to
+        cross-KV window cross[i]) -> raw logits [len(sample_rows)][n_vocab] of the listed rows."""
+        t, p, sl, cr, sr = (np.ascontiguousarray(a, np.int32) for a in (token, pos, slot, cross, sample_rows))
+        assert len(t) == len(p) == len(sl) == len(cr)
+        out = np.empty((len(sr), self.n_vocab), np.float32)
+        _check(self.L.ss_engine_decode_rows(self.h, _p(t), _p(p), _p(sl), _p(cr), len(t), _p(sr), len(sr), _p(out)))
         return out
 
     def process_logits(self, raw, hist, has_ts: bool, seek_delta: int, params: Params | None = None):

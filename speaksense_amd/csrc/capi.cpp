@@ -90,7 +90,8 @@ const char* ss_engine_token_str(const ss_engine* e, int32_t id) {
 int ss_engine_tokenize(const ss_engine* e, const char* text, int32_t* ids, int32_t n_max) {
     if (!e || !text || (n_max > 0 && !ids)) return fail(SS_ERR_ARG, "ss_engine_tokenize: bad argument");
     const std::vector<int> t = tokenize(e->e->hm.vocab, text);
-    if ((int)t.size() > n_max) return -(int)t.size();
+    if (!ids && n_max == 0) return (int)t.size();       // size query
+    if ((int)t.size() > n_max) return fail(SS_ERR_BUFFER, "ss_engine_tokenize: buffer too small: " + std::to_string(t.size()) + " tokens needed");
     for (size_t i = 0; i < t.size(); i++) ids[i] = t[i];
     return (int)t.size();
 }
@@ -101,7 +102,8 @@ int ss_model_tokenize(const char* path, const char* text, int32_t* ids, int32_t 
     HostModel m;
     load_ggml_model(path, m, true);
     const std::vector<int> t = tokenize(m.vocab, text);
-    if ((int)t.size() > n_max) return fail(SS_ERR_ARG, "ss_model_tokenize: buffer too small");
+    if (!ids && n_max == 0) return (int)t.size();       // size query
+    if ((int)t.size() > n_max) return fail(SS_ERR_BUFFER, "ss_model_tokenize: buffer too small: " + std::to_string(t.size()) + " tokens needed");
     for (size_t i = 0; i < t.size(); i++) ids[i] = t[i];
     return (int)t.size();
     SS_CATCH
@@ -155,7 +157,10 @@ int ss_pool_submit(ss_pool* p, ss_session* s, const float* pcm, int32_t n_sample
     const int n = (int)p->engines.size();
     std::vector<int32_t> load(n);
     for (int i = 0; i < n; i++) load[i] = p->engines[i]->e->load.load();
-    const int k = ss_pool_pick(load.data(), n, p->cursor.fetch_add(1));
+    int k = ss_pool_pick(load.data(), n, p->cursor.fetch_add(1));
+    // A session with a ticket outstanding stays on the engine that holds it: the one-chunk-per-session-at-a-time guard (`running` in
+    // start_worker / admit_more) is per engine, so a second chunk routed elsewhere would run concurrently on the same Session state.
+    if (s->s.in_flight.load() > 0 && s->s.pool_engine >= 0 && s->s.pool_engine < n) k = s->s.pool_engine;
     s->s.eng = p->engines[k]->e;       // the session's state is host-side only: this chunk runs on engine k
     s->s.pool_engine = k;
     return ss_submit(s, pcm, n_samples, params, out);
@@ -205,13 +210,16 @@ int ss_submit_ex(ss_session* s, const float* pcm, int32_t n_samples, const ss_pa
     if (params) t->job.P = *params; else ss_default_params(&t->job.P);
     if (bad_prompt(t->job.P, s->s.eng)) { delete t; return fail(SS_ERR_ARG, "ss_submit: bad prompt_tokens"); }
     capture_prompt(t->job, s->s.eng);
+    t->job.eng = s->s.eng;             // the ticket remembers the engine that owns it (a pool session may be re-pointed before ss_wait)
+    s->s.in_flight.fetch_add(1);
     s->s.eng->submit(&t->job);
     *out = t;
     return SS_OK;
 }
 int ss_wait(ss_ticket* t) {
     if (!t) return fail(SS_ERR_ARG, "ss_wait: null ticket");
-    t->job.sess->eng->wait(&t->job);
+    (t->job.eng ? t->job.eng : t->job.sess->eng)->wait(&t->job);
+    t->job.sess->in_flight.fetch_sub(1);
     const int st = t->job.status;
     const std::string why = t->job.err.empty() ? std::string("chunk failed") : t->job.err;
     delete t;
@@ -290,6 +298,15 @@ int ss_session_set_encoder(ss_session* s, const float* enc) {
     if (!s || !enc) return fail(SS_ERR_ARG, "ss_session_set_encoder: bad argument");
     SS_TRY s->s.eng->set_encoder_host(enc); return SS_OK; SS_CATCH
 }
+int ss_engine_set_encoder_window(ss_engine* e, int32_t window, const float* enc) {
+    if (!e || !enc) return fail(SS_ERR_ARG, "ss_engine_set_encoder_window: bad argument");
+    SS_TRY e->e->set_encoder_window_host(enc, window); return SS_OK; SS_CATCH
+}
+int ss_engine_decode_rows(ss_engine* e, const int32_t* token, const int32_t* pos, const int32_t* slot, const int32_t* cross, int32_t n_rows,
+                          const int32_t* sample_rows, int32_t n_sample_rows, float* logits_out) {
+    if (!e || !token || !pos || !slot || !cross || !sample_rows || !logits_out) return fail(SS_ERR_ARG, "ss_engine_decode_rows: null argument");
+    SS_TRY e->e->decode_rows_host(token, pos, slot, cross, n_rows, sample_rows, n_sample_rows, logits_out); return SS_OK; SS_CATCH
+}
 int ss_session_decode(ss_session* s, const int32_t* tokens, int32_t n, int32_t n_past, float* logits_out) {
     if (!s || !tokens || !logits_out || n <= 0 || n_past < 0 || n_past + n > s->s.eng->hm.hp.n_text_ctx) return fail(SS_ERR_ARG, "ss_session_decode: bad argument");
     for (int i = 0; i < n; i++) if (tokens[i] < 0 || tokens[i] >= s->s.eng->hm.hp.n_vocab) return fail(SS_ERR_ARG, "ss_session_decode: token out of range");
@@ -302,9 +319,13 @@ int ss_process_logits(ss_engine* e, const float* raw, const int32_t* hist, int32
     if (params) P = *params; else ss_default_params(&P);
     SS_TRY e->e->process_logits_host(raw, hist, n_hist, has_ts, seek_delta, P, out6); return SS_OK; SS_CATCH
 }
+// last_ms / last_cnt describe the group that most recently FINISHED on any lane (a blocking call may have run on a lane other than 0);
+// each lane writes its own under its `mu`, the engine keeps which lane was last
 int ss_engine_last_timing(const ss_engine* e, float out_ms[4]) {
     if (!e || !out_ms) return fail(SS_ERR_ARG, "null argument");
-    memcpy(out_ms, e->e->last_ms, 16);
+    EngineBase* L = e->e->lane(std::min(std::max(e->e->last_lane.load(), 0), e->e->n_lanes() - 1));
+    std::lock_guard<std::mutex> lk(L->mu);
+    memcpy(out_ms, L->last_ms, 16);
     return SS_OK;
 }
 int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[6], int32_t* n_lanes) {
@@ -323,7 +344,9 @@ int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[6], i
 }
 int ss_engine_last_counters(const ss_engine* e, int64_t out4[4]) {
     if (!e || !out4) return fail(SS_ERR_ARG, "null argument");
-    for (int i = 0; i < 4; i++) out4[i] = e->e->last_cnt[i];
+    EngineBase* L = e->e->lane(std::min(std::max(e->e->last_lane.load(), 0), e->e->n_lanes() - 1));
+    std::lock_guard<std::mutex> lk(L->mu);
+    for (int i = 0; i < 4; i++) out4[i] = L->last_cnt[i];
     return SS_OK;
 }
 void ss_default_denoise_config(ss_denoise_config* c) {

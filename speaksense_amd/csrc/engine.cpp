@@ -181,6 +181,8 @@ struct EngineT : EngineBase {
     double* u_h = nullptr;         // = stage_h[stage_cur].u: one uniform draw per sampled row (t > 0)
     DBuf u_d;
     hipEvent_t ev[4];
+    std::vector<hipEvent_t> enc_event_pool;   // timing events of the encoder sections (run_group), reused across groups
+    int lane_index = 0;
 
     std::vector<std::unique_ptr<EngineT>> extra_lanes;   // lanes 1.. (lane 0 = this); they borrow this engine's weight arena
     int n_lanes() const override { return 1 + (int)extra_lanes.size(); }
@@ -241,7 +243,7 @@ struct EngineT : EngineBase {
             int nl = o.n_lanes > 0 ? o.n_lanes : 2;
             if (const char* lv = getenv("SS_LANES")) nl = atoi(lv);
             nl = std::min(std::max(nl, 1), 8);
-            for (int i = 1; i < nl; i++) { extra_lanes.emplace_back(new EngineT(path, o, this)); extra_lanes.back()->owner = this; }
+            for (int i = 1; i < nl; i++) { extra_lanes.emplace_back(new EngineT(path, o, this)); extra_lanes.back()->owner = this; extra_lanes.back()->lane_index = i; }
             start_worker();
         }
     }
@@ -257,6 +259,7 @@ struct EngineT : EngineBase {
         for (auto& kv : step_graphs) { if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph); }
         if (samp_h) (void)hipHostFree(samp_h);
         for (auto& e : ev) (void)hipEventDestroy(e);
+        for (auto& e : enc_event_pool) (void)hipEventDestroy(e);
         if (st) (void)hipStreamDestroy(st);
     }
 
@@ -940,12 +943,10 @@ struct EngineT : EngineBase {
     JobState setup_job(Job* j, int i) {
             const Vocab& vocab = hm.vocab;
             Session* s = j->sess;
-            s->segments.clear(); s->tokens.clear(); s->sampled.clear(); s->n_encode = s->n_decode = s->n_fail = s->n_windows = 0;
-            if (j->P.no_context) s->prompt_past.clear();
-            if (!j->prompt_tokens.empty()) {   // "prepend the prompt tokens to the prompt_past"
-                s->prompt_past.insert(s->prompt_past.end(), j->prompt_tokens.begin(), j->prompt_tokens.end());
-                std::rotate(s->prompt_past.begin(), s->prompt_past.end() - j->prompt_tokens.size(), s->prompt_past.end());
-            }
+            s->segments.clear(); s->tokens.clear(); s->sampled.clear(); s->n_encode = s->n_decode = s->n_fail = s->n_windows = 0;   // "clear old results"
+            // The carried text context (prompt_past) is only touched once the chunk is known to decode: whisper_full_with_state returns for < 1 s
+            // of audio before it reaches "if (params.no_context) prompt_past.clear()" / "prepend the prompt tokens", and a refused call must
+            // leave a context-carrying caller's state as it was (see the end of this function).
             JobState q; q.job = j; q.slot = (int)i;
             j->status = 0;
             const ss_params& P = j->P;
@@ -989,6 +990,13 @@ struct EngineT : EngineBase {
                 q.seek = q.seek_start; q.seek_end = P.duration_ms == 0 ? q.n_len_org : q.seek_start + P.duration_ms / 10;
                 q.alive = q.seek_end >= q.seek_start + 100;  // "if length of spectrogram is less than 1.0s, return"
             }
+            if (q.alive && !P.detect_language) {   // detect_language returns right after the detection, before the context is touched
+                if (P.no_context) s->prompt_past.clear();
+                if (!j->prompt_tokens.empty()) {   // "prepend the prompt tokens to the prompt_past"
+                    s->prompt_past.insert(s->prompt_past.end(), j->prompt_tokens.begin(), j->prompt_tokens.end());
+                    std::rotate(s->prompt_past.begin(), s->prompt_past.end() - j->prompt_tokens.size(), s->prompt_past.end());
+                }
+            }
             return q;
     }
 
@@ -1027,7 +1035,23 @@ struct EngineT : EngineBase {
         std::vector<int> free_cross, free_dec;
         for (int i = B - 1; i >= 0; i--) free_cross.push_back(i);
         for (int i = S - 1; i >= 0; i--) free_dec.push_back(i);
-        std::vector<std::pair<hipEvent_t, hipEvent_t>> enc_events;
+        // encoder sections are stamped as they are enqueued; a pair is folded into ms_enc (and its events go back to the lane's pool) as soon as
+        // it has completed, so a long-lived group holds a handful of events, and an exception on the way out releases the rest (EncEvents dtor)
+        struct EncEvents {
+            std::vector<hipEvent_t>& pool; std::deque<std::pair<hipEvent_t, hipEvent_t>> live; float ms = 0.f;
+            explicit EncEvents(std::vector<hipEvent_t>& p) : pool(p) {}
+            hipEvent_t take() { if (pool.empty()) { hipEvent_t e; SS_HIP(hipEventCreate(&e)); return e; } hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+            void fold(bool wait) {
+                while (!live.empty()) {
+                    if (!wait && hipEventQuery(live.front().second) != hipSuccess) break;
+                    float a = 0;
+                    if (hipEventElapsedTime(&a, live.front().first, live.front().second) == hipSuccess) ms += a;
+                    pool.push_back(live.front().first); pool.push_back(live.front().second);
+                    live.pop_front();
+                }
+            }
+            ~EncEvents() { for (auto& p : live) { pool.push_back(p.first); pool.push_back(p.second); } }
+        } enc_events(enc_event_pool);
         auto n_jobs_alive = [&]() { int n = 0; for (auto& q : js) n += q.job && q.alive; return n; };
         while (true) {
             sweep();
@@ -1079,13 +1103,13 @@ struct EngineT : EngineBase {
                     fresh.push_back(&w);
                 }
                 const int Wn = (int)fresh.size();
-                hipEvent_t e0, e1;
-                SS_HIP(hipEventCreate(&e0)); SS_HIP(hipEventCreate(&e1));
+                enc_events.fold(false);
+                hipEvent_t e0 = enc_events.take(), e1 = enc_events.take();
+                enc_events.live.push_back({e0, e1});
                 SS_HIP(hipEventRecord(e0, st));
                 encoder_pass(Wn, false);
                 cross_kv_pass(Wn, cmap.data());
                 SS_HIP(hipEventRecord(e1, st));
-                enc_events.push_back({e0, e1});
                 for (Window* w : fresh) { w->job->sess->n_encode++; w->job->sess->n_windows++; }
                 cnt_windows += Wn;
                 if (others_running) cnt_midstart += Wn;
@@ -1119,24 +1143,20 @@ struct EngineT : EngineBase {
                 } else ++it;
             }
         }
-        float ms_enc = 0.f;
         sweep();
         SS_HIP(hipEventRecord(ev[2], st));
         SS_HIP(hipEventSynchronize(ev[2]));
         float ms_mel = 0, ms_tot = 0;
         SS_HIP(hipEventElapsedTime(&ms_mel, ev[0], ev[1]));
         SS_HIP(hipEventElapsedTime(&ms_tot, ev[0], ev[2]));
-        for (auto& ee : enc_events) {   // encoder sections were stamped as they were enqueued; everything has completed by now
-            float a = 0;
-            SS_HIP(hipEventElapsedTime(&a, ee.first, ee.second));
-            ms_enc += a;
-            (void)hipEventDestroy(ee.first); (void)hipEventDestroy(ee.second);
-        }
+        enc_events.fold(true);   // everything has completed by now
+        const float ms_enc = enc_events.ms;
         const float ms_dec = std::max(0.0f, ms_tot - ms_mel - ms_enc);   // decoder passes + their host turnarounds: what is left of the group
         last_ms[0] = ms_mel; last_ms[1] = ms_enc; last_ms[2] = ms_dec; last_ms[3] = ms_tot;
         last_cnt[0] = cnt_passes; last_cnt[1] = cnt_rows; last_cnt[2] = cnt_windows; last_cnt[3] = cnt_admitted;
         for (int i = 0; i < 4; i++) { tot_ms[i] += last_ms[i]; tot_cnt[i] += last_cnt[i]; }
         tot_cnt[4] += cnt_midstart;
+        owner->last_lane.store(lane_index);
     }
 
     // "these tokens determine the task that will be performed": [sot, lang, task] (multilingual) or [sot], + [notimestamps]
@@ -1514,6 +1534,49 @@ struct EngineT : EngineBase {
             SS_HIP(hipStreamSynchronize(st));
         }
         SS_HIP(hipMemcpyAsync(logits_out, logits.p, (size_t)n_vocab * 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(hipStreamSynchronize(st));
+    }
+    // stage hook: cross-KV of one window from a given encoder output (cache slot `window` of lane 0)
+    void set_encoder_window_host(const float* encv, int window) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
+        if (window < 0 || window >= B) throw Error(SS_ERR_ARG, "set_encoder_window: window outside the engine's batch");
+        SS_HIP(hipMemcpyAsync(encF.p, encv, (size_t)n_ctx * da * 4, hipMemcpyHostToDevice, st));
+        launch_f32_to_T<T>(encF.as<float>(), encT.as<T>(), (size_t)n_ctx * da, st);
+        if (fp8_enc) launch_quantize_f8<T>(encT.as<T>(), da, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, n_ctx, da, st);
+        cross_kv_pass(1, &window);
+        SS_HIP(hipStreamSynchronize(st));
+    }
+    // stage hook: ONE decoder launch over n rows (the pass the batched engine runs: rows of different windows and slots side by side); raw logits
+    // of the rows listed in samp_rows.  The kernels are chosen exactly as in run_group (decoder_step): <= 16 rows the fused step, 17..64 the
+    // multi-tile GEMVs, rows x heads >= direct_pairs the unsplit cross-attention.
+    void decode_rows_host(const int32_t* token, const int32_t* pos, const int32_t* slot, const int32_t* crossw, int n, const int32_t* samp_rows, int n_samp,
+                          float* logits_out) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
+        if (n < 1 || n > 64 || n_samp < 1 || n_samp > n) throw Error(SS_ERR_ARG, "decode_rows: 1..64 rows, 1..n sampling rows");
+        for (int i = 0; i < n; i++)
+            if (token[i] < 0 || token[i] >= n_vocab || pos[i] < 0 || pos[i] >= n_tctx || slot[i] < 0 || slot[i] >= S || crossw[i] < 0 || crossw[i] >= B)
+                throw Error(SS_ERR_ARG, "decode_rows: row " + std::to_string(i) + " out of range");
+        ss_params P; ss_default_params(&P);
+        const RuleConsts rc = rule_consts(P);
+        stage_acquire();
+        for (int i = 0; i < n; i++) {
+            RowCtl c{};
+            c.token = token[i]; c.pos = pos[i]; c.slot = slot[i]; c.cross = crossw[i]; c.n_hist = 1;
+            ctl_h[i] = c;
+        }
+        std::vector<int> sr;
+        for (int k = 0; k < n_samp; k++) {
+            if (samp_rows[k] < 0 || samp_rows[k] >= n) { stage_release(); throw Error(SS_ERR_ARG, "decode_rows: sampling row out of range"); }
+            ctl_h[64 + k] = ctl_h[samp_rows[k]];
+            sr.push_back(samp_rows[k]);
+        }
+        decoder_step(n, rc, sr, false);
+        stage_release();
+        SS_HIP(hipMemcpy2DAsync(logits_out, (size_t)n_vocab * 4, logits.p, (size_t)n_vocab_pad * 4, (size_t)n_vocab * 4, n_samp, hipMemcpyDeviceToHost, st));
         SS_HIP(hipStreamSynchronize(st));
     }
     void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6]) override {

@@ -39,12 +39,14 @@ struct Session {
     int n_encode = 0, n_decode = 0, n_fail = 0, n_windows = 0;
     std::vector<int> prompt_past;  // whisper_state::prompt_past: text context carried between windows (and calls, unless no_context)
     int pool_engine = -1;          // ss_pool: engine index of the last chunk
+    std::atomic<int> in_flight{0}; // tickets submitted and not yet waited for (ss_pool_submit keeps such a session on its engine)
     int lang_id = -1;              // whisper_full_lang_id: language of the last chunk (given or detected)
     CountingRng rng;  // whisper_state::rng (std::mt19937 seeded with 0 once per state, never reseeded per call)
 };
 
 struct Job {  // one chunk handed to transcribe (== one whisper_full_with_state call)
     Session* sess = nullptr;
+    struct EngineBase* eng = nullptr;   // async submit: the engine whose queue holds this job (ss_wait waits there, whatever sess->eng says by then)
     const float* pcm = nullptr;
     int n_samples = 0;
     bool pcm_on_device = false;
@@ -64,6 +66,7 @@ struct EngineBase {
     std::mutex mu;  // serialises device work
     float last_ms[4] = {0, 0, 0, 0};
     long last_cnt[4] = {0, 0, 0, 0};   // last group: decoder passes, decoder rows, encoder windows
+    std::atomic<int> last_lane{0};     // (lane 0 only) index of the lane whose group finished last: what ss_engine_last_timing / _counters report
     virtual ~EngineBase() {}
     virtual void run_jobs(std::vector<Job*>& jobs) = 0;  // blocking, any count (grouped by max_batch); takes this lane's `mu`
     virtual void run_jobs_locked(std::vector<Job*>& jobs) = 0;   // caller holds `mu`
@@ -71,6 +74,9 @@ struct EngineBase {
     virtual void encode_host(const float* mel, int n_len, int seek, float* enc_out) = 0;
     virtual void set_encoder_host(const float* enc) = 0;
     virtual void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out) = 0;
+    virtual void set_encoder_window_host(const float* enc, int window) = 0;
+    virtual void decode_rows_host(const int32_t* token, const int32_t* pos, const int32_t* slot, const int32_t* cross, int n, const int32_t* samp_rows, int n_samp,
+                                  float* logits_out) = 0;
     virtual void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6]) = 0;
     virtual void probe_gemm(int batch, int reps, float* avg_ms, double* flops) = 0;
     virtual void denoise_host(const float* pcm, int n, const ss_denoise_config& cfg, int force_type, float* out, int* noise_type, float* norm_var, float* ms) = 0;

@@ -201,7 +201,11 @@ template <int WM> struct G256 {
 
 // DMA4 (WM = 2 only): waves 0-3 issue ALL the LDS-DMA (two 16-row slots each per pass) and are the only ones that wait on vmcnt; waves 4-7
 // never wait on it inside the main loop, so THEIR output stores of the previous tile drain in the background for a whole tile.
-template <typename T, int KIND, int WM, bool DMA4 = false>
+// ST16: f16 / bf16 output kinds store 16 B per lane instead of 8.  A lane's accumulator quad is 4 consecutive output columns = 8 bytes, and the
+// four lanes frow + 16 fg of a fragment row cover 32 contiguous bytes; one v_permlane16_swap per dword between the fragments ni and ni + 1
+// regroups them so that a lane holds 8 consecutive columns of ONE fragment: half the store instructions for the same bytes.  The
+// epilogue's tail is store-issue-bound (cdna_hip_programming.md T21: halving the instruction count at equal bytes halved it).
+template <typename T, int KIND, int WM, bool DMA4 = false, bool ST16 = false>
 __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Mfma<T>::V8 V8;
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     // their HBM/L2 latency (7 % of an FC1 tile when exposed) hides under the epilogue.  gfx9's vmcnt retires in order and counts stores:
     // the waits for those stages must therefore allow the `carry` stores issued after them to remain outstanding.
     constexpr bool EARLY = WM == 2;
-    constexpr int kCarry = 24;        // a full interior tile issues 32 output stores per thread after the prologue; 8 kept as margin
+    constexpr int kCarry = ST16 ? 12 : 24;   // a full interior tile issues 32 (ST16: 16) output stores per thread after the prologue; margin kept
     bool pro_issued = false;
     int issued = 0, carry = 0;
     for (int vb = blockIdx.x; vb < nbn * nbm; vb += gridDim.x) {
@@ -457,6 +461,55 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
                 *(f32x4*)(outp + orow + n) = cur[ni] + v;
             }
         }
+    } else if constexpr (ST16 && (KIND == EPI_STORE_T || KIND == EPI_GELU_T || KIND == EPI_CROSS_KV)) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int mi = 0; mi < 8; mi++) {
+            const long m = m0 + wm * 128 + mi * 16 + frow;
+            const bool row_ok = m < g.M;        // the swaps below involve every lane: no early exit
+            const long orow = row_ok ? (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo : 0;
+            u32x2 pk[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) {
+                const f32x4 v = acc[ni][mi] + bias_v[ni];
+                V4 o;
+                if constexpr (KIND == EPI_STORE_T) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
+                } else if constexpr (KIND == EPI_GELU_T) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
+                } else {   // EPI_CROSS_KV: the K half of every layer's [K; V] column block is pre-scaled
+                    const int nq = n0 + wn * 64 + ni * 16 + fg * 4;
+                    const float sc = (nq % (2 * g.d)) < g.d ? g.scale : 1.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
+                }
+                pk[ni] = __builtin_bit_cast(u32x2, o);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; p += 2) {
+                // rows (16-lane groups) 1 and 3 of the first register swap with rows 0 and 2 of the second: afterwards a lane with fg even holds
+                // columns [(fg >> 1) * 8, +8) of fragment p, a lane with fg odd the same columns of fragment p + 1
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                             : "+v"(pk[p][0]), "+v"(pk[p + 1][0]), "+v"(pk[p][1]), "+v"(pk[p + 1][1]));
+                if (!row_ok) continue;
+                const int n = n0 + wn * 64 + (p + (fg & 1)) * 16 + (fg >> 1) * 8;
+                const u32x4 o16 = {pk[p][0], pk[p][1], pk[p + 1][0], pk[p + 1][1]};
+                if constexpr (KIND == EPI_CROSS_KV) {
+                    const int H = g.d / 64;
+                    const int l = n / (2 * g.d), rem = n % (2 * g.d), kv = rem / g.d, hj = rem % g.d, h = hj >> 6, j = hj & 63;
+                    int b = (int)(m / g.rows_per_batch);
+                    const int t = (int)(m % g.rows_per_batch);
+                    if (g.use_batch_map) b = g.batch_map[b];
+                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j;
+                    *(u32x4*)((T*)g.out + off) = o16;
+                } else {
+                    *(u32x4*)((T*)g.out + orow + n) = o16;
+                }
+            }
+        }
     } else if constexpr (!SWAP) {
 #pragma unroll
         for (int mi = 0; mi < 8; mi++) {
@@ -547,6 +600,13 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
             const bool dma4 = dma4_env ? dma4_env[0] == '1' : (KIND == EPI_STORE_T || KIND == EPI_GELU_T || KIND == EPI_CROSS_KV);
             const int nwg = (g.N / TN) * ((g.M + G256<2>::TM - 1) / G256<2>::TM);
             if (dma4) {
+                static const bool st16 = getenv("SS_GEMM_ST16") == nullptr || getenv("SS_GEMM_ST16")[0] != '0';   // TEMP A/B switch (round 3)
+                if (st16) {
+                    static std::atomic<uint64_t> attr256w{0};
+                    once_per_device(attr256w, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
+                    gemm256_kernel<T, KIND, 2, true, true><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();
+                    return;
+                }
                 static std::atomic<uint64_t> attr256d{0};
                 once_per_device(attr256d, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
                 gemm256_kernel<T, KIND, 2, true><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();

@@ -197,7 +197,11 @@ float* whisper_get_logits_from_state(struct whisper_state*) { unsupported("whisp
 int whisper_tokenize(struct whisper_context* ctx, const char* text, whisper_token* tokens, int n_max_tokens) {
     if (!ctx || !text) return -1;
     const int n = ss_engine_tokenize(ctx->eng, text, tokens, n_max_tokens);
-    if (n < 0) wlog("whisper_tokenize: too many resulting tokens: %d (max %d)\n", -n, n_max_tokens);
+    if (n == SS_ERR_BUFFER) {   // whisper.h's convention: -(tokens needed)
+        const int need = ss_engine_tokenize(ctx->eng, text, nullptr, 0);
+        wlog("whisper_tokenize: too many resulting tokens: %d (max %d)\n", need, n_max_tokens);
+        return -need;
+    }
     return n;
 }
 int whisper_lang_max_id(void) { return 99; }

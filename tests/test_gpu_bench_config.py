@@ -1,0 +1,170 @@
+"""GPU: the engine configuration bench.py MEASURES, under the oracle.
+
+bench.py's default line runs `Engine(max_batch=32, n_lanes=3)` on the real large-v3 shape (BASELINE.json configs[2], SURVEY.md section 8d
+config #3; reference call site /root/reference/src/asr/whisper.rs:75).  At 27-32 rows per decoder pass the engine takes kernel paths no
+8-row test reaches: rows x heads >= 320 switches the cross-attention to its unsplit form (`dec_cross_attn_q_kernel<T,1>`, the fp8 engine's
+`dec_cross_attn_q8_kernel<T,1>`), and every projection runs through the multi-tile GEMVs (`dec_gemv_wide_kernel<*,2>` for 17..32 rows,
+`<*,4>` for 33..64) -- together ~45 % of the benchmark's GPU time.  Two kinds of test, each for f16 / bf16 / fp8:
+
+(i)  stage: `ss_engine_decode_rows` -- ONE decoder pass over 32 and over 64 rows (sequences of 8 prompt positions each, attending to different
+     cross-KV windows) against the oracle's logits for each sequence, at full depth (32 layers);
+(ii) whole path: 32 chunks submitted asynchronously in Mode F, one lane carries them as 32-row passes (asserted from the engine's own
+     counters), every chunk's ids must equal its single-chunk run (8-row kernels) or the difference must be a near tie proven on the oracle,
+     and chunks of the batch are force-replayed on the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from speaksense_amd import synth
+from conftest import report
+from test_gpu_parity import GAP_TOL_BF16, GAP_TOL_F16, check_against_oracle
+from test_gpu_fp8 import GAP_TOL_FP8
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_REPLAY = {"f16": 2, "bf16": 1, "fp8": 1}          # oracle windows per dtype (each ~1 min on 64 host threads)
+
+
+@pytest.fixture(scope="module")
+def large_v3_path():
+    sys.path.insert(0, ROOT)
+    import bench
+    from speaksense_amd import ggml_io
+    path = bench.model_path_for("large-v3")
+    if not os.path.exists(path):
+        ggml_io.write_model(path + ".tmp", "large-v3", seed=0)
+        os.replace(path + ".tmp", path)
+    return path
+
+
+@pytest.fixture(scope="module")
+def oracle_threads():
+    from oracle import binding as orc
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    orc.set_thread_cap(min(64, ncpu))
+    yield orc
+    orc.set_thread_cap(16)
+
+
+def _modes(orc, which):
+    from speaksense_amd import binding
+    return {"f16": (binding.DTYPE_F16, orc.MODE_GGML_F16, GAP_TOL_F16, 6e-3),
+            "bf16": (binding.DTYPE_BF16, orc.MODE_BF16, GAP_TOL_BF16, 5e-2),
+            "fp8": (binding.DTYPE_FP8, orc.MODE_FP8, GAP_TOL_FP8, 5e-2)}[which]
+
+
+@pytest.fixture(scope="module", params=["f16", "bf16", "fp8"])
+def bench_engine(request, large_v3_path):
+    """What bench.py creates (bench.py: `--device-batch 32 --lanes 3`).  One option differs: the batch former may wait 0.5 s for a full batch
+    (bench.py hands over device pointers in microseconds; this test copies host PCM at submit, and a former that only waits the default
+    2 ms would start with the handful of chunks queued by then and spread the rest over the other lanes)."""
+    from speaksense_amd import binding
+    from oracle import binding as orc
+    dtype = _modes(orc, request.param)[0]
+    eng = binding.Engine(large_v3_path, dtype=dtype, max_batch=32, n_lanes=3, batch_wait_us=500000)
+    yield request.param, eng
+    eng.close()
+
+
+def test_decoder_pass_32_and_64_rows_vs_oracle(bench_engine, large_v3_path, oracle_threads):
+    """(i) One decoder pass of the benchmarked shape against the oracle.  4 (then 8) sequences x 8 prompt positions = 32 (64) rows in ONE launch;
+    sequence s sits in self-KV slot 5 s and attends to cross-KV window s % 4, whose cache was filled from an encoder-output matrix that
+    the oracle state of the same sequence gets too.  The logits of every sequence's last row are held to the per-step tolerance of the
+    8-row stage tests (f16 6e-3 sigma; bf16 / fp8 5e-2), and the argmax must agree wherever the oracle's own top-2 is outside that noise."""
+    orc = oracle_threads
+    which, eng = bench_engine
+    _, omode, _, tol = _modes(orc, which)
+    om = orc.OracleModel(large_v3_path)
+    rng = np.random.default_rng(7)
+    n_win = 4
+    # encoder outputs of four different chunks (from the device's own encoder: any matrix would do, both sides get the same one, but the
+    # conditioning must be that of real ln_post outputs -- with white noise of unit scale the oracle's own f16 and f32 modes are 1e-1 sigma apart)
+    encs = [eng.encode(om.log_mel(synth.speech_like(200 + w)), 0) for w in range(n_win)]
+    for w in range(n_win):
+        eng.set_encoder_window(w, encs[w])
+    text = rng.integers(300, 40000, (8, 8))
+    worst = {}
+    for n_seq in (4, 8):
+        token, pos, slot, cross, samp = [], [], [], [], []
+        seqs = []
+        for s in range(n_seq):
+            toks = [om.sot, om.sot + 1 + s, om.transcribe] + [int(t) for t in text[s][:5]]
+            seqs.append(toks)
+            for i, t in enumerate(toks):
+                token.append(t); pos.append(i); slot.append(5 * s); cross.append(s % n_win)
+            samp.append(len(token) - 1)
+        assert len(token) == 8 * n_seq
+        got = eng.decode_rows(token, pos, slot, cross, samp)
+        w_n = 0.0
+        for s in range(n_seq):
+            ost = om.new_state(omode)
+            ost.set_encoder(encs[s % n_win])
+            ref = ost.decode(seqs[s], 0)
+            ost.close()
+            sd = float(ref.std())
+            e = float(np.abs(got[s] - ref).max()) / sd
+            w_n = max(w_n, e)
+            assert e < tol, f"{which}, {8 * n_seq}-row pass, sequence {s}: max|logits - oracle| / std = {e}"
+            top2 = np.sort(ref)[-2:]
+            if top2[1] - top2[0] > 2 * tol * sd:
+                assert int(got[s].argmax()) == int(ref.argmax()), f"{which}, {8 * n_seq}-row pass, sequence {s}"
+        worst[8 * n_seq] = w_n
+    # the same sequences one at a time (8 rows: the <= 16-row kernels, key-split cross-attention) must agree with the wide pass to far below the
+    # oracle tolerance: the row count changes the kernels, not the arithmetic type
+    s = 1
+    toks = [om.sot, om.sot + 1 + s, om.transcribe] + [int(t) for t in text[s][:5]]
+    alone = eng.decode_rows(toks, list(range(8)), [5 * s] * 8, [s % n_win] * 8, [7])
+    d = float(np.abs(alone[0] - got[s]).max()) / float(got[s].std())
+    assert d < tol / 3, d
+    report(f"large-v3 {which} decoder pass vs oracle at the benchmarked row counts (unsplit cross-attention, multi-tile GEMVs): worst max|logits - oracle| / std "
+           f"= {worst[32]:.2e} at 32 rows, {worst[64]:.2e} at 64 rows; 8-row pass vs 64-row pass {d:.2e}")
+    om.close()
+
+
+def test_bench_engine_32_row_passes_vs_oracle(bench_engine, large_v3_path, oracle_threads):
+    """(ii) 32 chunks through ss_submit / ss_wait, Mode F (32 greedy steps): the configuration whose throughput BENCH_r*.json reports."""
+    from speaksense_amd import binding
+    orc = oracle_threads
+    which, eng = bench_engine
+    _, omode, gap_tol, _ = _modes(orc, which)
+    P = binding.default_params(language="en", fixed_steps=32)
+    pcms = [synth.speech_like(100 + i) for i in range(32)]
+    t0 = eng.totals()
+    ses = [eng.new_session() for _ in pcms]
+    tickets = [s.submit(p, P) for s, p in zip(ses, pcms)]     # host PCM (1.9 MB copied per submit): the batch former's wait below covers the ~30 ms
+    res = [s.wait(t) for s, t in zip(ses, tickets)]
+    t1 = eng.totals()
+    passes, rows = t1["decoder_passes"] - t0["decoder_passes"], t1["decoder_rows"] - t0["decoder_rows"]
+    assert passes > 0 and rows / passes >= 24, f"the batch former split the chunks: {rows} rows over {passes} passes"
+    assert all(len(r["tokens"]) == 32 and r["n_encode"] == 1 and r["n_fail"] == 0 for r in res)
+    n_distinct = len({tuple(r["tokens"]) for r in res})
+    assert n_distinct > 1        # the audio matters (random weights: greedy streams fall into a handful of attractors, so not 32 distinct ones)
+    om = orc.OracleModel(large_v3_path)
+    OP = orc.default_params(language="en", fixed_steps=32)
+    tid_slack = om.beg if which == "fp8" else None
+    # every chunk against its own single-chunk run (1-3 rows per pass: the <= 16-row kernels and the key-split cross-attention)
+    n_same, differing = 0, []
+    for i, p in enumerate(pcms):
+        single = eng.new_session().transcribe(p, P)
+        if list(single["tokens"]) == list(res[i]["tokens"]):
+            n_same += 1
+        else:
+            differing.append(i)
+    # f16: a different row count only changes accumulation order, so a flip needs a tie at the 1e-4 sigma level; bf16 / e4m3 round coarser
+    assert n_same >= (31 if which == "f16" else 28), f"{which}: only {n_same}/32 chunks equal their single-chunk run"
+    replay = differing[:2] + [i for i in (3, 17) if i not in differing]
+    replay = replay[:max(N_REPLAY[which], len(differing[:2]))]
+    worst = 0.0
+    for i in replay:
+        _, gap = check_against_oracle(res[i], om, orc, omode, pcms[i], OP, f"large-v3 {which} bench config, chunk {i}", gap_tol, replay_only=True,
+                                      tid_slack_beg=tid_slack)
+        worst = max(worst, gap)
+    report(f"large-v3 {which}, Engine(max_batch=32, n_lanes=3), 32 chunks async: {rows / passes:.1f} rows per decoder pass; {n_distinct} distinct token streams; {n_same}/32 chunks identical to "
+           f"their single-chunk runs; chunks {replay} force-replayed on the oracle, largest near-tie margin {worst:.4f} (tolerance {gap_tol})")
+    om.close()

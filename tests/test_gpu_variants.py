@@ -301,6 +301,7 @@ def test_c_harness_matches_python_binding(toy_ml_path, eng, tmp_path):
         assert [p.split(" ")[:2] for p in py] == [q.split(" ")[:2] for q in nat]
 
 
+@pytest.mark.timeout(600)
 def test_pool_two_engines_on_one_gpu(toy_ml_path):
     """ss_pool_*: the multi-GPU router with a device list that names GPU 0 twice (the box has one GPU; on a node it would be [0..7]).  Chunks of one
     session alternate between the engines (its state is host-side), every result equals the single-engine result, and a burst spreads evenly."""
@@ -328,6 +329,21 @@ def test_pool_two_engines_on_one_gpu(toy_ml_path):
     for a, b in zip(want, got):
         assert list(a["tokens"]) == list(b["tokens"])
     assert sorted(s.last_engine() for s in ses) == [0] * 4 + [1] * 4
+    # several tickets outstanding on ONE pool session (a single engine runs such chunks one after another in submission order): the router
+    # must keep them on the engine that holds the first -- on two engines they would run concurrently on one Session, and ss_wait of the
+    # first ticket would wait on the wrong engine's condition variable
+    s_ref2, s_pool2 = single.new_session(), pool.new_session()
+    pcms3 = [synth.speech_like(90 + k, 16000 * 9) for k in range(3)]
+    for x in pcms3:
+        last_ref = s_ref2.transcribe(x, P)                       # serial, context carried (no_context = 0)
+    tickets = [s_pool2.submit(x, P) for x in pcms3]
+    engines_used = s_pool2.last_engine()
+    for t in tickets:
+        last_pool = s_pool2.wait(t)
+    assert s_pool2.last_engine() == engines_used
+    assert list(last_pool["tokens"]) == list(last_ref["tokens"])
+    b = s_pool2.transcribe(pcms3[0], P)                          # nothing in flight any more: the router may move the session again
+    assert len(b["tokens"]) > 0
     pool.close(); single.close()
 
 

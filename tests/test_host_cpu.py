@@ -189,6 +189,26 @@ def test_tokenizer_matches_regex_restatement(tmp_path):
     om.close()
 
 
+def test_tokenize_buffer_convention(tmp_path):
+    """Both tokenize entry points share ONE convention: count >= 0; SS_ERR_BUFFER (-6, nothing written) when n_max is too small -- never a
+    value that collides with another SS_ERR_* code; (NULL, 0) is the size query."""
+    import ctypes as C
+    from speaksense_amd import binding, ggml_io
+    path = str(tmp_path / "toy.bin")
+    ggml_io.write_model(path, "toy", seed=1)
+    L = binding.lib()
+    text = b"it's a long way to go"
+    need = L.ss_model_tokenize(path.encode(), text, None, 0)
+    assert need == len(binding.model_tokenize(path, text)) and need >= 4
+    small = np.full(need - 1, -7, np.int32)
+    assert L.ss_model_tokenize(path.encode(), text, small.ctypes.data_as(C.c_void_p), len(small)) == -6
+    assert (small == -7).all() and b"tokens needed" in L.ss_last_error()
+    for k in range(need):           # the old -(needed) convention returned -1 == SS_ERR_ARG when one token was needed, -2..-5 likewise
+        buf = np.zeros(max(k, 1), np.int32)
+        assert L.ss_model_tokenize(path.encode(), text, buf.ctypes.data_as(C.c_void_p), k) == -6
+    assert L.ss_model_tokenize(path.encode(), None, None, 0) == -1
+
+
 def test_pool_routing_rule():
     """ss_pool_pick: least-loaded engine, ties go round-robin from the cursor (north_star: chunks 'sharded round-robin across the 8 GPUs')."""
     from speaksense_amd import binding
