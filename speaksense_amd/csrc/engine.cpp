@@ -434,9 +434,9 @@ struct EngineT : EngineBase {
     // ------------------------------------------------------------------------------------------
     GemmDesc gd(const void* A, long lda, const void* Wt, int M, int N, int K, int kind, const float* bias, void* out, long ldo) {
         GemmDesc g{};
-        g.A = A; g.lda = lda; g.a_rows_per_batch = (long)1 << 40; g.a_batch_stride = 0;
+        g.A = A; g.lda = lda; g.a_rows_per_batch = 0; g.a_batch_stride = 0;
         g.W = Wt; g.M = M; g.N = N; g.K = K; g.kind = kind; g.bias = bias; g.out = out; g.ldo = ldo;
-        g.o_rows_per_batch = (long)1 << 40; g.o_batch_stride = 0; g.scale = 1.0f; g.rows_per_batch = n_ctx; g.d = da; g.Tpad = Tpad;
+        g.o_rows_per_batch = 0; g.o_batch_stride = 0; g.scale = 1.0f; g.rows_per_batch = n_ctx; g.d = da; g.Tpad = Tpad;
         g.n_batch = B; g.gelu_f16_in = dtype_is_f16;
         return g;
     }

@@ -55,6 +55,15 @@ __device__ __forceinline__ void tile_of_block(int bid, int nbm, int nbn, int* mb
     *nb = g * GN + rem % gn;
 }
 
+// Element offset of operand / output row m.  rpb == 0 (every GEMM but the conv stem): plain rows, m * ld.  Otherwise the rows come in batches of
+// rpb (a window of the padded time-major conv input): 32-bit division.  rpb is a kernel argument, so the test is a scalar branch.  (Written with
+// 64-bit `/` and `%` on a "no batching" sentinel of 2^40 this cost ~120 instructions per row and 24 rows per tile and wave: 3 VALU per MFMA.)
+__device__ __forceinline__ long row_off(long m, int rpb, long batch_stride, long ld) {
+    if (rpb == 0) return m * ld;
+    const unsigned b = (unsigned)m / (unsigned)rpb;
+    return (long)b * batch_stride + (long)((unsigned)m - b * (unsigned)rpb) * ld;
+}
+
 template <typename T>
 __device__ __forceinline__ void glds16(const T* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,

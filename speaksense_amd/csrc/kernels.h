@@ -33,14 +33,14 @@ enum EpiKind {
     EPI_STORE_F32,     // out f32[m][n] = acc + bias[n]
 };
 struct GemmDesc {
-    // A operand: row m at A + (m / a_rows_per_batch) * a_batch_stride + (m % a_rows_per_batch) * lda   (elements)
-    const void* A; long lda; long a_rows_per_batch; long a_batch_stride;
+    // A operand: row m at A + m * lda, or with a_rows_per_batch > 0 (conv stem) at A + (m / a_rows_per_batch) * a_batch_stride + (m % a_rows_per_batch) * lda   (elements)
+    const void* A; long lda; int a_rows_per_batch; long a_batch_stride;
     const void* W;            // [N][K], K contiguous
     int M, N, K;
     int kind;
     const float* bias;        // [N] or null
-    void* out; long ldo;      // row m at out + (m / o_rows_per_batch) * o_batch_stride + (m % o_rows_per_batch) * ldo
-    long o_rows_per_batch; long o_batch_stride;
+    void* out; long ldo;      // row m at out + m * ldo, or with o_rows_per_batch > 0 as for A
+    int o_rows_per_batch; long o_batch_stride;
     const float* res;         // EPI_RES_F32 (same addressing as out)
     const float* pos;         // EPI_GELU_POS_F32: [rows_per_batch][N]
     float scale;              // EPI_STORE_T / EPI_CROSS_KV(K part)

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
         const int c = cpos ^ ((r >> 1) & 7);
         long m = m0 + r;
         if (m > g.M - 1) m = g.M - 1;
-        xsrc[p] = A + (m / g.a_rows_per_batch) * g.a_batch_stride + (m % g.a_rows_per_batch) * g.lda + c * 8;
+        xsrc[p] = A + row_off(m, g.a_rows_per_batch, g.a_batch_stride, g.lda) + c * 8;
         wsrc[p] = W + (long)(n0 + r) * g.K + c * 8;
     }
     char* const sX0 = smem;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
         for (int mi = 0; mi < 4; mi++) {
             const long m = m0 + wm * 64 + mi * 16 + frow;
             if (m >= g.M) continue;
-            const long orow = (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo;
+            const long orow = row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo);
 #pragma unroll
             for (int ni = 0; ni < 4; ni++) {
                 const int n = n0 + wn * 64 + ni * 16 + fg * 4;
@@ -203,10 +203,11 @@ template <int WM> struct G256 {
 // never wait on it inside the main loop, so THEIR output stores of the previous tile drain in the background for a whole tile.
 // ST16: f16 / bf16 output kinds store 16 B per lane instead of 8.  A lane's accumulator quad is 4 consecutive output columns = 8 bytes, and the
 // four lanes frow + 16 fg of a fragment row cover 32 contiguous bytes; one v_permlane16_swap per dword between the fragments ni and ni + 1
-// regroups them so that a lane holds 8 consecutive columns of ONE fragment: half the store instructions for the same bytes.  The
-// epilogue's tail is store-issue-bound (cdna_hip_programming.md T21: halving the instruction count at equal bytes halved it).
-template <typename T, int KIND, int WM, bool DMA4 = false, bool ST16 = false>
+// regroups them so that a lane holds 8 consecutive columns of ONE fragment: half the store instructions for the same bytes (measured r03_g:
+// QK projection +4..6 %, FC1 +-2 %: this epilogue is not store-issue-bound the way cdna_hip_programming.md T21's attention tail is).
+template <typename T, int KIND, int WM, bool DMA4 = false>
 __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
+    constexpr bool ST16 = WM == 2 && (KIND == EPI_STORE_T || KIND == EPI_GELU_T || KIND == EPI_CROSS_KV);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Mfma<T>::V8 V8;
     typedef typename Mfma<T>::V4 V4;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
                 if (p * RPP < TM) {
                     long m = m0 + ra;
                     if (m > g.M - 1) m = g.M - 1;
-                    soff[p * NSLOT + u] = (unsigned)(((m / g.a_rows_per_batch) * g.a_batch_stride + (m % g.a_rows_per_batch) * g.lda + c * 8) * (long)sizeof(T));
+                    soff[p * NSLOT + u] = (unsigned)((row_off(m, g.a_rows_per_batch, g.a_batch_stride, g.lda) + c * 8) * (long)sizeof(T));
                 } else {
                     soff[p * NSLOT + u] = (unsigned)(((long)(n0 + ra - TM) * g.K + c * 8) * (long)sizeof(T));
                 }
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
             long m = m0 + wm * 128 + mi * 16 + frow;
             if (m > g.M - 1) m = g.M - 1;
             const int n = n0 + wn * 64 + ni * 16 + fg * 4;
-            if constexpr (KIND == EPI_RES_F32) return resp + (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo + n;
+            if constexpr (KIND == EPI_RES_F32) return resp + row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo) + n;
             else return posp + (long)(m % g.rows_per_batch) * g.N + n;
         };
         f32x4 nxt[4];
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
             }
             const long m = m0 + wm * 128 + mi * 16 + frow;
             if (m >= g.M) continue;
-            const long orow = (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo;
+            const long orow = row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo);
 #pragma unroll
             for (int ni = 0; ni < 4; ni++) {
                 const int n = n0 + wn * 64 + ni * 16 + fg * 4;
@@ -461,14 +462,14 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
                 *(f32x4*)(outp + orow + n) = cur[ni] + v;
             }
         }
-    } else if constexpr (ST16 && (KIND == EPI_STORE_T || KIND == EPI_GELU_T || KIND == EPI_CROSS_KV)) {
+    } else if constexpr (ST16) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int mi = 0; mi < 8; mi++) {
             const long m = m0 + wm * 128 + mi * 16 + frow;
             const bool row_ok = m < g.M;        // the swaps below involve every lane: no early exit
-            const long orow = row_ok ? (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo : 0;
+            const long orow = row_ok ? row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo) : 0;
             u32x2 pk[4];
 #pragma unroll
             for (int ni = 0; ni < 4; ni++) {
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
         for (int mi = 0; mi < 8; mi++) {
             const long m = m0 + wm * 128 + mi * 16 + frow;
             if (m >= g.M) continue;
-            const long orow = (m / g.o_rows_per_batch) * g.o_batch_stride + (m % g.o_rows_per_batch) * g.ldo;
+            const long orow = row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo);
 #pragma unroll
             for (int ni = 0; ni < 4; ni++) {
                 const int n = n0 + wn * 64 + ni * 16 + fg * 4;
@@ -600,13 +601,6 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
             const bool dma4 = dma4_env ? dma4_env[0] == '1' : (KIND == EPI_STORE_T || KIND == EPI_GELU_T || KIND == EPI_CROSS_KV);
             const int nwg = (g.N / TN) * ((g.M + G256<2>::TM - 1) / G256<2>::TM);
             if (dma4) {
-                static const bool st16 = getenv("SS_GEMM_ST16") == nullptr || getenv("SS_GEMM_ST16")[0] != '0';   // TEMP A/B switch (round 3)
-                if (st16) {
-                    static std::atomic<uint64_t> attr256w{0};
-                    once_per_device(attr256w, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
-                    gemm256_kernel<T, KIND, 2, true, true><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();
-                    return;
-                }
                 static std::atomic<uint64_t> attr256d{0};
                 once_per_device(attr256d, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
                 gemm256_kernel<T, KIND, 2, true><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();
@@ -805,8 +799,8 @@ void gemm_selftest(int M, int N, int K, int kind, float* max_err, float* max_ref
     SS_HIP(hipMemsetAsync(mx, 0, 8, st));
     st_ref<T><<<dim3((N + 255) / 256, M), 256, 0, st>>>(A, W, bias, res, ref, M, N, K, kind);
     GemmDesc g{};
-    g.A = A; g.lda = K; g.a_rows_per_batch = 1L << 40; g.W = W; g.M = M; g.N = N; g.K = K; g.kind = kind; g.bias = bias; g.out = out; g.ldo = N;
-    g.o_rows_per_batch = 1L << 40; g.scale = 1.0f; g.rows_per_batch = 1500;
+    g.A = A; g.lda = K; g.a_rows_per_batch = 0; g.W = W; g.M = M; g.N = N; g.K = K; g.kind = kind; g.bias = bias; g.out = out; g.ldo = N;
+    g.o_rows_per_batch = 0; g.scale = 1.0f; g.rows_per_batch = 1500;
     if (kind == EPI_RES_F32) { SS_HIP(hipMemcpyAsync(out, res, (size_t)M * N * 4, hipMemcpyDeviceToDevice, st)); g.res = (const float*)out; }   // in place, as the engine uses it
     launch_gemm<T>(g, st);
     st_diff<T><<<1024, 256, 0, st>>>(out, ref, (size_t)M * N, f32out, mx);

@@ -37,8 +37,8 @@ int main(int argc, char** argv) {
         hipMemset(bias, 0, s.N * 4); hipMemset(out, 0, (size_t)s.M * s.N * 4);
         for (int ki = 0; ki < 3; ki++) {
             GemmDesc g{};
-            g.A = A; g.lda = s.K; g.a_rows_per_batch = 1L << 40; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = kinds[ki]; g.bias = bias;
-            g.out = out; g.ldo = s.N; g.o_rows_per_batch = 1L << 40; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500;
+            g.A = A; g.lda = s.K; g.a_rows_per_batch = 0; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = kinds[ki]; g.bias = bias;
+            g.out = out; g.ldo = s.N; g.o_rows_per_batch = 0; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500;
             launch_gemm<f16>(g, st);
             hipEventRecord(e0, st);
             const int reps = 10;
@@ -51,8 +51,8 @@ int main(int argc, char** argv) {
             long long* tr; hipMalloc(&tr, 256 * 8 * 4 * 8); hipMemset(tr, 0, 256 * 8 * 4 * 8);
             for (int ki = 0; ki < 3; ki++) {
                 GemmDesc g{};
-                g.A = A; g.lda = s.K; g.a_rows_per_batch = 1L << 40; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = kinds[ki]; g.bias = bias;
-                g.out = out; g.ldo = s.N; g.o_rows_per_batch = 1L << 40; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500; g.trace = tr;
+                g.A = A; g.lda = s.K; g.a_rows_per_batch = 0; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = kinds[ki]; g.bias = bias;
+                g.out = out; g.ldo = s.N; g.o_rows_per_batch = 0; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500; g.trace = tr;
                 launch_gemm<f16>(g, st); hipDeviceSynchronize();
                 std::vector<long long> h(256 * 8 * 4);
                 hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);
@@ -74,8 +74,8 @@ int main(int argc, char** argv) {
             hipMalloc(&Cf, (size_t)s.M * s.N * 4);
             ref_gemm<<<dim3((s.N + 255) / 256, s.M), 256>>>(A, W, bias, Cf, s.M, s.N, s.K);
             GemmDesc g{};
-            g.A = A; g.lda = s.K; g.a_rows_per_batch = 1L << 40; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = EPI_STORE_F32; g.bias = bias;
-            g.out = out; g.ldo = s.N; g.o_rows_per_batch = 1L << 40; g.scale = 1.0f; g.rows_per_batch = 1500;
+            g.A = A; g.lda = s.K; g.a_rows_per_batch = 0; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = EPI_STORE_F32; g.bias = bias;
+            g.out = out; g.ldo = s.N; g.o_rows_per_batch = 0; g.scale = 1.0f; g.rows_per_batch = 1500;
             launch_gemm<f16>(g, st); hipDeviceSynchronize();
             std::vector<float> a((size_t)s.M * s.N), b((size_t)s.M * s.N);
             hipMemcpy(a.data(), out, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), Cf, b.size() * 4, hipMemcpyDeviceToHost);
