@@ -113,7 +113,7 @@ def algorithmic_work(hp, batch: int, n_steps: int, n_prompt: int):
                 dec_bytes_step=float(dec_weight_bytes + batch * cross_kv_bytes))
 
 
-def pmc_traffic(model: str, batch: int, dtype: str, what: str):
+def pmc_traffic(model: str, batch: int, dtype: str, what: str, alg_bytes_now: float = 0.0):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this command (profiles/pmc_traffic.json):
     (2 x FETCH_SIZE + WRITE_SIZE) KiB, the x2 being the gfx950 FETCH_SIZE correction for 16-B/lane streams
     (MI355X_MICROARCH.md, HBM section; validated here on the cross-attention kernel: 62.2 MB measured vs 61.4 MB algorithmic).
@@ -122,7 +122,13 @@ def pmc_traffic(model: str, batch: int, dtype: str, what: str):
     try:
         j = json.load(open(p))
         k = j.get(f"{model}/batch{batch}/{dtype}/{what}")
-        return None if k is None else float(k["bytes_per_launch"])
+        if k is None:
+            return None
+        if what == "decoder_pass" and alg_bytes_now and k.get("algorithmic_bytes"):
+            # the counters were collected on passes of k["rows_per_launch"] rows; a pass of this run carries other row counts (and self-KV lengths):
+            # scale by the ratio of the algorithmic bytes, i.e. report (measured / algorithmic at the PMC run) x (algorithmic now)
+            return float(k["bytes_per_launch"]) * alg_bytes_now / float(k["algorithmic_bytes"])
+        return float(k["bytes_per_launch"])
     except Exception:
         return None
 
@@ -149,7 +155,7 @@ def cpu_baseline(path: str, hp, n_steps: int, n_prompt: int):
     chunk_s = min(runs)
     return {"value": round(CHUNK_SEC / chunk_s, 4), "unit": "audio-sec/s", "cores": cores, "kind": "port",
             "sample": f"1 chunk: log-mel + conv stem + {n_enc}/{hp.n_audio_layer} encoder layers + {n_cross}/{hp.n_text_layer} cross-KV layers + "
-                      f"{n_dec} decode steps timed (nothing extrapolated in the encoder; the decoder steps stand for {n_steps + n_prompt} positions) "
+                      f"{n_dec} decode steps timed (nothing extrapolated in the encoder; the decoder share is EXTRAPOLATED from those {n_dec} steps to {n_steps + n_prompt} positions) "
                       f"(est. {chunk_s:.1f} s per 30 s chunk; two repeats: {runs[0]:.1f} / {runs[1]:.1f} s, faster one reported); "
                       f"oracle/whisper_oracle.cpp ggml-f16 mode, {cores} OpenMP threads"}
 
@@ -170,6 +176,7 @@ def main():
                     "i-1 is collected, so one batch's encoder pass overlaps the other's decode chain on the engine's lanes; 1 = strictly one batch at a time")
     ap.add_argument("--device-batch", type=int, default=32, help="engine max_batch: chunks the batch former may put into ONE device batch (0 = --batch). "
                     "Larger than --batch with --inflight > 1 lets it merge queued steps into one decode chain (more rows per weight pass)")
+    ap.add_argument("--no-steady", action="store_true", help="skip the steady-state estimate reported beside the headline")
     ap.add_argument("--host-pcm", action="store_true", help="headline steps take host f32 PCM (H2D inside the timed region) instead of HBM-resident PCM")
     ap.add_argument("--dry-run", action="store_true", help="CPU test of the sharding/timing plumbing: stub workload, gloo backend")
     ap.add_argument("--dist-backend", default=None, help="override (default nccl on GPU); 'gloo' + SS_BENCH_DEVICE=0 lets several ranks share one GPU for testing")
@@ -289,6 +296,29 @@ def main():
     lat_main = list(latencies)
     audio_sec = n_gpus * args.batch * args.steps * CHUNK_SEC
     value = audio_sec / dt
+    # Beside the headline: the steady-state rate of the pipelined engine.  The K timed steps above are submitted and collected inside the timed
+    # region, so with `inflight` steps outstanding they also pay the pipeline's fill and drain (K = 20 with 3 lanes x 32-chunk device batches is
+    # five lane-batches: the last round runs on two lanes), which a continuously fed service does not.  Estimator: keep the pipeline full, record
+    # every collect (step() = submit one step + collect the oldest); a collect that BLOCKS returns at the completion time of its step, the
+    # collects that return at once after it belong to the same burst (a device batch completes several steps together).  Between two blocked
+    # collects p < q exactly idx_q - idx_p steps completed in T_q - T_p: no step finished before the window is counted, none is cut off.
+    steady = None
+    if inflight > 1 and not args.no_steady:
+        for _ in range(2 * inflight):
+            step()
+        marks_ss = []
+        for i in range(max(args.steps, 2 * inflight) + inflight):
+            ts = time.perf_counter()
+            step()
+            te = time.perf_counter()
+            if te - ts > 5e-3:
+                marks_ss.append((i, te))
+        drain()
+        torch.cuda.synchronize()
+        if len(marks_ss) >= 2 and marks_ss[-1][0] - marks_ss[0][0] >= inflight:
+            n_ss, dt_ss = marks_ss[-1][0] - marks_ss[0][0], marks_ss[-1][1] - marks_ss[0][1]
+            steady = {"value": round(n_gpus * args.batch * n_ss * CHUNK_SEC / dt_ss, 2), "unit": "audio-sec/s", "steps": n_ss, "seconds": round(dt_ss, 4),
+                      "note": "pipeline kept full; window between two blocked collects (completion instants), steps counted by completion; single rank's clock"}
     # the other entry point (SURVEY.md section 8d counts xRT "from host f32 PCM"): a few steps, reported beside the headline, never as `value`
     state["host"] = not args.host_pcm
     n_alt = max(inflight, min(4, args.steps))
@@ -302,6 +332,31 @@ def main():
         step()
         drain()
     lat_unloaded = list(latencies)[1:]
+
+    # BASELINE configs[2] read literally: ONE batch of 8 chunks at a time on an engine that can hold no more (max_batch = --batch, one lane):
+    # nothing merged, nothing overlapped.  Reported beside the headline with its own decoder-pass roofline.
+    strict = None
+    if inflight > 1 or eng.max_batch != args.batch or tot1["n_lanes"] != 1:
+        eng1 = binding.Engine(path, device=local_rank_dev, dtype={"f16": binding.DTYPE_F16, "bf16": binding.DTYPE_BF16, "fp8": binding.DTYPE_FP8}[args.dtype],
+                              max_batch=args.batch, n_lanes=1)
+        ses1 = [eng1.new_session() for _ in my_chunks]
+        strict_same = []
+        def one():
+            tk = [s_.submit_device(p_, n_, P) for s_, (p_, n_) in zip(ses1, ptrs)]
+            r1 = [s_.wait(t_) for s_, t_ in zip(ses1, tk)]
+            if args.fixed_steps > 0 and any(len(r["tokens"]) != args.fixed_steps for r in r1):
+                raise SystemExit("[bench] INVALID strict step: wrong token count")
+            strict_same.append([tuple(int(t) for t in r["tokens"]) for r in r1] == first_tokens)
+        one()
+        torch.cuda.synchronize()
+        a0 = eng1.totals(); t_s = time.perf_counter()
+        n_strict = 3
+        for _ in range(n_strict):
+            one()
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t_s; a1 = eng1.totals()
+        strict = {"dt": dt_s, "n": n_strict, "d": {k: a1[k] - a0[k] for k in a0 if k != "n_lanes"}, "same_ids": all(strict_same)}
+        eng1.close()
 
     if rank == 0:
         n_steps_dec = args.fixed_steps if args.fixed_steps > 0 else int(np.mean(tok_counts[args.warmup:args.warmup + args.steps]) / max(1, len(my_chunks)))
@@ -323,7 +378,7 @@ def main():
         pass_bytes = dec_weight_bytes + rows_per_pass * (cross_kv_row + self_kv_row)
         hbm_gbs = pass_bytes * passes * args.steps / dt / 1e9
         hbm_gbs_single = pass_bytes / (pass_ms * 1e-3) / 1e9
-        conc = dd["decode_ms"] * 1e-3 / dt          # average number of decoder passes running at once
+        conc = dec_ms * args.steps * 1e-3 / dt          # average number of decoder passes running at once
         gemm_batch = eng.max_batch                   # the encoder GEMMs run over a whole device batch: M = engine max_batch * 1500 rows
         gemm_ms, gemm_flops = eng.probe_gemm(gemm_batch, 20)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12
@@ -344,6 +399,9 @@ def main():
                        "chunks_per_step": n_gpus * args.batch, "parallelism": f"dp{n_gpus} (independent chunks, no collective)",
                        "steps_in_flight": inflight, "engine_lanes": tot1["n_lanes"], "engine_max_batch": eng.max_batch,
                        "validated": "every timed step: tokens per chunk == fixed_steps, >= 1 encoder window per chunk, ids identical to the first step"},
+            "timing": "value: barrier + device sync on both sides, all K steps submitted and collected inside the timed region (incl. the pipeline's fill and drain); "
+                      "steady_state: the same engine kept full, rate between two completion instants",
+            "steady_state": steady,
             "p50_chunk_latency_ms": round(1e3 * float(np.median(lat_main)), 2),
             "p50_chunk_latency_unloaded_ms": round(1e3 * float(np.median(lat_unloaded)), 2),
             ("value_from_host_pcm" if not args.host_pcm else "value_hbm_resident_pcm"): round(value_alt, 2),
@@ -355,7 +413,8 @@ def main():
                                    f"{100.0 * dec_ms / max(1e-9, enc_ms + dec_ms):.0f}% of device time; achieved = bytes of all passes / wall time of the timed region",
                          "achieved": round(hbm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_gbs / HBM_PEAK_GBS, 4),
                          "achieved_one_pass_alone": round(hbm_gbs_single, 1), "passes_overlapping": round(conc, 2),
-                         "traffic": pmc_traffic(args.model, args.batch, args.dtype, "decoder_pass"),
+                         "traffic": pmc_traffic(args.model, args.batch, args.dtype, "decoder_pass", pass_bytes),
+                         "traffic_note": "profiles/pmc_traffic.json: (2 x FETCH_SIZE + WRITE_SIZE) of every decoder-side kernel per pass from separate rocprofv3 --pmc runs of this command, scaled from the rows per pass of that run to this run's by the ratio of the algorithmic bytes",
                          "algorithmic_bytes": pass_bytes, "avg_launch_ms": round(pass_ms, 5), "launches_per_step": round(passes, 2), "rows_per_launch": round(rows_per_pass, 2)},
             "phase_roofline": {
                 "encoder_phase_tflops": round(args.batch * work["enc_flops"] / (enc_ms * 1e-3) / 1e12, 1),
@@ -372,6 +431,19 @@ def main():
                 "decode_pass_ms": round(pass_ms, 4),
                 "whole_chunk_tflops": round(n_gpus * args.batch * work["flops_chunk"] * args.steps / dt / 1e12, 1)},
         }
+        if strict is not None:
+            sd = strict["d"]
+            s_pass_ms = sd["decode_ms"] / max(1, sd["decoder_passes"])
+            s_rows = sd["decoder_rows"] / max(1, sd["decoder_passes"])
+            s_bytes = dec_weight_bytes + s_rows * (cross_kv_row + self_kv_row)
+            out["batch8_strict"] = {
+                "what": f"one batch of {args.batch} chunks at a time on Engine(max_batch={args.batch}, n_lanes=1): nothing merged across steps, nothing overlapped (BASELINE configs[2] read literally)",
+                "value": round(n_gpus * args.batch * strict["n"] * CHUNK_SEC / strict["dt"], 2), "unit": "audio-sec/s",
+                "p50_chunk_latency_ms": round(1e3 * strict["dt"] / strict["n"], 2), "ids_identical_to_pipelined_engine": strict["same_ids"],
+                "phase_ms": {"encode_cross_kv": round(sd["encode_ms"] / strict["n"], 2), "decode": round(sd["decode_ms"] / strict["n"], 2)},
+                "roofline": {"bound": "hbm", "kernel": "decoder pass (as above)", "achieved": round(s_bytes / (s_pass_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(s_bytes / (s_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": s_bytes, "avg_launch_ms": round(s_pass_ms, 5),
+                             "rows_per_launch": round(s_rows, 2)}}
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(path, hp, n_steps_dec, n_prompt)

@@ -50,6 +50,7 @@ struct GemmDesc {
     int use_batch_map;        // EPI_CROSS_KV: window b of this launch writes cache slot batch_map[b] instead of b
     unsigned char batch_map[128];
     int stagger_ticks, stagger_groups;   // set by launch_gemm: start-time stagger of the persistent workgroups (see gemm256_kernel)
+    int dbg_flags;            // dev tool (tools/diag/gemm_shapes.py, env SS_GEMM_DBG): 1 = compute the epilogue but skip its stores
     long long* trace;         // dev tool (tools/gemm_bench.cpp): per workgroup and tile {start, loop start, loop end, stores issued} s_memtime stamps; null in the product
 };
 template <typename T> void launch_gemm(const GemmDesc& g, hipStream_t st);

@@ -496,6 +496,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
                 asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
                              : "+v"(pk[p][0]), "+v"(pk[p + 1][0]), "+v"(pk[p][1]), "+v"(pk[p + 1][1]));
                 if (!row_ok) continue;
+                if (g.dbg_flags & 1) { asm volatile("" :: "v"(pk[p][0]), "v"(pk[p][1]), "v"(pk[p + 1][0]), "v"(pk[p + 1][1])); continue; }
                 const int n = n0 + wn * 64 + (p + (fg & 1)) * 16 + (fg >> 1) * 8;
                 const u32x4 o16 = {pk[p][0], pk[p][1], pk[p + 1][0], pk[p + 1][1]};
                 if constexpr (KIND == EPI_CROSS_KV) {
@@ -593,6 +594,8 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
         static const int st_groups = getenv("SS_GEMM_STAGGER_GROUPS") ? atoi(getenv("SS_GEMM_STAGGER_GROUPS")) : 4;
         GemmDesc gs = g;
         gs.stagger_ticks = st_ticks; gs.stagger_groups = st_groups > 0 ? st_groups : 1;
+        static const int dbg = getenv("SS_GEMM_DBG") ? atoi(getenv("SS_GEMM_DBG")) : 0;
+        gs.dbg_flags = dbg;
         const GemmDesc& g = gs;
         if (one_wg) {
             // f16-output kinds: half the waves do all the staging (main loop -9 %, their partners' stores drain unobserved); the f32 residual

@@ -42,9 +42,15 @@ if len(sys.argv) > 3:
         j = json.load(open(sys.argv[3]))
     except Exception:
         j = {}
+    rows_pl = alg_b = None
+    try:     # the bench line of the PMC run itself: rows per pass and algorithmic bytes of THAT run (bench.py scales the counters to other row counts)
+        bl = json.loads([l for l in open(f"{d}/bench_FETCH_SIZE.log") if l.startswith("{")][-1])
+        rows_pl, alg_b = bl["roofline"]["rows_per_launch"], bl["roofline"]["algorithmic_bytes"]
+    except Exception:
+        pass
     src = f"profiles/{tag}_pmc.md (tools/gpu_pmc.sh: rocprofv3 --kernel-trace --pmc, one counter per pass of the bench command)"
     if n_pass:
-        j[f"large-v3/batch8/{dtype}/decoder_pass"] = {"bytes_per_launch": dec_bytes / n_pass, "passes": n_pass, "source": src,
+        j[f"large-v3/batch8/{dtype}/decoder_pass"] = {"bytes_per_launch": dec_bytes / n_pass, "passes": n_pass, "rows_per_launch": rows_pl, "algorithmic_bytes": alg_b, "source": src,
                                                  "note": "sum over every decoder-side kernel of (2 x FETCH_SIZE + WRITE_SIZE) / decoder passes; the pass carried the rows the default bench configuration merges (see rows_per_launch)"}
     if fc1:
         j[f"large-v3/batch8/{dtype}/fc1"] = {"bytes_per_launch": fc1, "source": src, "note": "max over the launches of the FC1 GEMM kernel (gemm256_kernel<EPI_GELU_T> / gemm_f8_kernel<F8_GELU_F8>)"}
