@@ -160,6 +160,41 @@ def cpu_baseline(path: str, hp, n_steps: int, n_prompt: int):
                       f"oracle/whisper_oracle.cpp ggml-f16 mode, {cores} OpenMP threads"}
 
 
+def cpu_baseline_whisper_cpp():
+    """upstream whisper.cpp (what the reference's whisper-rs calls, /root/reference/src/asr/whisper.rs:75,131-143) on the box's host
+    cores, same synthetic PCM, real ggml weights -- only where a box has both (WHISPER_CPP_MAIN, ASR_MODEL_PATH; tests/test_gpu_vs_whisper_cpp.py uses
+    the same variables).  Timed at -t 16 (the reference's n_threads) and at -t <cores>; the faster one is `value`.  Returns None when unavailable."""
+    import shutil
+    import subprocess
+    import tempfile
+    import wave
+    from speaksense_amd import synth
+    main_bin = os.environ.get("WHISPER_CPP_MAIN") or shutil.which("whisper-cli") or shutil.which("whisper-cpp")
+    model = os.environ.get("ASR_MODEL_PATH")
+    if not main_bin or not os.path.exists(main_bin) or not model or not os.path.exists(model):
+        return None
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    tmp = tempfile.mkdtemp()
+    wav = os.path.join(tmp, "chunk0.wav")
+    with wave.open(wav, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((np.clip(synth.speech_like(0), -1, 1) * 32767.0).astype("<i2").tobytes())
+    runs = {}
+    for t in sorted({16, min(ncpu, 64)}):
+        t0 = time.perf_counter()
+        r = subprocess.run([main_bin, "-m", model, "-f", wav, "-l", "en", "-t", str(t), "-bo", "5", "-np"], capture_output=True, text=True)
+        if r.returncode != 0:
+            return None
+        runs[t] = time.perf_counter() - t0          # includes the model load, as one `whisper_full` call of a cold process does
+    best_t = min(runs, key=runs.get)
+    return {"value": round(CHUNK_SEC / runs[best_t], 4), "unit": "audio-sec/s", "cores": best_t, "kind": "reference",
+            "sample": "whisper.cpp CPU (" + os.path.basename(main_bin) + f", greedy best_of 5) on chunk 0 of the same synthetic PCM, weights {os.path.basename(model)}; "
+                      + "; ".join(f"-t {t}: {v:.1f} s per 30 s chunk" for t, v in sorted(runs.items())) + " (process start and model load included)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -449,6 +484,13 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(path, hp, n_steps_dec, n_prompt)
             except Exception as e:  # never fabricate a number
                 out["cpu_baseline"] = {"value": None, "unit": "audio-sec/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+            try:     # BASELINE.md B0 where the box has whisper.cpp + real weights: it becomes THE baseline, the port is kept beside it
+                b0 = cpu_baseline_whisper_cpp()
+                if b0 is not None:
+                    b0["port"] = out["cpu_baseline"]
+                    out["cpu_baseline"] = b0
+            except Exception as e:
+                out["cpu_baseline"]["whisper_cpp"] = f"unavailable: {e}"
         print(json.dumps(out))
     eng.close()
     if dist is not None:

@@ -155,6 +155,12 @@ int ss_result_tokens(const ss_session* s, int32_t* ids, float* plog); /* plog ma
  * drops: the stream a step-by-step replay on another implementation needs (tests: forced replay on the oracle) */
 int32_t ss_result_n_sampled_tokens(const ss_session* s);
 int ss_result_sampled_tokens(const ss_session* s, int32_t* ids);
+/* every id ANY decoder of the chunk sampled -- the attempts that failed and the best_of decoders that lost included -- in the order
+ * whisper_full_with_state calls whisper_sample_token: window, temperature attempt, step, decoder.  With it another implementation can replay the
+ * chunk call by call, sampled (t > 0) attempts included: it draws the same uniforms from the same generator and checks that each id here is
+ * the one its own cumulative distribution selects, or sits within rounding of the boundary (tests: oracle `full(trace=...)`). */
+int32_t ss_result_n_trace_tokens(const ss_session* s);
+int ss_result_trace_tokens(const ss_session* s, int32_t* ids);
 int32_t ss_result_lang_id(const ss_session* s);                        /* language used by the last chunk (whisper_full_lang_id), -1 for .en models */
 int ss_result_counters(const ss_session* s, int32_t out4[4]);         /* n_encode, n_decode_steps, n_fail, n_windows */
 

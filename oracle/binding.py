@@ -61,6 +61,9 @@ def lib():
         L.orc_full_default_params.argtypes = [C.POINTER(FullParams)]
         L.orc_full.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FullParams)]
         L.orc_full_forced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FullParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_full_trace.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(FullParams), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_n_trace.argtypes = [C.c_void_p]
+        L.orc_trace.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_n_sampled.argtypes = [C.c_void_p]
         L.orc_e4m3_round.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_e8m0_exponent.argtypes = [C.c_float]
@@ -220,13 +223,28 @@ class OracleState:
         tid = self.L.orc_process_logits(self.h, _p(raw), _p(h), len(h), int(has_ts), seek_delta, C.byref(params), _p(lp), _p(o5))
         return tid, lp, o5
 
-    def full(self, pcm: np.ndarray, params: FullParams | None = None, forced=None):
+    def full(self, pcm: np.ndarray, params: FullParams | None = None, forced=None, trace=None):
         """`forced` (test hook): token ids of another implementation; greedy step g takes forced[g] instead of the argmax and the result
-        carries `forced_gap[g]` = logprob(oracle's best) - logprob(forced[g]) and `forced_best[g]` = the oracle's own pick at that step."""
+        carries `forced_gap[g]` = logprob(oracle's best) - logprob(forced[g]) and `forced_best[g]` = the oracle's own pick at that step.
+        `trace` (test hook): EVERY id the other implementation sampled, in whisper_sample_token call order (failed attempts and losing best_of
+        decoders included); sampled (t > 0) calls are replayed too: `trace_kind[g]` 0 = greedy (gap as above), 1 = sampled, `trace_gap[g]` then
+        is the distance of the uniform the oracle drew (same generator, same position) to trace[g]'s interval of the oracle's cumulative distribution,
+        and `trace_sens[g]` = F (1 - F) / T at the interval boundary nearer to the uniform: a logit perturbation of +-delta moves that boundary by
+        at most 2 delta trace_sens[g] (first order)."""
         pcm = np.ascontiguousarray(pcm, np.float32)
         params = params or default_params()
         extra = {}
-        if forced is None:
+        if trace is not None:
+            ids = np.ascontiguousarray(trace, np.int32)
+            gaps = np.zeros(max(1, len(ids)), np.float32)
+            best = np.zeros(max(1, len(ids)), np.int32)
+            kind = np.zeros(max(1, len(ids)), np.int32)
+            sens = np.zeros(max(1, len(ids)), np.float32)
+            used = np.zeros(1, np.int32)
+            rc = self.L.orc_full_trace(self.h, _p(pcm), len(pcm), C.byref(params), _p(ids), len(ids), _p(gaps), _p(best), _p(kind), _p(sens), _p(used))
+            k = int(used[0])
+            extra = dict(trace_gap=gaps[:k].copy(), trace_best=best[:k].copy(), trace_kind=kind[:k].copy(), trace_sens=sens[:k].copy())
+        elif forced is None:
             rc = self.L.orc_full(self.h, _p(pcm), len(pcm), C.byref(params))
         else:
             ids = np.ascontiguousarray(forced, np.int32)
@@ -251,6 +269,11 @@ class OracleState:
         if ns:
             self.L.orc_sampled(self.h, _p(sampled))
         extra["sampled"] = sampled
+        nt = self.L.orc_n_trace(self.h)
+        tr = np.zeros(nt, np.int32)
+        if nt:
+            self.L.orc_trace(self.h, _p(tr))
+        extra["trace"] = tr
         extra["lang_id"] = int(self.L.orc_lang_id(self.h))
         c = np.zeros(3, np.int32)
         self.L.orc_counters(self.h, _p(c))

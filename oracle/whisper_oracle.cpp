@@ -661,6 +661,13 @@ struct State {
     // A second implementation's token stream is thereby checked step by step against this one ON ITS OWN TRAJECTORY: every pick must be
     // the oracle's best or within numerical noise of it, across all windows (seek / prompt_past / segments follow from the tokens).
     std::vector<int> forced; size_t forced_pos = 0; std::vector<float> forced_gap; std::vector<int> forced_best;
+    // forced_all (trace replay): EVERY whisper_sample_token call consumes an entry, sampled (t > 0) calls included.  A sampled call still draws
+    // from s.rng exactly as std::discrete_distribution does (the generator stays in step), then records how far the uniform it drew lies from
+    // the interval of the cumulative distribution that selects forced[g] (0 = the forced id is this implementation's own draw), and takes forced[g].
+    std::vector<int> trace_rec;           // every id any whisper_sample_token call of the last full() returned, in call order (test hook)
+    bool forced_all = false; std::vector<int> forced_kind;
+    std::vector<float> forced_sens;       // sampled calls: F (1 - F) / T at the interval boundary nearer to the uniform (how far a logit perturbation moves that boundary)
+    float t_cur = 0.0f;                   // temperature of the running attempt   // per consumed entry: 0 greedy (gap = log-probability distance), 1 sampled (gap = CDF distance)
 };
 
 void cross_kv(State& s, int max_layers = -1) {
@@ -828,14 +835,37 @@ TokenData sample_token(State& s, Decoder& dec, bool best) {
             const int f = s.forced[s.forced_pos++];
             float gap = INFINITY;
             if (f >= 0 && f < n_logits && probs[f] > 0.0f) gap = r.plog - logprobs[f];
-            s.forced_gap.push_back(gap); s.forced_best.push_back(r.id);
+            s.forced_gap.push_back(gap); s.forced_best.push_back(r.id); s.forced_kind.push_back(0); s.forced_sens.push_back(0.0f);
             if (f >= 0 && f < n_logits) { r.id = f; r.p = probs[f]; r.plog = logprobs[f]; }
         }
     } else {
+        std::mt19937 rng_before = s.rng;
         std::discrete_distribution<> dist(probs.begin(), probs.end());
         r.id = dist(s.rng); r.p = probs[r.id]; r.plog = logprobs[r.id];
+        if (s.forced_all && s.forced_pos < s.forced.size()) {
+            const int f = s.forced[s.forced_pos++];
+            float gap = INFINITY, sens = 0.0f;
+            if (f >= 0 && f < n_logits) {
+                // libstdc++'s discrete_distribution: p_i / sum (double), partial sums cp, last = 1; operator() returns lower_bound(cp, u)
+                const double u = std::generate_canonical<double, std::numeric_limits<double>::digits>(rng_before);
+                double sum = 0.0;
+                for (int i = 0; i < n_logits; i++) sum += probs[i];
+                double acc = 0.0, lo = 0.0, hi = 0.0;
+                for (int i = 0; i <= f; i++) { lo = acc; acc += probs[i] / sum; hi = acc; }
+                if (f == n_logits - 1) hi = 1.0;
+                gap = u <= lo ? (float)(lo - u) : (u > hi ? (float)(u - hi) : 0.0f);
+                if (f != r.id && gap == 0.0f) gap = 1e-30f;   // inside by this recomputation, outside by the library's: a boundary case, still reported as a flip
+                // A perturbation of every logit by at most +-delta (before the division by T) moves a cumulative probability F to at most
+                // F e^(d) / (F e^(d) + (1 - F) e^(-d)), d = delta / T, i.e. by 2 d F (1 - F) to first order: the test bounds the gap by that.
+                const double Fb = u <= lo ? lo : hi;
+                sens = (float)(Fb * (1.0 - Fb) / std::max(1e-6f, s.t_cur));
+            }
+            s.forced_gap.push_back(gap); s.forced_best.push_back(r.id); s.forced_kind.push_back(1); s.forced_sens.push_back(sens);
+            if (f >= 0 && f < n_logits) { r.id = f; r.p = probs[f]; r.plog = logprobs[f]; }
+        }
     }
     if (r.id >= vocab.token_beg) { r.tid = r.id; r.pt = r.p; }
+    s.trace_rec.push_back(r.id);
     return r;
 }
 
@@ -859,7 +889,7 @@ void sequence_score(const FullParams& P, Sequence& q) {
 // ---------------------------------------------------------------------------------------------
 int full(State& s, const float* samples, int n_samples, const FullParams& P) {
     const Model& m = *s.m; const Vocab& vocab = m.vocab; const HParams& hp = m.hp;
-    s.result_all.clear(); s.all_tokens.clear(); s.sampled_all.clear();
+    s.result_all.clear(); s.all_tokens.clear(); s.sampled_all.clear(); s.trace_rec.clear();
     s.n_encode = s.n_decode = s.n_fail = 0;
     if (n_samples > 0) {
         s.n_len = mel_n_len(n_samples); s.n_len_org = mel_n_len_org(n_samples);
@@ -925,6 +955,7 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
         int best_decoder_id = 0;
         for (int it = 0; it < (int)temperatures.size(); it++) {
             const float t_cur = temperatures[it];
+            s.t_cur = t_cur;
             int n_cur = 1;
             if (t_cur > 0.0f) n_cur = P.best_of;
             n_cur = std::max(1, n_cur);
@@ -1120,12 +1151,28 @@ int orc_full(void* sp, const float* pcm, int n, const FullParams* P) { return fu
 // forced replay (see State::forced): returns orc_full's code; gaps_out / best_out get one entry per consumed forced token, *n_used their count
 int orc_full_forced(void* sp, const float* pcm, int n, const FullParams* P, const int32_t* ids, int n_ids, float* gaps_out, int32_t* best_out, int32_t* n_used) {
     State& s = *(State*)sp;
-    s.forced.assign(ids, ids + n_ids); s.forced_pos = 0; s.forced_gap.clear(); s.forced_best.clear();
+    s.forced.assign(ids, ids + n_ids); s.forced_pos = 0; s.forced_gap.clear(); s.forced_best.clear(); s.forced_kind.clear(); s.forced_sens.clear();
     const int rc = full(s, pcm, n, *P);
     const int k = (int)s.forced_gap.size();
     for (int i = 0; i < k; i++) { gaps_out[i] = s.forced_gap[i]; best_out[i] = s.forced_best[i]; }
     *n_used = k;
     s.forced.clear(); s.forced_pos = 0;
+    return rc;
+}
+int orc_n_trace(void* sp) { return (int)((State*)sp)->trace_rec.size(); }
+void orc_trace(void* sp, int32_t* out) { State& s = *(State*)sp; for (size_t i = 0; i < s.trace_rec.size(); i++) out[i] = s.trace_rec[i]; }
+// trace replay (see State::forced_all): ids = every id the other implementation sampled, in whisper_sample_token call order (ss_result_trace_tokens);
+// kind_out[i] = 0 greedy call (gaps_out = log-probability distance to this implementation's argmax), 1 sampled call (gaps_out = distance of
+// the uniform this implementation drew to the forced id's interval of its cumulative distribution)
+int orc_full_trace(void* sp, const float* pcm, int n, const FullParams* P, const int32_t* ids, int n_ids, float* gaps_out, int32_t* best_out, int32_t* kind_out,
+                   float* sens_out, int32_t* n_used) {
+    State& s = *(State*)sp;
+    s.forced.assign(ids, ids + n_ids); s.forced_pos = 0; s.forced_gap.clear(); s.forced_best.clear(); s.forced_kind.clear(); s.forced_sens.clear(); s.forced_all = true;
+    const int rc = full(s, pcm, n, *P);
+    const int k = (int)s.forced_gap.size();
+    for (int i = 0; i < k; i++) { gaps_out[i] = s.forced_gap[i]; best_out[i] = s.forced_best[i]; kind_out[i] = s.forced_kind[i]; sens_out[i] = s.forced_sens[i]; }
+    *n_used = k;
+    s.forced.clear(); s.forced_pos = 0; s.forced_all = false;
     return rc;
 }
 int orc_lang_id(void* sp) { return ((State*)sp)->lang_id; }

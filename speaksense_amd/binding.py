@@ -76,6 +76,8 @@ def lib():
         L.ss_result_tokens.argtypes = [vp, vp, vp]
         L.ss_result_n_sampled_tokens.argtypes = [vp]
         L.ss_result_sampled_tokens.argtypes = [vp, vp]
+        L.ss_result_n_trace_tokens.argtypes = [vp]
+        L.ss_result_trace_tokens.argtypes = [vp, vp]
         L.ss_result_counters.argtypes = [vp, vp]
         L.ss_result_lang_id.argtypes = [vp]
         L.ss_engine_tokenize.argtypes = [vp, C.c_char_p, vp, i32]
@@ -383,9 +385,13 @@ class Session:
         sampled = np.zeros(ns, np.int32)
         if ns:
             self.L.ss_result_sampled_tokens(self.h, _p(sampled))
+        nt = self.L.ss_result_n_trace_tokens(self.h)
+        trace = np.zeros(nt, np.int32)
+        if nt:
+            self.L.ss_result_trace_tokens(self.h, _p(trace))
         c = np.zeros(4, np.int32)
         self.L.ss_result_counters(self.h, _p(c))
-        return dict(segments=segs, tokens=ids, plog=plog, sampled=sampled, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]),
+        return dict(segments=segs, tokens=ids, plog=plog, sampled=sampled, trace=trace, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]),
                     n_windows=int(c[3]), lang_id=int(self.L.ss_result_lang_id(self.h)))
 
     def rng_draws(self) -> int:

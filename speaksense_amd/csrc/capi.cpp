@@ -271,6 +271,12 @@ int ss_result_sampled_tokens(const ss_session* s, int32_t* ids) {
     for (size_t i = 0; i < s->s.sampled.size(); i++) ids[i] = s->s.sampled[i];
     return SS_OK;
 }
+int32_t ss_result_n_trace_tokens(const ss_session* s) { return s ? (int32_t)s->s.trace.size() : 0; }
+int ss_result_trace_tokens(const ss_session* s, int32_t* ids) {
+    if (!s || !ids) return fail(SS_ERR_ARG, "null argument");
+    for (size_t i = 0; i < s->s.trace.size(); i++) ids[i] = s->s.trace[i];
+    return SS_OK;
+}
 int32_t ss_result_lang_id(const ss_session* s) { return s ? s->s.lang_id : -1; }
 int ss_result_counters(const ss_session* s, int32_t out4[4]) {
     if (!s || !out4) return fail(SS_ERR_ARG, "null argument");

@@ -101,6 +101,7 @@ struct Window {
     int best = 0;
     bool skip = false;     // detect_language only: the window is not decoded
     bool done = false;     // accepted attempt, ready to be finalised
+    std::vector<int> trace;   // every id any decoder of this window sampled, in whisper_full's call order: attempt, step, decoder (ss_result_trace_tokens)
 };
 struct JobState {
     Job* job; int slot; int n_len = 0, n_len_org = 0, seek = 0, seek_start = 0, seek_end = 0; bool alive = false;
@@ -943,7 +944,7 @@ struct EngineT : EngineBase {
     JobState setup_job(Job* j, int i) {
             const Vocab& vocab = hm.vocab;
             Session* s = j->sess;
-            s->segments.clear(); s->tokens.clear(); s->sampled.clear(); s->n_encode = s->n_decode = s->n_fail = s->n_windows = 0;   // "clear old results"
+            s->segments.clear(); s->tokens.clear(); s->sampled.clear(); s->trace.clear(); s->n_encode = s->n_decode = s->n_fail = s->n_windows = 0;   // "clear old results"
             // The carried text context (prompt_past) is only touched once the chunk is known to decode: whisper_full_with_state returns for < 1 s
             // of audio before it reaches "if (params.no_context) prompt_past.clear()" / "prepend the prompt tokens", and a refused call must
             // leave a context-carrying caller's state as it was (see the end of this function).
@@ -1406,6 +1407,7 @@ struct EngineT : EngineBase {
             if (tk.id >= vocab.token_beg) { tk.tid = tk.id; tk.pt = tk.p; }
         }
         q.tokens.push_back(tk);
+        w.trace.push_back(tk.id);
         q.sum_logprobs_all += tk.plog;
         const int i = q.i++;
         bool done = false;
@@ -1442,6 +1444,7 @@ struct EngineT : EngineBase {
         const std::vector<TokenData>& tk = bd.tokens;
         for (auto& t : tk) s->tokens.push_back(t);
         s->sampled.insert(s->sampled.end(), bd.sampled.begin(), bd.sampled.end());
+        s->trace.insert(s->trace.end(), w.trace.begin(), w.trace.end());
         // update prompt_past: the past context that was fed (without [prev] and the task tokens) + this window's text
         {
             std::vector<int> np;

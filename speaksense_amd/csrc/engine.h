@@ -35,6 +35,7 @@ struct Session {
     struct EngineBase* eng = nullptr;
     std::vector<Segment> segments;
     std::vector<TokenData> tokens;
+    std::vector<int> trace;        // every id ANY decoder sampled (failed attempts and losing best_of decoders included), in whisper_full's call order
     std::vector<int> sampled;      // every id the winning decoder of each window sampled (incl. the tail past result_len that `tokens` drops)
     int n_encode = 0, n_decode = 0, n_fail = 0, n_windows = 0;
     std::vector<int> prompt_past;  // whisper_state::prompt_past: text context carried between windows (and calls, unless no_context)

@@ -70,3 +70,30 @@ def test_full_structure(om):
     r = st.full(synth.speech_like(4), orc.default_params(language="en", fixed_steps=12))
     assert len(r["tokens"]) == 12 and r["n_encode"] == 1 and om.eot not in list(r["tokens"])
     st.close()
+
+
+def test_trace_replay_is_exact_on_the_oracle_itself(tmp_path):
+    """The test hook the sampled-attempt parity rests on (oracle `full(trace=...)`): a chunk that walks the temperature ladder, replayed on a fresh
+    state from its own trace, must consume every entry, recompute each uniform from the generator state before the call, find it INSIDE the
+    interval of the cumulative distribution that selects the traced id (gap exactly 0: the recomputed CDF is libstdc++'s) and reproduce the
+    result; a trace with one sampled id replaced by its upper neighbour must show a positive gap at exactly that call."""
+    import numpy as np
+    from oracle import binding as orc
+    from speaksense_amd import ggml_io, synth
+    path = str(tmp_path / "toy.en.bin")
+    ggml_io.write_model(path, "toy.en", seed=1)
+    om = orc.OracleModel(path)
+    pcm = synth.speech_like(5, 16000 * 30)
+    P = orc.default_params(language="en")
+    ref = om.new_state(orc.MODE_GGML_F16).full(pcm, P)
+    assert ref["n_fail"] >= 1 and len(ref["trace"]) > len(ref["sampled"])          # failed attempts and losing decoders are in the trace
+    rep = om.new_state(orc.MODE_GGML_F16).full(pcm, P, trace=ref["trace"])
+    assert len(rep["trace_gap"]) == len(ref["trace"]) and int(rep["trace_kind"].sum()) > 100
+    assert float(rep["trace_gap"].max()) == 0.0 and (rep["trace_best"] == ref["trace"]).all()
+    assert list(rep["tokens"]) == list(ref["tokens"]) and rep["n_fail"] == ref["n_fail"]
+    k = int(np.nonzero(rep["trace_kind"] == 1)[0][7])
+    bad = ref["trace"].copy()
+    bad[k] = bad[k] + 1 if bad[k] + 1 < om.n_vocab else bad[k] - 1
+    rep2 = om.new_state(orc.MODE_GGML_F16).full(pcm, P, trace=bad)
+    assert rep2["trace_gap"][k] > 0.0 and rep2["trace_best"][k] == ref["trace"][k] and float(rep2["trace_gap"][:k].max()) == 0.0
+    om.close()
