@@ -48,6 +48,12 @@ PRESETS = {
     "tiny.en": HParams(51864, 1500, 384, 6, 4, 448, 384, 6, 4, 80, 1),
     "base.en": HParams(51864, 1500, 512, 8, 6, 448, 512, 8, 6, 80, 1),
     "large-v3": HParams(51866, 1500, 1280, 20, 32, 448, 1280, 20, 32, 128, 1),
+    # the other shapes /root/reference/script/download-ggml-model.sh:36-48 can fetch
+    "large-v3-turbo": HParams(51866, 1500, 1280, 20, 32, 448, 1280, 20, 4, 128, 1),     # 32 encoder / 4 decoder layers
+    "medium": HParams(51865, 1500, 1024, 16, 24, 448, 1024, 16, 24, 80, 1),             # v2-era multilingual vocabulary: 99 languages, ids shifted by one
+    "medium.en": HParams(51864, 1500, 1024, 16, 24, 448, 1024, 16, 24, 80, 1),
+    "small.en": HParams(51864, 1500, 768, 12, 12, 448, 768, 12, 12, 80, 1),
+    "small.en-tdrz": HParams(51864, 1500, 768, 12, 12, 448, 768, 12, 12, 80, 1),        # same file layout; fine-tuned to emit [_SOLM_] at speaker turns (tdrz_enable)
     # toy shapes for fast CPU tests: same context sizes / vocabulary rules, tiny width
     "toy.en": HParams(51864, 1500, 128, 2, 2, 448, 128, 2, 2, 80, 1),
     "toy": HParams(51866, 1500, 128, 2, 2, 448, 128, 2, 2, 128, 1),
@@ -56,6 +62,11 @@ PRESETS = {
     # large-v3's width, head count, mel count and vocabulary with 2 layers per stack: every large-v3 kernel configuration (split-K plans,
     # LayerNorm register tiling, 20-head attention) at 1/16 of the oracle's cost
     "wide2": HParams(51866, 1500, 1280, 20, 2, 448, 1280, 20, 2, 128, 1),
+    # the same idea for the other widths of the download script: medium (d = 1024, 16 heads, 51865-token vocabulary), small.en / small.en-tdrz
+    # (d = 768, 12 heads) and large-v3-turbo's asymmetry (more encoder than decoder layers)
+    "medium2": HParams(51865, 1500, 1024, 16, 2, 448, 1024, 16, 2, 80, 1),
+    "small2.en": HParams(51864, 1500, 768, 12, 2, 448, 768, 12, 2, 80, 1),
+    "turbo41": HParams(51866, 1500, 1280, 20, 4, 448, 1280, 20, 1, 128, 1),
 }
 
 

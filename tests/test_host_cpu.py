@@ -38,6 +38,24 @@ def test_presets_match_survey():
     assert 1.50e9 < n_params < 1.60e9   # 1541 M
 
 
+def test_presets_of_the_download_script(tmp_path):
+    """The other models /root/reference/script/download-ggml-model.sh:36-48 fetches: parameter counts of the published checkpoints, and the
+    special-token table of the 51865-token vocabulary (99 languages: every id after the language block sits one lower than in large-v3)."""
+    from oracle import binding as orc
+    def n_params(name):
+        return sum(int(np.prod(s)) for _, s, _ in ggml_io.tensor_specs(ggml_io.PRESETS[name]))
+    assert 0.80e9 < n_params("large-v3-turbo") < 0.82e9          # 809 M
+    assert 0.76e9 < n_params("medium") < 0.78e9                  # 769 M
+    assert 0.24e9 < n_params("small.en") < 0.25e9                # 244 M
+    t = ggml_io.PRESETS["large-v3-turbo"]
+    assert (t.n_audio_layer, t.n_text_layer) == (32, 4)
+    path = str(tmp_path / "m.bin")
+    ggml_io.write_model(path, ggml_io.HParams(51865, 1500, 128, 2, 1, 448, 128, 2, 1, 80, 1), seed=2)
+    om = orc.OracleModel(path)
+    assert (om.eot, om.sot, om.translate, om.transcribe, om.solm, om.prev, om.nosp, om.not_, om.beg) == (50257, 50258, 50358, 50359, 50360, 50361, 50362, 50363, 50364)
+    om.close()
+
+
 def test_punctuation_and_promo_filter():
     # /root/reference/src/asr/whisper.rs:175-201
     assert asr.add_punctuation("你好吗") == "你好吗？"
