@@ -49,8 +49,6 @@ struct GemmDesc {
     int gelu_f16_in;          // f16 engines: gelu(f16(x)) like ggml's table (no-op for bf16)
     int use_batch_map;        // EPI_CROSS_KV: window b of this launch writes cache slot batch_map[b] instead of b
     unsigned char batch_map[128];
-    int stagger_ticks, stagger_groups;   // set by launch_gemm: start-time stagger of the persistent workgroups (see gemm256_kernel)
-    int dbg_flags;            // dev tool (tools/diag/gemm_shapes.py, env SS_GEMM_DBG): 1 = compute the epilogue but skip its stores
     long long* trace;         // dev tool (tools/gemm_bench.cpp): per workgroup and tile {start, loop start, loop end, stores issued} s_memtime stamps; null in the product
 };
 template <typename T> void launch_gemm(const GemmDesc& g, hipStream_t st);
@@ -114,14 +112,6 @@ __device__ __forceinline__ float pow2_neg_of_e8m0(int e) {   // 2^-(e - 127), e 
     return __builtin_bit_cast(float, (unsigned)(254 - e) << 23);
 }
 
-// Skinny GEMM for decode steps: M <= 64 rows, weights streamed once.  out[m][n] = sum_k X[m][k] W[n][k]
-enum SkinnyEpi {
-    SK_STORE_T = 0,  // out T[m][ldo] = (acc + bias) * scale
-    SK_GELU_T,       // out T = gelu(acc + bias)
-    SK_RES_F32,      // out f32[m][n] += acc + bias
-    SK_LOGITS_F32,   // out f32[m][ldo] = acc   (n < n_valid only)
-    SK_SELF_QKV,     // n in [0,d): q -> out T[m][d] * scale; [d,2d): k*scale -> kcache; [2d,3d): v -> vcache  (row m -> slot/pos via ctl)
-};
 struct RowCtl {       // one per decode row; lives in pinned host memory mapped into the device
     int32_t token;    // input token id
     int32_t pos;      // position (= n_past)
@@ -134,25 +124,11 @@ struct RowCtl {       // one per decode row; lives in pinned host memory mapped 
     int32_t want_probs;           // t > 0: also write the full probability row
     int32_t pad;
 };
-struct SkinnyDesc {
-    const void* X; long ldx;  // T [M][ldx]
-    const void* W;            // T [N][K]
-    int M, N, K;
-    int kind;
-    const float* bias;
-    void* out; long ldo;
-    float scale;
-    int n_valid;              // SK_LOGITS_F32
-    // SK_SELF_QKV
-    const RowCtl* ctl; void* kcache; void* vcache; long slot_stride; int d;  // caches: [slot][n_text_ctx][d] for this layer
-    int gelu_f16_in;
-};
-template <typename T> void launch_skinny(const SkinnyDesc& g, hipStream_t st);
 
 // Fused decode-step GEMV for M <= 16 rows (kernels_decode.hip): prologue + 16-row weight tiles x split-K + epilogue
 constexpr int kPartRows = 64;   // row stride of the split-K partial buffers [S][kPartRows][N]: a decoder pass carries up to 64 token rows
-enum DecPro { PRO_LN = 0, PRO_T = 1, PRO_COMBINE = 2 };
-enum DecEpi { DEPI_PART = 0, DEPI_QKV = 1, DEPI_GELU_T = 2, DEPI_LOGITS = 3, DEPI_RES = 4 };
+enum DecPro { PRO_LN = 0, PRO_T = 1 };   // PRO_LN: the descriptor of a dec_reduce_ln launch; PRO_T: a GEMV whose activations are T rows (Xt)
+enum DecEpi { DEPI_PART = 0, DEPI_QKV = 1, DEPI_GELU_T = 2, DEPI_LOGITS = 3 };
 struct DecGemvDesc {
     int pro, epi;
     // PRO_LN: x = x_in (or tok/pos embedding when ctl != null) + bias_prev + sum_p parts[p]; optional write-back; LayerNorm
@@ -163,9 +139,7 @@ struct DecGemvDesc {
     const RowCtl* ctl; const void* tok_emb; const float* pos_emb;   // embedding prologue (layer 0)
     const int* row_idx;                     // optional row gather (final LayerNorm of the sampling rows)
     const void* Xt; long ldx;               // PRO_T: T [M][ldx]
-    const float* cross_parts;               // PRO_COMBINE: [M][H][4][66]
     const void* W; int M, N, K, S;          // W: T [N][K]
-    int NT;                                 // output columns per workgroup, 1..16 (0 = 16): narrow tiles fill the chip without split-K
     const float* bias; void* out; long ldo; float scale; int n_valid;
     float* part_out;                        // DEPI_PART: [S][kPartRows][N]
     const RowCtl* ctl_rows; void* kcache; void* vcache; long slot_stride; int d;   // DEPI_QKV
@@ -192,10 +166,6 @@ void launch_enc_attention_f8(const T* q, const T* k, long ld, const T* vT, int T
 // Decoder self-attention for M rows (one new token each): q T [M][d] (pre-scaled), caches [slot][n_ctx][d]; n_kv = pos+1
 template <typename T>
 void launch_dec_self_attention(const T* q, const T* kcache, const T* vcache, long slot_stride, int d, int H, const RowCtl* ctl, int M, T* out, hipStream_t st);
-// Decoder cross-attention: q T [M][d] (pre-scaled); cross cache for this layer: K [b][h][Tn][64], V same (kv stride between them)
-template <typename T>
-void launch_dec_cross_attention(const T* q, const T* kc, const T* vc, long b_stride, int d, int H, int Tn, const RowCtl* ctl, int M,
-                                float* scratch, T* out, hipStream_t st);
 
 // unsplit variant: one workgroup per (row, head) writes the normalised output T [M][d] directly (no partials, no combine launch)
 template <typename T>
@@ -216,8 +186,6 @@ void launch_dec_cross_attention_f8(const float* qpart, int n_qpart, const float*
 // row_idx (optional): output row r normalises input row row_idx[r] (gather)
 template <typename T> void launch_layernorm(const float* x, const float* w, const float* b, T* y, int rows, int d, const int* row_idx, hipStream_t st);
 template <typename T> void launch_layernorm_f32out(const float* x, const float* w, const float* b, float* y, int rows, int d, hipStream_t st);
-// x[m][:] = te[token_m][:] + pe[pos_m][:]
-template <typename T> void launch_embed(const T* te, const float* pe, const RowCtl* ctl, int M, int d, float* x, hipStream_t st);
 // conversions
 template <typename T> void launch_f32_to_T(const float* in, T* out, size_t n, hipStream_t st);
 template <typename T> void launch_T_to_f32(const T* in, float* out, size_t n, hipStream_t st);

@@ -420,6 +420,7 @@ static void launch_f8_kind(const GemmF8Desc& g, hipStream_t st) {
     int n_cu = device_cu_count() / 8 * 8;
     if (n_cu < 8) n_cu = 8;
     const int nwg = (g.N / QTN) * ((g.M + QTM - 1) / QTM);
+#ifdef SS_DEV_KNOCKOUTS   // NOT in the product build (speaksense_amd/build.py): tools/gemm_fp8_ko.py compiles its own library with -DSS_DEV_KNOCKOUTS
     if constexpr (KIND == F8_STORE_T) {   // dev tool: knock-out variants of the k loop (wrong results, timing only)
         static const int ko = [] {
             const int v = getenv("SS_F8_KO") ? atoi(getenv("SS_F8_KO")) : 0;
@@ -431,6 +432,7 @@ static void launch_f8_kind(const GemmF8Desc& g, hipStream_t st) {
         switch (ko) { SS_KO_CASE(1) SS_KO_CASE(2) SS_KO_CASE(3) SS_KO_CASE(4) SS_KO_CASE(7) SS_KO_CASE(8) SS_KO_CASE(15) SS_KO_CASE(16) SS_KO_CASE(20) SS_KO_CASE(28) default: break; }
 #undef SS_KO_CASE
     }
+#endif
     gemm_f8_kernel<T, KIND><<<nwg < n_cu ? nwg : n_cu, 512, kQLds, st>>>(g); SS_LAUNCH_CHECK();
 }
 

@@ -576,3 +576,27 @@ def test_lanes_under_concurrent_callers(toy_ml_path):
     tot = eng.totals()
     assert tot["n_lanes"] == 2 and tot["encoder_windows"] >= len(pcms)
     eng.close()
+
+
+@pytest.mark.parametrize("env", [{"SS_DECODE_GRAPH": "0"}, {"SS_DECODE_CHAIN": "0"}, {"SS_DECODE_GRAPH": "0", "SS_DECODE_CHAIN": "0"}])
+def test_decode_issue_modes(toy_ml_path, om, orc, monkeypatch, env):
+    """The two switches left in the engine change how a decoder pass is ISSUED, not which kernels run: SS_DECODE_GRAPH=0 launches the pass kernel by
+    kernel instead of replaying its captured hipGraph, SS_DECODE_CHAIN=0 waits for every step's samples before enqueuing the next step (no
+    device-side advance of the control blocks).  Every mode must give the oracle's tokens and segments -- greedy, a batch of 4 with an early EOT
+    and a multi-window chunk, and the sampled fallback ladder."""
+    from speaksense_amd import binding
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    eng = binding.Engine(toy_ml_path, dtype=binding.DTYPE_F16, max_batch=4)
+    P, OP = binding.default_params(language="en", temperature_inc=0.0), orc.default_params(language="en", temperature_inc=0.0)
+    pcms = [synth.speech_like(3), synth.speech_like(4, 16000 * 47), synth.speech_like(6, 16000 * 9), synth.silence()]
+    got = eng.transcribe_batch([eng.new_session() for _ in pcms], pcms, P)
+    for x, g in zip(pcms, got):
+        ref = om.new_state(orc.MODE_GGML_F16).full(x, OP)
+        assert list(g["tokens"]) == list(ref["tokens"]) and [(s["t0"], s["t1"], s["text"]) for s in g["segments"]] == [(s["t0"], s["t1"], s["text"]) for s in ref["segments"]]
+    x = synth.speech_like(5)      # walks the temperature ladder (tests/test_gpu_parity.py::test_full_path_default_ladder_f16)
+    g = eng.new_session().transcribe(x, binding.default_params(language="en"))
+    from test_gpu_parity import GAP_TOL_F16, check_trace_against_oracle
+    assert g["n_fail"] >= 1
+    check_trace_against_oracle(g, om, orc, orc.MODE_GGML_F16, x, orc.default_params(language="en"), f"issue mode {env}", GAP_TOL_F16)
+    eng.close()

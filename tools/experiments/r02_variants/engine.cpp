@@ -4,7 +4,7 @@
 // whisper.cpp's whisper_full_with_state window loop (seek / temperature fallback / segmenting),
 // re-organised so that many independent 30 s windows (from different sessions) advance in lock-step on one GPU:
 // one encoder pass over W windows (M = W*1500 rows per GEMM), then KV-cached decoding of all their decoders as rows of
-// the same GEMVs so every decoder weight is read once per pass for the whole batch.  Sampling rules run on the device;
+// skinny GEMMs so every decoder weight is read once per step for the whole batch.  Sampling rules run on the device;
 // only {id,p,plog,tid,pt,ptsum} per row return to the host each step.  No CPU fallback: without a HIP device
 // engine creation fails with SS_ERR_DEVICE.
 #include "engine.h"
@@ -155,7 +155,7 @@ struct EngineT : EngineBase {
     DBuf ln8, ln_sc, att8, att_sc, ff8, ff_sc;   // fp8 engine: quantised activations + their exponent bytes
     DBuf cross_sc;                               // fp8 engine: exponent bytes of the e4m3 cross cache, [L][B][kv][h][t]
     long Mpad = 0;
-    DBuf lnd, qd, attd, ffd, logits, probs, cscratch, ctl_d;
+    DBuf xd, lnd, qd, attd, ffd, logits, probs, cscratch, ctl_d;
     // Host staging for one decoder launch: control blocks, sampling-row indices and the uniform draws.  H2D copies from pinned memory read
     // their source when the copy EXECUTES, and the stream may be backlogged (encoder pass, earlier launches of the same round), so every
     // launch fills its own block of a ring and a block is only rewritten after the event recorded behind its copies has completed.
@@ -227,10 +227,19 @@ struct EngineT : EngineBase {
         }
         alloc_workspaces();
         plan_decode();
-        // two switches that change HOW the step is issued, not which kernels run (both under test: tests/test_gpu_variants.py::test_decode_issue_modes)
-        { const char* gv = getenv("SS_DECODE_GRAPH"); use_graph = !(gv && gv[0] == '0'); }     // 0: launch the step kernel by kernel instead of replaying its hipGraph
-        { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }   // 0: wait for every step's samples before enqueuing the next step
+        use_fused = getenv("SS_DECODE_UNFUSED") == nullptr;
+        cross_direct = getenv("SS_CROSS_DIRECT") != nullptr;
+        combine_separate = getenv("SS_COMBINE_FUSED") == nullptr;   // fused prologue measured slower (865 vs 940 xRT): opt-in only
+        { const char* gv = getenv("SS_DECODE_GRAPH"); use_graph = !(gv && gv[0] == '0'); }
+        step_timing = getenv("SS_STEP_TIMING") != nullptr;
+        { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }
+        ln_fused = getenv("SS_DECODE_LN_FUSED") ? atoi(getenv("SS_DECODE_LN_FUSED")) : 0;   // 1 both seams, 2 self-attention seam only, 3 cross-attention seam only
+        if (const char* dp = getenv("SS_CROSS_DIRECT_PAIRS")) direct_pairs = atoi(dp);
         if (const char* sm = getenv("SS_CB_START_MIN")) cb_start_min = std::max(1, atoi(sm));
+        wide_ok = getenv("SS_DECODE_WIDE") ? atoi(getenv("SS_DECODE_WIDE")) != 0 : true;   // 17..64 rows through the fused step (0: the older per-op kernels)
+        wide_ok = wide_ok && ln_fused == 0 && combine_separate && !cross_direct && pl_qkv.NW <= 4 && pl_dd.NW <= 4 && pl_fc1.NW <= 4 && pl_fc2.NW <= 4 && pl_logits.NW <= 4;
+        decode_v2 = narrow_ok && getenv("SS_DECODE_V2") != nullptr && ln_fused == 0 && combine_separate && !cross_direct;
+        if (decode_v2) wide_ok = false;
         if (!donor) {
             int nl = o.n_lanes > 0 ? o.n_lanes : 2;
             if (const char* lv = getenv("SS_LANES")) nl = atoi(lv);
@@ -243,6 +252,9 @@ struct EngineT : EngineBase {
         stop_worker();          // joins the workers of every lane (they live in lane 0); a lane itself has none
         extra_lanes.clear();    // before the weight arena goes
         if (st) (void)hipStreamSynchronize(st);   // a chained decode step may still be in flight: it writes into the pinned buffers freed below
+        if (step_timing && tm_n > 1)
+            fprintf(stderr, "[ss] decode steps %ld: launch call %.1f us, wait for samples %.1f us, host between steps %.1f us (averages)\n", tm_n, tm_launch / tm_n,
+                    tm_wait / tm_n, tm_host / (tm_n - 1));
         if (stage_h) (void)hipHostFree(stage_h);
         for (auto& e : stage_ev) (void)hipEventDestroy(e);
         for (auto& kv : step_graphs) { if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph); }
@@ -405,7 +417,7 @@ struct EngineT : EngineBase {
         if (fp8_enc) cross_sc.alloc((size_t)L * B * 2 * H * n_ctx);
         kself.alloc((size_t)L * S * n_tctx * d * 2); vself.alloc((size_t)L * S * n_tctx * d * 2);
         const int R = 64;  // rows per decode launch
-        lnd.alloc((size_t)R * d * 2); qd.alloc((size_t)R * d * 2); attd.alloc((size_t)R * d * 2);
+        xd.alloc((size_t)R * d * 4); lnd.alloc((size_t)R * d * 2); qd.alloc((size_t)R * d * 2); attd.alloc((size_t)R * d * 2);
         ffd.alloc((size_t)R * 4 * d * 2); logits.alloc((size_t)R * n_vocab_pad * 4); probs.alloc((size_t)R * n_vocab_pad * 4);
         cscratch.alloc((size_t)R * H * 4 * 66 * 4); ctl_d.alloc(2 * R * sizeof(RowCtl));
         samp_d.alloc(R * sizeof(SampleOut)); rowidx_d.alloc(R * 4); rules_scratch.alloc((size_t)R * 64 * 8 * 4);
@@ -533,9 +545,15 @@ struct EngineT : EngineBase {
         launch_gemm<T>(g, st);
     }
 
+    SkinnyDesc sd(const void* X, long ldx, const void* Wt, int M, int N, int K, int kind, const float* bias, void* out, long ldo) {
+        SkinnyDesc g{};
+        g.X = X; g.ldx = ldx; g.W = Wt; g.M = M; g.N = N; g.K = K; g.kind = kind; g.bias = bias; g.out = out; g.ldo = ldo; g.scale = 1.0f;
+        g.gelu_f16_in = dtype_is_f16; g.d = d;
+        return g;
+    }
     // ---- fused decode step (M <= 16): 8 launches per layer, see kernels_decode.hip ----
     struct Plan { int S, NW; };
-    Plan pl_qkv, pl_dd, pl_fc1, pl_fc2, pl_logits;
+    Plan pl_qkv, pl_dd, pl_d1, pl_fc1, pl_fc2, pl_logits;
     DBuf xa, xb, p1, pq, p2, p3;
     void plan_decode() {
         dec_gemv_plan(3 * d, d, &pl_qkv.S, &pl_qkv.NW); pl_qkv.S = 1; fix_nw(pl_qkv, d);
@@ -543,12 +561,28 @@ struct EngineT : EngineBase {
         dec_gemv_plan(4 * d, d, &pl_fc1.S, &pl_fc1.NW); pl_fc1.S = 1; fix_nw(pl_fc1, d);
         dec_gemv_plan(d, 4 * d, &pl_fc2.S, &pl_fc2.NW);
         pl_logits.S = 1; fix_nw(pl_logits, d);
+        fix_nw(pl_d1, d);   // d x d projections with the whole K sum in one workgroup (residual epilogue, LayerNorm prologue)
+        pn_qkv = plan_narrow(3 * d, d); pn_dd = plan_narrow(d, d); pn_fc1 = plan_narrow(4 * d, d); pn_fc2 = plan_narrow(d, 4 * d);
+        narrow_ok = pn_qkv.NW && pn_dd.NW && pn_fc1.NW && pn_fc2.NW && d <= 2048;
         const size_t pb = (size_t)4 * kPartRows * d * 4;   // <= 4 split-K slots of kPartRows token rows
         xa.alloc((size_t)kPartRows * d * 4); xb.alloc((size_t)kPartRows * d * 4); p1.alloc(pb); pq.alloc(pb); p2.alloc(pb); p3.alloc(pb);
     }
     void fix_nw(Plan& p, int K) {  // direct epilogues need S == 1: pick the widest block whose per-wave k is a multiple of 32 and <= 320
         for (int nw = 4; nw >= 1; nw >>= 1) if (K % nw == 0 && (K / nw) % 32 == 0 && K / nw <= 320) { p.NW = nw; p.S = 1; return; }
         throw Error(SS_ERR_MODEL, "model: width not supported by the fused decode step");
+    }
+    // narrow-tile plan (whole K in one workgroup): fewest waves (<= 16) whose per-wave k is a multiple of 32 and <= 320; output columns per
+    // workgroup so that the grid is a whole number of workgroups per CU where the shape allows (N = 1280: 5 columns -> 256 workgroups)
+    struct NPlan { int NW = 0, NT = 16; };
+    NPlan pn_qkv, pn_dd, pn_fc1, pn_fc2;
+    bool narrow_ok = false;
+    NPlan plan_narrow(int N, int K) {
+        NPlan p;
+        for (int nw = 1; nw <= 16; nw <<= 1) if (K % nw == 0 && (K / nw) % 32 == 0 && K / nw <= 320) { p.NW = nw; break; }
+        const int cus = device_cu_count();
+        const int k = (N + cus * 16 - 1) / (cus * 16);
+        p.NT = std::min(16, std::max(1, (N + cus * k - 1) / (cus * k)));
+        return p;
     }
     DecGemvDesc dgd(int pro, int epi, const void* Wt, int M, int N, int K, int S) {
         DecGemvDesc g{};
@@ -593,7 +627,74 @@ struct EngineT : EngineBase {
         SS_HIP(hipMemcpyAsync(samp_hb[step_parity], samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
         SS_HIP(hipEventRecord(ev_step[step_parity], st));
     }
+    // ---- decode step, 9 launches per layer: no split-K, no partials, no stand-alone reductions (opt-in, measured slower: see decode_v2) ----------
+    // Every projection runs as narrow tiles (pn_*: the whole K sum inside one workgroup), so its epilogue is the real one and the residual
+    // stream x (f32, xa) is updated IN PLACE by the three d-wide projections; the three LayerNorms are prologues of the GEMVs that consume
+    // them (each workgroup normalises the <= 16 rows itself while its weight fragments are in flight).
+    //   QKV[LN1] -> self-attention -> out-proj(+x) -> cross-q[LNc] -> cross-attention -> combine -> out-proj(+x) -> FC1[LN2]+GELU -> FC2(+x)
+    void fused_body2(int M, int n_samp) {
+        const RowCtl* ctl = ctl_d.as<RowCtl>();
+        const long slot_stride = (long)n_tctx * d, layer_stride = (long)S * slot_stride;
+        const long cb_stride = (long)2 * H * n_ctx * 64, cl_stride = (long)B * cb_stride;
+        float* x = xa.as<float>();
+        for (int il = 0; il < L; il++) {
+            const DecL& e = dec[il];
+            {   // LN1 -> QKV; q scaled, K/V appended to the cache.  Layer 0: x = token + positional embedding, written back by workgroup 0
+                DecGemvDesc g = dgd(PRO_LN, DEPI_QKV, e.wqkv, M, 3 * d, d, 1);
+                g.NT = pn_qkv.NT;
+                if (il == 0) { g.ctl = ctl; g.tok_emb = tok_emb; g.pos_emb = dec_pos; g.x_out = x; }
+                else g.x_in = x;
+                g.ln_w = e.ln1w; g.ln_b = e.ln1b; g.bias = e.bqkv; g.out = qd.p; g.ldo = d; g.scale = qscale;
+                g.ctl_rows = ctl; g.kcache = kself.as<T>() + il * layer_stride; g.vcache = vself.as<T>() + il * layer_stride; g.slot_stride = slot_stride;
+                launch_dec_gemv<T>(g, pn_qkv.NW, st);
+            }
+            launch_dec_self_attention<T>(qd.as<T>(), kself.as<T>() + il * layer_stride, vself.as<T>() + il * layer_stride, slot_stride, d, H, ctl, M,
+                                         attd.as<T>(), st);
+            {   // x += bo + Wo a
+                DecGemvDesc g = dgd(PRO_T, DEPI_RES, e.wo, M, d, d, 1);
+                g.NT = pn_dd.NT; g.Xt = attd.p; g.ldx = d; g.bias = e.bo; g.x_in = x; g.x_out = x;
+                launch_dec_gemv<T>(g, pn_dd.NW, st);
+            }
+            {   // LNc -> cross query (raw sums; bias, scale and rounding happen where it is consumed)
+                DecGemvDesc g = dgd(PRO_LN, DEPI_PART, e.wcq, M, d, d, 1);
+                g.NT = pn_dd.NT; g.x_in = x; g.ln_w = e.lncw; g.ln_b = e.lncb; g.part_out = pq.as<float>();
+                launch_dec_gemv<T>(g, pn_dd.NW, st);
+            }
+            const T* kc = cross.as<T>() + il * cl_stride;
+            launch_dec_cross_attention_q<T>(pq.as<float>(), 1, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
+                                            cscratch.as<float>(), st);
+            launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
+            {   // x += bco + Wco a
+                DecGemvDesc g = dgd(PRO_T, DEPI_RES, e.wco, M, d, d, 1);
+                g.NT = pn_dd.NT; g.Xt = attd.p; g.ldx = d; g.bias = e.bco; g.x_in = x; g.x_out = x;
+                launch_dec_gemv<T>(g, pn_dd.NW, st);
+            }
+            {   // LN2 -> FC1 + GELU
+                DecGemvDesc g = dgd(PRO_LN, DEPI_GELU_T, e.w1, M, 4 * d, d, 1);
+                g.NT = pn_fc1.NT; g.x_in = x; g.ln_w = e.ln2w; g.ln_b = e.ln2b; g.bias = e.b1; g.out = ffd.p; g.ldo = 4 * d;
+                launch_dec_gemv<T>(g, pn_fc1.NW, st);
+            }
+            {   // x += b2 + W2 f
+                DecGemvDesc g = dgd(PRO_T, DEPI_RES, e.w2, M, d, 4 * d, 1);
+                g.NT = pn_fc2.NT; g.Xt = ffd.p; g.ldx = 4 * d; g.bias = e.b2; g.x_in = x; g.x_out = x;
+                launch_dec_gemv<T>(g, pn_fc2.NW, st);
+            }
+        }
+        if (n_samp == 0) return;
+        {   // final LayerNorm once (gathering the sampling rows), then logits = x . tok_emb^T
+            DecGemvDesc g = dgd(PRO_LN, DEPI_LOGITS, tok_emb, n_samp, n_vocab_pad, d, 1);
+            g.x_in = x; g.ln_w = lnw; g.ln_b = lnb; g.row_idx = rowidx_d.as<int>();
+            launch_dec_reduce_ln<T>(g, lnd.as<T>(), st);
+            DecGemvDesc q = dgd(PRO_T, DEPI_LOGITS, tok_emb, n_samp, n_vocab_pad, d, 1);
+            q.Xt = lnd.p; q.ldx = d; q.out = logits.p; q.ldo = n_vocab_pad; q.n_valid = n_vocab;
+            launch_dec_gemv<T>(q, pl_logits.NW, st);
+        }
+    }
     void fused_body(int M, int n_samp) {
+        if (decode_v2) {
+            if (fp8_enc) throw Error(SS_ERR_UNSUPPORTED, "fp8: the e4m3 cross cache is only wired into the default decode step (unset SS_DECODE_V2)");
+            fused_body2(M, n_samp); return;
+        }
         const RowCtl* ctl = ctl_d.as<RowCtl>();
         const long slot_stride = (long)n_tctx * d, layer_stride = (long)S * slot_stride;
         const long cb_stride = (long)2 * H * n_ctx * 64, cl_stride = (long)B * cb_stride;
@@ -615,8 +716,19 @@ struct EngineT : EngineBase {
             }
             launch_dec_self_attention<T>(qd.as<T>(), kself.as<T>() + il * layer_stride, vself.as<T>() + il * layer_stride, slot_stride, d, H, ctl, M,
                                          attd.as<T>(), st);
-            const int n_qpart = pl_dd.S;
-            {
+            int n_qpart = pl_dd.S;
+            if (ln_fused == 1 || ln_fused == 2) {
+                // out-projection with the whole K sum in one workgroup: its epilogue IS the residual update (x = x + bo + W a), and the
+                // LayerNorm in front of the cross query is the next GEMV's prologue: two launches instead of four
+                DecGemvDesc g = dgd(PRO_T, DEPI_RES, e.wo, M, d, d, 1);
+                g.Xt = attd.p; g.ldx = d; g.bias = e.bo; g.x_in = xcur; g.x_out = xnext;
+                launch_dec_gemv<T>(g, pl_d1.NW, st);
+                std::swap(xcur, xnext);
+                DecGemvDesc q = dgd(PRO_LN, DEPI_PART, e.wcq, M, d, d, 1);
+                q.x_in = xcur; q.ln_w = e.lncw; q.ln_b = e.lncb; q.part_out = pq.as<float>();
+                launch_dec_gemv<T>(q, pl_d1.NW, st);
+                n_qpart = 1;
+            } else {
                 {   // attention out-projection, split-K partials
                     DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wo, M, d, d, pl_dd.S);
                     g.Xt = attd.p; g.ldx = d; g.part_out = p1.as<float>();
@@ -634,27 +746,40 @@ struct EngineT : EngineBase {
             const T* kc = cross.as<T>() + il * cl_stride;
             // key splits exist to fill the chip when there are few (row, head) pairs; from M * H >= direct_pairs on, one workgroup per pair
             // streams all 1500 keys and writes the normalised output itself: no partials, no combine launch
-            const bool direct = M * H >= direct_pairs;
+            const bool direct = cross_direct || (ln_fused == 0 && M * H >= direct_pairs);
             if (fp8_enc) {   // e4m3 cross cache: the same two forms over codes + exponent bytes (half the bytes of the stream that bounds the pass)
                 const long sc_b = (long)2 * H * n_ctx;
                 launch_dec_cross_attention_f8<T>(pq.as<float>(), n_qpart, e.bcq, qscale, cross.as<unsigned char>() + il * cl_stride,
                                                  cross_sc.as<unsigned char>() + il * (long)B * sc_b, cb_stride, sc_b, d, H, n_ctx, ctl, M,
                                                  direct ? nullptr : cscratch.as<float>(), attd.as<T>(), st);
-                if (!direct) launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
+                if (!direct && combine_separate) launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
             } else if (direct) {
                 launch_dec_cross_attention_direct<T>(pq.as<float>(), n_qpart, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
                                                      attd.as<T>(), st);
             } else {
                 launch_dec_cross_attention_q<T>(pq.as<float>(), n_qpart, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
                                                 cscratch.as<float>(), st);
-                launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
+                if (combine_separate) launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
             }
-            {   // cross out-projection, split-K partials
+            if (!direct && !combine_separate) {   // cross out-projection partials; the split-key combine is this GEMV's prologue
+                DecGemvDesc g = dgd(PRO_COMBINE, DEPI_PART, e.wco, M, d, d, pl_dd.S);
+                g.cross_parts = cscratch.as<float>(); g.part_out = p2.as<float>();
+                launch_dec_gemv<T>(g, pl_dd.NW, st);
+            } else if (ln_fused == 1 || ln_fused == 3) {
+                DecGemvDesc g = dgd(PRO_T, DEPI_RES, e.wco, M, d, d, 1);
+                g.Xt = attd.p; g.ldx = d; g.bias = e.bco; g.x_in = xcur; g.x_out = xnext;
+                launch_dec_gemv<T>(g, pl_d1.NW, st);
+                std::swap(xcur, xnext);
+            } else {
                 DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wco, M, d, d, pl_dd.S);
                 g.Xt = attd.p; g.ldx = d; g.part_out = p2.as<float>();
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
             }
-            {   // x += bco + sum P2; LN2 -> FC1 + GELU
+            if ((ln_fused == 1 || ln_fused == 3) && !direct && combine_separate) {   // LN2 is FC1's prologue
+                DecGemvDesc g = dgd(PRO_LN, DEPI_GELU_T, e.w1, M, 4 * d, d, 1);
+                g.x_in = xcur; g.ln_w = e.ln2w; g.ln_b = e.ln2b; g.bias = e.b1; g.out = ffd.p; g.ldo = 4 * d;
+                launch_dec_gemv<T>(g, pl_fc1.NW, st);
+            } else {   // x += bco + sum P2; LN2 -> FC1 + GELU
                 DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
                 r.x_in = xcur; r.x_out = xnext; r.parts = p2.as<float>(); r.n_parts = pl_dd.S; r.bias_prev = e.bco; r.ln_w = e.ln2w; r.ln_b = e.ln2b;
                 launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
@@ -690,17 +815,89 @@ struct EngineT : EngineBase {
         SS_HIP(hipMemcpyAsync(u_d.p, u_h, (size_t)n_samp * sizeof(double), hipMemcpyHostToDevice, st));
         launch_sample_draw(probs.as<float>(), n_vocab_pad, n_vocab, ctl_rows, n_samp, u_d.as<double>(), samp_d.as<SampleOut>(), st);
     }
-    // one decoder pass (<= kPartRows rows); returns the parity of the result buffer / event to wait on
+    // returns the parity of the result buffer / event to wait on for a fused step, -1 for the skinny path (samp_h after a stream sync)
     int decoder_step(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs) {
-        if (M < 1 || M > kPartRows) throw Error(-1, "internal: decoder pass of " + std::to_string(M) + " rows");
-        decoder_step_fused(M, rc, samp_rows, any_probs);
-        return step_parity;
+        // the fused step carries up to 16 rows in every variant and up to 64 (multi-tile GEMVs) in its default form
+        if (use_fused && (M <= 16 || (wide_ok && M <= kPartRows))) { decoder_step_fused(M, rc, samp_rows, any_probs); return step_parity; }
+        if (fp8_enc) throw Error(SS_ERR_UNSUPPORTED, "fp8: the e4m3 cross cache is only wired into the fused decode step (unset SS_DECODE_UNFUSED / SS_DECODE_WIDE=0)");
+        const int n_samp = (int)samp_rows.size();
+        cnt_passes++; cnt_rows += M;
+        SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
+        if (n_samp) {
+            memcpy(rowidx_h, samp_rows.data(), (size_t)n_samp * 4);
+            SS_HIP(hipMemcpyAsync(rowidx_d.p, rowidx_h, (size_t)n_samp * 4, hipMemcpyHostToDevice, st));
+        }
+        const RowCtl* ctl = ctl_d.as<RowCtl>();
+        if (!use_graph) skinny_body(M, n_samp);
+        else {   // the 17..64-row steps of the sampled attempts and long prompts replay a captured graph too (host launch cost: ~0.7 ms per step)
+            StepGraph& sg = step_graphs[(1 << 20) + M * 1024 + n_samp];
+            if (sg.uses++ == 0) skinny_body(M, n_samp);
+            else {
+                if (!sg.exec) {
+                    SS_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                    try { skinny_body(M, n_samp); } catch (...) { hipGraph_t g = nullptr; (void)hipStreamEndCapture(st, &g); if (g) (void)hipGraphDestroy(g); throw; }
+                    SS_HIP(hipStreamEndCapture(st, &sg.graph));
+                    SS_HIP(hipGraphInstantiate(&sg.exec, sg.graph, nullptr, nullptr, 0));
+                }
+                SS_HIP(hipGraphLaunch(sg.exec, st));
+            }
+        }
+        if (n_samp == 0) return -1;
+        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st);
+        if (any_probs) draw_on_device(ctl + 64, n_samp);
+        SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
+        return -1;
+    }
+    void skinny_body(int M, int n_samp) {
+        const RowCtl* ctl = ctl_d.as<RowCtl>();
+        launch_embed<T>(tok_emb, dec_pos, ctl, M, d, xd.as<float>(), st);
+        const long slot_stride = (long)n_tctx * d, layer_stride = (long)S * slot_stride;
+        const long cb_stride = (long)2 * H * n_ctx * 64, cl_stride = (long)B * cb_stride;
+        for (int il = 0; il < L; il++) {
+            const DecL& e = dec[il];
+            launch_layernorm<T>(xd.as<float>(), e.ln1w, e.ln1b, lnd.as<T>(), M, d, nullptr, st);
+            {
+                SkinnyDesc g = sd(lnd.p, d, e.wqkv, M, 3 * d, d, SK_SELF_QKV, e.bqkv, qd.p, d);
+                g.scale = qscale; g.ctl = ctl; g.kcache = kself.as<T>() + il * layer_stride; g.vcache = vself.as<T>() + il * layer_stride;
+                g.slot_stride = slot_stride;
+                launch_skinny<T>(g, st);
+            }
+            launch_dec_self_attention<T>(qd.as<T>(), kself.as<T>() + il * layer_stride, vself.as<T>() + il * layer_stride, slot_stride, d, H, ctl, M,
+                                         attd.as<T>(), st);
+            launch_skinny<T>(sd(attd.p, d, e.wo, M, d, d, SK_RES_F32, e.bo, xd.p, d), st);
+            launch_layernorm<T>(xd.as<float>(), e.lncw, e.lncb, lnd.as<T>(), M, d, nullptr, st);
+            {
+                SkinnyDesc g = sd(lnd.p, d, e.wcq, M, d, d, SK_STORE_T, e.bcq, qd.p, d);
+                g.scale = qscale;
+                launch_skinny<T>(g, st);
+            }
+            const T* kc = cross.as<T>() + il * cl_stride;
+            launch_dec_cross_attention<T>(qd.as<T>(), kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M, cscratch.as<float>(), attd.as<T>(), st);
+            launch_skinny<T>(sd(attd.p, d, e.wco, M, d, d, SK_RES_F32, e.bco, xd.p, d), st);
+            launch_layernorm<T>(xd.as<float>(), e.ln2w, e.ln2b, lnd.as<T>(), M, d, nullptr, st);
+            launch_skinny<T>(sd(lnd.p, d, e.w1, M, 4 * d, d, SK_GELU_T, e.b1, ffd.p, 4 * d), st);
+            launch_skinny<T>(sd(ffd.p, 4 * d, e.w2, M, d, 4 * d, SK_RES_F32, e.b2, xd.p, d), st);
+        }
+        if (n_samp == 0) return;
+        // gather the sampling rows: final LayerNorm reads x[samp_rows[i]] and writes compact row i
+        launch_layernorm<T>(xd.as<float>(), lnw, lnb, lnd.as<T>(), n_samp, d, rowidx_d.as<int>(), st);
+        {
+            SkinnyDesc g = sd(lnd.p, d, tok_emb, n_samp, n_vocab_pad, d, SK_LOGITS_F32, nullptr, logits.p, n_vocab_pad);
+            g.n_valid = n_vocab;
+            launch_skinny<T>(g, st);
+        }
     }
     DBuf samp_d, rowidx_d, rules_scratch;
     long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0, cnt_admitted = 0, cnt_midstart = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
-    bool use_graph = true, chain_steps = true;
+    bool use_fused = true, cross_direct = false, combine_separate = true, use_graph = true;
+    int ln_fused = 0;
+    bool chain_steps = true;
+    bool wide_ok = true;
     int cb_start_min = 4;     // SS_CB_START_MIN: windows that must be waiting before a running group pauses its decoders for their encoder pass
-    static constexpr int direct_pairs = 320;   // (rows x heads) from which the cross-attention runs unsplit (large-v3: 16 rows; +2.3 % at 32-row passes, -12 % at 8)
+    int direct_pairs = 320;   // SS_CROSS_DIRECT_PAIRS: (rows x heads) from which the cross-attention runs unsplit (large-v3: 16 rows)
+    bool decode_v2 = false;  // SS_DECODE_V2=1: the 9-launch step below (narrow tiles, LayerNorm prologues); measured SLOWER than the 12-launch step
+                             // (2.39 vs 2.18 ms per pass alone, 1304 vs 1533 xRT with two lanes): kept for A/B runs only
+    bool step_timing = false; double tm_launch = 0, tm_wait = 0, tm_host = 0; long tm_n = 0; std::chrono::steady_clock::time_point tm_prev;
 
     RuleConsts rule_consts(const ss_params& P) {
         const Vocab& v = hm.vocab;
@@ -1117,7 +1314,7 @@ struct EngineT : EngineBase {
         // of step t has already written the control blocks of step t+1.  Such a step is enqueued BEFORE the host waits for step t, so
         // the GPU never idles through the sample -> host -> upload -> launch turnaround.  The host still accepts every sample with the
         // same rules one step behind; decoders that end simply ignore their row of the step that was already in flight.
-        const bool simple = chain_steps && rows.size() == decs_in.size() && rows.size() <= (size_t)kPartRows &&
+        const bool simple = chain_steps && use_fused && rows.size() == decs_in.size() && rows.size() <= (size_t)(wide_ok ? kPartRows : 16) &&
                             std::all_of(rows.begin(), rows.end(), [](const RowCtl& c) { return c.temperature <= 0.0f; });
         auto may_continue = [&]() {   // is there a decoder that will still be running after the step that is in flight?
             for (auto& dr : decs_in) {
@@ -1170,12 +1367,21 @@ struct EngineT : EngineBase {
                     samp_rows.push_back(m);
                 }
             }
+            const auto tt0 = std::chrono::steady_clock::now();
             const int par = decoder_step(M, rc, samp_rows, any_probs);
             stage_release();
+            const auto tt1 = std::chrono::steady_clock::now();
             if (samp_rows.empty()) continue;
-            if (simple && may_continue()) launch_chained();
-            SS_HIP(hipEventSynchronize(ev_step[par]));
-            const SampleOut* res = samp_hb[par];
+            if (simple && par >= 0 && may_continue()) launch_chained();
+            if (par >= 0) SS_HIP(hipEventSynchronize(ev_step[par])); else SS_HIP(hipStreamSynchronize(st));
+            const SampleOut* res = par >= 0 ? samp_hb[par] : samp_h;
+            const auto tt2 = std::chrono::steady_clock::now();
+            if (step_timing) {   // SS_STEP_TIMING=1: where the host spends a decode step (printed when the engine is destroyed)
+                tm_launch += std::chrono::duration<double, std::micro>(tt1 - tt0).count();
+                tm_wait += std::chrono::duration<double, std::micro>(tt2 - tt1).count();
+                if (tm_n > 0) tm_host += std::chrono::duration<double, std::micro>(tt0 - tm_prev).count();
+                tm_prev = tt2; tm_n++;
+            }
             for (size_t k = 0; k < samp_rows.size(); k++) {
                 const RowRef& rr = refs[r0 + samp_rows[k]];
                 accept_sample(*rr.w, rr.w->decs[rr.j], state_of(js, rr.w->job), res[k], nullptr);

@@ -34,8 +34,149 @@ template <> struct MfmaA<f16> {
 
 
 // ---------------------------------------------------------------------------------------------
+// encoder flash attention: grid (ceil(Tn/(64*QT)), H, B), 256 threads; wave w owns 16*QT query rows (QT column tiles).
+// K / V^T fragments come straight from L2 into VGPRs (K/V of one head = 384 KB, L2-resident; staging them through LDS
+// measured as pure overhead at this size) and are software-prefetched one 32-key chunk ahead (register double buffer),
+// so the MFMAs of chunk c overlap the loads of chunk c+1.  Each fragment is reused by QT query tiles.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int QT>
+__global__ __launch_bounds__(256) void enc_attn_kernel(const T* __restrict__ q, const T* __restrict__ k, long ld, const T* __restrict__ vT,
+                                                       int Tpad, T* __restrict__ out, long ldo, int H, int Tn) {
+    typedef typename MfmaA<T>::V8 V8;
+    typedef typename MfmaA<T>::V4 V4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    // XCD-aware remap: the dispatcher places consecutive workgroup ids on different XCDs; give each XCD a contiguous
+    // range of logical ids so the query blocks of one (batch, head) share one L2 (K/V fetched once, not once per XCD:
+    // FETCH_SIZE showed 8x the algorithmic bytes without this)
+    const int nqb = (Tn + 64 * QT - 1) / (64 * QT);
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, qq = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    }
+    const int qb = bid % nqb, h = (bid / nqb) % H, b = bid / (nqb * H);
+    const int q0 = qb * (64 * QT) + wave * (16 * QT);
+    if (q0 >= Tn) return;
+    const long rowbase = (long)b * Tn;
+
+    V8 qf[QT][2];
+#pragma unroll
+    for (int qi = 0; qi < QT; qi++) {
+        int qr = q0 + qi * 16 + frow;
+        if (qr > Tn - 1) qr = Tn - 1;
+        const T* p = q + (rowbase + qr) * ld + h * 64 + fg * 8;
+        qf[qi][0] = *(const V8*)p;
+        qf[qi][1] = *(const V8*)(p + 32);
+    }
+    f32x4 o[4][QT];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < QT; j++) o[i][j] = (f32x4){0, 0, 0, 0};
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int j = 0; j < QT; j++) { mrun[j] = -1e30f; lrun[j] = 0.f; }
+    const T* vbase = vT + ((long)(b * H + h) * 64) * Tpad + (long)frow * Tpad + fg * 4;
+    const T* kbase = k + rowbase * ld + h * 64 + fg * 8;
+    const float c2 = 0.125f * 1.44269504088896341f;  // 1/sqrt(64) * log2(e)
+    const int nchunk = (Tn + 31) / 32;
+
+    V8 kf[2][2];
+    V4 vlo[4], vhi[4];
+    auto load_chunk = [&](int kc) {
+        const int key0 = kc * 32;
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) {
+            int kr = key0 + kt * 16 + frow;
+            if (kr > Tn - 1) kr = Tn - 1;
+            const T* p = kbase + (long)kr * ld;
+            kf[kt][0] = *(const V8*)p;
+            kf[kt][1] = *(const V8*)(p + 32);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) {
+            const T* p = vbase + (long)(dt * 16) * Tpad + key0;
+            vlo[dt] = *(const V4*)p;
+            vhi[dt] = *(const V4*)(p + 16);
+        }
+    };
+    load_chunk(0);
+    for (int kc = 0; kc < nchunk; kc++) {
+        const int key0 = kc * 32;
+        // move the prefetched chunk into the working set, then immediately issue the next chunk's loads
+        V8 kw[2][2], vf[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; kt++) { kw[kt][0] = kf[kt][0]; kw[kt][1] = kf[kt][1]; }
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) vf[dt] = (V8){vlo[dt][0], vlo[dt][1], vlo[dt][2], vlo[dt][3], vhi[dt][0], vhi[dt][1], vhi[dt][2], vhi[dt][3]};
+        if (kc + 1 < nchunk) load_chunk(kc + 1);
+        const bool tail = key0 + 32 > Tn;
+#pragma unroll
+        for (int qi = 0; qi < QT; qi++) {
+            f32x4 s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++) {
+                f32x4 a = (f32x4){0, 0, 0, 0};
+                a = MfmaA<T>::mma(kw[kt][0], qf[qi][0], a);
+                a = MfmaA<T>::mma(kw[kt][1], qf[qi][1], a);
+                s[kt] = a;
+            }
+            // softmax in the exp2 domain: p = 2^(s*c - m), c = scale*log2(e); m tracks max(s)*c.  One FMA + one v_exp_f32 per score.
+            float mx = -1e30f;
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (tail && key0 + kt * 16 + fg * 4 + r >= Tn) s[kt][r] = -1e30f;
+                    mx = fmaxf(mx, s[kt][r]);
+                }
+            mx = rows_max(mx);   // VALU permlane swaps, not ds_bpermute: this sits in the softmax dependency chain
+            mx *= c2;
+            if (__any(mx > mrun[qi])) {   // wave-uniform: the running max of most rows stops moving after a few chunks
+                const float mnew = fmaxf(mrun[qi], mx);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[qi] - mnew);
+                mrun[qi] = mnew;
+                lrun[qi] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++) o[dt][qi] *= alpha;
+            }
+            const float mcur = mrun[qi];
+            float psum = 0.f;
+            V8 pf;
+#pragma unroll
+            for (int kt = 0; kt < 2; kt++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c2, -mcur));
+                    psum += pv;
+                    pf[kt * 4 + r] = (T)pv;
+                }
+            lrun[qi] += psum;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) o[dt][qi] = MfmaA<T>::mma(vf[dt], pf, o[dt][qi]);
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < QT; qi++) {
+        const float l = rows_sum(lrun[qi]);
+        const float inv = 1.0f / l;
+        const int qr = q0 + qi * 16 + frow;
+        if (qr < Tn) {
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                V4 ov;
+#pragma unroll
+                for (int r = 0; r < 4; r++) ov[r] = (T)(o[dt][qi][r] * inv);
+                *(V4*)(out + (rowbase + qr) * ldo + h * 64 + dt * 16 + fg * 4) = ov;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // encoder flash attention, LDS-staged form: grid ceil(Tn / (64 QT)) * H * B workgroups of 256 threads; wave w owns 16 QT query rows.
-// The first form of this kernel (tools/experiments/r02_variants/kernels_attn.hip: enc_attn_kernel) let every wave pull its own K / V^T fragments from L2 in 32-key chunks: 8-B pieces of V^T rows and half lines of
+// The version above lets every wave pull its own K / V^T fragments from L2 in 32-key chunks: 8-B pieces of V^T rows and half lines of
 // K rows, i.e. 3x the useful bytes through the CU's L1, re-read by every wave.  Here K and V^T tiles of 64 keys (whole 128-B lines)
 // are DMA'd global -> LDS once per workgroup (global_load_lds, 3-stage ring, one s_barrier per chunk) and shared by the four waves.
 //  * S^T = K Q^T with the K rows of a 32-key group permuted (MFMA row i of tile t <-> key (i>>2)*8 + (t&1)*4 + (i&3)), so the
@@ -57,8 +198,7 @@ __global__ __launch_bounds__(256, 2) void enc_attn_lds_kernel(const T* __restric
     const int frow = lane & 15, fg = lane >> 4;
     const int nqb = (Tn + 64 * QT - 1) / (64 * QT);
     int bid = blockIdx.x;
-    {   // XCD-aware remap: the dispatcher places consecutive workgroup ids on different XCDs; each XCD gets a contiguous range of logical ids
-        // so the query blocks of one (batch, head) share one L2 (K / V fetched once, not once per XCD)
+    {   // XCD-aware remap (see enc_attn_kernel)
         const int nwg = gridDim.x, qq = nwg / 8, rr = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     }
@@ -236,7 +376,21 @@ static void launch_enc_attention_lds(const T* q, const T* k, long ld, const T* v
 
 template <typename T>
 void launch_enc_attention(const T* q, const T* k, long ld, const T* vT, int Tpad, T* out, long ldo, int B, int H, int Tn, hipStream_t st) {
-    launch_enc_attention_lds<T, 4>(q, k, ld, vT, Tpad, out, ldo, B, H, Tn, st);   // 4 query tiles per wave; 2 and 3 measured the same (VALU-bound)
+    static const int qt = getenv("SS_ATTN_QT") ? atoi(getenv("SS_ATTN_QT")) : 3;
+    static const int lds_qt = getenv("SS_ATTN_LDS") ? atoi(getenv("SS_ATTN_LDS")) : 4;   // 0 = the direct-from-L2 kernel
+    if (lds_qt == 4) { launch_enc_attention_lds<T, 4>(q, k, ld, vT, Tpad, out, ldo, B, H, Tn, st); return; }
+    if (lds_qt == 3) { launch_enc_attention_lds<T, 3>(q, k, ld, vT, Tpad, out, ldo, B, H, Tn, st); return; }
+    if (lds_qt == 2) { launch_enc_attention_lds<T, 2>(q, k, ld, vT, Tpad, out, ldo, B, H, Tn, st); return; }
+    if (qt == 4) {
+        dim3 grid(((Tn + 255) / 256) * H * B);
+        enc_attn_kernel<T, 4><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn); SS_LAUNCH_CHECK();
+    } else if (qt == 3) {
+        dim3 grid(((Tn + 191) / 192) * H * B);
+        enc_attn_kernel<T, 3><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn); SS_LAUNCH_CHECK();
+    } else {
+        dim3 grid(((Tn + 127) / 128) * H * B);
+        enc_attn_kernel<T, 2><<<grid, 256, 0, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn); SS_LAUNCH_CHECK();
+    }
 }
 template <typename T>
 void launch_enc_attention_f8(const T* q, const T* k, long ld, const T* vT, int Tpad, unsigned char* out8, long ldo, unsigned char* out_scale, long ldsc, int B, int H, int Tn, hipStream_t st) {
@@ -342,11 +496,80 @@ template void launch_dec_self_attention<bf16>(const bf16*, const bf16*, const bf
 template void launch_dec_self_attention<f16>(const f16*, const f16*, const f16*, long, int, int, const RowCtl*, int, f16*, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
-// decoder cross-attention, second half: flash-decoding combine of the key-split partials (max, sum, o[64]) that dec_cross_attn_q_kernel
-// (kernels_decode.hip; grid (NSPLIT, H, M)) leaves in scratch
+// decoder cross-attention: grid (NSPLIT, H, M), 256 threads; K/V [b][h][Tn][64] contiguous per (b,h);
+// split s covers keys [s*per, (s+1)*per); partial (max, sum, o[64]) to scratch, combined by a second kernel
 // ---------------------------------------------------------------------------------------------
 constexpr int kCrossSplit = 4;
 constexpr int kCrossPart = 66;  // floats per partial: m, l, o[64]
+
+template <typename T>
+__global__ __launch_bounds__(256) void dec_cross_attn_kernel(const T* __restrict__ q, const T* __restrict__ kc, const T* __restrict__ vc,
+                                                             long b_stride, int d, int H, int Tn, const RowCtl* __restrict__ ctl,
+                                                             float* __restrict__ scratch) {
+    typedef typename MfmaA<T>::V8 V8;
+    __shared__ float s_sc[512];
+    __shared__ float s_red[8];
+    __shared__ float s_o[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane >> 3, c = lane & 7;
+    const int sp = blockIdx.x, h = blockIdx.y, m = blockIdx.z;
+    const int per = (Tn + kCrossSplit - 1) / kCrossSplit;
+    const int k_beg = sp * per, k_end = min(Tn, k_beg + per), nk = k_end - k_beg;
+    const RowCtl rc = ctl[m];
+    const T* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
+    const T* V = vc + (long)rc.cross * b_stride + (long)h * Tn * 64;
+    float qv[8];
+    {
+        const V8 t = *(const V8*)(q + (long)m * d + h * 64 + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) qv[e] = (float)t[e];
+    }
+    // phase 1: scores.  One wave-instruction reads 8 key rows x 128 B
+    float mx = -1e30f;
+    for (int i = wave * 8 + r; i < nk; i += 32) {
+        const V8 kv = *(const V8*)(K + (long)(k_beg + i) * 64 + c * 8);
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) a += qv[e] * (float)kv[e];
+        a = sum_lanes8(a);
+        if (c == 0) s_sc[i] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) s_red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    float sum = 0.f;
+    for (int i = tid; i < nk; i += 256) {
+        const float p = (float)(T)__expf(s_sc[i] - mx);
+        s_sc[i] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) s_red[4 + wave] = sum;
+    __syncthreads();
+    sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    // phase 2: o[c*8+e] += p[key] V[key][c*8+e]
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = wave * 8 + r; i < nk; i += 32) {
+        const V8 vv = *(const V8*)(V + (long)(k_beg + i) * 64 + c * 8);
+        const float p = s_sc[i];
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += p * (float)vv[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        acc[e] = sum_stride8(acc[e]);
+    }
+    if (r == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) s_o[wave][c * 8 + e] = acc[e];
+    }
+    __syncthreads();
+    float* part = scratch + ((long)(m * H + h) * kCrossSplit + sp) * kCrossPart;
+    if (tid < 64) part[2 + tid] = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
+    if (tid == 0) { part[0] = mx; part[1] = sum; }
+}
 
 template <typename T>
 __global__ void dec_cross_combine_kernel(const float* __restrict__ scratch, int d, int H, T* __restrict__ out) {
@@ -369,10 +592,20 @@ __global__ void dec_cross_combine_kernel(const float* __restrict__ scratch, int 
 }
 
 template <typename T>
+void launch_dec_cross_attention(const T* q, const T* kc, const T* vc, long b_stride, int d, int H, int Tn, const RowCtl* ctl, int M, float* scratch,
+                                T* out, hipStream_t st) {
+    if ((Tn + kCrossSplit - 1) / kCrossSplit > 512) throw Error(-1, "cross attention: n_audio_ctx too large");
+    dim3 grid(kCrossSplit, H, M);
+    dec_cross_attn_kernel<T><<<grid, 256, 0, st>>>(q, kc, vc, b_stride, d, H, Tn, ctl, scratch); SS_LAUNCH_CHECK();
+    dec_cross_combine_kernel<T><<<M, 256, 0, st>>>(scratch, d, H, out); SS_LAUNCH_CHECK();
+}
+template <typename T>
 void launch_dec_cross_combine(const float* scratch, int d, int H, int M, T* out, hipStream_t st) {
     dec_cross_combine_kernel<T><<<M, 256, 0, st>>>(scratch, d, H, out); SS_LAUNCH_CHECK();
 }
 template void launch_dec_cross_combine<bf16>(const float*, int, int, int, bf16*, hipStream_t);
 template void launch_dec_cross_combine<f16>(const float*, int, int, int, f16*, hipStream_t);
+template void launch_dec_cross_attention<bf16>(const bf16*, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int, float*, bf16*, hipStream_t);
+template void launch_dec_cross_attention<f16>(const f16*, const f16*, const f16*, long, int, int, int, const RowCtl*, int, float*, f16*, hipStream_t);
 
 }  // namespace ss

@@ -1,23 +1,27 @@
-// Decode-step kernels for gfx950: one token row for each of up to 64 sequences (a decoder PASS of the batched engine).
+// Fused decode-step GEMVs for gfx950 (M <= 16 rows: one token for each of up to 16 sequences).
 //
-// A decoder pass is HBM-bound (1.6 GB of decoder weights + rows x 246 MB of cross-KV for large-v3) but, launched as one small kernel per
-// graph node the way ggml does (/root/reference/resources/ggml-metal.metal:1307-1363 kernel_mul_mv_f16_f32, :571-621 kernel_norm, :54-151 add/mul),
-// it is launch/latency-bound: ~350 dependent launches per step.  Here a layer is 11-12 launches:
-//   dec_reduce_ln_kernel   residual add + bias of the previous projection + deterministic reduction of its split-K partials (+ token/positional
-//                          embedding for layer 0) -> LayerNorm -> f16/bf16 rows                                           (one wave per row)
-//   dec_gemv_kernel        <= 16 rows: weight fragments AND activation fragments go straight from HBM/L2 into VGPRs, all loads issued before
-//                          the first 16x16x32 MFMA (16-row weight tile = A operand, token rows = B operand); epilogues: q/k/v scaling +
-//                          KV-cache append, GELU, logits, or raw split-K partials for the next reduce
-//   dec_gemv_wide_kernel   17..64 rows: the same with 2 or 4 column tiles fed by one fetch of the weight fragments
-//   dec_cross_attn_q(8)_kernel   cross-attention over the 1500 encoder positions with the q projection's reduction in its prologue
-// Split-K goes across workgroups (grid = N/16 x S) so that N = d projections still launch >= 256 workgroups; partials are summed in a fixed
-// order by the consumer, so results are run-to-run identical (no float atomics).
-// Variants measured slower and archived (tools/experiments/r02_variants/kernels_decode.hip): LayerNorm / flash-decoding-combine prologues inside the
-// GEMV, narrow output tiles without split-K, a residual-update epilogue, non-temporal weight loads (-1.2 %).
+// A decoder step is HBM-bound (1.8 GB of weights + B x 246 MB of cross-KV per step for large-v3) but, launched as one
+// small kernel per graph node the way ggml does (/root/reference/resources/ggml-metal.metal:1307-1363 kernel_mul_mv_f16_f32,
+// :571-621 kernel_norm, :54-151 add/mul), it is launch/latency-bound: ~350 dependent launches per step.  Here every
+// projection is ONE launch that fills the chip and carries its neighbours with it:
+//   prologue : residual add + bias of the previous projection + deterministic reduction of its split-K partials
+//              (+ token/positional embedding for layer 0) -> LayerNorm -> f16/bf16 operand tile in LDS;
+//              or the flash-decoding combine of the cross-attention partials
+//   body     : weight fragments are prefetched into VGPRs BEFORE the prologue (both HBM latencies overlap), then
+//              16x16x32 MFMAs with the 16-row weight tile as A operand and the (<=16) token rows as B operand
+//   epilogue : q/k/v scaling + KV-cache append, GELU, logits, or raw split-K partials for the next prologue
+// Split-K goes across workgroups (grid = N/16 x S) so that N = d projections still launch >= 256 workgroups; partials
+// are summed in a fixed order by the consumer, so results are run-to-run identical (no float atomics).
 #include "kernels.h"
 #include "wave_ops.h"
 
-#define SS_LDW(p) (*(p))   // streamed-once operands (decoder weights, cross K/V): plain loads
+// streamed-once operands (decoder weights, cross K/V).  Non-temporal loads (MI355X_MICROARCH.md "nt-weights") measured 1.2 % SLOWER here
+// (A/B/A/B on one box: 2.28 vs 2.25 ms per step), so plain loads are the default; -DSS_NT builds the nt variant.
+#ifdef SS_NT
+#define SS_LDW(p) __builtin_nontemporal_load(p)
+#else
+#define SS_LDW(p) (*(p))
+#endif
 
 
 namespace ss {
@@ -46,12 +50,13 @@ template <> __device__ __forceinline__ float gelu_in_round_d<bf16>(float x, int)
 template <> __device__ __forceinline__ float gelu_in_round_d<f16>(float x, int on) { return on ? (float)(f16)x : x; }
 
 constexpr int kMaxFrag = 10;      // <= 320 k per wave
+constexpr int kXsPad = 8;         // LDS row padding (elements)
 constexpr int kCrossSplitD = 4, kCrossPartD = 66;
 
 // x = [x_in | tok+pos embedding] + bias_prev + sum_p parts[p]  (fixed order, branch-free: up to 4 partial slots, unused
 // slots re-read slot 0 with weight 0 so that every load is independent and in flight together), optional write-back,
 // LayerNorm over the full row, normalised columns [kbeg, kbeg+kslice) written to dst as T.  One wave per row.
-template <typename T, int NI>
+template <typename T, int NI, bool PLAIN = false>   // PLAIN: x = x_in only (no embedding, partials, bias or write-back): the fused-prologue form
 __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bool write_x, int kbeg, int kslice, T* dst) {
     // NI float4 per lane cover the row (d <= NI*256); lanes past the end load a clamped (valid) address and are masked,
     // so no load sits behind a divergent branch: all of them are in flight together.
@@ -65,7 +70,11 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
     f32x4 ww[NI], bb[NI];   // issued with the row loads: the LayerNorm affine must not cost its own memory round trip
 #pragma unroll
     for (int i = 0; i < NI; i++) { ww[i] = *(const f32x4*)(g.ln_w + cc[i]); bb[i] = *(const f32x4*)(g.ln_b + cc[i]); }
-    if (g.ctl) {  // layer 0: token + positional embedding (replaces ggml get_rows + add)
+    if constexpr (PLAIN) {
+        const float* xr = g.x_in + (long)r * d;
+#pragma unroll
+        for (int i = 0; i < NI; i++) v[i] = *(const f32x4*)(xr + cc[i]);
+    } else if (g.ctl) {  // layer 0: token + positional embedding (replaces ggml get_rows + add)
         const RowCtl rc = g.ctl[r];
         const T* te = (const T*)g.tok_emb + (long)rc.token * d;
         const float* pe = g.pos_emb + (long)rc.pos * d;
@@ -101,9 +110,11 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
         if (!ok[i]) v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         sum += v[i][0] + v[i][1] + v[i][2] + v[i][3];
     }
-    if (write_x && g.x_out) {
+    if constexpr (!PLAIN) {
+        if (write_x && g.x_out) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) if (ok[i]) *(f32x4*)(g.x_out + (long)r * d + cc[i]) = v[i];
+            for (int i = 0; i < NI; i++) if (ok[i]) *(f32x4*)(g.x_out + (long)r * d + cc[i]) = v[i];
+        }
     }
     sum = wave_sum(sum);
     const float mean = sum / d;
@@ -125,7 +136,8 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
     }
 }
 
-// one wave per row
+// stand-alone form (one wave per row): used in front of GEMVs with thousands of workgroups (logits), where a per-workgroup
+// prologue would repeat the reduction too often
 template <typename T, int NI>
 __global__ __launch_bounds__(64) void dec_reduce_ln_kernel(DecGemvDesc g, T* out) {
     ln_row<T, NI>(g, blockIdx.x, threadIdx.x, true, 0, g.K, out + (long)blockIdx.x * g.K);
@@ -136,6 +148,8 @@ template <typename T, int EPI>
 __device__ __forceinline__ void dec_epilogue(const DecGemvDesc& g, int s, int m, int n, float v) {
     if constexpr (EPI == DEPI_PART) {
         g.part_out[((long)s * kPartRows + m) * g.N + n] = v;
+    } else if constexpr (EPI == DEPI_RES) {   // residual stream: x_out = x_in + bias + W a  (S == 1: the whole K sum is here)
+        g.x_out[(long)m * g.N + n] = (g.x_in[(long)m * g.N + n] + g.bias[n]) + v;
     } else {
         if (g.bias) v += g.bias[n];
         if constexpr (EPI == DEPI_GELU_T) {
@@ -155,19 +169,25 @@ __device__ __forceinline__ void dec_epilogue(const DecGemvDesc& g, int s, int m,
     }
 }
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
+// NT = g.NT output columns per workgroup (1..16; the MFMA tile is 16 wide, rows >= NT are never loaded nor stored).  Narrow tiles are how a
+// projection with few outputs (N = d) still fills the chip WITHOUT split-K: N / NT >= 256 workgroups each own the whole K sum, so the epilogue
+// can be the real one (residual update, q scaling, GELU) and no partials / reduce launch exists.  MAXT = 1024 carries K = 4d in 16 waves.
+template <typename T, int PRO, int EPI, int NI, int MAXT>
+__global__ __launch_bounds__(MAXT) void dec_gemv_kernel(DecGemvDesc g) {
     typedef typename MfmaD<T>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
     const int frow = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * 16, s = blockIdx.y;
+    const int NT = g.NT;
+    const int n0 = blockIdx.x * NT, s = blockIdx.y;
     const int kslice = g.K / g.S, kbeg = s * kslice, kw = kslice / NW, kwb = wave * kw;   // kw % 32 == 0, kw <= 320
     const int nfr = kw / 32, npair = nfr / 2;
-    float* red = (float*)smem_d;   // [NW][16][17]
+    T* xs = (T*)smem_d;                                   // [16][kslice + pad]
+    const int xld = kslice + kXsPad;
+    float* red = (float*)(smem_d + (PRO == PRO_T ? (size_t)0 : (size_t)16 * xld * sizeof(T)));  // [NW][16][17]
 
     // ---- weight prefetch: lane loads 32 contiguous bytes of its row per MFMA pair ----
-    const bool wrow = n0 + frow < g.N;          // this lane's weight row exists
+    const bool wrow = frow < NT && n0 + frow < g.N;          // this lane's weight row exists
     const T* wp = (const T*)g.W + (long)(wrow ? n0 + frow : 0) * g.K + kbeg + kwb;
     V8 wf[kMaxFrag];
 #pragma unroll
@@ -180,8 +200,47 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     }
     V8 wtail = {};
     if ((nfr & 1) && wrow) wtail = SS_LDW((const V8*)(wp + npair * 64 + fg * 8));
+
+    // ---- prologue: build the operand tile xs[m][0..kslice) ----
+    if constexpr (PRO == PRO_LN) {
+        for (int m = wave; m < 16; m += NW) {
+            if (m >= g.M) {
+                for (int c = lane; c < kslice; c += 64) xs[m * xld + c] = (T)0.0f;
+                continue;
+            }
+            if (g.n_parts == 0 && !g.bias_prev && !g.ctl) ln_row<T, NI, true>(g, m, lane, false, kbeg, kslice, xs + m * xld);
+            else ln_row<T, NI>(g, m, lane, blockIdx.x == 0 && s == 0, kbeg, kslice, xs + m * xld);
+        }
+    } else if constexpr (PRO == PRO_COMBINE) {
+        // flash-decoding combine of the cross-attention partials for the columns of this K slice
+        const int H = g.K / 64, h0 = kbeg >> 6, hs = kslice >> 6;   // kslice is a multiple of 64 (checked on the host)
+        float* wtab = red;                                           // [16][hs][5] split weights + denominator (red is reused after the sync)
+        for (int idx = tid; idx < g.M * hs; idx += blockDim.x) {
+            const int m = idx / hs, hh = idx % hs;
+            const float* part = g.cross_parts + (long)(m * H + h0 + hh) * kCrossSplitD * kCrossPartD;
+            const float m0 = part[0], m1 = part[kCrossPartD], m2 = part[2 * kCrossPartD], m3 = part[3 * kCrossPartD];
+            const float l0 = part[1], l1 = part[kCrossPartD + 1], l2 = part[2 * kCrossPartD + 1], l3 = part[3 * kCrossPartD + 1];
+            const float mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+            const float w0 = __expf(m0 - mx), w1 = __expf(m1 - mx), w2 = __expf(m2 - mx), w3 = __expf(m3 - mx);
+            float den = 0.f;                     // same order as dec_cross_combine_kernel: num / den
+            den += w0 * l0; den += w1 * l1; den += w2 * l2; den += w3 * l3;
+            float* wt = wtab + idx * 5;
+            wt[0] = w0; wt[1] = w1; wt[2] = w2; wt[3] = w3; wt[4] = den;
+        }
+        for (int idx = tid + g.M * kslice; idx < 16 * kslice; idx += blockDim.x) xs[(idx / kslice) * xld + idx % kslice] = (T)0.0f;
+        __syncthreads();
+#pragma unroll 4
+        for (int idx = tid; idx < g.M * kslice; idx += blockDim.x) {
+            const int m = idx / kslice, cc = idx % kslice, hh = cc >> 6, j = cc & 63;
+            const float* part = g.cross_parts + (long)(m * H + h0 + hh) * kCrossSplitD * kCrossPartD + 2 + j;
+            const float* wt = wtab + (m * hs + hh) * 5;
+            float num = 0.f;
+            num += wt[0] * part[0]; num += wt[1] * part[kCrossPartD]; num += wt[2] * part[2 * kCrossPartD]; num += wt[3] * part[3 * kCrossPartD];
+            xs[m * xld + cc] = (T)(num / wt[4]);
+        }
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    {
+    if constexpr (PRO == PRO_T) {
         // activations: B fragments straight from L2 into VGPRs, issued together with the weight prefetch (no LDS staging,
         // no barrier before the MFMAs).  Token rows >= M read row 0: MFMA columns are independent and never stored.
         const T* xg = (const T*)g.Xt + (long)(frow < g.M ? frow : 0) * g.ldx + kbeg + kwb;
@@ -203,6 +262,21 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
             }
         }
         if (nfr & 1) acc = MfmaD<T>::mma(wtail, xtail, acc);
+    } else {
+        __syncthreads();
+        const T* xr = xs + frow * xld + kwb;
+#pragma unroll
+        for (int j = 0; j < kMaxFrag / 2; j++) {
+            if (j < npair) {
+                const V8 x0 = *(const V8*)(xr + j * 64 + fg * 16), x1 = *(const V8*)(xr + j * 64 + fg * 16 + 8);
+                acc = MfmaD<T>::mma(wf[2 * j], x0, acc);
+                acc = MfmaD<T>::mma(wf[2 * j + 1], x1, acc);
+            }
+        }
+        if (nfr & 1) {
+            const V8 x0 = *(const V8*)(xr + npair * 64 + fg * 8);
+            acc = MfmaD<T>::mma(wtail, x0, acc);
+        }
     }
     // D[n][m]: lane holds n = fg*4 + r, m = frow
 #pragma unroll
@@ -212,7 +286,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     // ---- epilogue: 16 m x 16 n outputs ----
     for (int idx = tid; idx < 256; idx += blockDim.x) {
         const int m = idx >> 4, nn = idx & 15, n = n0 + nn;
-        if (m < g.M && n < g.N) {
+        if (m < g.M && nn < NT && n < g.N) {
             float v = 0.f;
             for (int w = 0; w < NW; w++) v += red[(w * 16 + m) * 17 + nn];
             dec_epilogue<T, EPI>(g, s, m, n, v);
@@ -220,11 +294,30 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     }
 }
 
-template <typename T, int EPI>
+template <typename T, int PRO, int EPI, int NI, int MAXT>
+static void launch_dg3(const DecGemvDesc& g, int NW, hipStream_t st) {
+    const int kslice = g.K / g.S;
+    size_t red_f = (size_t)NW * 16 * 17, wtab_f = (size_t)16 * (kslice / 64 + 1) * 5;
+    const size_t lds = (PRO == PRO_T ? 0 : (size_t)16 * (kslice + kXsPad) * sizeof(T)) + (red_f > wtab_f ? red_f : wtab_f) * 4;
+    static std::atomic<uint64_t> attr{0};
+    once_per_device(attr, [] { SS_HIP(hipFuncSetAttribute((const void*)dec_gemv_kernel<T, PRO, EPI, NI, MAXT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); });
+    dim3 grid((g.N + g.NT - 1) / g.NT, g.S);
+    dec_gemv_kernel<T, PRO, EPI, NI, MAXT><<<grid, NW * 64, lds, st>>>(g); SS_LAUNCH_CHECK();
+}
+template <typename T, int PRO, int EPI, int NI>
+static void launch_dg2(const DecGemvDesc& g, int NW, hipStream_t st) {
+    if (NW <= 4) launch_dg3<T, PRO, EPI, NI, 256>(g, NW, st);
+    else launch_dg3<T, PRO, EPI, NI, 1024>(g, NW, st);
+}
+template <typename T, int PRO, int EPI>
 static void launch_dg(const DecGemvDesc& g, int NW, hipStream_t st) {
-    const size_t lds = (size_t)NW * 16 * 17 * 4;
-    dim3 grid((g.N + 15) / 16, g.S);
-    dec_gemv_kernel<T, EPI><<<grid, NW * 64, lds, st>>>(g); SS_LAUNCH_CHECK();
+    if constexpr (PRO == PRO_LN) {
+        if (g.K <= 512) launch_dg2<T, PRO, EPI, 2>(g, NW, st);
+        else if (g.K <= 1280) launch_dg2<T, PRO, EPI, 5>(g, NW, st);
+        else launch_dg2<T, PRO, EPI, 8>(g, NW, st);
+    } else {
+        launch_dg2<T, PRO, EPI, 1>(g, NW, st);
+    }
 }
 
 
@@ -336,28 +429,43 @@ template void launch_dec_reduce_ln<bf16>(const DecGemvDesc&, bf16*, hipStream_t)
 template void launch_dec_reduce_ln<f16>(const DecGemvDesc&, f16*, hipStream_t);
 
 template <typename T>
-void launch_dec_gemv(const DecGemvDesc& g, int NW, hipStream_t st) {
-    if (NW < 1 || NW > 4 || (NW & (NW - 1))) throw Error(-1, "dec_gemv: bad wave count");
-    if (g.M < 1 || g.M > kPartRows || g.K % g.S || (g.K / g.S) % NW || ((g.K / g.S) / NW) % 32 || (g.K / g.S) / NW > 320)
-        throw Error(-1, "dec_gemv: bad shape");
-    if (g.epi != DEPI_PART && g.S != 1) throw Error(-1, "dec_gemv: direct epilogues need S == 1");
+void launch_dec_gemv(const DecGemvDesc& g0, int NW, hipStream_t st) {
+    DecGemvDesc g = g0;
+    if (g.NT <= 0) g.NT = 16;
+    if (g.NT > 16 || NW < 1 || NW > 16 || (NW & (NW - 1))) throw Error(-1, "dec_gemv: bad tile / wave count");
     if (g.M > 16) {   // 17..64 rows: the multi-tile kernel
+        if (g.M > kPartRows || g.pro != PRO_T || NW > 4 || g.NT != 16 || g.K % g.S || (g.K / g.S) % NW || ((g.K / g.S) / NW) % 32 || (g.K / g.S) / NW > 320)
+            throw Error(-1, "dec_gemv: bad shape for the 17..64-row kernel");
+        if (g.epi != DEPI_PART && g.S != 1) throw Error(-1, "dec_gemv: direct epilogues need S == 1");
         switch (g.epi) {
             case DEPI_PART: launch_dgw<T, DEPI_PART>(g, NW, st); break;
             case DEPI_QKV: launch_dgw<T, DEPI_QKV>(g, NW, st); break;
             case DEPI_GELU_T: launch_dgw<T, DEPI_GELU_T>(g, NW, st); break;
             case DEPI_LOGITS: launch_dgw<T, DEPI_LOGITS>(g, NW, st); break;
-            default: throw Error(-1, "dec_gemv: unsupported epilogue");
+            default: throw Error(-1, "dec_gemv: unsupported epilogue for the 17..64-row kernel");
         }
         return;
     }
-    switch (g.epi) {
-        case DEPI_PART: launch_dg<T, DEPI_PART>(g, NW, st); break;
-        case DEPI_QKV: launch_dg<T, DEPI_QKV>(g, NW, st); break;
-        case DEPI_GELU_T: launch_dg<T, DEPI_GELU_T>(g, NW, st); break;
-        case DEPI_LOGITS: launch_dg<T, DEPI_LOGITS>(g, NW, st); break;
-        default: throw Error(-1, "dec_gemv: unsupported epilogue");
+    if (g.n_parts > 4) throw Error(-1, "dec_gemv: at most 4 split-K partials");
+    if (g.pro == PRO_COMBINE && (g.K / g.S) % 64) throw Error(-1, "dec_gemv: combine prologue needs K slices of whole heads");
+    if (g.M < 1 || g.M > 16 || g.K % g.S || (g.K / g.S) % NW || ((g.K / g.S) / NW) % 32 || (g.K / g.S) / NW > 320)
+        throw Error(-1, "dec_gemv: bad shape");
+    if (g.epi != DEPI_PART && g.S != 1) throw Error(-1, "dec_gemv: direct epilogues need S == 1");
+    if (g.pro == PRO_LN && g.K > 2048) throw Error(-1, "dec_gemv: LayerNorm prologue needs K <= 2048");
+#define DG(P, E) launch_dg<T, P, E>(g, NW, st)
+    switch (g.pro * 8 + g.epi) {
+        case PRO_LN * 8 + DEPI_QKV: DG(PRO_LN, DEPI_QKV); break;
+        case PRO_LN * 8 + DEPI_PART: DG(PRO_LN, DEPI_PART); break;
+        case PRO_LN * 8 + DEPI_GELU_T: DG(PRO_LN, DEPI_GELU_T); break;
+        case PRO_T * 8 + DEPI_LOGITS: DG(PRO_T, DEPI_LOGITS); break;
+        case PRO_T * 8 + DEPI_PART: DG(PRO_T, DEPI_PART); break;
+        case PRO_T * 8 + DEPI_RES: DG(PRO_T, DEPI_RES); break;
+        case PRO_T * 8 + DEPI_QKV: DG(PRO_T, DEPI_QKV); break;
+        case PRO_T * 8 + DEPI_GELU_T: DG(PRO_T, DEPI_GELU_T); break;
+        case PRO_COMBINE * 8 + DEPI_PART: DG(PRO_COMBINE, DEPI_PART); break;
+        default: throw Error(-1, "dec_gemv: unsupported prologue/epilogue pair");
     }
+#undef DG
 }
 template void launch_dec_gemv<bf16>(const DecGemvDesc&, int, hipStream_t);
 template void launch_dec_gemv<f16>(const DecGemvDesc&, int, hipStream_t);

@@ -1,5 +1,5 @@
-// MFMA GEMMs for gfx950 (CDNA4): the encoder / cross-KV projections (compute-bound, bf16|f16 MFMA roofline).  The decode-step
-// projections (HBM-bound: weights streamed once per pass) live in kernels_decode.hip.
+// MFMA GEMMs for gfx950 (CDNA4): the encoder / cross-KV projections (compute-bound, bf16|f16 MFMA roofline) and the
+// skinny decode-step projections (HBM-bound: weights streamed once per step).
 //
 // Replaces ggml's mul_mat + add + gelu graph nodes that whisper.cpp builds for the encoder conv stem, the QKV/O and
 // FFN projections, the cross-KV precompute and the decoder projections (op inventory in
@@ -183,7 +183,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
 // LDS rows are 64 B (32 k); chunk c of row r sits at position c ^ (3 * ((r >> 3) & 1)), applied on the DMA source
 // address and on the ds_read_b128 side: every 16-lane ds_read_b128 service group then touches 16 distinct 16-B slots.
 // ---------------------------------------------------------------------------------------------
-// (The WM template parameter is a remnant of a 128 x 256, two-workgroups-per-CU variant that measured 15-20 % slower: only WM = 2 is instantiated.)
+// WM = 1 variant: 128 (m) x 256 (n) tile, 256 threads = 4 waves (4 n x 1 m, same 64 n x 128 m wave tile), 3-stage ring of 24 KB
+// = 72 KB, so TWO workgroups share a CU: while one is in its epilogue (bias/GELU/residual VALU work and the output stores, which
+// cost 20-50 % of a tile when exposed) the other one's main loop keeps the matrix pipes busy.
 #ifndef SS_RING
 #define SS_RING 4   // LDS ring depth of the 256 x 256 kernel (-DSS_RING=3|5 for experiments): 3 stages measured +40 % main-loop time, 5 (all 160 KB) +27 %
 #endif
@@ -217,6 +219,15 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     const int nbn = g.N / TN, nbm = (g.M + TM - 1) / TM;
     // persistent: one workgroup per CU walks tiles vb = blockIdx.x + j*gridDim.x (gridDim.x is a multiple of 8, so the XCD
     // of the remap is preserved); the next tile's DMA prologue is issued right behind the previous tile's output stores
+    // All workgroups run tiles of equal duration, so without this they reach their epilogues together and the chip writes
+    // 256 x 128 KB at once (measured: the store-only epilogue then takes 25 % of a tile).  Group j = (blockIdx / 8) % groups
+    // starts j * stagger_ticks later (blockIdx % 8 is the XCD, so every XCD holds all groups): the output bursts interleave
+    // with other groups' main loops.
+    if (g.stagger_ticks > 0) {
+        const long long wait = (long long)((blockIdx.x >> 3) % g.stagger_groups) * g.stagger_ticks;
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
     const T* __restrict__ A = (const T*)g.A;
     const T* __restrict__ W = (const T*)g.W;
     // staging: NP DMA instructions per thread per stage; pass p covers RPP rows of [X tile; W tile] (16 per wave), 4 lanes per 64-B row
@@ -485,6 +496,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
                 asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
                              : "+v"(pk[p][0]), "+v"(pk[p + 1][0]), "+v"(pk[p][1]), "+v"(pk[p + 1][1]));
                 if (!row_ok) continue;
+                if (g.dbg_flags & 1) { asm volatile("" :: "v"(pk[p][0]), "v"(pk[p][1]), "v"(pk[p + 1][0]), "v"(pk[p + 1][1])); continue; }
                 const int n = n0 + wn * 64 + (p + (fg & 1)) * 16 + (fg >> 1) * 8;
                 const u32x4 o16 = {pk[p][0], pk[p][1], pk[p + 1][0], pk[p + 1][1]};
                 if constexpr (KIND == EPI_CROSS_KV) {
@@ -573,18 +585,39 @@ template <typename T, int KIND>
 static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
     static std::atomic<uint64_t> attr128{0};
     once_per_device(attr128, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds)); });
-    if (g.N % TN == 0 && g.K % TK == 0 && g.K >= 4 * TK && g.M >= 1024) {
-        // 256 x 256 tiles, one persistent workgroup per CU (a multiple of 8 so the XCD of the remap is preserved).  Measured and archived under
-        // tools/experiments/r02_variants/: two 128 x 256 workgroups per CU (-15..20 %), a start-time stagger of the workgroups (no change, r03_i: worse).
-        int n_cu = device_cu_count() / 8 * 8;
+    static const bool force128 = getenv("SS_GEMM128") != nullptr;
+    if (!force128 && g.N % TN == 0 && g.K % TK == 0 && g.K >= 4 * TK && g.M >= 1024) {
+        static const bool one_wg = getenv("SS_GEMM_2WG") == nullptr;   // default: 256 x 256, one workgroup per CU; the 128 x 256 two-per-CU form measured 15-20 % slower
+        int n_cu = device_cu_count() / 8 * 8;   // persistent grid, a multiple of 8 so the XCD of the remap is preserved
         if (n_cu < 8) n_cu = 8;
-        // f16-output kinds: half the waves do all the staging (main loop -9 %, their partners' stores drain unobserved); the f32 residual
-        // kinds move 4x the epilogue bytes and measured 20 % slower that way (tools/gemm_bench.cpp)
-        static constexpr bool dma4 = KIND == EPI_STORE_T || KIND == EPI_GELU_T || KIND == EPI_CROSS_KV;
-        const int nwg = (g.N / TN) * ((g.M + G256<2>::TM - 1) / G256<2>::TM);
-        static std::atomic<uint64_t> attr256{0};
-        once_per_device(attr256, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 2, dma4>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
-        gemm256_kernel<T, KIND, 2, dma4><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();
+        static const int st_ticks = getenv("SS_GEMM_STAGGER") ? atoi(getenv("SS_GEMM_STAGGER")) : 0;
+        static const int st_groups = getenv("SS_GEMM_STAGGER_GROUPS") ? atoi(getenv("SS_GEMM_STAGGER_GROUPS")) : 4;
+        GemmDesc gs = g;
+        gs.stagger_ticks = st_ticks; gs.stagger_groups = st_groups > 0 ? st_groups : 1;
+        static const int dbg = getenv("SS_GEMM_DBG") ? atoi(getenv("SS_GEMM_DBG")) : 0;
+        gs.dbg_flags = dbg;
+        const GemmDesc& g = gs;
+        if (one_wg) {
+            // f16-output kinds: half the waves do all the staging (main loop -9 %, their partners' stores drain unobserved); the f32 residual
+            // kinds move 4x the epilogue bytes and measured 20 % slower that way (tools/gemm_bench.cpp)
+            static const char* dma4_env = getenv("SS_GEMM_DMA4");
+            const bool dma4 = dma4_env ? dma4_env[0] == '1' : (KIND == EPI_STORE_T || KIND == EPI_GELU_T || KIND == EPI_CROSS_KV);
+            const int nwg = (g.N / TN) * ((g.M + G256<2>::TM - 1) / G256<2>::TM);
+            if (dma4) {
+                static std::atomic<uint64_t> attr256d{0};
+                once_per_device(attr256d, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
+                gemm256_kernel<T, KIND, 2, true><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();
+                return;
+            }
+            static std::atomic<uint64_t> attr256{0};
+            once_per_device(attr256, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
+            gemm256_kernel<T, KIND, 2><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();
+        } else {
+            static std::atomic<uint64_t> attr128x{0};
+            once_per_device(attr128x, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<1>::kLds)); });
+            const int nwg = (g.N / TN) * ((g.M + G256<1>::TM - 1) / G256<1>::TM);
+            gemm256_kernel<T, KIND, 1><<<nwg < 2 * n_cu ? nwg : 2 * n_cu, 256, G256<1>::kLds, st>>>(g); SS_LAUNCH_CHECK();
+        }
         return;
     }
     const int nwg = (g.N / BN) * ((g.M + BM - 1) / BM);
@@ -607,6 +640,117 @@ void launch_gemm(const GemmDesc& g, hipStream_t st) {
 }
 template void launch_gemm<bf16>(const GemmDesc&, hipStream_t);
 template void launch_gemm<f16>(const GemmDesc&, hipStream_t);
+
+// ---------------------------------------------------------------------------------------------
+// Skinny GEMM (decode steps).  One workgroup = 16 weight rows; its 4 waves split K and reduce through LDS.
+// W tile is the MFMA A operand (16 n x 32 k per instruction, streamed once from HBM straight to VGPRs: no reuse,
+// so no LDS staging); X^T (up to 64 rows = 4 column tiles) is the B operand, re-read from L2.
+// Each lane loads 32 contiguous bytes of a weight row per pair of MFMAs, so 4 lanes cover one 128-B line.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int KIND, int MT>
+__global__ __launch_bounds__(256) void skinny_kernel(SkinnyDesc g) {
+    typedef typename Mfma<T>::V8 V8;
+    __shared__ float red[4][MT][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const T* __restrict__ W = (const T*)g.W;
+    const T* __restrict__ X = (const T*)g.X;
+    const int kslice = g.K / 4, kbeg = wave * kslice;   // K % 128 == 0 checked on the host
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const T* wp = W + (long)(n0 + frow) * g.K + kbeg + fg * 16;
+    const T* xp[MT];
+    bool xok[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        const int m = i * 16 + frow;
+        xok[i] = m < g.M;
+        xp[i] = X + (long)(xok[i] ? m : 0) * g.ldx + kbeg + fg * 16;
+    }
+    // k-slot mapping: MFMA pair j consumes k = kbeg + 64 j + 16 fg + [0,8) and + [8,16)  (same for W and X)
+    const int npair = kslice / 64, tail32 = (kslice % 64) != 0;  // kslice is a multiple of 32
+    const V8 zero = {};
+    for (int j = 0; j < npair; j++) {
+        const V8 w0 = *(const V8*)(wp + j * 64), w1 = *(const V8*)(wp + j * 64 + 8);
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const V8 x0 = xok[i] ? *(const V8*)(xp[i] + j * 64) : zero;
+            const V8 x1 = xok[i] ? *(const V8*)(xp[i] + j * 64 + 8) : zero;
+            acc[i] = Mfma<T>::mma(w0, x0, acc[i]);
+            acc[i] = Mfma<T>::mma(w1, x1, acc[i]);
+        }
+    }
+    if (tail32) {  // last 32 k of the slice: lane group fg takes 8 contiguous
+        const long o = (long)npair * 64 - fg * 16 + fg * 8;
+        const V8 w0 = *(const V8*)(wp + o);
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            const V8 x0 = xok[i] ? *(const V8*)(xp[i] + o) : zero;
+            acc[i] = Mfma<T>::mma(w0, x0, acc[i]);
+        }
+    }
+    // D[n][m]: lane holds n = fg*4 + r, m = frow
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[wave][i][frow][fg * 4 + r] = acc[i][r];
+    __syncthreads();
+    // 16 n x (MT*16) m outputs; thread -> (m = tid / 16, n = tid % 16) per column tile
+    for (int i = 0; i < MT; i++) {
+        const int m = i * 16 + (tid >> 4), nn = tid & 15, n = n0 + nn;
+        if (m >= g.M) continue;
+        float v = red[0][i][tid >> 4][nn] + red[1][i][tid >> 4][nn] + red[2][i][tid >> 4][nn] + red[3][i][tid >> 4][nn];
+        if (g.bias) v += g.bias[n];
+        if constexpr (KIND == SK_STORE_T) {
+            ((T*)g.out)[(long)m * g.ldo + n] = (T)(v * g.scale);
+        } else if constexpr (KIND == SK_GELU_T) {
+            ((T*)g.out)[(long)m * g.ldo + n] = (T)gelu_tanh_f(gelu_in_round<T>(v, g.gelu_f16_in));
+        } else if constexpr (KIND == SK_RES_F32) {
+            float* o = (float*)g.out + (long)m * g.ldo + n;
+            *o = *o + v;
+        } else if constexpr (KIND == SK_LOGITS_F32) {
+            if (n < g.n_valid) ((float*)g.out)[(long)m * g.ldo + n] = v;
+        } else if constexpr (KIND == SK_SELF_QKV) {
+            const int d = g.d;
+            if (n < d) ((T*)g.out)[(long)m * g.ldo + n] = (T)(v * g.scale);
+            else {
+                const RowCtl c = g.ctl[m];
+                const long off = (long)c.slot * g.slot_stride + (long)c.pos * d;
+                if (n < 2 * d) ((T*)g.kcache)[off + (n - d)] = (T)(v * g.scale);
+                else ((T*)g.vcache)[off + (n - 2 * d)] = (T)v;
+            }
+        }
+    }
+}
+
+template <typename T, int KIND>
+static void launch_skinny_kind(const SkinnyDesc& g, hipStream_t st) {
+    const int blocks = (g.N + 15) / 16;
+    if (g.M <= 16) { skinny_kernel<T, KIND, 1><<<blocks, 256, 0, st>>>(g); SS_LAUNCH_CHECK(); }
+    else if (g.M <= 32) { skinny_kernel<T, KIND, 2><<<blocks, 256, 0, st>>>(g); SS_LAUNCH_CHECK(); }
+    else if (g.M <= 48) { skinny_kernel<T, KIND, 3><<<blocks, 256, 0, st>>>(g); SS_LAUNCH_CHECK(); }
+    else { skinny_kernel<T, KIND, 4><<<blocks, 256, 0, st>>>(g); SS_LAUNCH_CHECK(); }
+}
+
+template <typename T>
+void launch_skinny(const SkinnyDesc& g, hipStream_t st) {
+    if (g.K % 128 || g.M <= 0 || g.M > 64) throw Error(-1, "skinny gemm: K must be a multiple of 128 and 1 <= M <= 64");
+    switch (g.kind) {
+        case SK_STORE_T: launch_skinny_kind<T, SK_STORE_T>(g, st); break;
+        case SK_GELU_T: launch_skinny_kind<T, SK_GELU_T>(g, st); break;
+        case SK_RES_F32: launch_skinny_kind<T, SK_RES_F32>(g, st); break;
+        case SK_LOGITS_F32: launch_skinny_kind<T, SK_LOGITS_F32>(g, st); break;
+        case SK_SELF_QKV: launch_skinny_kind<T, SK_SELF_QKV>(g, st); break;
+        default: throw Error(-1, "skinny gemm: bad epilogue kind");
+    }
+}
+template void launch_skinny<bf16>(const SkinnyDesc&, hipStream_t);
+template void launch_skinny<f16>(const SkinnyDesc&, hipStream_t);
+
 
 // ---------------------------------------------------------------------------------------------
 // self-test hook (ss_selftest_gemm): the tiled kernels against a one-thread-per-output reference on seeded operands.  The parity tests

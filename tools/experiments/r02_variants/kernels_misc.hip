@@ -82,6 +82,21 @@ void launch_layernorm_f32out(const float* x, const float* w, const float* b, flo
 template void launch_layernorm_f32out<bf16>(const float*, const float*, const float*, float*, int, int, hipStream_t);
 template void launch_layernorm_f32out<f16>(const float*, const float*, const float*, float*, int, int, hipStream_t);
 
+// ---------------------------------------------------------------------------------------------
+// token + positional embedding
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void embed_kernel(const T* __restrict__ te, const float* __restrict__ pe, const RowCtl* __restrict__ ctl, int d, float* __restrict__ x) {
+    const int m = blockIdx.x;
+    const RowCtl c = ctl[m];
+    for (int i = threadIdx.x; i < d; i += blockDim.x) x[(long)m * d + i] = (float)te[(long)c.token * d + i] + pe[(long)c.pos * d + i];
+}
+template <typename T>
+void launch_embed(const T* te, const float* pe, const RowCtl* ctl, int M, int d, float* x, hipStream_t st) {
+    embed_kernel<T><<<M, 256, 0, st>>>(te, pe, ctl, d, x); SS_LAUNCH_CHECK();
+}
+template void launch_embed<bf16>(const bf16*, const float*, const RowCtl*, int, int, float*, hipStream_t);
+template void launch_embed<f16>(const f16*, const float*, const RowCtl*, int, int, float*, hipStream_t);
 
 template <typename TI, typename TO>
 __global__ void convert_kernel(const TI* __restrict__ in, TO* __restrict__ out, size_t n) {
