@@ -613,6 +613,11 @@ struct EngineT : EngineBase {
                 g.ctl_rows = ctl; g.kcache = kself.as<T>() + il * layer_stride; g.vcache = vself.as<T>() + il * layer_stride; g.slot_stride = slot_stride;
                 launch_dec_gemv<T>(g, pl_qkv.NW, st);
             }
+            // key splits exist to fill the chip when there are few (row, head) pairs; from M * H >= direct_pairs on, one workgroup per pair
+            // streams all 1500 keys and writes the normalised output itself: no partials, no combine launch.  (Folding the row-local projections
+            // around the two attention blocks into such (row, head) workgroups -- 7 launches per layer instead of 11 -- was built, is oracle-green
+            // and measured SLOWER: 4.3-4.45 ms against 3.65 ms per 32-row pass; tools/experiments/r03_fused_attention_blocks/.)
+            const bool direct = M * H >= direct_pairs;
             launch_dec_self_attention<T>(qd.as<T>(), kself.as<T>() + il * layer_stride, vself.as<T>() + il * layer_stride, slot_stride, d, H, ctl, M,
                                          attd.as<T>(), st);
             const int n_qpart = pl_dd.S;
@@ -632,9 +637,6 @@ struct EngineT : EngineBase {
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
             }
             const T* kc = cross.as<T>() + il * cl_stride;
-            // key splits exist to fill the chip when there are few (row, head) pairs; from M * H >= direct_pairs on, one workgroup per pair
-            // streams all 1500 keys and writes the normalised output itself: no partials, no combine launch
-            const bool direct = M * H >= direct_pairs;
             if (fp8_enc) {   // e4m3 cross cache: the same two forms over codes + exponent bytes (half the bytes of the stream that bounds the pass)
                 const long sc_b = (long)2 * H * n_ctx;
                 launch_dec_cross_attention_f8<T>(pq.as<float>(), n_qpart, e.bcq, qscale, cross.as<unsigned char>() + il * cl_stride,

@@ -575,7 +575,7 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
     once_per_device(attr128, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds)); });
     if (g.N % TN == 0 && g.K % TK == 0 && g.K >= 4 * TK && g.M >= 1024) {
         // 256 x 256 tiles, one persistent workgroup per CU (a multiple of 8 so the XCD of the remap is preserved).  Measured and archived under
-        // tools/experiments/r02_variants/: two 128 x 256 workgroups per CU (-15..20 %), a start-time stagger of the workgroups (no change, r03_i: worse).
+        // tools/experiments/r02_variants/: two 128 x 256 workgroups per CU (-15..20 %), a start-time stagger of the workgroups (no change, r03_i: worse); static wave priorities (s_setprio 1 for waves 4-7: -5 %, for the staging waves 0-3: no change, r03_r).
         int n_cu = device_cu_count() / 8 * 8;
         if (n_cu < 8) n_cu = 8;
         // f16-output kinds: half the waves do all the staging (main loop -9 %, their partners' stores drain unobserved); the f32 residual
