@@ -175,6 +175,174 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
     }
 }
 
+// The epilogue of a 256 x 256 tile whose accumulators are laid out as in gemm256_kernel: wave (wm, wn) owns rows [m0 + 128 wm, +128) x columns
+// [n0 + 64 wn, +64), acc[ni][mi] = the 16 x 16 fragment at (column group ni, row group mi); a lane holds 4 consecutive columns of row frow
+// (SWAP: 4 consecutive rows of column frow).  A function of its own so that other main loops can share it (tools/experiments/r03_gemm_8phase/).
+template <typename T, int KIND, bool ST16>
+__device__ __forceinline__ void epilogue256(const GemmDesc& g, f32x4 (&acc)[4][8], const f32x4 (&bias_v)[4], int m0, int n0, int wm, int wn, int frow, int fg) {
+    typedef typename Mfma<T>::V8 V8;
+    typedef typename Mfma<T>::V4 V4;
+    constexpr bool SWAP = (KIND == EPI_VT);
+    // s_memtime stamps (tools/gemm_bench.cpp, SS_TRACE): on FC1 the store-only epilogue is 25 % of a tile, +GELU 28 %, +f32 residual 48 %.
+    // Neither a start-time stagger of the workgroups, nor a second workgroup per CU (128 x 256 tiles), nor an LDS-transposed epilogue that
+    // writes whole 128-B lines (4x fewer requests) shortened it: a CU drains its 128 KB tile at ~10 B/clk whatever the request shape.
+    if constexpr (KIND == EPI_RES_F32 || KIND == EPI_GELU_POS_F32) {
+        // f32 output added to a second f32 operand (residual / positional embedding): the operand rows are loaded one row group AHEAD of
+        // the stores, so each wait for loads leaves the previous group's stores in flight (the compiler counts them into its vmcnt)
+        // every element is read and then written by the same thread exactly once, so treating operand and output as non-aliasing is safe even
+        // when they are the same buffer (x += ...); without it the compiler drains all stores (vmcnt(0)) before each group of loads
+        const float* __restrict__ resp = g.res;
+        const float* __restrict__ posp = g.pos;
+        float* __restrict__ outp = (float*)g.out;
+        auto src_of = [&](int mi, int ni) -> const float* {
+            long m = m0 + wm * 128 + mi * 16 + frow;
+            if (m > g.M - 1) m = g.M - 1;
+            const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+            if constexpr (KIND == EPI_RES_F32) return resp + row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo) + n;
+            else return posp + (long)(m % g.rows_per_batch) * g.N + n;
+        };
+        f32x4 nxt[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) nxt[ni] = *(const f32x4*)src_of(0, ni);
+#pragma unroll
+        for (int mi = 0; mi < 8; mi++) {
+            f32x4 cur[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) cur[ni] = nxt[ni];
+            if (mi + 1 < 8) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ni++) nxt[ni] = *(const f32x4*)src_of(mi + 1, ni);
+            }
+            const long m = m0 + wm * 128 + mi * 16 + frow;
+            if (m >= g.M) continue;
+            const long orow = row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo);
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) {
+                const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+                f32x4 v = acc[ni][mi] + bias_v[ni];
+                if constexpr (KIND == EPI_GELU_POS_F32) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
+                }
+                *(f32x4*)(outp + orow + n) = cur[ni] + v;
+            }
+        }
+    } else if constexpr (ST16) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int mi = 0; mi < 8; mi++) {
+            const long m = m0 + wm * 128 + mi * 16 + frow;
+            const bool row_ok = m < g.M;        // the swaps below involve every lane: no early exit
+            const long orow = row_ok ? row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo) : 0;
+            u32x2 pk[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) {
+                const f32x4 v = acc[ni][mi] + bias_v[ni];
+                V4 o;
+                if constexpr (KIND == EPI_STORE_T) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
+                } else if constexpr (KIND == EPI_GELU_T) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
+                } else {   // EPI_CROSS_KV: the K half of every layer's [K; V] column block is pre-scaled
+                    const int nq = n0 + wn * 64 + ni * 16 + fg * 4;
+                    const float sc = (nq % (2 * g.d)) < g.d ? g.scale : 1.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
+                }
+                pk[ni] = __builtin_bit_cast(u32x2, o);
+            }
+#pragma unroll
+            for (int p = 0; p < 4; p += 2) {
+                // rows (16-lane groups) 1 and 3 of the first register swap with rows 0 and 2 of the second: afterwards a lane with fg even holds
+                // columns [(fg >> 1) * 8, +8) of fragment p, a lane with fg odd the same columns of fragment p + 1
+                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                             : "+v"(pk[p][0]), "+v"(pk[p + 1][0]), "+v"(pk[p][1]), "+v"(pk[p + 1][1]));
+                if (!row_ok) continue;
+                const int n = n0 + wn * 64 + (p + (fg & 1)) * 16 + (fg >> 1) * 8;
+                const u32x4 o16 = {pk[p][0], pk[p][1], pk[p + 1][0], pk[p + 1][1]};
+                if constexpr (KIND == EPI_CROSS_KV) {
+                    const int H = g.d / 64;
+                    const int l = n / (2 * g.d), rem = n % (2 * g.d), kv = rem / g.d, hj = rem % g.d, h = hj >> 6, j = hj & 63;
+                    int b = (int)(m / g.rows_per_batch);
+                    const int t = (int)(m % g.rows_per_batch);
+                    if (g.use_batch_map) b = g.batch_map[b];
+                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j;
+                    *(u32x4*)((T*)g.out + off) = o16;
+                } else {
+                    *(u32x4*)((T*)g.out + orow + n) = o16;
+                }
+            }
+        }
+    } else if constexpr (!SWAP) {
+#pragma unroll
+        for (int mi = 0; mi < 8; mi++) {
+            const long m = m0 + wm * 128 + mi * 16 + frow;
+            if (m >= g.M) continue;
+            const long orow = row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo);
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) {
+                const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+                f32x4 v = acc[ni][mi] + bias_v[ni];
+                if constexpr (KIND == EPI_STORE_T) {
+                    V4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
+                    *(V4*)((T*)g.out + orow + n) = o;
+                } else if constexpr (KIND == EPI_GELU_T) {
+                    V4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
+                    *(V4*)((T*)g.out + orow + n) = o;
+                } else if constexpr (KIND == EPI_RES_F32) {
+                    const f32x4 rsd = *(const f32x4*)(g.res + orow + n);
+                    *(f32x4*)((float*)g.out + orow + n) = rsd + v;
+                } else if constexpr (KIND == EPI_STORE_F32) {
+                    *(f32x4*)((float*)g.out + orow + n) = v;
+                } else if constexpr (KIND == EPI_GELU_POS_F32) {
+                    const f32x4 pe = *(const f32x4*)(g.pos + (long)(m % g.rows_per_batch) * g.N + n);
+                    f32x4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in)) + pe[r];
+                    *(f32x4*)((float*)g.out + orow + n) = o;
+                } else if constexpr (KIND == EPI_CROSS_KV) {
+                    const int H = g.d / 64;
+                    const int l = n / (2 * g.d), rem = n % (2 * g.d), kv = rem / g.d, hj = rem % g.d, h = hj >> 6, j = hj & 63;
+                    int b = (int)(m / g.rows_per_batch);
+                    const int t = (int)(m % g.rows_per_batch);
+                    if (g.use_batch_map) b = g.batch_map[b];
+                    const float sc = kv == 0 ? g.scale : 1.0f;
+                    V4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
+                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j;
+                    *(V4*)((T*)g.out + off) = o;
+                }
+            }
+        }
+    } else {
+        const int H = g.d / 64;
+#pragma unroll
+        for (int ni = 0; ni < 4; ni++) {
+            const int n = n0 + wn * 64 + ni * 16 + frow;
+            const float b = bias_v[ni][0];
+            const int h = n >> 6, j = n & 63;
+#pragma unroll
+            for (int mi = 0; mi < 8; mi++) {
+                const long m = m0 + wm * 128 + mi * 16 + fg * 4;
+                if (m >= g.M) continue;
+                const int bb = (int)(m / g.rows_per_batch), t = (int)(m % g.rows_per_batch);
+                V4 o;
+#pragma unroll
+                for (int r = 0; r < 4; r++) o[r] = (T)(acc[ni][mi][r] + b);
+                *(V4*)((T*)g.out + (((long)(bb * H + h) * 64 + j) * g.Tpad + t)) = o;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // 256 x 256 x 32 tile, 512 threads = 8 waves (4 n x 2 m), each wave 64 n x 128 m = 4 x 8 MFMA tiles (128 acc VGPRs).
 // 4-stage LDS ring (4 x 32 KB), filled by global_load_lds 16 B DMA; three stages stay in flight across the single
@@ -407,164 +575,7 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
         }
     }
     // ---------------- epilogue ----------------
-    // s_memtime stamps (tools/gemm_bench.cpp, SS_TRACE): on FC1 the store-only epilogue is 25 % of a tile, +GELU 28 %, +f32 residual 48 %.
-    // Neither a start-time stagger of the workgroups, nor a second workgroup per CU (128 x 256 tiles), nor an LDS-transposed epilogue that
-    // writes whole 128-B lines (4x fewer requests) shortened it: a CU drains its 128 KB tile at ~10 B/clk whatever the request shape.
-    if constexpr (KIND == EPI_RES_F32 || KIND == EPI_GELU_POS_F32) {
-        // f32 output added to a second f32 operand (residual / positional embedding): the operand rows are loaded one row group AHEAD of
-        // the stores, so each wait for loads leaves the previous group's stores in flight (the compiler counts them into its vmcnt)
-        // every element is read and then written by the same thread exactly once, so treating operand and output as non-aliasing is safe even
-        // when they are the same buffer (x += ...); without it the compiler drains all stores (vmcnt(0)) before each group of loads
-        const float* __restrict__ resp = g.res;
-        const float* __restrict__ posp = g.pos;
-        float* __restrict__ outp = (float*)g.out;
-        auto src_of = [&](int mi, int ni) -> const float* {
-            long m = m0 + wm * 128 + mi * 16 + frow;
-            if (m > g.M - 1) m = g.M - 1;
-            const int n = n0 + wn * 64 + ni * 16 + fg * 4;
-            if constexpr (KIND == EPI_RES_F32) return resp + row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo) + n;
-            else return posp + (long)(m % g.rows_per_batch) * g.N + n;
-        };
-        f32x4 nxt[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ni++) nxt[ni] = *(const f32x4*)src_of(0, ni);
-#pragma unroll
-        for (int mi = 0; mi < 8; mi++) {
-            f32x4 cur[4];
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++) cur[ni] = nxt[ni];
-            if (mi + 1 < 8) {
-#pragma unroll
-                for (int ni = 0; ni < 4; ni++) nxt[ni] = *(const f32x4*)src_of(mi + 1, ni);
-            }
-            const long m = m0 + wm * 128 + mi * 16 + frow;
-            if (m >= g.M) continue;
-            const long orow = row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo);
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++) {
-                const int n = n0 + wn * 64 + ni * 16 + fg * 4;
-                f32x4 v = acc[ni][mi] + bias_v[ni];
-                if constexpr (KIND == EPI_GELU_POS_F32) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] = gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
-                }
-                *(f32x4*)(outp + orow + n) = cur[ni] + v;
-            }
-        }
-    } else if constexpr (ST16) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-        for (int mi = 0; mi < 8; mi++) {
-            const long m = m0 + wm * 128 + mi * 16 + frow;
-            const bool row_ok = m < g.M;        // the swaps below involve every lane: no early exit
-            const long orow = row_ok ? row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo) : 0;
-            u32x2 pk[4];
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++) {
-                const f32x4 v = acc[ni][mi] + bias_v[ni];
-                V4 o;
-                if constexpr (KIND == EPI_STORE_T) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
-                } else if constexpr (KIND == EPI_GELU_T) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (T)gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
-                } else {   // EPI_CROSS_KV: the K half of every layer's [K; V] column block is pre-scaled
-                    const int nq = n0 + wn * 64 + ni * 16 + fg * 4;
-                    const float sc = (nq % (2 * g.d)) < g.d ? g.scale : 1.0f;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
-                }
-                pk[ni] = __builtin_bit_cast(u32x2, o);
-            }
-#pragma unroll
-            for (int p = 0; p < 4; p += 2) {
-                // rows (16-lane groups) 1 and 3 of the first register swap with rows 0 and 2 of the second: afterwards a lane with fg even holds
-                // columns [(fg >> 1) * 8, +8) of fragment p, a lane with fg odd the same columns of fragment p + 1
-                asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
-                             : "+v"(pk[p][0]), "+v"(pk[p + 1][0]), "+v"(pk[p][1]), "+v"(pk[p + 1][1]));
-                if (!row_ok) continue;
-                const int n = n0 + wn * 64 + (p + (fg & 1)) * 16 + (fg >> 1) * 8;
-                const u32x4 o16 = {pk[p][0], pk[p][1], pk[p + 1][0], pk[p + 1][1]};
-                if constexpr (KIND == EPI_CROSS_KV) {
-                    const int H = g.d / 64;
-                    const int l = n / (2 * g.d), rem = n % (2 * g.d), kv = rem / g.d, hj = rem % g.d, h = hj >> 6, j = hj & 63;
-                    int b = (int)(m / g.rows_per_batch);
-                    const int t = (int)(m % g.rows_per_batch);
-                    if (g.use_batch_map) b = g.batch_map[b];
-                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j;
-                    *(u32x4*)((T*)g.out + off) = o16;
-                } else {
-                    *(u32x4*)((T*)g.out + orow + n) = o16;
-                }
-            }
-        }
-    } else if constexpr (!SWAP) {
-#pragma unroll
-        for (int mi = 0; mi < 8; mi++) {
-            const long m = m0 + wm * 128 + mi * 16 + frow;
-            if (m >= g.M) continue;
-            const long orow = row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo);
-#pragma unroll
-            for (int ni = 0; ni < 4; ni++) {
-                const int n = n0 + wn * 64 + ni * 16 + fg * 4;
-                f32x4 v = acc[ni][mi] + bias_v[ni];
-                if constexpr (KIND == EPI_STORE_T) {
-                    V4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
-                    *(V4*)((T*)g.out + orow + n) = o;
-                } else if constexpr (KIND == EPI_GELU_T) {
-                    V4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (T)gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
-                    *(V4*)((T*)g.out + orow + n) = o;
-                } else if constexpr (KIND == EPI_RES_F32) {
-                    const f32x4 rsd = *(const f32x4*)(g.res + orow + n);
-                    *(f32x4*)((float*)g.out + orow + n) = rsd + v;
-                } else if constexpr (KIND == EPI_STORE_F32) {
-                    *(f32x4*)((float*)g.out + orow + n) = v;
-                } else if constexpr (KIND == EPI_GELU_POS_F32) {
-                    const f32x4 pe = *(const f32x4*)(g.pos + (long)(m % g.rows_per_batch) * g.N + n);
-                    f32x4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in)) + pe[r];
-                    *(f32x4*)((float*)g.out + orow + n) = o;
-                } else if constexpr (KIND == EPI_CROSS_KV) {
-                    const int H = g.d / 64;
-                    const int l = n / (2 * g.d), rem = n % (2 * g.d), kv = rem / g.d, hj = rem % g.d, h = hj >> 6, j = hj & 63;
-                    int b = (int)(m / g.rows_per_batch);
-                    const int t = (int)(m % g.rows_per_batch);
-                    if (g.use_batch_map) b = g.batch_map[b];
-                    const float sc = kv == 0 ? g.scale : 1.0f;
-                    V4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
-                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j;
-                    *(V4*)((T*)g.out + off) = o;
-                }
-            }
-        }
-    } else {
-        const int H = g.d / 64;
-#pragma unroll
-        for (int ni = 0; ni < 4; ni++) {
-            const int n = n0 + wn * 64 + ni * 16 + frow;
-            const float b = bias_v[ni][0];
-            const int h = n >> 6, j = n & 63;
-#pragma unroll
-            for (int mi = 0; mi < 8; mi++) {
-                const long m = m0 + wm * 128 + mi * 16 + fg * 4;
-                if (m >= g.M) continue;
-                const int bb = (int)(m / g.rows_per_batch), t = (int)(m % g.rows_per_batch);
-                V4 o;
-#pragma unroll
-                for (int r = 0; r < 4; r++) o[r] = (T)(acc[ni][mi][r] + b);
-                *(V4*)((T*)g.out + (((long)(bb * H + h) * 64 + j) * g.Tpad + t)) = o;
-            }
-        }
-    }
+    epilogue256<T, KIND, ST16>(g, acc, bias_v, m0, n0, wm, wn, frow, fg);
     if (tr && tid == 0) tr[3] = __builtin_amdgcn_s_memtime();
     }  // tile loop
 }
@@ -575,7 +586,7 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
     once_per_device(attr128, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds)); });
     if (g.N % TN == 0 && g.K % TK == 0 && g.K >= 4 * TK && g.M >= 1024) {
         // 256 x 256 tiles, one persistent workgroup per CU (a multiple of 8 so the XCD of the remap is preserved).  Measured and archived under
-        // tools/experiments/r02_variants/: two 128 x 256 workgroups per CU (-15..20 %), a start-time stagger of the workgroups (no change, r03_i: worse); static wave priorities (s_setprio 1 for waves 4-7: -5 %, for the staging waves 0-3: no change, r03_r).
+        // tools/experiments/r02_variants/: two 128 x 256 workgroups per CU (-15..20 %), a start-time stagger of the workgroups (no change, r03_i: worse); static wave priorities (s_setprio 1 for waves 4-7: -5 %, for the staging waves 0-3: no change, r03_r); an 8-phase main loop (tools/experiments/r03_gemm_8phase/: correct, 860-890 against 1090 TF/s at 4096^3).
         int n_cu = device_cu_count() / 8 * 8;
         if (n_cu < 8) n_cu = 8;
         // f16-output kinds: half the waves do all the staging (main loop -9 %, their partners' stores drain unobserved); the f32 residual
