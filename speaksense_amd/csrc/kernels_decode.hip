@@ -5,10 +5,9 @@
 // it is launch/latency-bound: ~350 dependent launches per step.  Here a layer is 11-12 launches:
 //   dec_reduce_ln_kernel   residual add + bias of the previous projection + deterministic reduction of its split-K partials (+ token/positional
 //                          embedding for layer 0) -> LayerNorm -> f16/bf16 rows                                           (one wave per row)
-//   dec_gemv_kernel        <= 16 rows: weight fragments AND activation fragments go straight from HBM/L2 into VGPRs, all loads issued before
-//                          the first 16x16x32 MFMA (16-row weight tile = A operand, token rows = B operand); epilogues: q/k/v scaling +
-//                          KV-cache append, GELU, logits, or raw split-K partials for the next reduce
-//   dec_gemv_wide_kernel   17..64 rows: the same with 2 or 4 column tiles fed by one fetch of the weight fragments
+//   dec_gemv_kernel        weight fragments AND activation fragments go straight from HBM/L2 into VGPRs, all loads issued before the first
+//                          16x16x32 MFMA (16-row weight tile = A operand, 1 / 2 / 4 column tiles of 16 token rows = B operands fed by ONE fetch
+//                          of the weight fragments); epilogues: q/k/v scaling + KV-cache append, GELU, logits, or raw split-K partials
 //   dec_cross_attn_q(8)_kernel   cross-attention over the 1500 encoder positions with the q projection's reduction in its prologue
 // Split-K goes across workgroups (grid = N/16 x S) so that N = d projections still launch >= 256 workgroups; partials are summed in a fixed
 // order by the consumer, so results are run-to-run identical (no float atomics).
@@ -45,7 +44,6 @@ template <typename T> __device__ __forceinline__ float gelu_in_round_d(float x, 
 template <> __device__ __forceinline__ float gelu_in_round_d<bf16>(float x, int) { return x; }
 template <> __device__ __forceinline__ float gelu_in_round_d<f16>(float x, int on) { return on ? (float)(f16)x : x; }
 
-constexpr int kMaxFrag = 10;      // <= 320 k per wave
 constexpr int kCrossSplitD = 4, kCrossPartD = 66;
 
 // x = [x_in | tok+pos embedding] + bias_prev + sum_p parts[p]  (fixed order, branch-free: up to 4 partial slots, unused
@@ -155,135 +153,58 @@ __device__ __forceinline__ void dec_epilogue(const DecGemvDesc& g, int s, int m,
     }
 }
 
-template <typename T, int EPI>
+// k offset (elements, within this wave's k range) of fragment f of a lane group fg: fragments come in pairs that cover 64 k, lane group fg
+// owning the 32 contiguous bytes [16 fg, 16 fg + 16) of a pair; an odd last fragment covers 32 k with 8 per lane group.  W and X use the same map.
+template <int NFR> __device__ __forceinline__ int frag_koff(int f, int fg) {
+    return (NFR & 1) && f == NFR - 1 ? (NFR / 2) * 64 + fg * 8 : (f >> 1) * 64 + fg * 16 + (f & 1) * 8;
+}
+
+// NFR = 32-k fragments per wave (k per wave = 32 NFR <= 320), a template parameter: with a run-time count the loads sat behind branches and
+// hipcc put `s_waitcnt vmcnt(0)` between the weight loads, the activation loads of the first column tile and those of the second -- three
+// dependent memory round trips per GEMV (r03: 10.9 us per 32-row projection in the pipeline).  Now every load of the workgroup -- NFR weight
+// fragments from HBM, CT x NFR activation fragments from L2 -- is issued before the first MFMA.  CT = column tiles of 16 token rows (1, 2, 4).
+template <typename T, int EPI, int CT, int NFR>
 __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     typedef typename MfmaD<T>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
     const int frow = lane & 15, fg = lane >> 4;
     const int n0 = blockIdx.x * 16, s = blockIdx.y;
-    const int kslice = g.K / g.S, kbeg = s * kslice, kw = kslice / NW, kwb = wave * kw;   // kw % 32 == 0, kw <= 320
-    const int nfr = kw / 32, npair = nfr / 2;
-    float* red = (float*)smem_d;   // [NW][16][17]
-
-    // ---- weight prefetch: lane loads 32 contiguous bytes of its row per MFMA pair ----
-    const bool wrow = n0 + frow < g.N;          // this lane's weight row exists
-    const T* wp = (const T*)g.W + (long)(wrow ? n0 + frow : 0) * g.K + kbeg + kwb;
-    V8 wf[kMaxFrag];
-#pragma unroll
-    for (int j = 0; j < kMaxFrag / 2; j++) {
-        wf[2 * j] = V8{}; wf[2 * j + 1] = V8{};
-        if (j < npair && wrow) {
-            wf[2 * j] = SS_LDW((const V8*)(wp + j * 64 + fg * 16));
-            wf[2 * j + 1] = SS_LDW((const V8*)(wp + j * 64 + fg * 16 + 8));
-        }
-    }
-    V8 wtail = {};
-    if ((nfr & 1) && wrow) wtail = SS_LDW((const V8*)(wp + npair * 64 + fg * 8));
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    {
-        // activations: B fragments straight from L2 into VGPRs, issued together with the weight prefetch (no LDS staging,
-        // no barrier before the MFMAs).  Token rows >= M read row 0: MFMA columns are independent and never stored.
-        const T* xg = (const T*)g.Xt + (long)(frow < g.M ? frow : 0) * g.ldx + kbeg + kwb;
-        V8 xf[kMaxFrag];
-#pragma unroll
-        for (int j = 0; j < kMaxFrag / 2; j++) {
-            if (j < npair) {
-                xf[2 * j] = *(const V8*)(xg + j * 64 + fg * 16);
-                xf[2 * j + 1] = *(const V8*)(xg + j * 64 + fg * 16 + 8);
-            }
-        }
-        V8 xtail = {};
-        if (nfr & 1) xtail = *(const V8*)(xg + npair * 64 + fg * 8);
-#pragma unroll
-        for (int j = 0; j < kMaxFrag / 2; j++) {
-            if (j < npair) {
-                acc = MfmaD<T>::mma(wf[2 * j], xf[2 * j], acc);
-                acc = MfmaD<T>::mma(wf[2 * j + 1], xf[2 * j + 1], acc);
-            }
-        }
-        if (nfr & 1) acc = MfmaD<T>::mma(wtail, xtail, acc);
-    }
-    // D[n][m]: lane holds n = fg*4 + r, m = frow
-#pragma unroll
-    for (int r = 0; r < 4; r++) red[(wave * 16 + frow) * 17 + fg * 4 + r] = acc[r];
-    __syncthreads();
-
-    // ---- epilogue: 16 m x 16 n outputs ----
-    for (int idx = tid; idx < 256; idx += blockDim.x) {
-        const int m = idx >> 4, nn = idx & 15, n = n0 + nn;
-        if (m < g.M && n < g.N) {
-            float v = 0.f;
-            for (int w = 0; w < NW; w++) v += red[(w * 16 + m) * 17 + nn];
-            dec_epilogue<T, EPI>(g, s, m, n, v);
-        }
-    }
-}
-
-template <typename T, int EPI>
-static void launch_dg(const DecGemvDesc& g, int NW, hipStream_t st) {
-    const size_t lds = (size_t)NW * 16 * 17 * 4;
-    dim3 grid((g.N + 15) / 16, g.S);
-    dec_gemv_kernel<T, EPI><<<grid, NW * 64, lds, st>>>(g); SS_LAUNCH_CHECK();
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// The same GEMV for 17..64 token rows (CT = 2 or 4 column tiles of 16): the weight fragments are fetched ONCE and used by CT MFMAs each, so
-// a decoder pass over up to 64 rows (several device batches merged, best_of = 5 sampled decoders, long prompts) still streams the decoder
-// weights once.  Activations straight from L2 (PRO_T); epilogues as above.
-// ---------------------------------------------------------------------------------------------
-template <typename T, int EPI, int CT>
-__global__ __launch_bounds__(256) void dec_gemv_wide_kernel(DecGemvDesc g) {
-    typedef typename MfmaD<T>::V8 V8;
-    extern __shared__ __attribute__((aligned(16))) char smem_d[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
-    const int frow = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * 16, s = blockIdx.y;
-    const int kslice = g.K / g.S, kbeg = s * kslice, kw = kslice / NW, kwb = wave * kw;
-    const int nfr = kw / 32, npair = nfr / 2;
+    const int kbeg = s * (g.K / g.S) + wave * (32 * NFR);
     float* red = (float*)smem_d;   // [NW][CT*16][17]
-    const T* wp = (const T*)g.W + (long)(n0 + frow) * g.K + kbeg + kwb;
-    V8 wf[kMaxFrag];
+    const T* wp = (const T*)g.W + (long)(n0 + frow) * g.K + kbeg;      // N is a multiple of 16 (checked on the host): every weight row exists
+    V8 wf[NFR];
 #pragma unroll
-    for (int j = 0; j < kMaxFrag / 2; j++) {
-        if (j < npair) {
-            wf[2 * j] = SS_LDW((const V8*)(wp + j * 64 + fg * 16));
-            wf[2 * j + 1] = SS_LDW((const V8*)(wp + j * 64 + fg * 16 + 8));
-        }
-    }
-    V8 wtail = {};
-    if (nfr & 1) wtail = SS_LDW((const V8*)(wp + npair * 64 + fg * 8));
+    for (int f = 0; f < NFR; f++) wf[f] = SS_LDW((const V8*)(wp + frag_koff<NFR>(f, fg)));
+    // activations: B fragments straight from L2 into VGPRs (no LDS staging, no barrier before the MFMAs).  Token rows >= M read row 0: MFMA
+    // columns are independent and never stored.  Two column tiles' loads are in flight at a time (CT = 4: 2 + 2, to stay under 168 VGPRs).
     f32x4 acc[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ct++) {
-        acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int m = ct * 16 + frow;
-        const T* xg = (const T*)g.Xt + (long)(m < g.M ? m : 0) * g.ldx + kbeg + kwb;
-        V8 xf[kMaxFrag];
+    for (int c0 = 0; c0 < CT; c0 += 2) {
+        constexpr int CB = CT >= 2 ? 2 : 1;
+        V8 xf[CB][NFR];
 #pragma unroll
-        for (int j = 0; j < kMaxFrag / 2; j++) {
-            if (j < npair) {
-                xf[2 * j] = *(const V8*)(xg + j * 64 + fg * 16);
-                xf[2 * j + 1] = *(const V8*)(xg + j * 64 + fg * 16 + 8);
-            }
-        }
-        V8 xtail = {};
-        if (nfr & 1) xtail = *(const V8*)(xg + npair * 64 + fg * 8);
+        for (int ct = 0; ct < CB; ct++) {
+            const int m = (c0 + ct) * 16 + frow;
+            const T* xg = (const T*)g.Xt + (long)(m < g.M ? m : 0) * g.ldx + kbeg;
 #pragma unroll
-        for (int j = 0; j < kMaxFrag / 2; j++) {
-            if (j < npair) {
-                acc[ct] = MfmaD<T>::mma(wf[2 * j], xf[2 * j], acc[ct]);
-                acc[ct] = MfmaD<T>::mma(wf[2 * j + 1], xf[2 * j + 1], acc[ct]);
-            }
+            for (int f = 0; f < NFR; f++) xf[ct][f] = *(const V8*)(xg + frag_koff<NFR>(f, fg));
         }
-        if (nfr & 1) acc[ct] = MfmaD<T>::mma(wtail, xtail, acc[ct]);
+        __builtin_amdgcn_sched_barrier(0);     // every load above is issued before the first MFMA below (left alone, hipcc trickles them in between the MFMAs to save registers)
+#pragma unroll
+        for (int ct = 0; ct < CB; ct++) {
+            acc[c0 + ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < NFR; f++) acc[c0 + ct] = MfmaD<T>::mma(wf[f], xf[ct][f], acc[c0 + ct]);
+        }
     }
+    // D[n][m]: lane holds n = fg*4 + r, m = frow
 #pragma unroll
     for (int ct = 0; ct < CT; ct++)
 #pragma unroll
         for (int r = 0; r < 4; r++) red[((wave * CT + ct) * 16 + frow) * 17 + fg * 4 + r] = acc[ct][r];
     __syncthreads();
+    // ---- epilogue: (CT * 16) m x 16 n outputs ----
     for (int idx = tid; idx < CT * 256; idx += blockDim.x) {
         const int m = idx >> 4, nn = idx & 15, n = n0 + nn;
         if (m < g.M && n < g.N) {
@@ -293,16 +214,34 @@ __global__ __launch_bounds__(256) void dec_gemv_wide_kernel(DecGemvDesc g) {
         }
     }
 }
-template <typename T, int EPI, int CT>
-static void launch_dgw2(const DecGemvDesc& g, int NW, hipStream_t st) {
+
+template <typename T, int EPI, int CT, int NFR>
+static void launch_dg4(const DecGemvDesc& g, int NW, hipStream_t st) {
     const size_t lds = (size_t)NW * CT * 16 * 17 * 4;
-    dim3 grid((g.N + 15) / 16, g.S);
-    dec_gemv_wide_kernel<T, EPI, CT><<<grid, NW * 64, lds, st>>>(g); SS_LAUNCH_CHECK();
+    dim3 grid(g.N / 16, g.S);
+    dec_gemv_kernel<T, EPI, CT, NFR><<<grid, NW * 64, lds, st>>>(g); SS_LAUNCH_CHECK();
+}
+template <typename T, int EPI, int CT>
+static void launch_dg3(const DecGemvDesc& g, int NW, hipStream_t st) {
+    switch (((g.K / g.S) / NW) / 32) {
+        case 1: launch_dg4<T, EPI, CT, 1>(g, NW, st); break;
+        case 2: launch_dg4<T, EPI, CT, 2>(g, NW, st); break;
+        case 3: launch_dg4<T, EPI, CT, 3>(g, NW, st); break;
+        case 4: launch_dg4<T, EPI, CT, 4>(g, NW, st); break;
+        case 5: launch_dg4<T, EPI, CT, 5>(g, NW, st); break;
+        case 6: launch_dg4<T, EPI, CT, 6>(g, NW, st); break;
+        case 7: launch_dg4<T, EPI, CT, 7>(g, NW, st); break;
+        case 8: launch_dg4<T, EPI, CT, 8>(g, NW, st); break;
+        case 9: launch_dg4<T, EPI, CT, 9>(g, NW, st); break;
+        case 10: launch_dg4<T, EPI, CT, 10>(g, NW, st); break;
+        default: throw Error(-1, "dec_gemv: k per wave must be 32..320");
+    }
 }
 template <typename T, int EPI>
-static void launch_dgw(const DecGemvDesc& g, int NW, hipStream_t st) {
-    if (g.M <= 32) launch_dgw2<T, EPI, 2>(g, NW, st);
-    else launch_dgw2<T, EPI, 4>(g, NW, st);
+static void launch_dg(const DecGemvDesc& g, int NW, hipStream_t st) {
+    if (g.M <= 16) launch_dg3<T, EPI, 1>(g, NW, st);
+    else if (g.M <= 32) launch_dg3<T, EPI, 2>(g, NW, st);
+    else launch_dg3<T, EPI, 4>(g, NW, st);
 }
 
 // choose split-K so the grid has >= ~256 workgroups; per-wave k must be a multiple of 32 and <= 320
@@ -338,19 +277,9 @@ template void launch_dec_reduce_ln<f16>(const DecGemvDesc&, f16*, hipStream_t);
 template <typename T>
 void launch_dec_gemv(const DecGemvDesc& g, int NW, hipStream_t st) {
     if (NW < 1 || NW > 4 || (NW & (NW - 1))) throw Error(-1, "dec_gemv: bad wave count");
-    if (g.M < 1 || g.M > kPartRows || g.K % g.S || (g.K / g.S) % NW || ((g.K / g.S) / NW) % 32 || (g.K / g.S) / NW > 320)
+    if (g.M < 1 || g.M > kPartRows || g.N % 16 || g.K % g.S || (g.K / g.S) % NW || ((g.K / g.S) / NW) % 32 || (g.K / g.S) / NW > 320)
         throw Error(-1, "dec_gemv: bad shape");
     if (g.epi != DEPI_PART && g.S != 1) throw Error(-1, "dec_gemv: direct epilogues need S == 1");
-    if (g.M > 16) {   // 17..64 rows: the multi-tile kernel
-        switch (g.epi) {
-            case DEPI_PART: launch_dgw<T, DEPI_PART>(g, NW, st); break;
-            case DEPI_QKV: launch_dgw<T, DEPI_QKV>(g, NW, st); break;
-            case DEPI_GELU_T: launch_dgw<T, DEPI_GELU_T>(g, NW, st); break;
-            case DEPI_LOGITS: launch_dgw<T, DEPI_LOGITS>(g, NW, st); break;
-            default: throw Error(-1, "dec_gemv: unsupported epilogue");
-        }
-        return;
-    }
     switch (g.epi) {
         case DEPI_PART: launch_dg<T, DEPI_PART>(g, NW, st); break;
         case DEPI_QKV: launch_dg<T, DEPI_QKV>(g, NW, st); break;
