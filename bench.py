@@ -212,6 +212,8 @@ def main():
     ap.add_argument("--device-batch", type=int, default=32, help="engine max_batch: chunks the batch former may put into ONE device batch (0 = --batch). "
                     "Larger than --batch with --inflight > 1 lets it merge queued steps into one decode chain (more rows per weight pass)")
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state estimate reported beside the headline")
+    ap.add_argument("--headline-only", action="store_true", help="only the timed region (no steady-state, host-PCM, unloaded-latency or batch8_strict side measurements): "
+                    "the counter passes of tools/gpu.sh pmc use it so that every decoder pass they count belongs to the benchmarked configuration")
     ap.add_argument("--host-pcm", action="store_true", help="headline steps take host f32 PCM (H2D inside the timed region) instead of HBM-resident PCM")
     ap.add_argument("--dry-run", action="store_true", help="CPU test of the sharding/timing plumbing: stub workload, gloo backend")
     ap.add_argument("--dist-backend", default=None, help="override (default nccl on GPU); 'gloo' + SS_BENCH_DEVICE=0 lets several ranks share one GPU for testing")
@@ -338,7 +340,7 @@ def main():
     # collects that return at once after it belong to the same burst (a device batch completes several steps together).  Between two blocked
     # collects p < q exactly idx_q - idx_p steps completed in T_q - T_p: no step finished before the window is counted, none is cut off.
     steady = None
-    if inflight > 1 and not args.no_steady:
+    if inflight > 1 and not args.no_steady and not args.headline_only:
         for _ in range(2 * inflight):
             step()
         marks_ss = []
@@ -357,13 +359,16 @@ def main():
     # the other entry point (SURVEY.md section 8d counts xRT "from host f32 PCM"): a few steps, reported beside the headline, never as `value`
     state["host"] = not args.host_pcm
     n_alt = max(inflight, min(4, args.steps))
-    dt_alt, _ = timed_steps(step, n_alt, 1, dist, torch.cuda.synchronize, drain)
-    value_alt = n_gpus * args.batch * n_alt * CHUNK_SEC / dt_alt
+    if args.headline_only:
+        value_alt = float("nan")
+    else:
+        dt_alt, _ = timed_steps(step, n_alt, 1, dist, torch.cuda.synchronize, drain)
+        value_alt = n_gpus * args.batch * n_alt * CHUNK_SEC / dt_alt
 
     # latency without queueing: one step at a time (submit 8 chunks, wait), the other end of the throughput/latency trade the headline makes
     state["host"] = args.host_pcm
     del latencies[:]
-    for _ in range(3):
+    for _ in range(0 if args.headline_only else 3):
         step()
         drain()
     lat_unloaded = list(latencies)[1:]
@@ -371,7 +376,7 @@ def main():
     # BASELINE configs[2] read literally: ONE batch of 8 chunks at a time on an engine that can hold no more (max_batch = --batch, one lane):
     # nothing merged, nothing overlapped.  Reported beside the headline with its own decoder-pass roofline.
     strict = None
-    if inflight > 1 or eng.max_batch != args.batch or tot1["n_lanes"] != 1:
+    if not args.headline_only and (inflight > 1 or eng.max_batch != args.batch or tot1["n_lanes"] != 1):
         eng1 = binding.Engine(path, device=local_rank_dev, dtype={"f16": binding.DTYPE_F16, "bf16": binding.DTYPE_BF16, "fp8": binding.DTYPE_FP8}[args.dtype],
                               max_batch=args.batch, n_lanes=1)
         ses1 = [eng1.new_session() for _ in my_chunks]
@@ -438,8 +443,8 @@ def main():
                       "steady_state: the same engine kept full, rate between two completion instants",
             "steady_state": steady,
             "p50_chunk_latency_ms": round(1e3 * float(np.median(lat_main)), 2),
-            "p50_chunk_latency_unloaded_ms": round(1e3 * float(np.median(lat_unloaded)), 2),
-            ("value_from_host_pcm" if not args.host_pcm else "value_hbm_resident_pcm"): round(value_alt, 2),
+            "p50_chunk_latency_unloaded_ms": round(1e3 * float(np.median(lat_unloaded)), 2) if lat_unloaded else None,
+            ("value_from_host_pcm" if not args.host_pcm else "value_hbm_resident_pcm"): None if value_alt != value_alt else round(value_alt, 2),
             "phase_ms": {"mel": round(dd["mel_ms"] / args.steps, 3), "encode_cross_kv": round(enc_ms, 2), "decode": round(dec_ms, 2),
                          "note": "device time per step on the lane that ran it; with steps_in_flight > 1 phases of different steps overlap"},
             "roofline": {"bound": "hbm",

@@ -34,13 +34,14 @@ for R in "$@"; do
       python tools/rocpd_stats.py gpurun_out/prof/${TAG}_${n}_results.db gpurun_out/${TAG}_${n}_kernel_stats.md | cut -c1-200 | head -${PROF_LINES:-45}
       [ -n "$KEEP_DB" ] || rm -f gpurun_out/prof/${TAG}_${n}_results.db ;;
     pmc)
-      DT=${ARGS:-f16}; mkdir -p gpurun_out/pmc; OUT=$PWD/gpurun_out/pmc
+      DT=${ARGS:-f16}; mkdir -p gpurun_out/pmc_$DT; OUT=$PWD/gpurun_out/pmc_$DT
       for C in FETCH_SIZE WRITE_SIZE; do
-        ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $OUT -o pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline --fixed-steps 6 --dtype $DT > $OUT/bench_$C.log 2> $OUT/bench_$C.err )
+        ( cd /tmp && rocprofv3 --kernel-trace --pmc $C -d $OUT -o pmc_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 0 --no-cpu-baseline --headline-only --fixed-steps 6 --dtype $DT > $OUT/bench_$C.log 2> $OUT/bench_$C.err )
       done
-      cp profiles/pmc_traffic.json gpurun_out/pmc/pmc_traffic.json 2>/dev/null
-      python tools/pmc_summary.py gpurun_out/pmc $TAG gpurun_out/pmc/pmc_traffic.json gpurun_out/${TAG}_pmc_$DT.md $DT
-      cp gpurun_out/pmc/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json; rm -f gpurun_out/pmc/*.db ;;
+      # one traffic file per call of this script: a second pmc recipe (another dtype) adds its entries to the first one's
+      [ -f gpurun_out/${TAG}_pmc_traffic.json ] || cp profiles/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json 2>/dev/null
+      python tools/pmc_summary.py $OUT $TAG gpurun_out/${TAG}_pmc_traffic.json gpurun_out/${TAG}_pmc_$DT.md $DT
+      rm -f $OUT/*.db ;;
     py)
       timeout ${PY_TIMEOUT:-1200} python $ARGS > gpurun_out/${TAG}_$n.log 2>&1; echo "py [$ARGS] rc=$?"; tail -${PY_LINES:-40} gpurun_out/${TAG}_$n.log | cut -c1-300 ;;
     sh)

@@ -1,4 +1,4 @@
-"""Summarise the rocprofv3 --pmc passes of the bench command (tools/gpu_pmc.sh): HBM-side bytes per decoder pass and per encoder FC1 launch.
+"""Summarise the rocprofv3 --pmc passes of the bench command (tools/gpu.sh pmc): HBM-side bytes per decoder pass and per encoder FC1 launch.
 bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes); the x2 is the gfx950 FETCH_SIZE correction for 16-B/lane streams (MI355X_MICROARCH.md, HBM).
 usage: python tools/pmc_summary.py <dir with pmc_FETCH_SIZE_results.db, pmc_WRITE_SIZE_results.db> <tag> [out.json] [out.md] [dtype]"""
 import json
@@ -48,7 +48,7 @@ if len(sys.argv) > 3:
         rows_pl, alg_b = bl["roofline"]["rows_per_launch"], bl["roofline"]["algorithmic_bytes"]
     except Exception:
         pass
-    src = f"profiles/{tag}_pmc.md (tools/gpu_pmc.sh: rocprofv3 --kernel-trace --pmc, one counter per pass of the bench command)"
+    src = f"profiles/{tag}_pmc.md (tools/gpu.sh pmc: rocprofv3 --kernel-trace --pmc, one counter per pass of the bench command)"
     if n_pass:
         j[f"large-v3/batch8/{dtype}/decoder_pass"] = {"bytes_per_launch": dec_bytes / n_pass, "passes": n_pass, "rows_per_launch": rows_pl, "algorithmic_bytes": alg_b, "source": src,
                                                  "note": "sum over every decoder-side kernel of (2 x FETCH_SIZE + WRITE_SIZE) / decoder passes; the pass carried the rows the default bench configuration merges (see rows_per_launch)"}
