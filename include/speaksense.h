@@ -188,6 +188,11 @@ int ss_session_decode(ss_session* s, const int32_t* tokens, int32_t n_tokens, in
  * The kernels are selected by the row count exactly as in ss_transcribe_batch (<= 16 rows: fused step; 17..64: multi-tile GEMVs; rows x
  * heads >= 320: the unsplit cross-attention).  logits_out: [n_sample_rows][n_vocab] raw logits of the listed rows, before any rule. */
 int ss_engine_set_encoder_window(ss_engine* e, int32_t window, const float* enc /* [n_audio_ctx][n_audio_state] */);
+/* fp8 engines only (SS_ERR_UNSUPPORTED otherwise): the FIRST quantisation point of the path -- LayerNorm 1 of encoder block 0 for the window at
+ * `seek` of a log-mel spectrogram -- as the e4m3 projections read it: codes [n_audio_ctx][n_audio_state] and one E8M0 exponent byte per
+ * (row, 64-column block) [n_audio_ctx][n_audio_state / 64]; value = e4m3(code) * 2^(exp - 127).  tests/test_gpu_fp8.py counts the codes that
+ * differ from the oracle's. */
+int ss_engine_fp8_first_quant(ss_engine* e, const float* mel, int32_t n_len, int32_t seek, uint8_t* codes, uint8_t* exps);
 int ss_engine_decode_rows(ss_engine* e, const int32_t* token, const int32_t* pos, const int32_t* slot, const int32_t* cross, int32_t n_rows,
                           const int32_t* sample_rows, int32_t n_sample_rows, float* logits_out);
 /* Fused logits rules + log-softmax + greedy pick on the device for one row of raw logits.

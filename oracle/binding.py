@@ -66,6 +66,7 @@ def lib():
         L.orc_trace.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_n_sampled.argtypes = [C.c_void_p]
         L.orc_e4m3_round.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_encode_fp8_first_quant.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.orc_e8m0_exponent.argtypes = [C.c_float]
         L.orc_quantize_rows_f8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_lang_id.argtypes = [C.c_void_p]
@@ -156,6 +157,14 @@ class OracleModel:
         out = np.empty((self.n_audio_ctx, self.n_audio_state), np.float32)
         o = OrcOpts(mode, gelu_erf, default_threads())
         self.L.orc_encode(self.h, _p(mel), mel.shape[1], seek, C.byref(o), _p(out))
+        return out
+
+    def encode_fp8_first_quant(self, mel: np.ndarray, seek: int = 0) -> np.ndarray:
+        """FP8 mode: LayerNorm 1 of encoder block 0 as the e4m3 projections see it (code x 2^s per element), [n_audio_ctx][n_audio_state]."""
+        mel = np.ascontiguousarray(mel, np.float32)
+        out = np.empty((self.n_audio_ctx, self.n_audio_state), np.float32)
+        if self.L.orc_encode_fp8_first_quant(self.h, _p(mel), mel.shape[1], seek, default_threads(), _p(out)) != 0:
+            raise RuntimeError("oracle: the FP8 encoder made no e4m3 projection")
         return out
 
     def time_sample(self, pcm, mode, n_enc_layers, n_cross_layers, n_dec_steps, n_threads):

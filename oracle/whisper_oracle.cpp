@@ -481,11 +481,14 @@ static const F8Weight& f8_weight(const float* W, int N, int K) {
     }
     return it->second;
 }
+// test tap: when set and still empty, receives the quantised-dequantised activations of the next e4m3 projection (orc_encode_fp8_first_quant)
+static std::vector<float>* g_f8_tap = nullptr;
 // C = scale[n] * (Aq . Wq) + bias
 static void matmul_f8(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, bool a_f16_first) {
     const F8Weight& w = f8_weight(W, N, K);
     std::vector<float> Aq((size_t)M * K);
     quantize_rows_f8(A, lda, Aq.data(), M, K, a_f16_first);
+    if (g_f8_tap && g_f8_tap->empty()) *g_f8_tap = Aq;
     matmul(Aq.data(), K, w.q.data(), nullptr, C, ldc, M, N, K, 0);
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < M; i++)
@@ -1114,6 +1117,20 @@ int orc_encode(void* mp, const float* mel, int n_len, int seek, const orc_opts* 
     Opts op; op.fp8 = o->mode == 3; op.mode = op.fp8 ? 1 : o->mode; op.gelu_erf = o->gelu_erf;
     if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
     encode(*(Model*)mp, mel, n_len, seek, op, enc_out); return 0;
+}
+// FP8 mode: the activations at the FIRST quantisation point of the path (LayerNorm 1 of encoder block 0, as the e4m3 projections see them:
+// code x 2^s per element), for the test that counts how many e4m3 codes differ between the device and this restatement.  out: [n_ctx][n_audio_state]
+int orc_encode_fp8_first_quant(void* mp, const float* mel, int n_len, int seek, int n_threads, float* out) {
+    Model& m = *(Model*)mp;
+    Opts op; op.fp8 = 1; op.mode = 1;
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+    std::vector<float> tap, enc((size_t)m.hp.n_audio_ctx * m.hp.n_audio_state);
+    g_f8_tap = &tap;
+    encode(m, mel, n_len, seek, op, enc.data());
+    g_f8_tap = nullptr;
+    if (tap.size() != enc.size()) return -1;
+    memcpy(out, tap.data(), tap.size() * 4);
+    return 0;
 }
 void* orc_state_new(void* mp, const orc_opts* o) {
     State* s = new State(); s->m = (Model*)mp; s->o.fp8 = o->mode == 3; s->o.mode = s->o.fp8 ? 1 : o->mode; s->o.gelu_erf = o->gelu_erf;

@@ -91,6 +91,7 @@ def lib():
         L.ss_session_set_encoder.argtypes = [vp, f32p]
         L.ss_session_decode.argtypes = [vp, vp, i32, i32, f32p]
         L.ss_engine_set_encoder_window.argtypes = [vp, i32, f32p]
+        L.ss_engine_fp8_first_quant.argtypes = [vp, f32p, i32, i32, C.c_void_p, C.c_void_p]
         L.ss_engine_decode_rows.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, f32p]
         L.ss_process_logits.argtypes = [vp, f32p, vp, i32, i32, i32, C.POINTER(Params), f32p]
         L.ss_default_denoise_config.argtypes = [C.POINTER(DenoiseConfig)]
@@ -230,6 +231,15 @@ class Engine:
         enc = np.ascontiguousarray(enc, np.float32)
         assert enc.shape == (self.n_audio_ctx, self.n_audio_state)
         _check(self.L.ss_engine_set_encoder_window(self.h, int(window), _p(enc)))
+
+    def fp8_first_quant(self, mel: np.ndarray, seek: int = 0):
+        """fp8 engines: (codes uint8 [n_audio_ctx][n_audio_state], exponent bytes uint8 [n_audio_ctx][n_audio_state / 64]) at the first quantisation
+        point (LayerNorm 1 of encoder block 0); value = e4m3(code) * 2^(exp - 127)."""
+        mel = np.ascontiguousarray(mel, np.float32)
+        codes = np.empty((self.n_audio_ctx, self.n_audio_state), np.uint8)
+        exps = np.empty((self.n_audio_ctx, self.n_audio_state // 64), np.uint8)
+        _check(self.L.ss_engine_fp8_first_quant(self.h, _p(mel), mel.shape[1], int(seek), codes.ctypes.data_as(C.c_void_p), exps.ctypes.data_as(C.c_void_p)))
+        return codes, exps
 
     def decode_rows(self, token, pos, slot, cross, sample_rows) -> np.ndarray:
         """Stage hook: ONE decoder pass over len(token) rows (row i = token[i] at position pos[i] of self-KV slot slot[i], attending to

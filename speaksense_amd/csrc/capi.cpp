@@ -308,6 +308,10 @@ int ss_engine_set_encoder_window(ss_engine* e, int32_t window, const float* enc)
     if (!e || !enc) return fail(SS_ERR_ARG, "ss_engine_set_encoder_window: bad argument");
     SS_TRY e->e->set_encoder_window_host(enc, window); return SS_OK; SS_CATCH
 }
+int ss_engine_fp8_first_quant(ss_engine* e, const float* mel, int32_t n_len, int32_t seek, uint8_t* codes, uint8_t* exps) {
+    if (!e || !mel || !codes || !exps || n_len <= 0 || seek < 0) return fail(SS_ERR_ARG, "ss_engine_fp8_first_quant: bad argument");
+    SS_TRY e->e->fp8_first_quant_host(mel, n_len, seek, codes, exps); return SS_OK; SS_CATCH
+}
 int ss_engine_decode_rows(ss_engine* e, const int32_t* token, const int32_t* pos, const int32_t* slot, const int32_t* cross, int32_t n_rows,
                           const int32_t* sample_rows, int32_t n_sample_rows, float* logits_out) {
     if (!e || !token || !pos || !slot || !cross || !sample_rows || !logits_out) return fail(SS_ERR_ARG, "ss_engine_decode_rows: null argument");

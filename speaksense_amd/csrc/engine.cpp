@@ -481,11 +481,16 @@ struct EngineT : EngineBase {
         g.rows_per_batch = n_ctx; g.d = da; g.Tpad = Tpad; g.n_batch = B; g.gelu_f16_in = dtype_is_f16;
         return g;
     }
+    uint8_t *tap8_codes = nullptr, *tap8_sc = nullptr;   // host buffers of the running fp8_first_quant_host call
     void encoder_layers_f8(int Wn, bool want_f32) {
         const int M = Wn * n_ctx;
         for (int il = 0; il < La; il++) {
             const EncL& e = enc[il];
             launch_layernorm_f8(x.as<float>(), e.ln1w, e.ln1b, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, M, da, st);
+            if (il == 0 && tap8_codes) {   // test hook fp8_first_quant_host: window 0's codes and exponent bytes at the first quantisation point
+                SS_HIP(hipMemcpyAsync(tap8_codes, ln8.p, (size_t)n_ctx * da, hipMemcpyDeviceToHost, st));
+                SS_HIP(hipMemcpyAsync(tap8_sc, ln_sc.p, (size_t)(da / 64) * Mpad, hipMemcpyDeviceToHost, st));
+            }
             launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8, e.sqkv, M, 2 * da, da, F8_STORE_T, e.bqkv, qk.p, 2 * da), st);
             launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8 + (size_t)2 * da * da, e.sqkv + 2 * da, M, da, da, F8_VT, e.bqkv + 2 * da, vT.p, 0), st);
             launch_enc_attention_f8<T>(qk.as<T>(), qk.as<T>() + da, 2 * da, vT.as<T>(), Tpad, att8.as<unsigned char>(), da, att_sc.as<unsigned char>(), Mpad, Wn, Ha, n_ctx, st);
@@ -1304,6 +1309,22 @@ struct EngineT : EngineBase {
         encoder_pass(1, true);
         SS_HIP(hipMemcpyAsync(enc_out, encF.p, (size_t)n_ctx * da * 4, hipMemcpyDeviceToHost, st));
         SS_HIP(hipStreamSynchronize(st));
+    }
+    void fp8_first_quant_host(const float* mel, int n_len, int seek, uint8_t* codes, uint8_t* exps) override {
+        if (!fp8_enc) throw Error(SS_ERR_UNSUPPORTED, "fp8_first_quant: the engine was not created with SS_DTYPE_FP8");
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
+        mel_d[0].ensure((size_t)n_mel * n_len * 4);
+        SS_HIP(hipMemcpyAsync(mel_d[0].p, mel, (size_t)n_mel * n_len * 4, hipMemcpyHostToDevice, st));
+        launch_mel_window<T>(mel_d[0].as<float>(), n_mel, n_len, seek, 2 * n_ctx, x0.as<T>(), st);
+        std::vector<uint8_t> sc((size_t)(da / 64) * Mpad);
+        tap8_codes = codes; tap8_sc = sc.data();
+        struct Clear { uint8_t*& a; uint8_t*& b; ~Clear() { a = nullptr; b = nullptr; } } clear{tap8_codes, tap8_sc};
+        encoder_pass(1, false);
+        SS_HIP(hipStreamSynchronize(st));
+        for (int m = 0; m < n_ctx; m++)        // exponent bytes out of the GEMM's tile-aware order into [row][64-column block]
+            for (int b = 0; b < da / 64; b++) exps[(size_t)m * (da / 64) + b] = sc[f8_scale_index(m, b, Mpad)];
     }
     void set_encoder_host(const float* encv) override {
         std::lock_guard<std::mutex> lk(mu);

@@ -76,6 +76,7 @@ struct EngineBase {
     virtual void set_encoder_host(const float* enc) = 0;
     virtual void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out) = 0;
     virtual void set_encoder_window_host(const float* enc, int window) = 0;
+    virtual void fp8_first_quant_host(const float* mel, int n_len, int seek, uint8_t* codes, uint8_t* exps) = 0;
     virtual void decode_rows_host(const int32_t* token, const int32_t* pos, const int32_t* slot, const int32_t* cross, int n, const int32_t* samp_rows, int n_samp,
                                   float* logits_out) = 0;
     virtual void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6]) = 0;
