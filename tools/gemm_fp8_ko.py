@@ -1,5 +1,7 @@
 """GPU dev tool: time the e4m3 GEMM's k loop with parts knocked out (SS_F8_KO bit mask: 1 barriers, 2 vmcnt waits, 4 DMA, 8 LDS reads, 16 MFMAs;
-results are wrong by construction, only the durations mean something).  Prints ms for the FC1 / FC2 shapes, kind STORE_T."""
+results are wrong by construction, only the durations mean something).  Prints ms for the FC1 / FC2 shapes, kind STORE_T.
+The knock-outs are compiled out of the product library: build a variant first,
+    bash tools/build_variant.sh kernels_gemm_fp8.hip -DSS_DEV_KNOCKOUTS      (-> gpurun_ab/libvariant.so, copy it over speaksense_amd/libspeaksense_hip.so on the box)"""
 import os
 import sys
 
