@@ -50,8 +50,22 @@ typedef struct ss_engine_opts {
     int32_t batch_wait_us;/* how long the batch former waits for more chunks before launching a partial batch */
     int32_t n_lanes;      /* device batches in flight at once over one copy of the weights (0 = default 2; env SS_LANES overrides): each lane has
                              its own stream, workspaces and KV caches, so one group's encoder pass and another's decode chain overlap */
-    int32_t reserved[2];
+    int32_t compat;       /* SS_COMPAT_* flags: which variant of a whisper.cpp-version-dependent behaviour the engine reproduces.  0 = whisper.cpp
+                             v1.5.0 .. v1.5.4, the range whisper-rs-sys 0.9.0 vendors (/root/reference/Cargo.lock:3888-3907); env SS_COMPAT (a number
+                             or names joined by '+': "rng_state", "openai_ts_rules") overrides it -- the whisper.h shim has no options struct */
+    int32_t reserved;
 } ss_engine_opts;
+
+/* Version-dependent behaviour (DESIGN.md section 2 holds the ledger: fact, upstream version range of each variant, switch).  Both variants of
+ * every flag are under the oracle's tests (same flag values there: oracle/binding.py COMPAT_*). */
+enum {
+    SS_COMPAT_RNG_STATE = 1,       /* whisper.cpp <= v1.4.x: ONE std::mt19937(0) in whisper_state; the best_of decoders draw from it in decoder order.
+                                      Default (flag clear, >= v1.5.0): every decoder owns a generator -- decoder 0's is seeded once per state and carried
+                                      across calls, decoders 1.. are re-seeded with 0 by every whisper_full call */
+    SS_COMPAT_OPENAI_TS_RULES = 2  /* OpenAI's timestamp rules where whisper.cpp's differ: the first sampled token must be a timestamp (whisper.cpp only
+                                      applies max_initial_ts); a timestamp may not repeat the last one unless a pair is open (`<=`; whisper.cpp `<`);
+                                      <|0.00|> counts as a timestamp seen (whisper.cpp: id > token_beg) */
+};
 
 /* The whisper_full_params fields the reference sets (whisper.rs:131-173) plus its per-request overrides
  * (language whisper.rs:60-63, stream mode whisper.rs:65-69, tdrz whisper.rs:136-139).  ss_default_params()
@@ -91,6 +105,11 @@ const char* ss_last_error(void); /* thread-local, valid until the next failing c
 
 /* ---- engine / session lifetime ---------------------------------------------------------------------- */
 int ss_engine_create(const char* ggml_model_path, const ss_engine_opts* opts, ss_engine** out);
+/* May be called with tickets outstanding: chunks still queued fail with SS_ERR_DEVICE, chunks a device group is running finish normally, threads
+ * blocked in ss_wait are woken and have left the engine before this returns.  Tickets waited for LATER return their recorded status without
+ * touching the engine, sessions may be freed later too.  What the caller must not do is let another thread ENTER ss_submit / ss_wait / a blocking
+ * transcribe call on this engine while it is being freed (the reference drops its Arc<WhisperContext> only when the last user is gone,
+ * src/asr/whisper.rs:17,26). */
 void ss_engine_free(ss_engine* e);
 int ss_engine_hparams(const ss_engine* e, int32_t out11[11]);       /* n_vocab ... ftype, ggml header order */
 int ss_engine_special_tokens(const ss_engine* e, int32_t out9[9]);  /* eot sot translate transcribe solm prev nosp not beg */
@@ -103,6 +122,9 @@ int ss_engine_tokenize(const ss_engine* e, const char* text, int32_t* ids, int32
 int ss_model_tokenize(const char* ggml_model_path, const char* text, int32_t* ids, int32_t n_max);
 
 ss_session* ss_session_create(ss_engine* e);
+/* A session whose chunks are still queued or running is written to by the engine's workers: ss_session_free BLOCKS until the engine has completed
+ * every chunk submitted on it (completion does not need ss_wait; after ss_engine_free everything is complete), then frees it.  The reference owns
+ * its WhisperState the same way: behind a Mutex held for the whole transcribe call (src/asr/whisper.rs:34-38,51). */
 void ss_session_free(ss_session* s);
 
 /* ---- one model on several GPUs of a node (wiring it slots under: /root/reference/src/main.rs:38-39,59,71 -- one
@@ -137,7 +159,10 @@ int ss_transcribe(ss_session* s, const float* pcm, int32_t n_samples, const ss_p
 int ss_submit(ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, ss_ticket** out);
 /* The same; pcm_on_device != 0: `pcm` is a device pointer on the engine's GPU, not copied -- it must stay valid until ss_wait returns. */
 int ss_submit_ex(ss_session* s, const float* pcm, int32_t n_samples, const ss_params* params, int32_t pcm_on_device, ss_ticket** out);
-int ss_wait(ss_ticket* t);      /* blocks; returns the chunk's status; frees the ticket */
+/* Blocks until the chunk is complete; returns its status; frees the ticket.  Valid after its session or its engine has been freed (the status was
+ * recorded on the ticket; results live on the session and are gone with it).  A ticket that is never waited for leaks its own memory (the copy of
+ * the samples) and nothing else: the engine keeps no reference to it once the chunk is complete. */
+int ss_wait(ss_ticket* t);
 
 /* ---- results of the session's last chunk (valid until its next transcribe/submit) -------------------- */
 int32_t ss_result_n_segments(const ss_session* s);
@@ -165,13 +190,17 @@ int32_t ss_result_lang_id(const ss_session* s);                        /* langua
 int ss_result_counters(const ss_session* s, int32_t out4[4]);         /* n_encode, n_decode_steps, n_fail, n_windows */
 
 /* ---- the session's sampler state --------------------------------------------------------------------- */
-/* whisper_state owns one std::mt19937(0) that the temperature-fallback sampler draws from and that is never reseeded, so in the reference
- * (one state per stream / per REST task, chunks one after another) a chunk that falls back to sampling sees a generator advanced by every
- * earlier chunk's draws.  ss_session_rng_draws: generator invocations consumed by this session so far.  ss_session_rng_discard: advance
- * the generator of a (fresh) session by n invocations -- with the two, chunks of one reference state can be decoded as a batch on fresh
- * sessions and still give the serial result (speaksense_amd/rest.py::TranscribeProcessor). */
+/* The one piece of sampler state a whisper_state carries from call to call is ONE std::mt19937(0) that is never reseeded: decoder 0's generator
+ * (whisper.cpp >= v1.5.0, the default; decoders 1.. are re-seeded by every call and carry nothing) or whisper_state::rng shared by all decoders
+ * (SS_COMPAT_RNG_STATE).  So in the reference (one state per stream / per REST task, chunks one after another) a chunk that falls back to
+ * sampling sees that generator advanced by every earlier chunk's draws from it.  ss_session_rng_draws: invocations of the carried generator
+ * consumed by this session so far.  ss_session_rng_discard: advance the carried generator of a (fresh) session by n invocations -- with the
+ * two, chunks of one reference state can be decoded as a batch on fresh sessions and still give the serial result
+ * (speaksense_amd/rest.py::TranscribeProcessor).  ss_session_rng_draws_decoder: the same count for the generator of decoder j >= 1 since the
+ * last chunk started (0 under SS_COMPAT_RNG_STATE, where those decoders own none). */
 int64_t ss_session_rng_draws(const ss_session* s);
 int ss_session_rng_discard(ss_session* s, int64_t n);
+int64_t ss_session_rng_draws_decoder(const ss_session* s, int32_t decoder);
 
 /* ---- per-stage hooks for parity tests (host f32 in / out; each runs the same device kernels) -------- */
 int32_t ss_mel_n_len(int32_t n_samples);
@@ -242,6 +271,10 @@ int ss_engine_last_counters(const ss_engine* e, int64_t out4[4]);
 /* Cumulative since engine creation, summed over the lanes: device ms [mel, encoder+cross-KV, decode, total] and work [decoder passes, decoder
  * rows, encoder windows, chunks admitted into a running group, windows started while other windows of their group were decoding, 0].  Differences around a timed region give the in-pipeline averages when several groups run concurrently. */
 int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[6], int32_t* n_lanes);
+/* The same counters for one lane (0 <= lane < n_lanes): how the batch former spread the work (tests: lane levelling). */
+int ss_engine_lane_counters(const ss_engine* e, int32_t lane, int64_t out_cnt[6]);
+/* hipMemGetInfo on the engine's device: bytes free / total (leak checks of the soak test; a service's health endpoint) */
+int ss_engine_mem_info(const ss_engine* e, int64_t* free_bytes, int64_t* total_bytes);
 /* average device time (ms) of `reps` launches of the dominant encoder GEMM (FC1: M=batch*1500, N=4d, K=d) on the
  * engine's stream, and its algorithmic FLOPs per launch: the roofline probe bench.py reports. */
 int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_ms, double* flops_per_launch);

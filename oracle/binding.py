@@ -11,6 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 MODE_F32, MODE_GGML_F16, MODE_BF16, MODE_FP8 = 0, 1, 2, 3   # FP8: GGML_F16 + e4m3 encoder-block / cross-KV projections (whisper_oracle.cpp header)
+# Version-dependent whisper.cpp behaviour (the ledger); 0 = v1.5.0 .. v1.5.4, what whisper-rs-sys 0.9.0 vendors.  Same values as
+# SS_COMPAT_* in include/speaksense.h.
+COMPAT_RNG_STATE = 1         # <= v1.4.x: one std::mt19937(0) in whisper_state shared by all best_of decoders
+COMPAT_OPENAI_TS_RULES = 2   # OpenAI's timestamp rules where whisper.cpp's differ (forced first timestamp, `<=` monotonic rule, <|0.00|> counts)
 
 
 class OrcOpts(C.Structure):
@@ -54,6 +58,9 @@ def lib():
         L.orc_state_new.restype = C.c_void_p
         L.orc_state_new.argtypes = [C.c_void_p, C.POINTER(OrcOpts)]
         L.orc_state_free.argtypes = [C.c_void_p]
+        L.orc_state_set_compat.argtypes = [C.c_void_p, C.c_int]
+        L.orc_state_rng_peek.restype = C.c_uint32
+        L.orc_state_rng_peek.argtypes = [C.c_void_p, C.c_int]
         L.orc_state_set_encoder.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_state_cross_kv.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -173,8 +180,8 @@ class OracleModel:
         self.L.orc_time_sample(self.h, _p(pcm), len(pcm), mode, n_enc_layers, n_cross_layers, n_dec_steps, n_threads, _p(out))
         return dict(mel_s=out[0], stem_s=out[1], enc_layer_s=out[2], cross_layer_s=out[3], dec_step_s=out[4])
 
-    def new_state(self, mode: int = MODE_F32, gelu_erf: int = 0) -> "OracleState":
-        return OracleState(self, mode, gelu_erf)
+    def new_state(self, mode: int = MODE_F32, gelu_erf: int = 0, compat: int = 0) -> "OracleState":
+        return OracleState(self, mode, gelu_erf, compat)
 
 
 def default_params(**kw) -> FullParams:
@@ -197,11 +204,18 @@ def default_params(**kw) -> FullParams:
 
 
 class OracleState:
-    def __init__(self, model: OracleModel, mode: int, gelu_erf: int):
+    def __init__(self, model: OracleModel, mode: int, gelu_erf: int, compat: int = 0):
         self.m = model
         self.L = model.L
         o = OrcOpts(mode, gelu_erf, default_threads())
         self.h = self.L.orc_state_new(model.h, C.byref(o))
+        self.compat = int(compat)
+        self.L.orc_state_set_compat(self.h, self.compat)
+
+    def rng_peek(self, decoder: int = 0) -> int:
+        """Next output of the generator decoder `decoder` would draw from (a copy is advanced, not the generator): two states whose samplers
+        consumed the same number of draws agree on it."""
+        return int(self.L.orc_state_rng_peek(self.h, decoder))
 
     def close(self):
         if self.h:

@@ -628,6 +628,10 @@ struct Decoder {
     std::vector<int> sampled;   // test hook: every id sampled in the current attempt, before the truncation to result_len
     int seek_delta = 0; bool failed = false, completed = false, has_ts = false;
     std::vector<float> probs, logits, logprobs;
+    // wcpp >= 1.5.0: `mutable std::mt19937 rng; // used for sampling at t > 0.0` lives in whisper_decoder (sampling runs on parallel threads there).
+    // Decoder 0 is seeded once with the state (whisper_init_state), decoders >= 1 are re-seeded by every whisper_full_with_state call (the
+    // WHISPER_DECODER_INIT block).  Under COMPAT_RNG_STATE (wcpp <= 1.4.x) every decoder draws from State::rng instead.
+    std::mt19937 rng{0};
 };
 struct Segment { int64_t t0, t1; std::string text; std::vector<TokenData> tokens; bool speaker_turn_next; };
 
@@ -645,6 +649,14 @@ struct FullParams {  // wcpp: whisper_full_params (fields the reference sets, wh
     const char* initial_prompt = nullptr;
 };
 
+// Version-dependent behaviour of whisper.cpp that this restatement can follow either way (same values as SS_COMPAT_* in include/speaksense.h).
+// Default 0 = what whisper.cpp v1.5.0 .. v1.5.4 does (the range whisper-rs-sys 0.9.0 vendors, /root/reference/Cargo.lock:3888-3907).
+enum {
+    COMPAT_RNG_STATE = 1,        // one std::mt19937(0) in whisper_state, drawn from by every best_of decoder in decoder order (wcpp <= 1.4.x)
+    COMPAT_OPENAI_TS_RULES = 2,  // OpenAI's timestamp rules where whisper.cpp's differ: the first sampled token must be a timestamp; timestamps may
+                                 // not repeat the last one unless a pair is open (`<=` instead of `<`); <|0.00|> counts as a timestamp seen
+};
+
 struct State {
     const Model* m; Opts o;
     std::vector<float> mel; int n_len = 0, n_len_org = 0;
@@ -656,7 +668,8 @@ struct State {
     std::vector<TokenData> all_tokens;    // concatenated accepted tokens over windows (test hook)
     std::vector<int> sampled_all;         // every id the winning decoder of each window sampled, incl. the tail past result_len (test hook)
     std::vector<float> logits;            // last decode: [n_tokens_out][n_vocab]
-    std::mt19937 rng{0};
+    std::mt19937 rng{0};                  // COMPAT_RNG_STATE only: whisper_state::rng of wcpp <= 1.4.x (seeded once per state, shared by all decoders)
+    int compat = 0;                       // COMPAT_* flags: which upstream variant of a version-dependent behaviour is restated (ledger)
     int n_fail = 0, n_encode = 0, n_decode = 0;
     int lang_id = -1;                     // wcpp: whisper_full_lang_id
     // Test hook (not whisper.cpp): forced replay.  Greedy sampling step g takes forced[g] instead of the argmax and records
@@ -794,7 +807,19 @@ void process_logits(const State& s, Decoder& dec, const FullParams& P, const flo
         const int tid0 = std::round(P.max_initial_ts / precision);
         for (int i = vocab.token_beg + tid0 + 1; i < n_logits; i++) logits[i] = -INFINITY;
     }
-    if (dec.has_ts) {
+    if (s.compat & COMPAT_OPENAI_TS_RULES) {
+        // openai/whisper decoding.py ApplyTimestampRules (= HF WhisperTimeStampLogitsProcessor): "suppress generating non-timestamp tokens at the
+        // beginning"; "timestamps shouldn't decrease; forbid timestamp tokens smaller than the last; also force each segment to have a nonzero length"
+        if (is_initial && !P.no_timestamps) for (int i = 0; i < vocab.token_beg; i++) logits[i] = -INFINITY;
+        int last = -1;
+        for (auto& t : tokens_cur) if (t.id >= vocab.token_beg) last = t.id;
+        if (last >= 0) {
+            const bool last_was_timestamp = tokens_cur.back().id >= vocab.token_beg;
+            const bool penultimate_was_timestamp = tokens_cur.size() < 2 || tokens_cur[tokens_cur.size() - 2].id >= vocab.token_beg;
+            const int timestamp_last = (last_was_timestamp && !penultimate_was_timestamp) ? last : last + 1;
+            for (int i = vocab.token_beg; i < timestamp_last && i < n_logits; i++) logits[i] = -INFINITY;
+        }
+    } else if (dec.has_ts) {
         const int tid0 = dec.seek_delta / 2;
         for (int i = vocab.token_beg; i < vocab.token_beg + tid0; i++) logits[i] = -INFINITY;
     }
@@ -842,9 +867,10 @@ TokenData sample_token(State& s, Decoder& dec, bool best) {
             if (f >= 0 && f < n_logits) { r.id = f; r.p = probs[f]; r.plog = logprobs[f]; }
         }
     } else {
-        std::mt19937 rng_before = s.rng;
+        std::mt19937& rng = (s.compat & COMPAT_RNG_STATE) ? s.rng : dec.rng;   // wcpp >= 1.5.0: dist(decoder.rng); <= 1.4.x: dist(state.rng)
+        std::mt19937 rng_before = rng;
         std::discrete_distribution<> dist(probs.begin(), probs.end());
-        r.id = dist(s.rng); r.p = probs[r.id]; r.plog = logprobs[r.id];
+        r.id = dist(rng); r.p = probs[r.id]; r.plog = logprobs[r.id];
         if (s.forced_all && s.forced_pos < s.forced.size()) {
             const int f = s.forced[s.forced_pos++];
             float gap = INFINITY, sens = 0.0f;
@@ -927,6 +953,7 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
     else temperatures.push_back(P.temperature);
     const int n_decoders = std::max(1, (int)P.best_of);
     s.decoders.resize(n_decoders);
+    for (int j = 1; j < n_decoders; j++) s.decoders[j].rng = std::mt19937(0);   // wcpp >= 1.5.0 "TAGS: WHISPER_DECODER_INIT": decoders 1.. are set up by every call; decoder 0's generator lives with the state
     if (P.no_context) s.prompt_past.clear();
     {   // wcpp "prepare prompt": initial_prompt -> tokens unless prompt_tokens is given; prepended to prompt_past (push_back + rotate)
         std::vector<int> pt;
@@ -1138,6 +1165,13 @@ void* orc_state_new(void* mp, const orc_opts* o) {
     s->decoders.resize(1); return s;
 }
 void orc_state_free(void* s) { delete (State*)s; }
+void orc_state_set_compat(void* s, int flags) { ((State*)s)->compat = flags; }   // COMPAT_* (default 0 = whisper.cpp v1.5.x)
+// invocations of a generator so far are not observable on std::mt19937; the tests compare generators by their next output instead
+uint32_t orc_state_rng_peek(void* sp, int decoder) {
+    State* s = (State*)sp;
+    std::mt19937 g = (s->compat & COMPAT_RNG_STATE) || decoder < 0 ? s->rng : s->decoders.at(decoder).rng;
+    return (uint32_t)g();
+}
 int orc_state_set_encoder(void* sp, const float* enc) {
     State* s = (State*)sp; const HParams& hp = s->m->hp;
     s->enc.assign(enc, enc + (size_t)hp.n_audio_ctx * hp.n_audio_state); cross_kv(*s); return 0;

@@ -72,13 +72,13 @@ class WhisperAsr:
     """`WhisperAsr::new(model_path)` (whisper.rs:21-28) -- loads the ggml model onto one MI355X."""
 
     def __init__(self, model_path: str, device: int = 0, dtype: int = binding.DTYPE_F16, max_batch: int = 8, batch_across_callers: bool = False,
-                 batch_wait_us: int = 2000):
+                 batch_wait_us: int = 2000, compat: int = 0):
         # batch_across_callers: transcribe_with_state goes through ss_submit/ss_wait, so chunks that concurrent callers (one thread
         # per gRPC stream, asr.rs:164) hand in at about the same time share one device batch; results are identical either way.
         self.batch_across_callers = batch_across_callers
         self.params_hook = None    # benchmarks only: callable(binding.Params) applied after build_params (e.g. Mode F fixed_steps on random weights)
         try:
-            self.engine = binding.Engine(model_path, device=device, dtype=dtype, max_batch=max_batch, batch_wait_us=batch_wait_us)
+            self.engine = binding.Engine(model_path, device=device, dtype=dtype, max_batch=max_batch, batch_wait_us=batch_wait_us, compat=compat)
         except binding.SpeakSenseError as e:
             raise RuntimeError(f"failed to open whisper model: {e}") from e  # whisper.rs:24
 

@@ -12,11 +12,13 @@ LIB_PATH = os.path.join(_HERE, "libspeaksense_hip.so")
 _LIB = None
 
 DTYPE_BF16, DTYPE_F16, DTYPE_FP8 = 0, 1, 2   # FP8: the f16 engine with e4m3 encoder / cross-KV projections
+# SS_COMPAT_* (include/speaksense.h): which variant of a whisper.cpp-version-dependent behaviour the engine reproduces; 0 = whisper.cpp v1.5.x
+COMPAT_RNG_STATE, COMPAT_OPENAI_TS_RULES = 1, 2
 
 
 class EngineOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("dtype", C.c_int32), ("max_batch", C.c_int32), ("max_decoders", C.c_int32),
-                ("batch_wait_us", C.c_int32), ("n_lanes", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("batch_wait_us", C.c_int32), ("n_lanes", C.c_int32), ("compat", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Params(C.Structure):
@@ -85,6 +87,10 @@ def lib():
         L.ss_session_rng_draws.argtypes = [vp]
         L.ss_session_rng_draws.restype = C.c_int64
         L.ss_session_rng_discard.argtypes = [vp, C.c_int64]
+        L.ss_engine_lane_counters.argtypes = [vp, i32, vp]
+        L.ss_engine_mem_info.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.ss_session_rng_draws_decoder.argtypes = [vp, i32]
+        L.ss_session_rng_draws_decoder.restype = C.c_int64
         L.ss_mel_n_len.argtypes = [i32]
         L.ss_log_mel.argtypes = [vp, f32p, i32, f32p, i32]
         L.ss_encode.argtypes = [vp, f32p, i32, i32, f32p]
@@ -171,9 +177,10 @@ def model_tokenize(model_path: str, text) -> list:
 
 class Engine:
     def __init__(self, model_path: str, device: int = 0, dtype: int = DTYPE_F16, max_batch: int = 8, max_decoders: int = 5,
-                 batch_wait_us: int = 2000, n_lanes: int = 0):
+                 batch_wait_us: int = 2000, n_lanes: int = 0, compat: int = 0):
         self.L = lib()
-        o = EngineOpts(device, dtype, max_batch, max_decoders, batch_wait_us, n_lanes)
+        o = EngineOpts(device, dtype, max_batch, max_decoders, batch_wait_us, n_lanes, compat)
+        self.compat = compat
         h = C.c_void_p()
         self.model_path = model_path
         _check(self.L.ss_engine_create(model_path.encode(), C.byref(o), C.byref(h)))
@@ -191,6 +198,17 @@ class Engine:
         if getattr(self, "h", None):
             self.L.ss_engine_free(self.h)
             self.h = None
+
+    def lane_counters(self, lane: int):
+        cnt = np.zeros(6, np.int64)
+        _check(self.L.ss_engine_lane_counters(self.h, lane, _p(cnt)))
+        return dict(decoder_passes=int(cnt[0]), decoder_rows=int(cnt[1]), encoder_windows=int(cnt[2]), admitted=int(cnt[3]), started_midway=int(cnt[4]))
+
+    def mem_info(self):
+        """(free, total) bytes of the engine's device (hipMemGetInfo)."""
+        f, t = C.c_int64(), C.c_int64()
+        _check(self.L.ss_engine_mem_info(self.h, C.byref(f), C.byref(t)))
+        return int(f.value), int(t.value)
 
     def __del__(self):
         try:
@@ -404,9 +422,10 @@ class Session:
         return dict(segments=segs, tokens=ids, plog=plog, sampled=sampled, trace=trace, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]),
                     n_windows=int(c[3]), lang_id=int(self.L.ss_result_lang_id(self.h)))
 
-    def rng_draws(self) -> int:
-        """Invocations of the session's std::mt19937 so far (whisper_state::rng, consumed only by temperature-fallback sampling)."""
-        return int(self.L.ss_session_rng_draws(self.h))
+    def rng_draws(self, decoder: int = 0) -> int:
+        """Invocations so far of the std::mt19937 the session carries from chunk to chunk (decoder 0's generator; whisper_state::rng under
+        COMPAT_RNG_STATE), consumed only by temperature-fallback sampling.  decoder >= 1: that decoder's own generator since the last chunk began."""
+        return int(self.L.ss_session_rng_draws_decoder(self.h, decoder)) if decoder else int(self.L.ss_session_rng_draws(self.h))
 
     def rng_discard(self, n: int):
         _check(self.L.ss_session_rng_discard(self.h, int(n)))
@@ -426,10 +445,10 @@ class Pool:
     """One model on several GPUs of a node (ss_pool_*): N engines, chunks routed to the least-loaded one, ties round-robin."""
 
     def __init__(self, model_path: str, device_ids, dtype: int = DTYPE_F16, max_batch: int = 8, max_decoders: int = 5, batch_wait_us: int = 2000,
-                 n_lanes: int = 0):
+                 n_lanes: int = 0, compat: int = 0):
         self.L = lib()
         ids = np.ascontiguousarray(device_ids, np.int32)
-        o = EngineOpts(0, dtype, max_batch, max_decoders, batch_wait_us, n_lanes)
+        o = EngineOpts(0, dtype, max_batch, max_decoders, batch_wait_us, n_lanes, compat)
         h = C.c_void_p()
         _check(self.L.ss_pool_create(model_path.encode(), _p(ids), len(ids), C.byref(o), C.byref(h)))
         self.h = h

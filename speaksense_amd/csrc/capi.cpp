@@ -115,7 +115,17 @@ ss_session* ss_session_create(ss_engine* e) {
     s->s.eng = e->e;
     return s;
 }
-void ss_session_free(ss_session* s) { delete s; }
+// A session with chunks still queued or running must outlive them (the worker writes the results into it): wait until the engine has completed
+// them.  Completion does not need ss_wait -- an abandoned ticket only leaks its own memory -- and after ss_engine_free every chunk is complete.
+void ss_session_free(ss_session* s) {
+    if (!s) return;
+    if (s->s.in_flight.load() > 0) {
+        EngineBase* e = s->s.eng;          // while in_flight > 0 the session stays on this engine (ss_pool_submit)
+        std::unique_lock<std::mutex> lk(e->qmu);
+        e->donecv.wait(lk, [&] { return s->s.in_flight.load() == 0; });
+    }
+    delete s;
+}
 
 int32_t ss_pool_pick(const int32_t* load, int32_t n, uint32_t cursor) {
     if (!load || n <= 0) return -1;
@@ -218,8 +228,8 @@ int ss_submit_ex(ss_session* s, const float* pcm, int32_t n_samples, const ss_pa
 }
 int ss_wait(ss_ticket* t) {
     if (!t) return fail(SS_ERR_ARG, "ss_wait: null ticket");
-    (t->job.eng ? t->job.eng : t->job.sess->eng)->wait(&t->job);
-    t->job.sess->in_flight.fetch_sub(1);
+    // done already (also: the engine has been freed since, or the session has): neither is touched
+    if (!t->job.done.load(std::memory_order_acquire)) t->job.eng->wait(&t->job);
     const int st = t->job.status;
     const std::string why = t->job.err.empty() ? std::string("chunk failed") : t->job.err;
     delete t;
@@ -285,6 +295,11 @@ int ss_result_counters(const ss_session* s, int32_t out4[4]) {
 }
 
 int64_t ss_session_rng_draws(const ss_session* s) { return s ? (int64_t)s->s.rng.n : 0; }
+int64_t ss_session_rng_draws_decoder(const ss_session* s, int32_t decoder) {
+    if (!s || decoder < 0) return 0;
+    if (decoder == 0) return (int64_t)s->s.rng.n;
+    return (size_t)decoder - 1 < s->s.rng_dec.size() ? (int64_t)s->s.rng_dec[(size_t)decoder - 1].n : 0;
+}
 int ss_session_rng_discard(ss_session* s, int64_t n) {
     if (!s || n < 0) return fail(SS_ERR_ARG, "ss_session_rng_discard: bad argument");
     s->s.rng.discard((uint64_t)n);
@@ -334,7 +349,7 @@ int ss_process_logits(ss_engine* e, const float* raw, const int32_t* hist, int32
 int ss_engine_last_timing(const ss_engine* e, float out_ms[4]) {
     if (!e || !out_ms) return fail(SS_ERR_ARG, "null argument");
     EngineBase* L = e->e->lane(std::min(std::max(e->e->last_lane.load(), 0), e->e->n_lanes() - 1));
-    std::lock_guard<std::mutex> lk(L->mu);
+    std::lock_guard<std::mutex> lk(L->stat_mu);   // never the device-work mutex: a worker holds that for a whole (possibly unbounded) group
     memcpy(out_ms, L->last_ms, 16);
     return SS_OK;
 }
@@ -345,17 +360,34 @@ int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[6], i
     const int n = e->e->n_lanes();
     for (int l = 0; l < n; l++) {
         EngineBase* L = e->e->lane(l);
-        std::lock_guard<std::mutex> lk(L->mu);    // a lane updates its totals at the end of a group, under its own lock
+        std::lock_guard<std::mutex> lk(L->stat_mu);    // a lane updates its totals at the end of a group, under this lock
         for (int i = 0; i < 4; i++) out_ms[i] += L->tot_ms[i];
         for (int i = 0; i < 6; i++) out_cnt[i] += L->tot_cnt[i];
     }
     if (n_lanes) *n_lanes = n;
     return SS_OK;
 }
+int ss_engine_lane_counters(const ss_engine* e, int32_t lane, int64_t out_cnt[6]) {
+    if (!e || !out_cnt || lane < 0 || lane >= e->e->n_lanes()) return fail(SS_ERR_ARG, "ss_engine_lane_counters: bad argument");
+    EngineBase* L = e->e->lane(lane);
+    std::lock_guard<std::mutex> lk(L->stat_mu);
+    for (int i = 0; i < 6; i++) out_cnt[i] = L->tot_cnt[i];
+    return SS_OK;
+}
+int ss_engine_mem_info(const ss_engine* e, int64_t* free_bytes, int64_t* total_bytes) {
+    if (!e || !free_bytes || !total_bytes) return fail(SS_ERR_ARG, "null argument");
+    SS_TRY
+    SS_HIP(hipSetDevice(e->e->opts.device));
+    size_t f = 0, t = 0;
+    SS_HIP(hipMemGetInfo(&f, &t));
+    *free_bytes = (int64_t)f; *total_bytes = (int64_t)t;
+    return SS_OK;
+    SS_CATCH
+}
 int ss_engine_last_counters(const ss_engine* e, int64_t out4[4]) {
     if (!e || !out4) return fail(SS_ERR_ARG, "null argument");
     EngineBase* L = e->e->lane(std::min(std::max(e->e->last_lane.load(), 0), e->e->n_lanes() - 1));
-    std::lock_guard<std::mutex> lk(L->mu);
+    std::lock_guard<std::mutex> lk(L->stat_mu);
     for (int i = 0; i < 4; i++) out4[i] = L->last_cnt[i];
     return SS_OK;
 }

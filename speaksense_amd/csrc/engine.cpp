@@ -77,6 +77,27 @@ struct DBuf {
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// ss_engine_opts.compat, overridden by env SS_COMPAT: a number, or flag names joined by '+' / ',' ("rng_state", "openai_ts_rules"; "" or "v1.5" = 0)
+static int resolve_compat(int from_opts) {
+    const char* e = getenv("SS_COMPAT");
+    if (!e) return from_opts;
+    std::string s(e);
+    if (s.empty() || s == "v1.5") return 0;
+    if (s.find_first_not_of("0123456789") == std::string::npos) return atoi(e);
+    int flags = 0;
+    size_t pos = 0;
+    while (pos <= s.size()) {
+        size_t end = s.find_first_of("+,", pos);
+        if (end == std::string::npos) end = s.size();
+        const std::string name = s.substr(pos, end - pos);
+        if (name == "rng_state") flags |= SS_COMPAT_RNG_STATE;
+        else if (name == "openai_ts_rules") flags |= SS_COMPAT_OPENAI_TS_RULES;
+        else if (!name.empty()) throw Error(SS_ERR_ARG, "SS_COMPAT: unknown flag '" + name + "'");
+        pos = end + 1;
+    }
+    return flags;
+}
+
 // per-decoder state (whisper_decoder + whisper_sequence)
 struct Dec {
     std::vector<TokenData> tokens;
@@ -231,6 +252,7 @@ struct EngineT : EngineBase {
         { const char* gv = getenv("SS_DECODE_GRAPH"); use_graph = !(gv && gv[0] == '0'); }     // 0: launch the step kernel by kernel instead of replaying its hipGraph
         { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }   // 0: wait for every step's samples before enqueuing the next step
         if (const char* sm = getenv("SS_CB_START_MIN")) cb_start_min = std::max(1, atoi(sm));
+        compat = donor ? donor->compat : resolve_compat(o.compat);
         if (!donor) {
             int nl = o.n_lanes > 0 ? o.n_lanes : 2;
             if (const char* lv = getenv("SS_LANES")) nl = atoi(lv);
@@ -538,7 +560,7 @@ struct EngineT : EngineBase {
         launch_gemm<T>(g, st);
     }
 
-    // ---- fused decode step (M <= 16): 8 launches per layer, see kernels_decode.hip ----
+    // ---- the decoder pass (1..64 rows): 11 launches per layer (10 from rows x heads >= direct_pairs on), see kernels_decode.hip / fused_body ----
     struct Plan { int S, NW; };
     Plan pl_qkv, pl_dd, pl_fc1, pl_fc2, pl_logits;
     DBuf xa, xb, p1, pq, p2, p3;
@@ -724,6 +746,7 @@ struct EngineT : EngineBase {
             rc.max_initial_tid = (int)std::round(P.max_initial_ts / precision);
         }
         rc.suppress_eot = P.fixed_steps > 0;
+        rc.openai_ts = (compat & SS_COMPAT_OPENAI_TS_RULES) != 0;
         return rc;
     }
 
@@ -756,12 +779,29 @@ struct EngineT : EngineBase {
             Session* s = j->sess;
             s->segments.clear(); s->tokens.clear(); s->sampled.clear(); s->trace.clear(); s->n_encode = s->n_decode = s->n_fail = s->n_windows = 0;   // "clear old results"
             // The carried text context (prompt_past) is only touched once the chunk is known to decode: whisper_full_with_state returns for < 1 s
-            // of audio before it reaches "if (params.no_context) prompt_past.clear()" / "prepend the prompt tokens", and a refused call must
-            // leave a context-carrying caller's state as it was (see the end of this function).
+            // of audio before it reaches "if (params.no_context) prompt_past.clear()" / "prepend the prompt tokens", and a call refused before that
+            // point must leave a context-carrying caller's state as it was (touch_context below; the one refusal that comes AFTER it in
+            // whisper.cpp, audio_ctx > n_audio_ctx -> -5, applies it first).
             JobState q; q.job = j; q.slot = (int)i;
             j->status = 0;
             const ss_params& P = j->P;
-            if (P.audio_ctx > n_ctx) { j->status = SS_ERR_AUDIO_CTX; j->err = "audio_ctx larger than the model's n_audio_ctx"; return q; }
+            // What whisper_full_with_state has already done to the state by the time it checks audio_ctx ("overwrite audio_ctx, max allowed is
+            // hparams.n_audio_ctx": return -5): decoders 1.. set up (their generators re-seeded), no_context applied, the prompt tokens prepended --
+            // all of it only for a chunk of >= 1 s that is not a detect_language call (those return earlier).
+            auto touch_context = [&]() {
+                if (!(compat & SS_COMPAT_RNG_STATE)) s->rng_dec.assign((size_t)std::max(0, (int)P.best_of - 1), CountingRng());
+                if (P.no_context) s->prompt_past.clear();
+                if (!j->prompt_tokens.empty()) {   // "prepend the prompt tokens to the prompt_past"
+                    s->prompt_past.insert(s->prompt_past.end(), j->prompt_tokens.begin(), j->prompt_tokens.end());
+                    std::rotate(s->prompt_past.begin(), s->prompt_past.end() - j->prompt_tokens.size(), s->prompt_past.end());
+                }
+            };
+            if (P.audio_ctx > n_ctx) {
+                j->status = SS_ERR_AUDIO_CTX; j->err = "audio_ctx larger than the model's n_audio_ctx";
+                const int s0 = P.offset_ms / 10, s1 = P.duration_ms == 0 ? (j->n_samples > 0 ? mel_n_len_org(j->n_samples) : 0) : s0 + P.duration_ms / 10;
+                if (P.best_of <= ND && P.offset_ms >= 0 && P.duration_ms >= 0 && j->n_samples > 0 && s1 >= s0 + 100 && !P.detect_language) touch_context();
+                return q;
+            }
             if (P.audio_ctx != 0 && P.audio_ctx != n_ctx) {   // the reference only ever passes 1500 or 0 (whisper.rs:144,68); a shortened encoder context is not built
                 j->status = SS_ERR_UNSUPPORTED; j->err = "audio_ctx must be 0 or the model's n_audio_ctx"; return q;
             }
@@ -801,13 +841,7 @@ struct EngineT : EngineBase {
                 q.seek = q.seek_start; q.seek_end = P.duration_ms == 0 ? q.n_len_org : q.seek_start + P.duration_ms / 10;
                 q.alive = q.seek_end >= q.seek_start + 100;  // "if length of spectrogram is less than 1.0s, return"
             }
-            if (q.alive && !P.detect_language) {   // detect_language returns right after the detection, before the context is touched
-                if (P.no_context) s->prompt_past.clear();
-                if (!j->prompt_tokens.empty()) {   // "prepend the prompt tokens to the prompt_past"
-                    s->prompt_past.insert(s->prompt_past.end(), j->prompt_tokens.begin(), j->prompt_tokens.end());
-                    std::rotate(s->prompt_past.begin(), s->prompt_past.end() - j->prompt_tokens.size(), s->prompt_past.end());
-                }
-            }
+            if (q.alive && !P.detect_language) touch_context();   // detect_language returns right after the detection, before the context is touched
             return q;
     }
 
@@ -963,10 +997,13 @@ struct EngineT : EngineBase {
         enc_events.fold(true);   // everything has completed by now
         const float ms_enc = enc_events.ms;
         const float ms_dec = std::max(0.0f, ms_tot - ms_mel - ms_enc);   // decoder passes + their host turnarounds: what is left of the group
-        last_ms[0] = ms_mel; last_ms[1] = ms_enc; last_ms[2] = ms_dec; last_ms[3] = ms_tot;
-        last_cnt[0] = cnt_passes; last_cnt[1] = cnt_rows; last_cnt[2] = cnt_windows; last_cnt[3] = cnt_admitted;
-        for (int i = 0; i < 4; i++) { tot_ms[i] += last_ms[i]; tot_cnt[i] += last_cnt[i]; }
-        tot_cnt[4] += cnt_midstart;
+        {
+            std::lock_guard<std::mutex> sl(stat_mu);
+            last_ms[0] = ms_mel; last_ms[1] = ms_enc; last_ms[2] = ms_dec; last_ms[3] = ms_tot;
+            last_cnt[0] = cnt_passes; last_cnt[1] = cnt_rows; last_cnt[2] = cnt_windows; last_cnt[3] = cnt_admitted;
+            for (int i = 0; i < 4; i++) { tot_ms[i] += last_ms[i]; tot_cnt[i] += last_cnt[i]; }
+            tot_cnt[4] += cnt_midstart;
+        }
         owner->last_lane.store(lane_index);
     }
 
@@ -1110,6 +1147,10 @@ struct EngineT : EngineBase {
                     c.last_ts = !q.tokens.empty() && q.tokens.back().id >= vocab.token_beg;
                     c.penult_ts = q.tokens.size() < 2 || q.tokens[q.tokens.size() - 2].id >= vocab.token_beg;
                     c.has_ts = q.has_ts; c.ts_min = q.seek_delta / 2;
+                    if (rc.openai_ts) {   // the rule reads the token history, not the decoder state: last id >= beg sampled in this attempt
+                        c.has_ts = 0; c.ts_min = 0;
+                        for (const TokenData& t : q.tokens) if (t.id >= vocab.token_beg) { c.has_ts = 1; c.ts_min = t.id - vocab.token_beg; }
+                    }
                     c.temperature = w->temperatures[w->it];
                     c.want_probs = c.temperature > 0.0f;
                 }
@@ -1170,9 +1211,14 @@ struct EngineT : EngineBase {
                 ctl_h[m] = rows[r0 + m];
                 if (refs[r0 + m].sample) {
                     ctl_h[64 + samp_rows.size()] = rows[r0 + m];
-                    if (rows[r0 + m].want_probs) {   // whisper_sample_token: dist(state.rng), one draw per sampled decoder in decoder order
+                    if (rows[r0 + m].want_probs) {
+                        // whisper_sample_token: dist(decoder.rng) -- decoder 0 draws from the generator the state carries, decoder j >= 1 from its
+                        // own (whisper.cpp >= 1.5.0); SS_COMPAT_RNG_STATE: dist(state.rng), one draw per sampled decoder in decoder order
                         any_probs = true;
-                        u_h[samp_rows.size()] = std::generate_canonical<double, std::numeric_limits<double>::digits>(refs[r0 + m].w->job->sess->rng);
+                        Session* rs = refs[r0 + m].w->job->sess;
+                        const int dj = refs[r0 + m].j;
+                        CountingRng& g = (dj == 0 || (compat & SS_COMPAT_RNG_STATE)) ? rs->rng : rs->rng_dec.at((size_t)dj - 1);
+                        u_h[samp_rows.size()] = std::generate_canonical<double, std::numeric_limits<double>::digits>(g);
                     }
                     samp_rows.push_back(m);
                 }
@@ -1320,7 +1366,9 @@ struct EngineT : EngineBase {
         launch_mel_window<T>(mel_d[0].as<float>(), n_mel, n_len, seek, 2 * n_ctx, x0.as<T>(), st);
         std::vector<uint8_t> sc((size_t)(da / 64) * Mpad);
         tap8_codes = codes; tap8_sc = sc.data();
-        struct Clear { uint8_t*& a; uint8_t*& b; ~Clear() { a = nullptr; b = nullptr; } } clear{tap8_codes, tap8_sc};
+        // on the way out -- also when a later launch of encoder_pass throws -- the stream is drained first: the two D2H copies encoder_layers_f8
+        // enqueued write into `sc` (this frame) and the caller's `codes`
+        struct Clear { uint8_t*& a; uint8_t*& b; hipStream_t s; ~Clear() { (void)hipStreamSynchronize(s); a = nullptr; b = nullptr; } } clear{tap8_codes, tap8_sc, st};
         encoder_pass(1, false);
         SS_HIP(hipStreamSynchronize(st));
         for (int m = 0; m < n_ctx; m++)        // exponent bytes out of the GEMM's tile-aware order into [row][64-column block]
@@ -1410,6 +1458,10 @@ struct EngineT : EngineBase {
         c.last_ts = n_hist > 0 && hist[n_hist - 1] >= vocab.token_beg;
         c.penult_ts = n_hist < 2 || hist[n_hist - 2] >= vocab.token_beg;
         c.has_ts = has_ts; c.ts_min = seek_delta / 2; c.temperature = 0.0f;
+        if (compat & SS_COMPAT_OPENAI_TS_RULES) {   // the rule reads the history itself (see round_rows)
+            c.has_ts = 0; c.ts_min = 0;
+            for (int i = 0; i < n_hist; i++) if (hist[i] >= vocab.token_beg) { c.has_ts = 1; c.ts_min = hist[i] - vocab.token_beg; }
+        }
         stage_acquire();
         ctl_h[0] = c;
         SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, sizeof(RowCtl), hipMemcpyHostToDevice, st));
@@ -1698,15 +1750,22 @@ void EngineBase::job_finished(Job* j, EngineBase* lane_) {
         if (q) {
             auto it = std::find(running.begin(), running.end(), std::make_pair(j, lane_));
             if (it != running.end()) running.erase(it);
-            load.fetch_sub(1);
-        }
-        j->done = true;      // after this the waiter may delete the ticket: `j` must not be touched again
+            complete_locked(j);
+        } else j->done.store(true, std::memory_order_release);
     }
     if (q) { donecv.notify_all(); qcv.notify_all(); }
+}
+// The one place a queued chunk becomes "done" (caller holds qmu).  Order matters: the session is released first (ss_session_free may delete it as
+// soon as in_flight reads 0, and it waits under qmu), `done` last -- after it the waiter may delete the ticket, so `j` must not be touched again.
+void EngineBase::complete_locked(Job* j) {
+    load.fetch_sub(1);
+    if (j->sess) j->sess->in_flight.fetch_sub(1);
+    j->done.store(true, std::memory_order_release);
 }
 int EngineBase::admit_more(int n_max, EngineBase* lane_, std::vector<Job*>& out) {
     if (workers_free.load() > 0) return 0;   // a lane with nothing to do starts a chunk sooner than a running group reaches its next window start
     std::lock_guard<std::mutex> lk(qmu);
+    if (stop) return 0;                      // the engine is going away: what is queued is failed by stop_worker, not started
     for (auto it = queue.begin(); it != queue.end() && (int)out.size() < n_max;) {
         bool dup = false;
         for (Job* b : out) if (b->sess == (*it)->sess) { dup = true; break; }
@@ -1738,9 +1797,14 @@ void EngineBase::start_worker() {
                     const int maxb = opts.max_batch > 0 ? opts.max_batch : 8;
                     if ((int)queue.size() < maxb && opts.batch_wait_us > 0)
                         qcv.wait_for(lk, std::chrono::microseconds(opts.batch_wait_us), [&] { return stop || (int)queue.size() >= maxb; });
+                    // Level the lanes when the queue is short: with fewer than (idle lanes x max_batch) chunks queued, filling this lane to max_batch
+                    // would leave the other idle lanes with nothing (64 chunks on three idle lanes: 32 / 32 / 0); take an even share instead
+                    // (22 / 21 / 21).  workers_free counts this worker and the ones queued up behind form_mu, i.e. the lanes with nothing to run.
+                    const int idle = std::max(1, workers_free.load());
+                    const int take = std::min(maxb, ((int)queue.size() + idle - 1) / idle);
                     // one chunk per session per batch (run_group writes the session's results): a second ticket of a session already in this
                     // batch stays queued, in order, for the next one
-                    for (auto it = queue.begin(); it != queue.end() && (int)batch.size() < maxb;) {
+                    for (auto it = queue.begin(); it != queue.end() && (int)batch.size() < take;) {
                         bool dup = false;
                         for (Job* b : batch) if (b->sess == (*it)->sess) { dup = true; break; }
                         if (!dup) for (auto& r : running) if (r.first->sess == (*it)->sess) { dup = true; break; }   // ... or still running on another lane
@@ -1774,9 +1838,8 @@ void EngineBase::start_worker() {
                         if (it->second != L) { ++it; continue; }
                         Job* j = it->first;
                         if (j->status == 0) { j->status = fail_code ? fail_code : SS_ERR_DEVICE; j->err = fail_code ? fail_what : "chunk left unfinished by its device group"; }
-                        j->done = true;
-                        load.fetch_sub(1);
                         it = running.erase(it);
+                        complete_locked(j);
                     }
                 }
                 donecv.notify_all();
@@ -1785,27 +1848,45 @@ void EngineBase::start_worker() {
         });
     }
 }
+// Engine teardown with work outstanding (ss_engine_free): chunks still QUEUED fail with SS_ERR_DEVICE at once, chunks a lane is running finish
+// normally (a group admits nothing more once `stop` is set), threads blocked in wait() are woken and have left before this returns.  Every
+// ticket is `done` afterwards, so a later ss_wait returns its recorded status without touching the engine.
 void EngineBase::stop_worker() {
     {
         std::lock_guard<std::mutex> lk(qmu);
         stop = true;
+        for (Job* j : queue) {
+            j->status = SS_ERR_DEVICE; j->err = "engine freed while the chunk was queued";
+            complete_locked(j);
+        }
+        queue.clear();
     }
-    qcv.notify_all();
+    qcv.notify_all(); donecv.notify_all();
     for (auto& w : workers) if (w.joinable()) w.join();
     workers.clear();
+    std::unique_lock<std::mutex> lk(qmu);
+    donecv.notify_all();
+    donecv.wait(lk, [this] { return n_waiters == 0; });
 }
 void EngineBase::submit(Job* j) {
     j->queued = true;
     load.fetch_add(1);
     {
         std::lock_guard<std::mutex> lk(qmu);
+        if (stop) {   // the engine is being freed: refuse instead of queueing behind workers that have gone
+            j->status = SS_ERR_DEVICE; j->err = "engine is shutting down";
+            complete_locked(j);
+            return;
+        }
         queue.push_back(j);
     }
     qcv.notify_all();
 }
 void EngineBase::wait(Job* j) {
     std::unique_lock<std::mutex> lk(qmu);
-    donecv.wait(lk, [&] { return j->done; });
+    n_waiters++;
+    donecv.wait(lk, [&] { return j->done.load(std::memory_order_acquire); });
+    if (--n_waiters == 0 && stop) donecv.notify_all();   // stop_worker waits for the last waiter to leave
 }
 
 EngineBase* make_engine_bf16(const char* path, const ss_engine_opts& o) { return new EngineT<bf16>(path, o, nullptr); }

@@ -40,9 +40,13 @@ struct Session {
     int n_encode = 0, n_decode = 0, n_fail = 0, n_windows = 0;
     std::vector<int> prompt_past;  // whisper_state::prompt_past: text context carried between windows (and calls, unless no_context)
     int pool_engine = -1;          // ss_pool: engine index of the last chunk
-    std::atomic<int> in_flight{0}; // tickets submitted and not yet waited for (ss_pool_submit keeps such a session on its engine)
+    std::atomic<int> in_flight{0}; // chunks submitted (ss_submit) that the engine has not completed yet: they write into this session.  ss_pool_submit keeps
+                                   // such a session on its engine; ss_session_free waits for 0.  Decremented by the engine under its qmu when the chunk is done
     int lang_id = -1;              // whisper_full_lang_id: language of the last chunk (given or detected)
-    CountingRng rng;  // whisper_state::rng (std::mt19937 seeded with 0 once per state, never reseeded per call)
+    CountingRng rng;  // the generator a state carries from call to call, seeded with 0 once, never reseeded: decoder 0's (whisper.cpp >= 1.5.0,
+                      // whisper_init_state) or whisper_state::rng shared by all decoders (SS_COMPAT_RNG_STATE, <= 1.4.x)
+    std::vector<CountingRng> rng_dec;   // [j - 1] = generator of decoder j >= 1: re-seeded with 0 by every chunk ("TAGS: WHISPER_DECODER_INIT" of
+                                        // whisper_full_with_state); unused under SS_COMPAT_RNG_STATE
 };
 
 struct Job {  // one chunk handed to transcribe (== one whisper_full_with_state call)
@@ -57,14 +61,16 @@ struct Job {  // one chunk handed to transcribe (== one whisper_full_with_state 
     std::vector<float> owned;  // async submit keeps its own copy
     bool queued = false;       // came through submit() (counts in `load`, lives in `running` while in flight)
     std::vector<int> prompt_tokens;   // P.prompt_tokens / tokenised P.initial_prompt, captured at the API boundary (P's pointers are not kept)
-    // async completion
-    bool done = false;
+    // async completion (set under the engine's qmu; read without it by ss_wait's fast path, hence atomic)
+    std::atomic<bool> done{false};
 };
 
 struct EngineBase {
     HostModel hm;
     ss_engine_opts opts{};
+    int compat = 0;   // SS_COMPAT_* in effect (opts.compat, overridden by env SS_COMPAT)
     std::mutex mu;  // serialises device work
+    std::mutex stat_mu;   // guards last_ms / last_cnt / tot_ms / tot_cnt: a metrics reader must never wait for `mu`, which a worker holds for a whole group
     float last_ms[4] = {0, 0, 0, 0};
     long last_cnt[4] = {0, 0, 0, 0};   // last group: decoder passes, decoder rows, encoder windows
     std::atomic<int> last_lane{0};     // (lane 0 only) index of the lane whose group finished last: what ss_engine_last_timing / _counters report
@@ -113,6 +119,8 @@ struct EngineBase {
     void job_finished(Job* j, EngineBase* lane_);                         // this chunk's results are final: wake its waiter now, not when the group ends
     int admit_more(int n_max, EngineBase* lane_, std::vector<Job*>& out); // pop up to n_max queued chunks (sessions not in flight) for a running group
     bool stop = false;
+    int n_waiters = 0;             // threads inside wait() (under qmu): stop_worker lets them leave before the engine goes
+    void complete_locked(Job* j);  // caller holds qmu: the chunk's status is final -- bookkeeping, then `done`
     std::atomic<unsigned> rr{0};
     std::atomic<int> workers_free{0};   // workers not running a batch right now (waiting for, or forming, one): queued chunks are theirs first
     void start_worker();

@@ -119,7 +119,7 @@ struct RowCtl {       // one per decode row; lives in pinned host memory mapped 
     int32_t cross;    // cross-KV index (window in the current batch)
     int32_t n_hist;   // tokens sampled so far in this window (0 => is_initial)
     int32_t last_ts, penult_ts;   // rule state (whisper_process_logits)
-    int32_t has_ts, ts_min;       // decoder.has_ts, seek_delta/2
+    int32_t has_ts, ts_min;       // decoder.has_ts, seek_delta/2   (RuleConsts.openai_ts: any id >= beg sampled so far, index of the last such id)
     float temperature;
     int32_t want_probs;           // t > 0: also write the full probability row
     int32_t pad;
@@ -194,6 +194,7 @@ template <typename T> void launch_T_to_f32(const T* in, float* out, size_t n, hi
 struct RuleConsts {
     int32_t n_vocab, eot, sot, translate, transcribe, solm, prev, nosp, not_, beg, blank /* id of " " or -1 */, n_lang;
     int32_t suppress_blank, no_timestamps, tdrz_enable, max_initial_tid /* -1 = off */, suppress_eot /* Mode F */;
+    int32_t openai_ts;   // SS_COMPAT_OPENAI_TS_RULES: RowCtl.has_ts / ts_min then mean "a timestamp (id >= beg) was sampled" / "the last one's index"
 };
 struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t pad[2]; };
 // scratch: >= M * 64 * 8 floats

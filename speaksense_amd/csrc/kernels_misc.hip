@@ -127,7 +127,10 @@ __device__ __forceinline__ float masked_logit(int i, float v, const RowCtl& c, c
         else if (i < rc.eot) kill = true;
     }
     if (is_initial && rc.max_initial_tid >= 0 && i > rc.beg + rc.max_initial_tid) kill = true;
-    if (c.has_ts && i >= rc.beg && i < rc.beg + c.ts_min) kill = true;
+    if (rc.openai_ts) {   // OpenAI's ApplyTimestampRules: forced first timestamp; ids up to the last timestamp are gone, the last itself unless a pair is open
+        if (is_initial && !rc.no_timestamps && i < rc.beg) kill = true;
+        if (c.has_ts && i >= rc.beg && i < rc.beg + c.ts_min + ((c.last_ts && !c.penult_ts) ? 0 : 1)) kill = true;
+    } else if (c.has_ts && i >= rc.beg && i < rc.beg + c.ts_min) kill = true;
     return kill ? kNegInf : v;
 }
 
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(64) void logits_rules_pick_kernel(const float* __re
         c.n_hist = nh;
         c.token = r.id;
         c.pos += 1;
-        if (r.id > rc.beg) { c.has_ts = 1; c.ts_min = r.id - rc.beg; }
+        if (rc.openai_ts ? r.id >= rc.beg : r.id > rc.beg) { c.has_ts = 1; c.ts_min = r.id - rc.beg; }
         ctl_upd[64 + m] = c;
         ctl_upd[row_of[m]] = c;
     }

@@ -196,6 +196,10 @@ float* whisper_get_logits_from_state(struct whisper_state*) { unsupported("whisp
 
 int whisper_tokenize(struct whisper_context* ctx, const char* text, whisper_token* tokens, int n_max_tokens) {
     if (!ctx || !text) return -1;
+    if (!tokens && n_max_tokens == 0) {   // whisper.h has no size query: n_max_tokens < needed returns -(needed) also here (whisper_token_count negates it)
+        const int need = ss_engine_tokenize(ctx->eng, text, nullptr, 0);
+        return need > 0 ? -need : need;
+    }
     const int n = ss_engine_tokenize(ctx->eng, text, tokens, n_max_tokens);
     if (n == SS_ERR_BUFFER) {   // whisper.h's convention: -(tokens needed)
         const int need = ss_engine_tokenize(ctx->eng, text, nullptr, 0);

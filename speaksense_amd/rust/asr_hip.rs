@@ -19,7 +19,7 @@ use std::sync::{Arc, Mutex};
 #[repr(C)] pub struct ss_session { _p: [u8; 0] }
 #[repr(C)] pub struct ss_ticket { _p: [u8; 0] }
 #[repr(C)] #[derive(Default)]
-pub struct ss_engine_opts { pub device: i32, pub dtype: i32, pub max_batch: i32, pub max_decoders: i32, pub batch_wait_us: i32, pub n_lanes: i32, pub reserved: [i32; 2] }
+pub struct ss_engine_opts { pub device: i32, pub dtype: i32, pub max_batch: i32, pub max_decoders: i32, pub batch_wait_us: i32, pub n_lanes: i32, pub compat: i32, pub reserved: i32 }
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct ss_params {
     pub best_of: i32, pub temperature: f32, pub temperature_inc: f32, pub entropy_thold: f32, pub logprob_thold: f32,
@@ -73,7 +73,7 @@ pub struct HipAsr { engine: Arc<EnginePtr> }
 impl HipAsr {
     pub fn new(model_path: String) -> Result<Self> {
         let path = CString::new(model_path)?;
-        let opts = ss_engine_opts { device: 0, dtype: 1 /* SS_DTYPE_F16 (ggml's arithmetic); 0 = bf16, 2 = fp8 (e4m3 encoder / cross-KV projections and cross cache, base and larger models) */, max_batch: 8, max_decoders: 5, batch_wait_us: 2000, n_lanes: 2, reserved: [0; 2] };
+        let opts = ss_engine_opts { device: 0, dtype: 1 /* SS_DTYPE_F16 (ggml's arithmetic); 0 = bf16, 2 = fp8 (e4m3 encoder / cross-KV projections and cross cache, base and larger models) */, max_batch: 8, max_decoders: 5, batch_wait_us: 2000, n_lanes: 2, compat: 0 /* whisper.cpp v1.5.x behaviour (what whisper-rs-sys 0.9.0 vendors); SS_COMPAT_* selects older / OpenAI variants */, reserved: 0 };
         let mut e: *mut ss_engine = std::ptr::null_mut();
         let rc = unsafe { ss_engine_create(path.as_ptr(), &opts, &mut e) };
         if rc != 0 { return Err(anyhow!("failed to open whisper model: {}", last_error())); }

@@ -39,7 +39,7 @@ int main(void) {
     F(ss_params, initial_prompt);
     printf("ss_params sizeof %zu 0\n", sizeof(struct ss_params));
     F(ss_engine_opts, device); F(ss_engine_opts, dtype); F(ss_engine_opts, max_batch); F(ss_engine_opts, max_decoders);
-    F(ss_engine_opts, batch_wait_us); F(ss_engine_opts, n_lanes); F(ss_engine_opts, reserved);
+    F(ss_engine_opts, batch_wait_us); F(ss_engine_opts, n_lanes); F(ss_engine_opts, compat); F(ss_engine_opts, reserved);
     printf("ss_engine_opts sizeof %zu 0\n", sizeof(struct ss_engine_opts));
     return 0;
 }

@@ -3,8 +3,8 @@
 bench.py's default line runs `Engine(max_batch=32, n_lanes=3)` on the real large-v3 shape (BASELINE.json configs[2], SURVEY.md section 8d
 config #3; reference call site /root/reference/src/asr/whisper.rs:75).  At 27-32 rows per decoder pass the engine takes kernel paths no
 8-row test reaches: rows x heads >= 320 switches the cross-attention to its unsplit form (`dec_cross_attn_q_kernel<T,1>`, the fp8 engine's
-`dec_cross_attn_q8_kernel<T,1>`), and every projection runs through the multi-tile GEMVs (`dec_gemv_wide_kernel<*,2>` for 17..32 rows,
-`<*,4>` for 33..64) -- together ~45 % of the benchmark's GPU time.  Two kinds of test, each for f16 / bf16 / fp8:
+`dec_cross_attn_q8_kernel<T,1>`), and every projection runs through the multi-tile GEMVs (`dec_gemv_kernel<T,EPI,CT,NFR>` with CT = 2 column tiles for 17..32 rows,
+CT = 4 for 33..64) -- together ~45 % of the benchmark's GPU time.  Two kinds of test, each for f16 / bf16 / fp8:
 
 (i)  stage: `ss_engine_decode_rows` -- ONE decoder pass over 32 and over 64 rows (sequences of 8 prompt positions each, attending to different
      cross-KV windows) against the oracle's logits for each sequence, at full depth (32 layers);

@@ -138,11 +138,14 @@ def test_rest_pipeline_resampled_and_failing_inputs(wasr, tmp_path):
         proc.process_audio({"path_type": "Local", "input_path": "x.wav", "params": {"type": "Transcribe", "params": {"language": "xx"}}})
 
 
-def test_sampler_state_carries_across_calls_and_can_be_replayed(wasr):
-    """whisper_state::rng is never reseeded: on one state the second call's sampled fallbacks depend on the first call's draws.  A fresh
-    session whose generator is advanced by the same number of draws reproduces that second call exactly (what the batched REST path does)."""
+@pytest.mark.parametrize("topo", ["per_decoder", "rng_state"])
+def test_sampler_state_carries_across_calls_and_can_be_replayed(toy_ml_path, topo):
+    """The generator a whisper_state carries (decoder 0's under whisper.cpp >= 1.5.0's per-decoder topology, whisper_state::rng under
+    SS_COMPAT_RNG_STATE) is never reseeded: on one state the second call's sampled fallbacks depend on the first call's draws.  A fresh session
+    whose carried generator is advanced by the same number of draws reproduces that second call exactly (what the batched REST path does).
+    per_decoder: decoders 1.. carry nothing -- each call re-seeds them -- and draw exactly as often as decoder 0 while all five run."""
     from speaksense_amd import binding
-    eng = wasr.engine
+    eng = binding.Engine(toy_ml_path, max_batch=4, compat=binding.COMPAT_RNG_STATE if topo == "rng_state" else 0)
     p = binding.default_params(language="en")
     sampled = None
     for seed in range(3, 12):                       # find a chunk whose default ladder falls back to sampling on this model
@@ -168,3 +171,11 @@ def test_sampler_state_carries_across_calls_and_can_be_replayed(wasr):
     assert list(replay["tokens"]) == list(second_on_same_state["tokens"]) and b.rng_draws() == d2
     assert [s["text"] for s in replay["segments"]] == [s["text"] for s in second_on_same_state["segments"]]
     assert len(first_again["tokens"]) > 0
+    if topo == "per_decoder":
+        # first call on a fresh state: five generators in the same position, the same distributions -> the same draws, call for call
+        assert [fresh.rng_draws(j) for j in range(1, 5)] == [d1] * 4
+        # decoders 1.. start every call from the same seed and the same distributions: they coincide with each other on every call
+        assert len({b.rng_draws(j) for j in range(1, 5)}) == 1 and b.rng_draws(1) > 0
+    else:
+        assert [fresh.rng_draws(j) for j in range(1, 5)] == [0] * 4 and d1 % 5 == 0
+    eng.close()

@@ -1,0 +1,224 @@
+"""Ownership rules of the C ABI under load: sessions freed with chunks in flight, engines freed with chunks queued,
+abandoned tickets, lane levelling, and a multi-minute soak of random submit / wait / free interleavings from 8 threads.
+
+The reference owns these objects through Arc / Mutex (/root/reference/src/asr/whisper.rs:17,26,34-38: one Arc<WhisperContext> shared by tokio tasks,
+each WhisperState behind a Mutex held for the whole call), so its callers cannot free a state that is in use; a C ABI has to say what happens."""
+import ctypes as C
+import os
+import random
+import threading
+import time
+
+import numpy as np
+import pytest
+
+from speaksense_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _P(**kw):
+    from speaksense_amd import binding
+    return binding.default_params(language="en", temperature_inc=0.0, **kw)
+
+
+def _key(r):
+    return (list(r["tokens"]), [(s["t0"], s["t1"], s["text"]) for s in r["segments"]])
+
+
+def test_session_free_blocks_until_its_chunks_are_complete(toy_ml_path):
+    """ss_session_free with tickets outstanding waits for the engine to complete them (the worker writes into the session): no use-after-free,
+    and ss_wait on those tickets afterwards still returns the recorded status."""
+    from speaksense_amd import binding
+    eng = binding.Engine(toy_ml_path, max_batch=4, n_lanes=2)
+    pcm = synth.speech_like(3)
+    ref = eng.new_session().transcribe(pcm, _P())
+    for rnd in range(6):
+        ses = [eng.new_session() for _ in range(10)]
+        tickets = [s.submit(pcm, _P()) for s in ses]          # 10 chunks on 2 lanes x 4: some run, some are queued
+        for s in ses[::2]:
+            s.close()                                         # blocks until that chunk is done; must not crash the worker
+        for s, t in zip(ses, tickets):
+            if s.h is None:
+                assert eng.L.ss_wait(t) == 0                  # the session is gone, the status is on the ticket
+            else:
+                assert _key(s.wait(t)) == _key(ref)
+                s.close()
+    eng.close()
+
+
+def test_engine_free_fails_queued_chunks_and_wakes_waiters(toy_ml_path):
+    """ss_engine_free with work outstanding: queued chunks fail with SS_ERR_DEVICE, running ones complete, a thread blocked in ss_wait returns,
+    tickets waited for after the engine has gone return their recorded status, sessions can be freed afterwards."""
+    from speaksense_amd import binding
+    eng = binding.Engine(toy_ml_path, max_batch=2, n_lanes=1, batch_wait_us=0)
+    L = eng.L
+    pcm = synth.speech_like(4, 16000 * 20)
+    ses = [eng.new_session() for _ in range(12)]
+    tickets = [s.submit(pcm, _P()) for s in ses]
+    got = {}
+
+    def waiter(i):
+        got[i] = L.ss_wait(tickets[i])
+    th = [threading.Thread(target=waiter, args=(i,)) for i in (0, 11)]   # one near the head, one at the tail of the queue
+    for t in th:
+        t.start()
+    time.sleep(0.02)
+    eng.close()                                               # 12 chunks, 2 per group: most are still queued
+    for t in th:
+        t.join(timeout=60)
+        assert not t.is_alive(), "a thread blocked in ss_wait was not woken by ss_engine_free"
+    codes = [got[0]] + [L.ss_wait(tickets[i]) for i in range(1, 11)] + [got[11]]
+    assert all(c in (0, -4) for c in codes), codes
+    assert codes.count(-4) >= 4, f"expected most queued chunks to fail with SS_ERR_DEVICE: {codes}"
+    assert codes[11] == -4
+    for s in ses:
+        s.close()                                             # after the engine: nothing in flight, plain delete
+
+
+def test_abandoned_ticket_leaks_nothing_on_the_device(toy_ml_path):
+    """A ticket that is never waited for: the chunk still completes, the session can be freed, device memory stays flat."""
+    from speaksense_amd import binding
+    eng = binding.Engine(toy_ml_path, max_batch=4, n_lanes=2)
+    pcm = synth.speech_like(5)
+    eng.new_session().transcribe(pcm, _P())
+    free0, _ = eng.mem_info()
+    for _ in range(40):
+        s = eng.new_session()
+        s.submit(pcm, _P())                                   # ticket dropped
+        s.close()                                             # waits for completion, frees the session
+    free1, _ = eng.mem_info()
+    assert abs(free1 - free0) < 8 << 20, (free0, free1)
+    eng.close()
+
+
+def test_short_queue_is_levelled_over_idle_lanes(toy_ml_path):
+    """64 chunks handed to an engine with three idle lanes of up to 32 windows each: the batch former gives the lanes 22 / 21 / 21, not
+    32 / 32 / 0, and the results are the serial ones."""
+    from speaksense_amd import binding
+    eng = binding.Engine(toy_ml_path, max_batch=32, n_lanes=3, batch_wait_us=200000)
+    pcms = [synth.speech_like(60 + i % 5, 16000 * 4) for i in range(64)]
+    P = _P(fixed_steps=24)
+    ref = [_key(eng.new_session().transcribe(p, P)) for p in pcms[:5]]
+    base = [eng.lane_counters(l)["encoder_windows"] for l in range(3)]
+    ses = [eng.new_session() for _ in pcms]
+    tickets = [s.submit(p, P) for s, p in zip(ses, pcms)]
+    for i, (s, t) in enumerate(zip(ses, tickets)):
+        assert _key(s.wait(t)) == ref[i % 5]
+    loads = sorted(eng.lane_counters(l)["encoder_windows"] - base[l] for l in range(3))
+    assert loads == [21, 21, 22], loads
+    eng.close()
+
+
+@pytest.mark.timeout(900)
+def test_soak_random_interleavings(toy_ml_path):
+    """~3 minutes (SS_SOAK_SECONDS): 8 threads submit chunks of random length (0.5 - 65 s) with random parameters -- refused ones included --
+    wait for them in random order, abandon some tickets, free sessions at random points (also with chunks in flight), while a ninth thread polls the
+    metrics entry points.  No hang (every thread finishes in time), device memory flat, and every result a thread did collect equals the
+    serial result of the same (audio, parameters) on a fresh session."""
+    from speaksense_amd import binding
+    seconds = float(os.environ.get("SS_SOAK_SECONDS", "180"))
+    eng = binding.Engine(toy_ml_path, max_batch=8, n_lanes=3)
+    lengths = [0.5, 1.0, 3.0, 7.5, 12.0, 29.9, 30.1, 44.0, 65.0]
+    audio = {(sd, ln): synth.speech_like(sd, int(16000 * ln)) for sd in (1, 2, 3) for ln in lengths}
+    variants = {
+        "greedy": dict(), "fixed": dict(fixed_steps=16), "no_ts": dict(no_timestamps=1), "single": dict(single_segment=1), "maxtok": dict(max_tokens=12),
+        "ladder": dict(temperature_inc=0.2), "offset": dict(offset_ms=1500), "bad_lang": dict(language="xx"), "bad_ctx": dict(audio_ctx=3000),
+        "bad_best": dict(best_of=9, temperature_inc=0.2), "detect": dict(language="auto"),
+    }
+
+    def params(v):
+        kw = dict(language="en", temperature_inc=0.0)
+        kw.update(variants[v])
+        return binding.default_params(**kw)
+    serial = {}
+    serial_lock = threading.Lock()
+
+    def expected(k):
+        with serial_lock:
+            if k not in serial:
+                s = eng.new_session()
+                try:
+                    serial[k] = ("ok", _key(s.transcribe(audio[k[0]], params(k[1]))))
+                except binding.SpeakSenseError as e:
+                    serial[k] = ("err", e.code)
+                s.close()
+            return serial[k]
+    eng.new_session().transcribe(audio[(1, 30.1)], params("ladder"))      # warm every graph shape before the memory baseline
+    for k in [((1, 3.0), "greedy"), ((2, 65.0), "greedy"), ((3, 12.0), "ladder")]:
+        expected(k)
+    free0, _ = eng.mem_info()
+    t_end = time.time() + seconds
+    stats = dict(chunks=0, refused=0, abandoned=0, freed_in_flight=0, checked=0)
+    errors = []
+    st_lock = threading.Lock()
+
+    def worker(wid):
+        rnd = random.Random(1000 + wid)
+        try:
+            while time.time() < t_end:
+                n_ses = rnd.randint(1, 5)
+                ses = [eng.new_session() for _ in range(n_ses)]
+                pending = []
+                for s in ses:
+                    for _ in range(rnd.randint(1, 2)):        # up to two tickets per session: they run in submission order
+                        k = ((rnd.choice((1, 2, 3)), rnd.choice(lengths)), rnd.choice(list(variants)))
+                        pending.append((s, s.submit(audio[k[0]], params(k[1])), k))
+                rnd.shuffle(pending)
+                last_of = {}
+                for s, t, k in pending:
+                    last_of[id(s)] = None
+                freed = set()
+                for s, t, k in pending:
+                    r = rnd.random()
+                    if id(s) in freed or r < 0.08:            # abandon the ticket (its session may already be gone)
+                        if id(s) in freed:
+                            code = eng.L.ss_wait(t)           # status only: the results went with the session
+                            exp = expected(k)
+                            assert (code == 0) == (exp[0] == "ok") or code == exp[1], (k, code, exp)
+                        else:
+                            with st_lock:
+                                stats["abandoned"] += 1
+                        continue
+                    if r < 0.18:                              # free the session with this (and maybe another) chunk in flight
+                        s.close(); freed.add(id(s))
+                        code = eng.L.ss_wait(t)
+                        with st_lock:
+                            stats["freed_in_flight"] += 1
+                        continue
+                    exp = expected(k)
+                    try:
+                        got = ("ok", _key(s.wait(t)))
+                    except binding.SpeakSenseError as e:
+                        got = ("err", e.code)
+                    # a session with two tickets holds the results of whichever chunk ran last: only the status is comparable then
+                    two = sum(1 for s2, _, _ in pending if s2 is s) > 1
+                    if two:
+                        assert got[0] == exp[0], (k, got[0], exp[0])
+                    else:
+                        assert got == exp, (k, got, exp)
+                    with st_lock:
+                        stats["chunks"] += 1; stats["checked"] += not two; stats["refused"] += got[0] == "err"
+                for s in ses:
+                    if id(s) not in freed:
+                        s.close()
+        except BaseException as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append((wid, repr(e)))
+
+    def poller():
+        while time.time() < t_end:
+            eng.totals(); eng.last_timing(); eng.mem_info()
+            time.sleep(0.005)
+    threads = [threading.Thread(target=worker, args=(w,)) for w in range(8)] + [threading.Thread(target=poller)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=seconds + 240)
+        assert not t.is_alive(), "soak: a thread hung"
+    assert not errors, errors
+    free1, _ = eng.mem_info()
+    from conftest import report
+    report(f"soak {seconds:.0f} s, 8 threads: {stats}, device memory free {free0 >> 20} -> {free1 >> 20} MiB")
+    assert stats["chunks"] > 200 and stats["refused"] > 5 and stats["freed_in_flight"] > 5 and stats["abandoned"] > 5
+    assert free0 - free1 < 64 << 20, f"device memory grew by {(free0 - free1) >> 20} MiB"
+    eng.close()

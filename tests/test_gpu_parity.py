@@ -109,15 +109,21 @@ def test_decoder_logits_match_oracle(toy_ml_path, orc, dtype):
 # ------------------------------------------------------------------------------------------------
 # fused logits rules + greedy pick: integer outputs identical
 # ------------------------------------------------------------------------------------------------
-def test_process_logits_matches_oracle(toy_en_path, toy_ml_path, orc):
+@pytest.mark.parametrize("rules", ["wcpp_1_5", "openai_ts_rules"])
+def test_process_logits_matches_oracle(toy_en_path, toy_ml_path, orc, rules):
+    """rules = "openai_ts_rules": SS_COMPAT_OPENAI_TS_RULES on both sides (the ledger's rows 2-4); the oracle's form of that
+    variant is itself pinned to HF transformers with no exclusions (tests/test_oracle_golden.py)."""
     from speaksense_amd import binding
     rng = np.random.default_rng(0)
+    compat = binding.COMPAT_OPENAI_TS_RULES if rules == "openai_ts_rules" else 0
+    assert binding.COMPAT_OPENAI_TS_RULES == orc.COMPAT_OPENAI_TS_RULES and binding.COMPAT_RNG_STATE == orc.COMPAT_RNG_STATE
     for path in (toy_en_path, toy_ml_path):
         om = orc.OracleModel(path)
-        eng = _eng(path, binding.DTYPE_BF16, max_batch=1)
-        ost = om.new_state(orc.MODE_F32)
+        eng = _eng(path, binding.DTYPE_BF16, max_batch=1, compat=compat)
+        ost = om.new_state(orc.MODE_F32, compat=compat)
         beg, eot = om.beg, om.eot
-        hists = [[], [beg + 10], [beg + 10, 500], [500, beg + 20], [beg + 5, beg + 9], [100, 200, 300], [beg + 40, 7, 8, beg + 80, beg + 80]]
+        hists = [[], [beg + 10], [beg + 10, 500], [500, beg + 20], [beg + 5, beg + 9], [100, 200, 300], [beg + 40, 7, 8, beg + 80, beg + 80],
+                 [beg], [beg, 17], [beg + 3, 21, 22, beg + 30], [beg + 3, 21, 22, beg + 30, beg + 30, 9]]
         for hist in hists:
             for trial in range(4):
                 raw = (9.0 * rng.standard_normal(om.n_vocab)).astype(np.float32)
@@ -180,15 +186,16 @@ def check_against_oracle(got, om, orc, mode, pcm, P, ctx, gap_tol, replay_only=F
 LOGIT_DELTA_F16 = GAP_TOL_F16 / 2
 
 
-def check_trace_against_oracle(got, om, orc, mode, pcm, P, ctx, gap_tol, logit_delta=LOGIT_DELTA_F16):
+def check_trace_against_oracle(got, om, orc, mode, pcm, P, ctx, gap_tol, logit_delta=LOGIT_DELTA_F16, compat=0):
     """The whole call -- every attempt of the temperature ladder, every best_of decoder, failed ones included -- replayed on the oracle call by
     call (oracle/binding.py `full(trace=...)`): `got["trace"]` is every id the device sampled in whisper_sample_token call order.
     Greedy calls: the device's id must be the oracle's argmax or within `gap_tol` log-probability of it.  Sampled calls (t > 0): the oracle draws
-    from the same mt19937 at the same position (std::discrete_distribution consumes one generate_canonical<double,53> per call on both sides);
+    from the same mt19937 at the same position (std::discrete_distribution consumes one generate_canonical<double,53> per call on both sides;
+    `compat` selects whose generator that is on both sides -- the decoder's own, whisper.cpp >= 1.5.0, or the state's, COMPAT_RNG_STATE);
     the device's id must be the id the oracle's own cumulative distribution selects for that uniform, or the uniform must lie within
     2 logit_delta F (1 - F) / T of that id's interval -- the distance a logit difference of logit_delta can move the boundary.  The replay then has to consume the trace exactly and reproduce tokens, segments, timestamps and the number of
     fallbacks.  Returns (n greedy flips, n sampled flips, worst greedy gap, worst cdf gap)."""
-    rep = om.new_state(mode).full(pcm, P, trace=got["trace"])
+    rep = om.new_state(mode, compat=compat).full(pcm, P, trace=got["trace"])
     gap, best, kind, sens = rep["trace_gap"], rep["trace_best"], rep["trace_kind"], rep["trace_sens"]
     assert len(gap) == len(got["trace"]), f"{ctx}: the oracle consumed {len(gap)} of the device's {len(got['trace'])} sampled ids (the control flow diverged)"
     assert list(rep["trace"]) == list(got["trace"]), f"{ctx}: the oracle sampled past the device's trace"
@@ -272,24 +279,32 @@ def test_full_path_real_widths_f16(tiny_en_path, base_en_path, wide2_path, orc, 
     eng.close(); om.close()
 
 
+TOPOLOGIES = {"per_decoder": 0, "rng_state": 1}   # the sampler's generator topology: whisper.cpp >= 1.5.0 (default) | <= 1.4.x (SS_COMPAT_RNG_STATE)
+
+
+@pytest.mark.parametrize("topo", list(TOPOLOGIES))
 @pytest.mark.parametrize("which", ["toy.en", "toy"])
-def test_full_path_default_ladder_f16(toy_en_path, toy_ml_path, orc, which):
+def test_full_path_default_ladder_f16(toy_en_path, toy_ml_path, orc, which, topo):
     """The reference's real parameters (/root/reference/src/asr/whisper.rs:131-143: Greedy{best_of 5}, temperature 0.0, whisper.cpp's default
     temperature_inc 0.2 -> ladder 0.0..1.0).  Chunks whose windows never leave t = 0 must match exactly (the inputs include chunks picked so
     that this branch is taken: tools/find_nofallback_seeds.py).  Once a window falls back to t > 0 its tokens are SAMPLED from
     device-computed probabilities with the session's mt19937, five decoders at a time.  Every such chunk -- 100 % of them -- must either equal
     the free-running oracle token for token, or pass the trace replay (check_trace_against_oracle): each of its hundreds of sampled picks is
     the oracle's own pick for the same uniform, or the uniform lies at the boundary between the two ids (within what f16 logit noise can move it), and the replay
-    reproduces the ladder bookkeeping (n_fail), windows, segments and timestamps."""
+    reproduces the ladder bookkeeping (n_fail), windows, segments and timestamps.
+    Both generator topologies: "per_decoder" = every best_of decoder draws from its own std::mt19937(0) (whisper.cpp >= 1.5.0, the
+    engine's and the oracle's default), "rng_state" = one generator in the state (<= 1.4.x, SS_COMPAT_RNG_STATE).  The trace replay proves the
+    topology call by call: a side drawing from another generator than the oracle's would fail at the first sampled call."""
     from speaksense_amd import binding
     path = toy_en_path if which == "toy.en" else toy_ml_path
+    compat = TOPOLOGIES[topo]
     om = orc.OracleModel(path)
-    eng = _eng(path, binding.DTYPE_F16, max_batch=4)
+    eng = _eng(path, binding.DTYPE_F16, max_batch=4, compat=compat)
     n_fb = n_fb_same = n_exact = n_calls = n_sflip = 0
     cases = [(s, 30) for s in (3, 4, 5, 6, 7, 8)] + ([(43, 9), (49, 9)] if which == "toy.en" else [])
     for seed, seconds in cases:
         pcm = synth.speech_like(seed, 16000 * seconds)
-        ref = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(language="en"))
+        ref = om.new_state(orc.MODE_GGML_F16, compat=compat).full(pcm, orc.default_params(language="en"))
         got = eng.new_session().transcribe(pcm, binding.default_params(language="en"))
         if ref["n_fail"] == 0:
             _same_result(got, ref, f"{which} seed {seed} (no fallback)")
@@ -302,14 +317,38 @@ def test_full_path_default_ladder_f16(toy_en_path, toy_ml_path, orc, which):
             _same_result(got, ref, f"{which} seed {seed} (fallback, same draws)")
             assert got["n_fail"] == ref["n_fail"]
         else:
-            _, fs, _, _ = check_trace_against_oracle(got, om, orc, orc.MODE_GGML_F16, pcm, orc.default_params(language="en"), f"{which} seed {seed} (fallback)",
-                                                     GAP_TOL_F16)
+            _, fs, _, _ = check_trace_against_oracle(got, om, orc, orc.MODE_GGML_F16, pcm, orc.default_params(language="en"), f"{which} {topo} seed {seed} (fallback)",
+                                                     GAP_TOL_F16, compat=compat)
             n_sflip += fs
         n_calls += len(got["trace"])
-    report(f"{which}: {n_exact} chunks without fallback identical; {n_fb_same}/{n_fb} fallback chunks identical call for call, the other {n_fb - n_fb_same} proven by "
+    report(f"{which} [{topo}]: {n_exact} chunks without fallback identical; {n_fb_same}/{n_fb} fallback chunks identical call for call, the other {n_fb - n_fb_same} proven by "
            f"trace replay ({n_calls} sampler calls in the fallback chunks, {n_sflip} picks at a CDF boundary)")
     assert n_exact >= 1, "fixture drifted: no chunk stays at temperature 0"
     assert n_fb >= 1, "fixture drifted: no chunk walks the temperature ladder"
+    eng.close(); om.close()
+
+
+@pytest.mark.parametrize("which", ["toy.en", "toy"])
+def test_full_path_openai_ts_rules_variant(toy_en_path, toy_ml_path, orc, which):
+    """SS_COMPAT_OPENAI_TS_RULES through the whole path (forced first timestamp, `<=` monotonic rule, <|0.00|> counts; ledger rows 2-4): greedy ids,
+    segments and timestamps identical to the oracle under the same flag -- including the chained steps, where the pick kernel advances the rule
+    state on the device -- and the flag must actually change something on this fixture (otherwise the test proves nothing)."""
+    from speaksense_amd import binding
+    path = toy_en_path if which == "toy.en" else toy_ml_path
+    om = orc.OracleModel(path)
+    eng = _eng(path, binding.DTYPE_F16, max_batch=4, compat=binding.COMPAT_OPENAI_TS_RULES)
+    n_diff = 0
+    for seed in (3, 4, 5, 6):
+        pcm = synth.speech_like(seed)
+        P = dict(language="en", temperature_inc=0.0)
+        ref = om.new_state(orc.MODE_GGML_F16, compat=orc.COMPAT_OPENAI_TS_RULES).full(pcm, orc.default_params(**P))
+        got = eng.new_session().transcribe(pcm, binding.default_params(**P))
+        _same_result(got, ref, f"{which} openai_ts_rules seed {seed}")
+        base = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(**P))
+        n_diff += list(base["tokens"]) != list(ref["tokens"])
+        assert len(ref["tokens"]) == 0 or ref["tokens"][0] >= om.beg, "first token of the first window is not a timestamp under the OpenAI rule"
+    report(f"{which}: SS_COMPAT_OPENAI_TS_RULES identical to the oracle's variant on 4 chunks; {n_diff}/4 differ from the v1.5.x rules")
+    assert n_diff >= 1
     eng.close(); om.close()
 
 

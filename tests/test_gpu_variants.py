@@ -414,6 +414,7 @@ def test_whisper_h_full_surface(toy_ml_path, eng, monkeypatch):
     buf = (C.c_int32 * 64)()
     n = L.whisper_tokenize(ctx, text, buf, 64)
     assert list(buf[:n]) == eng.tokenize(text) and L.whisper_tokenize(ctx, text, buf, 1) == -n
+    assert L.whisper_tokenize(ctx, text, None, 0) == -n      # whisper.h: -(needed) whenever n_max_tokens < needed, NULL buffer included (whisper_token_count relies on the sign)
 
     st = L.whisper_init_state(ctx)
     pcm = synth.speech_like(23, 16000 * 12)

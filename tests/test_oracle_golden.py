@@ -127,15 +127,18 @@ def test_oracle_matches_hf_on_more_shapes(name, model_dir):
     st.close(); om.close()
 
 
+@pytest.mark.parametrize("variant", ["wcpp_1_5", "openai_ts_rules"])
 @pytest.mark.parametrize("tag,preset", [("en", "toy.en"), ("ml", "toy")])
-def test_process_logits_matches_openai_rules(tag, preset, model_dir):
+def test_process_logits_matches_openai_rules(tag, preset, variant, model_dir):
     """whisper_process_logits (oracle restatement) against OpenAI's rules as HF transformers implements them (SuppressTokens*,
     WhisperTimeStampLogitsProcessor) on seeded logits x 12 token histories x 4 logit shapes, both vocabularies.  The two rule sets coincide
     except for three things, each excluded explicitly here and nowhere else:
       1. first step: OpenAI forces a timestamp (all text masked); whisper.cpp v1.5 only applies max_initial_ts -> the text region is not compared;
       2. monotonic timestamps: whisper.cpp masks ids < last timestamp (tid0 = seek_delta / 2); OpenAI masks <= last unless a pair is open
          -> the single id == last timestamp is not compared when OpenAI's "+1" branch is active;
-      3. whisper.cpp's has_ts needs id > token_beg, so a history whose only timestamp is <|0.00|> masks nothing -- the same single id as in 2."""
+      3. whisper.cpp's has_ts needs id > token_beg, so a history whose only timestamp is <|0.00|> masks nothing -- the same single id as in 2.
+    variant "openai_ts_rules" = the oracle's COMPAT_OPENAI_TS_RULES switch (ledger rows 2-4), which restates OpenAI's form of
+    exactly these three: under it NOTHING is excluded -- every mask bit and every top log-probability of every case must equal HF's."""
     from tests_golden_cases import rule_cases, rule_logits
     g = np.load(RULES_GOLD)
     path = os.path.join(model_dir, f"rules-{preset}.bin")
@@ -143,7 +146,8 @@ def test_process_logits_matches_openai_rules(tag, preset, model_dir):
     om = orc.OracleModel(path)
     assert om.n_vocab == int(g[f"{tag}_n_vocab"])
     beg, eot = om.beg, om.eot
-    st = om.new_state(orc.MODE_F32)
+    openai = variant == "openai_ts_rules"
+    st = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES if openai else 0)
     rng = np.random.default_rng(1234 + om.n_vocab)
     P = orc.default_params()
     n_cmp = 0
@@ -156,10 +160,10 @@ def test_process_logits_matches_openai_rules(tag, preset, model_dir):
         mine = np.isinf(lp)
         gold = np.unpackbits(g[f"{tag}_mask"][ci])[:om.n_vocab].astype(bool)
         skip = np.zeros(om.n_vocab, bool)
-        if not hist:
+        if not hist and not openai:
             skip[:beg] = True                                             # difference 1
         all_ts = [t for t in hist if t >= beg]
-        if all_ts:
+        if all_ts and not openai:
             pair_open = hist[-1] >= beg and not (len(hist) < 2 or hist[-2] >= beg)
             if not pair_open:
                 skip[all_ts[-1]] = True                                   # differences 2 and 3
@@ -168,7 +172,7 @@ def test_process_logits_matches_openai_rules(tag, preset, model_dir):
         # log-probabilities: relative to the most likely compared token (the skipped ids may carry mass that shifts the normaliser)
         top, topv = g[f"{tag}_top"][ci], g[f"{tag}_topv"][ci]
         keep = [j for j in range(len(top)) if cmp_[top[j]] and np.isfinite(topv[j])]
-        if hist and keep:
+        if (hist or openai) and keep:
             j0 = keep[0]
             for j in keep:
                 assert abs((lp[top[j]] - lp[top[j0]]) - (topv[j] - topv[j0])) < 2e-4 * max(1.0, abs(topv[j] - topv[j0])), (tag, hist, trial, int(top[j]))

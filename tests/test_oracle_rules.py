@@ -72,7 +72,8 @@ def test_full_structure(om):
     st.close()
 
 
-def test_trace_replay_is_exact_on_the_oracle_itself(tmp_path):
+@pytest.mark.parametrize("topo", ["per_decoder", "rng_state"])
+def test_trace_replay_is_exact_on_the_oracle_itself(tmp_path, topo):
     """The test hook the sampled-attempt parity rests on (oracle `full(trace=...)`): a chunk that walks the temperature ladder, replayed on a fresh
     state from its own trace, must consume every entry, recompute each uniform from the generator state before the call, find it INSIDE the
     interval of the cumulative distribution that selects the traced id (gap exactly 0: the recomputed CDF is libstdc++'s) and reproduce the
@@ -83,17 +84,76 @@ def test_trace_replay_is_exact_on_the_oracle_itself(tmp_path):
     path = str(tmp_path / "toy.en.bin")
     ggml_io.write_model(path, "toy.en", seed=1)
     om = orc.OracleModel(path)
+    compat = orc.COMPAT_RNG_STATE if topo == "rng_state" else 0
     pcm = synth.speech_like(5, 16000 * 30)
     P = orc.default_params(language="en")
-    ref = om.new_state(orc.MODE_GGML_F16).full(pcm, P)
+    ref = om.new_state(orc.MODE_GGML_F16, compat=compat).full(pcm, P)
     assert ref["n_fail"] >= 1 and len(ref["trace"]) > len(ref["sampled"])          # failed attempts and losing decoders are in the trace
-    rep = om.new_state(orc.MODE_GGML_F16).full(pcm, P, trace=ref["trace"])
+    rep = om.new_state(orc.MODE_GGML_F16, compat=compat).full(pcm, P, trace=ref["trace"])
     assert len(rep["trace_gap"]) == len(ref["trace"]) and int(rep["trace_kind"].sum()) > 100
     assert float(rep["trace_gap"].max()) == 0.0 and (rep["trace_best"] == ref["trace"]).all()
     assert list(rep["tokens"]) == list(ref["tokens"]) and rep["n_fail"] == ref["n_fail"]
     k = int(np.nonzero(rep["trace_kind"] == 1)[0][7])
     bad = ref["trace"].copy()
     bad[k] = bad[k] + 1 if bad[k] + 1 < om.n_vocab else bad[k] - 1
-    rep2 = om.new_state(orc.MODE_GGML_F16).full(pcm, P, trace=bad)
+    rep2 = om.new_state(orc.MODE_GGML_F16, compat=compat).full(pcm, P, trace=bad)
     assert rep2["trace_gap"][k] > 0.0 and rep2["trace_best"][k] == ref["trace"][k] and float(rep2["trace_gap"][:k].max()) == 0.0
+    om.close()
+
+
+def test_rng_topology_semantics(tmp_path):
+    """What the two generator topologies mean (ledger row 1).
+    per_decoder (whisper.cpp >= 1.5.0, default): every best_of decoder owns std::mt19937(0); decoder 0's is seeded with the state and carried
+    across calls, decoders 1.. are re-seeded by every call.  On a FRESH state all five generators are therefore in the same position, the
+    decoders start from the same distribution (they copy decoder 0's after the prompt) and draw the same uniforms: their sampled ids coincide call for
+    call, and from the second call on the same state only decoders 1..4 still coincide.  rng_state (<= 1.4.x): one generator, consecutive draws, the
+    decoders differ.  Greedy (t = 0) attempts are identical under both."""
+    import numpy as np
+    from oracle import binding as orc
+    from speaksense_amd import ggml_io, synth
+    path = str(tmp_path / "toy.en.bin")
+    ggml_io.write_model(path, "toy.en", seed=1)
+    om = orc.OracleModel(path)
+    pcm = synth.speech_like(5, 16000 * 30)
+    P = orc.default_params(language="en")
+
+    def sampled_groups(state, r):
+        """sampled calls of the trace grouped per step: replaying a state's own trace yields the kind of every call"""
+        rep = om.new_state(orc.MODE_GGML_F16, compat=state.compat)
+        # the replay state must be where `state` was BEFORE the call: advance its carried generator by replaying the earlier calls
+        for earlier in state._history:
+            rep.full(pcm, P)
+        out = rep.full(pcm, P, trace=r["trace"])
+        assert float(out["trace_gap"].max()) == 0.0
+        ids = np.asarray(r["trace"])[out["trace_kind"] == 1]
+        return ids
+
+    a = om.new_state(orc.MODE_GGML_F16); a._history = []
+    r1 = a.full(pcm, P)
+    assert r1["n_fail"] >= 1
+    ids = sampled_groups(a, r1)
+    assert len(ids) >= 50 and len(ids) % 5 == 0
+    g = ids.reshape(-1, 5)
+    assert (g == g[:, :1]).all(), "fresh state, per-decoder generators: the five decoders must sample the same ids"
+    a._history.append(1)
+    peek0 = a.rng_peek(0)
+    r2 = a.full(pcm, P)                                   # same audio, same state: decoder 0's generator has moved on, 1..4 start from 0 again
+    ids2 = sampled_groups(a, r2)
+    k = min(len(ids), len(ids2)) // 5 * 5
+    g2 = ids2[:k].reshape(-1, 5)
+    assert (g2[:, 1:] == g2[:, 1:2]).all() and (g2[:, 0] != g2[:, 1]).any(), "second call: decoders 1..4 coincide, decoder 0 does not"
+    assert (g2[0, 1:] == g[0, 1:]).all(), "decoders 1..4 are re-seeded by every call: their first draw repeats the first call's"
+    fresh = om.new_state(orc.MODE_GGML_F16)
+    assert fresh.rng_peek(0) != peek0 or len(ids) == 0     # the carried generator really advanced
+
+    s = om.new_state(orc.MODE_GGML_F16, compat=orc.COMPAT_RNG_STATE); s._history = []
+    q1 = s.full(pcm, P)
+    assert q1["n_fail"] >= 1
+    qs = sampled_groups(s, q1)
+    gq = qs[: len(qs) // 5 * 5].reshape(-1, 5)
+    assert (gq != gq[:, :1]).any(), "one shared generator: the decoders draw consecutive uniforms and differ"
+    assert list(q1["trace"]) != list(r1["trace"]), "the two topologies must be distinguishable on a chunk that falls back"
+    # greedy-only calls never touch a generator: identical under both
+    Pg = orc.default_params(language="en", temperature_inc=0.0)
+    assert list(om.new_state(orc.MODE_GGML_F16).full(pcm, Pg)["trace"]) == list(om.new_state(orc.MODE_GGML_F16, compat=orc.COMPAT_RNG_STATE).full(pcm, Pg)["trace"])
     om.close()
