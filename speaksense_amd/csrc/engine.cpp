@@ -211,8 +211,15 @@ struct EngineT : EngineBase {
     EngineBase* lane(int i) override { return i == 0 ? (EngineBase*)this : (EngineBase*)extra_lanes[i - 1].get(); }
 
     // donor != nullptr: a lane of `donor` -- same device, same weights (pointers into the donor's arena), own stream / workspaces / caches
-    EngineT(const char* path, const ss_engine_opts& o, EngineT* donor = nullptr) {
+    // lane_idx / n_lanes_total: this lane's place in the engine (decides its CU partition, if any); lane 0 works them out itself
+    EngineT(const char* path, const ss_engine_opts& o, EngineT* donor = nullptr, int lane_idx = 0, int n_lanes_total = 0) {
         opts = o;
+        lane_index = lane_idx;
+        if (!donor) {
+            n_lanes_total = o.n_lanes > 0 ? o.n_lanes : 2;
+            if (const char* lv = getenv("SS_LANES")) n_lanes_total = atoi(lv);
+            n_lanes_total = std::min(std::max(n_lanes_total, 1), 8);
+        }
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw Error(SS_ERR_DEVICE, "no HIP device visible: the MI355X path has no CPU fallback");
         if (o.device < 0 || o.device >= ndev) throw Error(SS_ERR_DEVICE, "bad device ordinal");
@@ -233,7 +240,7 @@ struct EngineT : EngineBase {
         if (fp8_enc && (da % 256 || d % 64)) throw Error(SS_ERR_UNSUPPORTED, "fp8: n_audio_state must be a multiple of 256 (k-step groups of the e4m3 GEMM)");
         if (d % 128 || da % 128) throw Error(SS_ERR_MODEL, "model: state size must be a multiple of 128");
         if (n_ctx % 4 || n_tctx > 448) throw Error(SS_ERR_MODEL, "model: unsupported context sizes");
-        SS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        create_lane_stream(lane_idx, n_lanes_total);
         AllocStreamScope alloc_scope(st);
         for (auto& e : ev) SS_HIP(hipEventCreate(&e));
         for (auto& e : ev_step) SS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -254,12 +261,23 @@ struct EngineT : EngineBase {
         if (const char* sm = getenv("SS_CB_START_MIN")) cb_start_min = std::max(1, atoi(sm));
         compat = donor ? donor->compat : resolve_compat(o.compat);
         if (!donor) {
-            int nl = o.n_lanes > 0 ? o.n_lanes : 2;
-            if (const char* lv = getenv("SS_LANES")) nl = atoi(lv);
-            nl = std::min(std::max(nl, 1), 8);
-            for (int i = 1; i < nl; i++) { extra_lanes.emplace_back(new EngineT(path, o, this)); extra_lanes.back()->owner = this; extra_lanes.back()->lane_index = i; }
+            for (int i = 1; i < n_lanes_total; i++) { extra_lanes.emplace_back(new EngineT(path, o, this, i, n_lanes_total)); extra_lanes.back()->owner = this; }
             start_worker();
         }
+    }
+    // SS_LANE_CUS=1 (experiment, VERDICT r03 #2a): confine every lane to its own CUs through a stream created with hipExtStreamCreateWithCUMask,
+    // so that one lane's latency-bound chain launches are not queued behind another lane's 248 MB cross-attention launch on the same CUs.
+    // What the mask can express on this driver was measured (tools/diag/cumask_probe.cpp, profiles/r04_b_cumask_probe.txt): the 256 user bits
+    // come in groups of 8, and CU c (0..31) of EVERY XCD is enabled iff any bit of group c is set -- a lane cannot be given whole XCDs, only the
+    // same slice of CUs in each of them.  Lane l gets CUs [32 l / n, 32 (l + 1) / n) of every XCD.  Unset: every lane may use the whole chip.
+    void create_lane_stream(int lane_idx, int n_lanes_total) {
+        const char* mode = getenv("SS_LANE_CUS");
+        if (!mode || !mode[0] || mode[0] == '0' || n_lanes_total < 2) { SS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); return; }
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int c0 = 32 * lane_idx / n_lanes_total, c1 = 32 * (lane_idx + 1) / n_lanes_total;
+        if (c1 <= c0) throw Error(SS_ERR_ARG, "SS_LANE_CUS: more lanes than CUs per XCD");
+        for (int c = c0; c < c1; c++) mask[c / 4] |= 0xffu << (8 * (c % 4));
+        SS_HIP(hipExtStreamCreateWithCUMask(&st, 8, mask));
     }
     ~EngineT() override {
         stop_worker();          // joins the workers of every lane (they live in lane 0); a lane itself has none
@@ -584,8 +602,20 @@ struct EngineT : EngineBase {
     }
     // The step is a fixed sequence of ~13 L dependent launches whose arguments do not change between steps (tokens, positions and
     // slots travel in ctl_d): after one plain pass per (M, n_samp) shape it is captured into a hipGraph and replayed.
-    struct StepGraph { int uses = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+    struct StepGraph { int uses = 0; long last_use = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
     std::map<int, StepGraph> step_graphs;
+    long graph_clock = 0;
+    static constexpr size_t kMaxStepGraphs = 96;   // a long-lived service sees up to 64 x 65 (rows, sampled rows) shapes: keep the recently used ones
+    void evict_step_graphs() {
+        while (step_graphs.size() > kMaxStepGraphs) {
+            auto victim = step_graphs.begin();
+            for (auto it = step_graphs.begin(); it != step_graphs.end(); ++it) if (it->second.last_use < victim->second.last_use) victim = it;
+            // a replay of this graph may still be executing: its exec must outlive it
+            if (victim->second.exec) { SS_HIP(hipStreamSynchronize(st)); (void)hipGraphExecDestroy(victim->second.exec); }
+            if (victim->second.graph) (void)hipGraphDestroy(victim->second.graph);
+            step_graphs.erase(victim);
+        }
+    }
     // chained = true: the control blocks are already on the device (the previous step's pick kernel advanced them), nothing is uploaded
     void decoder_step_fused(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs, bool chained = false) {
         const int n_samp = (int)samp_rows.size();
@@ -599,7 +629,9 @@ struct EngineT : EngineBase {
         }
         if (!use_graph) fused_body(M, n_samp);
         else {
+            if (!step_graphs.count(M * 1024 + n_samp)) evict_step_graphs();
             StepGraph& sg = step_graphs[M * 1024 + n_samp];
+            sg.last_use = ++graph_clock;
             if (sg.uses++ == 0) fused_body(M, n_samp);
             else {
                 if (!sg.exec) {
@@ -1797,11 +1829,23 @@ void EngineBase::start_worker() {
                     const int maxb = opts.max_batch > 0 ? opts.max_batch : 8;
                     if ((int)queue.size() < maxb && opts.batch_wait_us > 0)
                         qcv.wait_for(lk, std::chrono::microseconds(opts.batch_wait_us), [&] { return stop || (int)queue.size() >= maxb; });
-                    // Level the lanes when the queue is short: with fewer than (idle lanes x max_batch) chunks queued, filling this lane to max_batch
-                    // would leave the other idle lanes with nothing (64 chunks on three idle lanes: 32 / 32 / 0); take an even share instead
-                    // (22 / 21 / 21).  workers_free counts this worker and the ones queued up behind form_mu, i.e. the lanes with nothing to run.
+                    // Level the lanes when the queue is short: with more than one batch but fewer than (idle lanes x max_batch) chunks queued,
+                    // filling this lane to max_batch would leave the other idle lanes with little or nothing (64 chunks on three idle lanes:
+                    // 32 / 32 / 0); take an even share instead (22 / 21 / 21).  Up to max_batch chunks stay together: a pass streams the decoder
+                    // weights once whatever its row count, so splitting ONE batch over lanes buys nothing (measured: r04_a).  workers_free counts
+                    // this worker and the ones queued up behind form_mu, i.e. the lanes with nothing to run.
                     const int idle = std::max(1, workers_free.load());
-                    const int take = std::min(maxb, ((int)queue.size() + idle - 1) / idle);
+                    // chunks often arrive as a burst that is still being submitted when the first max_batch of them are here: with other lanes idle,
+                    // linger while the queue keeps growing (300 us without a new chunk ends it; bounded by batch_wait_us) so that the burst is seen whole
+                    if (idle > 1 && opts.batch_wait_us > 0) {
+                        const auto t_stop = std::chrono::steady_clock::now() + std::chrono::microseconds(opts.batch_wait_us);
+                        while (!stop && (int)queue.size() >= maxb && (int)queue.size() < idle * maxb && std::chrono::steady_clock::now() < t_stop) {
+                            const size_t before = queue.size();
+                            qcv.wait_for(lk, std::chrono::microseconds(300), [&] { return stop || queue.size() > before; });
+                            if (queue.size() == before) break;
+                        }
+                    }
+                    const int take = (int)queue.size() <= maxb ? maxb : std::min(maxb, ((int)queue.size() + idle - 1) / idle);
                     // one chunk per session per batch (run_group writes the session's results): a second ticket of a session already in this
                     // batch stays queued, in order, for the next one
                     for (auto it = queue.begin(); it != queue.end() && (int)batch.size() < take;) {

@@ -43,6 +43,10 @@ class HParams:
         return tuple(asdict(self).values())
 
 
+# write_model(path, shape, **NATURAL): see natural_tensor.  tools/natural_preset_stats.py measures fallbacks / lengths / distinct streams on the oracle.
+NATURAL = dict(style="natural", logit_gain=16.0, mlp_boost=4.0, ctrl_rho=0.75, cross_gain=0.5, cross_q_gain=8.0, pos_scale=0.4, self_gain=0.2,
+               ts_period=16, ts_rate=12.0, ts_align=0.9, eot_start=4, eot_ramp=25.0, eot_audio=2.0)
+
 PRESETS = {
     # real shapes (SURVEY.md §8 header)
     "tiny.en": HParams(51864, 1500, 384, 6, 4, 448, 384, 6, 4, 80, 1),
@@ -287,6 +291,97 @@ def _special_ids(hp: HParams):
     return eot, beg, n_prompt
 
 
+_CTRL = 64   # natural style: channels [d - 64, d) carry EOT and the timestamp tokens (and nothing else); [d - 128, d - 64) is ballast no token reads
+
+
+def natural_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logit_gain: float, ctx: dict):
+    """`style="natural"` (write_model(**NATURAL)): synthetic weights whose decoder behaves like a transcriber under whisper.cpp's FULL rules --
+    stays at temperature 0 (peaked next-token distribution, no loops: passes the logprob and entropy checks), emits increasing timestamp pairs and
+    ends with EOT after a number of tokens that depends on the audio -- so that natural-EOT decoding (bench Mode N) and parity at data-dependent
+    lengths have something meaningful to run on.  Returns None for tensors that keep the default random draw.  Construction:
+      * the text state splits into T (text), a 64-channel ballast B and a 64-channel control subspace C.  Text-token embeddings live in T only,
+        timestamp tokens and EOT in C only, nothing in B;
+      * the next token is a well-mixed function of (current token, position, audio): block 0's MLP reads LN(E_tok + P_pos + cross-attention(audio))
+        and its boosted, zero-mean output dominates the residual stream from there on -- no self-prediction through the tied embeddings and no
+        slow-moving history average, the two things that make a random decoder loop.  The audio enters BEFORE that non-linearity (block 0's
+        cross-attention, sharply peaked so that it returns the value rows of a few encoder positions, not their average), so it changes the map
+        instead of adding the same bonus to the same tokens at every step;
+      * every position's embedding carries a control vector of CONSTANT norm R in B + C (LayerNorm statistics, hence the scale of everything
+        else, do not depend on the position): mostly ballast, plus a component along EOT growing linearly with the position (EOT wins around
+        position eot_start + eot_ramp) and, at pair positions, along the embedding of THE timestamp that position should emit (beg + ts_rate x
+        tokens so far: timestamps grow with the text, are never near ties, and close / open segments in pairs).  Block 0's LayerNorms are deaf
+        to B + C (gain 0) and compensate the norm the control vector adds (gain x comp on T);
+      * the last block's cross-attention output has a rank-1 term along EOT: the audio moves the EOT logit, i.e. the length of the transcript."""
+    d = hp.n_text_state
+    if d < 256:
+        raise ValueError("natural style needs n_text_state >= 256")
+    eot, beg, n_prompt = _special_ids(hp)
+    T = d - 2 * _CTRL
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+    last = f"decoder.blocks.{hp.n_text_layer - 1}."
+    pos_scale, boost, rho = ctx.get("pos_scale", 0.4), ctx.get("mlp_boost", 4.0), ctx.get("ctrl_rho", 0.75)
+    sx = 0.6 * boost * np.sqrt(T)                        # per-element std of block 0's MLP output = of the final residual stream on T
+    R = rho * sx * np.sqrt(d)                            # norm of the control vector
+    a_star = 4.3 * np.sqrt(T / d) / (rho * np.sqrt(d))   # alignment with EOT at which the EOT logit reaches the expected best text logit
+    xT2 = T * (0.25 + pos_scale ** 2)                    # |E_tok + P_pos|^2 on T
+    comp = float(np.sqrt((xT2 + R * R) / xT2))
+    if name == "decoder.ln.weight":
+        g = logit_gain * np.sqrt(T / d + rho * rho) / (0.5 * np.sqrt(T))     # text logits get std `logit_gain`
+        return (g * (1.0 + 0.05 * rng.standard_normal(shape, dtype=np.float32))).astype(np.float32)
+    if name in ("decoder.blocks.0.attn_ln.weight", "decoder.blocks.0.cross_attn_ln.weight", "decoder.blocks.0.mlp_ln.weight"):
+        g = comp * (1.0 + 0.1 * rng.standard_normal(shape, dtype=np.float32))
+        g[T:] = 0.0
+        return g.astype(np.float32)
+    if name == "decoder.positional_embedding":
+        pe = pos_scale * rng.standard_normal(shape, dtype=np.float32)
+        pe[:, T:] = 0.0
+        u = np.zeros(d, np.float32); u[d - _CTRL:] = rng.standard_normal(_CTRL); u /= np.linalg.norm(u)
+        n = np.zeros(d, np.float32); n[T:d - _CTRL] = rng.standard_normal(_CTRL); n /= np.linalg.norm(n)
+        ctx.update(u_eot=u, n_bal=n, pe_plain=pe, R=R, a_star=a_star)
+        return None                                      # finished by the token-embedding draw (the timestamp pushes point at timestamp embeddings)
+    if name == "decoder.token_embedding.weight":
+        te = 0.5 * rng.standard_normal(shape, dtype=np.float32)
+        te[:, T:] = 0.0
+        te *= (0.5 * np.sqrt(T)) / np.linalg.norm(te, axis=1, keepdims=True)   # equal norms: among 50 k candidates the longer rows would win again and again
+        te[beg:] = 0.0
+        te[beg:, d - _CTRL:] = 0.5 * np.sqrt(d / _CTRL) * rng.standard_normal((shape[0] - beg, _CTRL), dtype=np.float32)
+        te[beg:] -= np.outer(te[beg:] @ ctx["u_eot"], ctx["u_eot"])       # a timestamp push never moves the EOT logit
+        te[eot] = 0.5 * np.sqrt(d) * ctx["u_eot"]
+        pe, u, n = ctx.pop("pe_plain"), ctx["u_eot"], ctx["n_bal"]
+        period, rate = int(ctx["ts_period"]), ctx.get("ts_rate", 25.0)
+        for p in range(pe.shape[0]):
+            s = np.zeros(d, np.float32)
+            i = p - (n_prompt - 1)                       # index of the token sampled FROM position p
+            if i >= 0 and (i == 0 or i % period in (period - 2, period - 1)):
+                k = 0 if i == 0 else min(shape[0] - beg - 1, int(rate * (i // period + 1) * period))
+                s += ctx.get("ts_align", 0.9) * te[beg + k] / np.linalg.norm(te[beg + k])
+            else:
+                s += min(0.95, max(0.0, a_star * (p - ctx["eot_start"]) / ctx.get("eot_ramp", 60.0))) * u
+            pe[p] += R * (s + np.sqrt(max(0.0, 1.0 - float(s @ s))) * n)
+        ctx["pe_final"] = pe.astype(np.float32)
+        return te.astype(np.float32)
+    if name == "decoder.blocks.0.mlp.2.weight":
+        w = boost * np.sqrt(d) * rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in) * np.sqrt(T / d)
+        w -= w.mean(axis=1, keepdims=True)               # the hidden units' common mean (GELU > 0 on average) maps to 0: no token is favoured at every step
+        w[T:] = 0.0                                      # and nothing is written into the ballast / control channels
+        return w.astype(np.float32)
+    if name == "decoder.blocks.0.cross_attn.query.weight":
+        return (ctx.get("cross_q_gain", 8.0) * rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
+    if name == "decoder.blocks.0.cross_attn.out.weight":
+        return (ctx.get("cross_gain", 0.5) * rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
+    if name == "decoder.blocks.0.attn.out.weight":       # the history average moves slowly: kept small
+        return (ctx.get("self_gain", 0.2) * rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
+    if name == last + "cross_attn_ln.weight" and hp.n_text_layer > 1:
+        g = 1.0 + 0.1 * rng.standard_normal(shape, dtype=np.float32)
+        g[T:] = 0.0                                      # the query of the cross-attention that moves the EOT logit does not see the EOT ramp
+        return g.astype(np.float32)
+    if name == last + "cross_attn.out.weight" and hp.n_text_layer > 1:
+        w = rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)
+        w += ctx.get("eot_audio", 0.3) * a_star * R * np.outer(ctx["u_eot"], rng.standard_normal(shape[1]).astype(np.float32) / np.sqrt(fan_in))
+        return w.astype(np.float32)
+    return None
+
+
 def synth_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logit_gain: float, ctx: dict) -> np.ndarray:
     """Seeded random weights with sane scales so activations stay O(1) through 32 layers, plus a little
     hand-built structure so that a random decoder behaves like a transcriber instead of a fixed point:
@@ -304,6 +399,16 @@ def synth_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logit_
     eot, beg, n_prompt = _special_ids(hp)
     if name == "encoder.positional_embedding":
         return sinusoids(shape[0], shape[1])
+    if ctx.get("style") == "natural":
+        if name == "decoder.positional_embedding":
+            natural_tensor(name, shape, hp, rng, logit_gain, ctx)
+            return None
+        t = natural_tensor(name, shape, hp, rng, logit_gain, ctx)
+        if t is not None:
+            return t
+        if name.startswith("decoder.") and len(shape) == 2 and not name.endswith("embedding.weight"):   # no structured heads / boosts of the default style
+            fan_in = int(np.prod(shape[1:]))
+            return (rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
     if name == "decoder.ln.weight":
         g = logit_gain / (0.5 * np.sqrt(shape[0]))
         return (g * (1.0 + 0.05 * rng.standard_normal(shape, dtype=np.float32))).astype(np.float32)
@@ -346,7 +451,7 @@ def synth_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logit_
 
 
 def write_model(path: str, hp: HParams | str, seed: int = 0, logit_gain: float = 9.0, tensors: dict | None = None,
-                ts_period: int = 12, eot_start: int = 40, ftype: int | str | None = None):
+                ts_period: int = 12, eot_start: int = 40, ftype: int | str | None = None, **style_kw):
     """Write a ggml legacy whisper model. `tensors` (name -> ndarray in PyTorch layout) overrides the
     synthetic draw -- used by the HF cross-check to export a transformers model's weights.
     `ftype` ("q5_0", "q5_1", "q8_0", "q4_0", "q4_1" or the ggml number): what whisper.cpp's quantize tool produces from the f16 file -- every
@@ -362,6 +467,7 @@ def write_model(path: str, hp: HParams | str, seed: int = 0, logit_gain: float =
     spec_hp = HParams(*(hp.astuple()[:10] + (base_ftype,)))
     rng = np.random.default_rng(seed)
     ctx = {"ts_period": ts_period, "eot_start": eot_start}
+    ctx.update(style_kw)    # style="natural" and its knobs: NATURAL / natural_tensor
     vocab = synth_vocab(hp.n_vocab)
     filt = mel_filters(hp.n_mels)
     with open(path, "wb") as f:
@@ -373,9 +479,18 @@ def write_model(path: str, hp: HParams | str, seed: int = 0, logit_gain: float =
         for t in vocab:
             f.write(struct.pack("<I", len(t)))
             f.write(t)
-        for name, shape, ttype in tensor_specs(spec_hp):
+        specs = list(tensor_specs(spec_hp))
+        drawn = {}
+        if ctx.get("style") == "natural" and tensors is None:
+            # the positional embedding is finished by the token-embedding draw: draw every tensor first, in file order (one seeded stream)
+            for name, shape, ttype in specs:
+                drawn[name] = synth_tensor(name, shape, hp, rng, logit_gain, ctx)
+            drawn["decoder.positional_embedding"] = ctx["pe_final"]
+        for name, shape, ttype in specs:
             if tensors is not None and name in tensors:
                 data = np.asarray(tensors[name], dtype=np.float32).reshape(shape)
+            elif name in drawn:
+                data = drawn.pop(name)
             else:
                 data = synth_tensor(name, shape, hp, rng, logit_gain, ctx)
             nb = name.encode()

@@ -177,5 +177,5 @@ def test_sampler_state_carries_across_calls_and_can_be_replayed(toy_ml_path, top
         # decoders 1.. start every call from the same seed and the same distributions: they coincide with each other on every call
         assert len({b.rng_draws(j) for j in range(1, 5)}) == 1 and b.rng_draws(1) > 0
     else:
-        assert [fresh.rng_draws(j) for j in range(1, 5)] == [0] * 4 and d1 % 5 == 0
+        assert [fresh.rng_draws(j) for j in range(1, 5)] == [0] * 4      # one generator: decoders 1.. own none
     eng.close()

@@ -81,14 +81,15 @@ def test_abandoned_ticket_leaks_nothing_on_the_device(toy_ml_path):
     from speaksense_amd import binding
     eng = binding.Engine(toy_ml_path, max_batch=4, n_lanes=2)
     pcm = synth.speech_like(5)
-    eng.new_session().transcribe(pcm, _P())
-    free0, _ = eng.mem_info()
-    for _ in range(40):
-        s = eng.new_session()
-        s.submit(pcm, _P())                                   # ticket dropped
-        s.close()                                             # waits for completion, frees the session
-    free1, _ = eng.mem_info()
-    assert abs(free1 - free0) < 8 << 20, (free0, free1)
+    def round_():
+        for _ in range(40):
+            s = eng.new_session()
+            s.submit(pcm, _P())                                   # ticket dropped
+            s.close()                                             # waits for completion, frees the session
+        return eng.mem_info()[0]
+    free0 = round_()                                              # first round: both lanes size their per-slot staging buffers (lazily, once)
+    free1 = round_()
+    assert abs(free1 - free0) < 4 << 20, (free0, free1)
     eng.close()
 
 
@@ -147,8 +148,9 @@ def test_soak_random_interleavings(toy_ml_path):
     eng.new_session().transcribe(audio[(1, 30.1)], params("ladder"))      # warm every graph shape before the memory baseline
     for k in [((1, 3.0), "greedy"), ((2, 65.0), "greedy"), ((3, 12.0), "ladder")]:
         expected(k)
-    free0, _ = eng.mem_info()
     t_end = time.time() + seconds
+    t_mid = time.time() + 0.4 * seconds      # memory baseline after 40 % of the run: by then every lane has sized its lazily allocated staging buffers
+    mem = {}                                 # and holds its full set of step graphs (LRU-capped, engine.cpp kMaxStepGraphs)
     stats = dict(chunks=0, refused=0, abandoned=0, freed_in_flight=0, checked=0)
     errors = []
     st_lock = threading.Lock()
@@ -207,7 +209,10 @@ def test_soak_random_interleavings(toy_ml_path):
 
     def poller():
         while time.time() < t_end:
-            eng.totals(); eng.last_timing(); eng.mem_info()
+            eng.totals(); eng.last_timing()
+            f = eng.mem_info()[0]
+            if "mid" not in mem and time.time() >= t_mid:
+                mem["mid"] = f
             time.sleep(0.005)
     threads = [threading.Thread(target=worker, args=(w,)) for w in range(8)] + [threading.Thread(target=poller)]
     for t in threads:
@@ -217,8 +222,9 @@ def test_soak_random_interleavings(toy_ml_path):
         assert not t.is_alive(), "soak: a thread hung"
     assert not errors, errors
     free1, _ = eng.mem_info()
+    free0 = mem.get("mid", free1)
     from conftest import report
-    report(f"soak {seconds:.0f} s, 8 threads: {stats}, device memory free {free0 >> 20} -> {free1 >> 20} MiB")
+    report(f"soak {seconds:.0f} s, 8 threads: {stats}, device memory free at 40 % of the run {free0 >> 20} MiB -> at the end {free1 >> 20} MiB")
     assert stats["chunks"] > 200 and stats["refused"] > 5 and stats["freed_in_flight"] > 5 and stats["abandoned"] > 5
-    assert free0 - free1 < 64 << 20, f"device memory grew by {(free0 - free1) >> 20} MiB"
+    assert free0 - free1 < 32 << 20, f"device memory grew by {(free0 - free1) >> 20} MiB over the last 60 % of the run"
     eng.close()

@@ -20,7 +20,7 @@ for R in "$@"; do
   case $KIND in
     tests)
       rm -f gpurun_out/parity_report.txt
-      ( time timeout ${TEST_TIMEOUT:-3000} python -m pytest ${ARGS:-tests} -q -m gpu -x --durations=15 ) > gpurun_out/${TAG}_pytest_$n.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_$n.log
+      ( time timeout ${TEST_TIMEOUT:-3000} python -m pytest ${ARGS:-tests} -q -m gpu ${PYTEST_X--x} --durations=15 ) > gpurun_out/${TAG}_pytest_$n.log 2>&1; echo "pytest rc=$?" >> gpurun_out/${TAG}_pytest_$n.log
       tail -30 gpurun_out/${TAG}_pytest_$n.log | cut -c1-300
       [ -f gpurun_out/parity_report.txt ] && cp gpurun_out/parity_report.txt gpurun_out/${TAG}_parity_report_$n.txt ;;
     smoke)
