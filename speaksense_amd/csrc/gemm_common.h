@@ -1,6 +1,8 @@
 // Shared by the MFMA GEMM translation units (kernels_gemm.hip: f16 / bf16 operands, kernels_gemm_fp8.hip: e4m3 operands):
 // MFMA wrappers, the GELU used by the fused epilogues, the XCD-aware tile rasterisation, the LDS-DMA and counted-wait helpers.
 #pragma once
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace ss {
@@ -26,6 +28,35 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     // == x * sigmoid(2u): one v_exp_f32 + one v_rcp_f32
     const float u = 0.79788456080286535588f * x * (1.0f + 0.044715f * x * x);
     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
+}
+// The same GELU for the four accumulator values a lane owns, written on float2 so that hipcc emits packed-f32 VALU (v_pk_mul_f32 / v_pk_fma_f32 /
+// v_pk_add_f32: two elements per full-rate instruction) and with the constants folded: per PAIR 1 add (bias, done by the caller) + 3 mul + 1 fma
+// + 1 add packed, 2 v_exp_f32 + 2 v_rcp_f32, and -- ROUND_IN, ggml's f16 GELU table input -- one v_cvt_pk_f16_f32 (RNE) + two v_cvt_f32_f16.
+// The scalar form above compiled to 6 v_mul + 2 v_add + 1 v_fma + 1 v_cndmask per ELEMENT beside the two transcendentals (r04: FC1 epilogue
+// ISA), i.e. ~76 issue cycles per element against ~52 here.  exp(-2u) = 2^(x * (C1 + C3 x^2)), C1 = -2 sqrt(2/pi) log2(e), C3 = 0.044715 C1.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+template <bool ROUND_IN>
+__device__ __forceinline__ f32x2 gelu_tanh_pk(f32x2 x) {
+    if constexpr (ROUND_IN) x = __builtin_convertvector(__builtin_convertvector(x, h16x2), f32x2);
+    constexpr float C1 = -2.0f * 0.79788456080286535588f * 1.44269504088896340736f, C3 = 0.044715f * C1;
+    const f32x2 x2 = x * x;
+    const f32x2 t = x2 * (f32x2){C3, C3} + (f32x2){C1, C1};
+    const f32x2 z = x * t;
+    f32x2 e = {__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])};
+    e += (f32x2){1.0f, 1.0f};
+    const f32x2 r = {__builtin_amdgcn_rcpf(e[0]), __builtin_amdgcn_rcpf(e[1])};
+    return x * r;
+}
+// four values -> four T (f16: packed RNE converts); round_in is warp-uniform (a kernel argument): a scalar branch, not a select per element
+template <typename T>
+__device__ __forceinline__ typename Mfma<T>::V4 gelu4(f32x4 v, int round_in) {
+    f32x2 a = {v[0], v[1]}, b = {v[2], v[3]};
+    if (std::is_same<T, f16>::value && round_in) { a = gelu_tanh_pk<true>(a); b = gelu_tanh_pk<true>(b); }
+    else { a = gelu_tanh_pk<false>(a); b = gelu_tanh_pk<false>(b); }
+    typename Mfma<T>::V4 o;
+    o[0] = (T)a[0]; o[1] = (T)a[1]; o[2] = (T)b[0]; o[3] = (T)b[1];
+    return o;
 }
 template <typename T> __device__ __forceinline__ float gelu_in_round(float x, int on);
 template <> __device__ __forceinline__ float gelu_in_round<bf16>(float x, int) { return x; }

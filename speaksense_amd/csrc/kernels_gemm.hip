@@ -122,9 +122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
                     for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
                     *(V4*)((T*)g.out + orow + n) = o;
                 } else if constexpr (KIND == EPI_GELU_T) {
-                    V4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (T)gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
+                    const V4 o = gelu4<T>(v, g.gelu_f16_in);
                     *(V4*)((T*)g.out + orow + n) = o;
                 } else if constexpr (KIND == EPI_RES_F32) {
                     const f32x4 rsd = *(const f32x4*)(g.res + orow + n);
@@ -244,8 +242,7 @@ __device__ __forceinline__ void epilogue256(const GemmDesc& g, f32x4 (&acc)[4][8
 #pragma unroll
                     for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
                 } else if constexpr (KIND == EPI_GELU_T) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (T)gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
+                    o = gelu4<T>(v, g.gelu_f16_in);
                 } else {   // EPI_CROSS_KV: the K half of every layer's [K; V] column block is pre-scaled
                     const int nq = n0 + wn * 64 + ni * 16 + fg * 4;
                     const float sc = (nq % (2 * g.d)) < g.d ? g.scale : 1.0f;
@@ -292,9 +289,7 @@ __device__ __forceinline__ void epilogue256(const GemmDesc& g, f32x4 (&acc)[4][8
                     for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
                     *(V4*)((T*)g.out + orow + n) = o;
                 } else if constexpr (KIND == EPI_GELU_T) {
-                    V4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (T)gelu_tanh_f(gelu_in_round<T>(v[r], g.gelu_f16_in));
+                    const V4 o = gelu4<T>(v, g.gelu_f16_in);
                     *(V4*)((T*)g.out + orow + n) = o;
                 } else if constexpr (KIND == EPI_RES_F32) {
                     const f32x4 rsd = *(const f32x4*)(g.res + orow + n);

@@ -300,10 +300,11 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(GemmF8Desc g) {
 #pragma unroll
                 for (int gq = 0; gq < 4; gq++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const float t = acc[ni][mi][gq * 4 + r];
-                        v[ni][gq][r] = gelu_tanh_f(gelu_in_round<T>(t, g.gelu_f16_in));
-                        amax = fmaxf(amax, fabsf(v[ni][gq][r]));
+                    for (int r = 0; r < 4; r += 2) {   // packed-f32 GELU (gemm_common.h gelu_tanh_pk): two elements per VALU instruction
+                        f32x2 t = {acc[ni][mi][gq * 4 + r], acc[ni][mi][gq * 4 + r + 1]};
+                        if (std::is_same<T, f16>::value && g.gelu_f16_in) t = gelu_tanh_pk<true>(t); else t = gelu_tanh_pk<false>(t);
+                        v[ni][gq][r] = t[0]; v[ni][gq][r + 1] = t[1];
+                        amax = fmaxf(amax, fmaxf(fabsf(t[0]), fabsf(t[1])));
                     }
             amax = swap32_max(amax);   // the other half of this row's 64 columns is in lane ^ 32
             const int e = e8m0_for_amax(amax);

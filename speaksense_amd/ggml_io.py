@@ -44,8 +44,8 @@ class HParams:
 
 
 # write_model(path, shape, **NATURAL): see natural_tensor.  tools/natural_preset_stats.py measures fallbacks / lengths / distinct streams on the oracle.
-NATURAL = dict(style="natural", logit_gain=16.0, mlp_boost=4.0, ctrl_rho=0.75, cross_gain=0.5, cross_q_gain=8.0, pos_scale=0.4, self_gain=0.2,
-               ts_period=16, ts_rate=12.0, ts_align=0.9, eot_start=4, eot_ramp=25.0, eot_audio=2.0)
+NATURAL = dict(style="natural", logit_gain=16.0, mlp_boost=4.0, ctrl_rho=0.75, cross_gain=0.2, cross_q_gain=8.0, pos_scale=0.4, self_gain=0.2,
+               ts_period=16, ts_rate=12.0, ts_align=0.9, eot_start=4, eot_ramp=160.0, eot_mean=50.0)
 
 PRESETS = {
     # real shapes (SURVEY.md §8 header)
@@ -311,7 +311,13 @@ def natural_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logi
         position eot_start + eot_ramp) and, at pair positions, along the embedding of THE timestamp that position should emit (beg + ts_rate x
         tokens so far: timestamps grow with the text, are never near ties, and close / open segments in pairs).  Block 0's LayerNorms are deaf
         to B + C (gain 0) and compensate the norm the control vector adds (gain x comp on T);
-      * the last block's cross-attention output has a rank-1 term along EOT: the audio moves the EOT logit, i.e. the length of the transcript."""
+      * one text token in `eot_mean` is a "sentence ender": channel 0 of T is a flag that only those tokens' embeddings set, hidden unit 0 of
+        block 0's MLP reads nothing but that flag and writes a large push along EOT, so the token after an ender is EOT with probability ~1.
+        The stream is a well-mixed, audio-dependent walk over the vocabulary, so it meets an ender after a geometrically distributed number of
+        steps: a different transcript length for every audio, no threshold to calibrate; the slow EOT ramp only guarantees an end.  (Tried first
+        and dropped: a rank-1 term on the last cross-attention output -- a random encoder's cross-attention output has a large component
+        common to all audios, large-v3 ended all 32 chunks after two tokens, r04_e -- and a random read-out of block 0's hidden units along EOT,
+        whose firing rate differed by orders of magnitude between model seeds.)"""
     d = hp.n_text_state
     if d < 256:
         raise ValueError("natural style needs n_text_state >= 256")
@@ -335,16 +341,25 @@ def natural_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logi
     if name == "decoder.positional_embedding":
         pe = pos_scale * rng.standard_normal(shape, dtype=np.float32)
         pe[:, T:] = 0.0
-        u = np.zeros(d, np.float32); u[d - _CTRL:] = rng.standard_normal(_CTRL); u /= np.linalg.norm(u)
-        n = np.zeros(d, np.float32); n[T:d - _CTRL] = rng.standard_normal(_CTRL); n /= np.linalg.norm(n)
+        pe[:, 0] = 0.0                                   # channel 0 is the sentence-ender flag: only token embeddings write it
+        # every control direction sums to zero over the channels: LayerNorm subtracts the channel mean, and a control vector of norm R with a
+        # non-zero mean would shift every text channel by the same large amount (it switched the sentence-ender flag on for every token)
+        cu, cn = rng.standard_normal(_CTRL), rng.standard_normal(_CTRL)
+        u = np.zeros(d, np.float32); u[d - _CTRL:] = cu - cu.mean(); u /= np.linalg.norm(u)
+        n = np.zeros(d, np.float32); n[T:d - _CTRL] = cn - cn.mean(); n /= np.linalg.norm(n)
         ctx.update(u_eot=u, n_bal=n, pe_plain=pe, R=R, a_star=a_star)
         return None                                      # finished by the token-embedding draw (the timestamp pushes point at timestamp embeddings)
     if name == "decoder.token_embedding.weight":
         te = 0.5 * rng.standard_normal(shape, dtype=np.float32)
         te[:, T:] = 0.0
+        te[:, 0] = 0.0
         te *= (0.5 * np.sqrt(T)) / np.linalg.norm(te, axis=1, keepdims=True)   # equal norms: among 50 k candidates the longer rows would win again and again
+        enders = np.nonzero(rng.random(eot) < 1.0 / ctx.get("eot_mean", 70.0))[0]
+        enders = enders[enders > 255]                    # (byte tokens stay ordinary)
+        te[enders, 0] = 2.0
         te[beg:] = 0.0
-        te[beg:, d - _CTRL:] = 0.5 * np.sqrt(d / _CTRL) * rng.standard_normal((shape[0] - beg, _CTRL), dtype=np.float32)
+        ts_rows = 0.5 * np.sqrt(d / _CTRL) * rng.standard_normal((shape[0] - beg, _CTRL), dtype=np.float32)
+        te[beg:, d - _CTRL:] = ts_rows - ts_rows.mean(axis=1, keepdims=True)
         te[beg:] -= np.outer(te[beg:] @ ctx["u_eot"], ctx["u_eot"])       # a timestamp push never moves the EOT logit
         te[eot] = 0.5 * np.sqrt(d) * ctx["u_eot"]
         pe, u, n = ctx.pop("pe_plain"), ctx["u_eot"], ctx["n_bal"]
@@ -363,22 +378,23 @@ def natural_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logi
     if name == "decoder.blocks.0.mlp.2.weight":
         w = boost * np.sqrt(d) * rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in) * np.sqrt(T / d)
         w -= w.mean(axis=1, keepdims=True)               # the hidden units' common mean (GELU > 0 on average) maps to 0: no token is favoured at every step
-        w[T:] = 0.0                                      # and nothing is written into the ballast / control channels
+        w[T:] = 0.0                                      # nothing is written into the ballast / control channels ...
+        w[0] = 0.0                                       # ... nor into the flag channel ...
+        w[:, 0] = 3.0 * a_star * R / 6.0 * ctx["u_eot"]  # ... except by hidden unit 0 (~6 after an ender, ~0 otherwise): a push of 3 x the EOT threshold
+        return w.astype(np.float32)
+    if name == "decoder.blocks.0.mlp.0.weight":
+        w = rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)
+        w[:, 0] = 0.0                                    # the flag is invisible to the successor map ...
+        w[0] = 0.0
+        w[0, 0] = 2.0                                    # ... and is all hidden unit 0 sees (z_0 ~ 3 for an ender)
+        return w.astype(np.float32)
+    if name in ("decoder.blocks.0.attn.out.weight", "decoder.blocks.0.cross_attn.out.weight"):
+        gain = ctx.get("self_gain", 0.2) if name.endswith("attn.out.weight") and "cross" not in name else ctx.get("cross_gain", 0.2)
+        w = gain * rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)
+        w[0] = 0.0                                       # the attention outputs of block 0 leave the flag channel alone
         return w.astype(np.float32)
     if name == "decoder.blocks.0.cross_attn.query.weight":
         return (ctx.get("cross_q_gain", 8.0) * rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
-    if name == "decoder.blocks.0.cross_attn.out.weight":
-        return (ctx.get("cross_gain", 0.5) * rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
-    if name == "decoder.blocks.0.attn.out.weight":       # the history average moves slowly: kept small
-        return (ctx.get("self_gain", 0.2) * rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)).astype(np.float32)
-    if name == last + "cross_attn_ln.weight" and hp.n_text_layer > 1:
-        g = 1.0 + 0.1 * rng.standard_normal(shape, dtype=np.float32)
-        g[T:] = 0.0                                      # the query of the cross-attention that moves the EOT logit does not see the EOT ramp
-        return g.astype(np.float32)
-    if name == last + "cross_attn.out.weight" and hp.n_text_layer > 1:
-        w = rng.standard_normal(shape, dtype=np.float32) / np.sqrt(fan_in)
-        w += ctx.get("eot_audio", 0.3) * a_star * R * np.outer(ctx["u_eot"], rng.standard_normal(shape[1]).astype(np.float32) / np.sqrt(fan_in))
-        return w.astype(np.float32)
     return None
 
 

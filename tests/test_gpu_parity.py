@@ -155,18 +155,18 @@ GAP_TOL_F16 = 4 * 3e-3 * 9.0      # 0.108 in log-probability units
 GAP_TOL_BF16 = 0.25               # measured with bf16-rounded weights AND activations in the oracle: every flip below 0.07 (run r02_j)
 
 
-def check_against_oracle(got, om, orc, mode, pcm, P, ctx, gap_tol, replay_only=False, tid_slack_beg=None):
+def check_against_oracle(got, om, orc, mode, pcm, P, ctx, gap_tol, replay_only=False, tid_slack_beg=None, compat=0):
     """Token ids identical to the free-running oracle -> full result comparison, returns (True, 0.0).
     Otherwise the device's sampled stream is REPLAYED on the oracle (every greedy step takes the device's token; oracle/binding.py): the test
     fails unless at every step the device's pick is the oracle's argmax or its log-probability is within `gap_tol` of it (a proven near tie
     given the identical prefix), AND the replayed run -- same tokens through the oracle's seek / prompt_past / segment logic -- gives the
     device's windows, segments and timestamps.  Returns (False, largest gap)."""
     if not replay_only:
-        ref = om.new_state(mode).full(pcm, P)
+        ref = om.new_state(mode, compat=compat).full(pcm, P)
         if list(got["tokens"]) == list(ref["tokens"]):
             _same_result(got, ref, ctx, tid_slack_beg)
             return True, 0.0
-    rep = om.new_state(mode).full(pcm, P, forced=got["sampled"])
+    rep = om.new_state(mode, compat=compat).full(pcm, P, forced=got["sampled"])
     gaps, best = rep["forced_gap"], rep["forced_best"]
     assert len(gaps) == len(got["sampled"]), f"{ctx}: the oracle consumed {len(gaps)} of the device's {len(got['sampled'])} sampled tokens (stopping rules differ)"
     assert list(rep["sampled"]) == list(got["sampled"]), f"{ctx}: the oracle sampled past the device's stream"
@@ -337,18 +337,21 @@ def test_full_path_openai_ts_rules_variant(toy_en_path, toy_ml_path, orc, which)
     path = toy_en_path if which == "toy.en" else toy_ml_path
     om = orc.OracleModel(path)
     eng = _eng(path, binding.DTYPE_F16, max_batch=4, compat=binding.COMPAT_OPENAI_TS_RULES)
-    n_diff = 0
+    n_diff = n_same = 0
     for seed in (3, 4, 5, 6):
-        pcm = synth.speech_like(seed)
+        pcm = synth.speech_like(seed, 16000 * 12)
         P = dict(language="en", temperature_inc=0.0)
-        ref = om.new_state(orc.MODE_GGML_F16, compat=orc.COMPAT_OPENAI_TS_RULES).full(pcm, orc.default_params(**P))
         got = eng.new_session().transcribe(pcm, binding.default_params(**P))
-        _same_result(got, ref, f"{which} openai_ts_rules seed {seed}")
+        # identical, or every pick a proven near tie on the oracle's variant (the toy models' timestamp logits are nearly flat: forcing a
+        # timestamp at every window start makes picks among them, which f16 noise can move -- r04_e: one flip in 200 windows)
+        ok, _ = check_against_oracle(got, om, orc, orc.MODE_GGML_F16, pcm, orc.default_params(**P), f"{which} openai_ts_rules seed {seed}", GAP_TOL_F16,
+                                     compat=orc.COMPAT_OPENAI_TS_RULES)
+        n_same += ok
         base = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(**P))
-        n_diff += list(base["tokens"]) != list(ref["tokens"])
-        assert len(ref["tokens"]) == 0 or ref["tokens"][0] >= om.beg, "first token of the first window is not a timestamp under the OpenAI rule"
-    report(f"{which}: SS_COMPAT_OPENAI_TS_RULES identical to the oracle's variant on 4 chunks; {n_diff}/4 differ from the v1.5.x rules")
-    assert n_diff >= 1
+        n_diff += list(base["tokens"]) != list(got["tokens"])
+        assert len(got["tokens"]) == 0 or got["tokens"][0] >= om.beg, "first token of the first window is not a timestamp under the OpenAI rule"
+    report(f"{which}: SS_COMPAT_OPENAI_TS_RULES: {n_same}/4 chunks identical to the oracle's variant, the rest proven near ties; {n_diff}/4 differ from the v1.5.x rules")
+    assert n_diff >= 1 and n_same >= 1
     eng.close(); om.close()
 
 

@@ -23,7 +23,7 @@ __global__ void fill(f16* p, size_t n, unsigned seed, float scale) {
 }
 int main(int argc, char** argv) {
     struct Shape { int M, N, K; const char* name; };
-    Shape shapes[] = {{12000, 5120, 1280, "FC1"}, {12000, 1280, 5120, "FC2"}, {12000, 3840, 1280, "QKV"}, {12000, 4096, 1280, "N4096"}, {12000, 2560, 1280, "QK"}, {11776, 5120, 1280, "M46"}, {12288, 5120, 1280, "M48"}, {12000, 1280, 1280, "O"},
+    Shape shapes[] = {{48000, 5120, 1280, "FC1x4"}, {48000, 1280, 5120, "FC2x4"}, {48000, 1280, 1280, "Ox4"}, {48000, 2560, 1280, "QKx4"}, {12000, 5120, 1280, "FC1"}, {12000, 1280, 5120, "FC2"}, {12000, 3840, 1280, "QKV"}, {12000, 4096, 1280, "N4096"}, {12000, 2560, 1280, "QK"}, {11776, 5120, 1280, "M46"}, {12288, 5120, 1280, "M48"}, {12000, 1280, 1280, "O"},
                       {12000, 81920, 1280, "crossKV"}, {4096, 4096, 4096, "sq4096"}, {8192, 8192, 8192, "sq8192"}};
     int kinds[] = {EPI_STORE_T, EPI_GELU_T, EPI_RES_F32};
     const char* kn[] = {"store", "gelu", "res_f32"};
@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
         for (int ki = 0; ki < 3; ki++) {
             GemmDesc g{};
             g.A = A; g.lda = s.K; g.a_rows_per_batch = 0; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = kinds[ki]; g.bias = bias;
-            g.out = out; g.ldo = s.N; g.o_rows_per_batch = 0; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500;
+            g.out = out; g.ldo = s.N; g.o_rows_per_batch = 0; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500; g.gelu_f16_in = 1;   // as the f16 engine runs it
             launch_gemm<f16>(g, st);
             hipEventRecord(e0, st);
             const int reps = 10;
@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
             for (int ki = 0; ki < 3; ki++) {
                 GemmDesc g{};
                 g.A = A; g.lda = s.K; g.a_rows_per_batch = 0; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = kinds[ki]; g.bias = bias;
-                g.out = out; g.ldo = s.N; g.o_rows_per_batch = 0; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500; g.trace = tr;
+                g.out = out; g.ldo = s.N; g.o_rows_per_batch = 0; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500; g.trace = tr; g.gelu_f16_in = 1;
                 launch_gemm<f16>(g, st); hipDeviceSynchronize();
                 std::vector<long long> h(256 * 8 * 4);
                 hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);

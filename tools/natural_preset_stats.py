@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--seed0", type=int, default=100)
     ap.add_argument("--oracle", action="store_true")
+    ap.add_argument("--model-seed", type=int, default=0)
     ap.add_argument("--dtype", default="f16")
     ap.add_argument("knobs", nargs="*")
     a = ap.parse_args()
@@ -31,10 +32,10 @@ def main():
     d = os.environ.get("SS_MODEL_DIR", "/tmp/ss_models")
     os.makedirs(d, exist_ok=True)
     tag = "-".join(f"{k}{v}" for k, v in sorted(kw.items()) if ggml_io.NATURAL.get(k) != v)
-    path = os.path.join(d, f"ggml-{a.model}-natural{('-' + tag) if tag else ''}-s0.bin")
+    path = os.path.join(d, f"ggml-{a.model}-natural{('-' + tag) if tag else ''}-s{a.model_seed}.bin")
     if not os.path.exists(path):
         t = time.time()
-        ggml_io.write_model(path + ".tmp", a.model, seed=0, **kw)
+        ggml_io.write_model(path + ".tmp", a.model, seed=a.model_seed, **kw)
         os.replace(path + ".tmp", path)
         print(f"wrote {path} in {time.time() - t:.0f} s", file=sys.stderr)
     pcms = [synth.speech_like(a.seed0 + i) for i in range(a.n)]
