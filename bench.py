@@ -99,6 +99,72 @@ def ensure_model(name: str, local_rank: int, dist) -> str:
     return path
 
 
+def mode_n_leg(args, device: int, dtype_code: int, n_chunks: int, rounds: int = 3):
+    """Side measurement `mode_n` (SURVEY.md section 8d "Mode N"): the reference's REAL decoding parameters (whisper.rs:131-173 -- greedy
+    best_of 5, temperature ladder, entropy / logprob checks, decode to EOT) on synthetic weights whose decoder behaves like a transcriber
+    (ggml_io.NATURAL: stays at temperature 0, ends with EOT after an audio-dependent number of tokens, a different stream for every audio).  Work
+    per chunk differs, so this is where continuous batching shows: rows freed by an early EOT are refilled with new windows.  `n_chunks`
+    distinct 30 s chunks stay in flight (resident in HBM); a finished chunk is replaced at once; `rounds` x n_chunks chunks are timed."""
+    import collections
+    import torch
+    from speaksense_amd import binding, ggml_io, synth
+    path = model_path_for(args.model + "-natural")
+    if not os.path.exists(path):
+        t = time.time()
+        ggml_io.write_model(path + ".tmp", args.model, seed=0, **ggml_io.NATURAL)
+        os.replace(path + ".tmp", path)
+        print(f"[bench] wrote the natural-EOT synthetic {args.model} model in {time.time() - t:.1f}s", file=sys.stderr)
+    eng = binding.Engine(path, device=device, dtype=dtype_code, max_batch=args.device_batch if args.device_batch > 0 else args.batch, n_lanes=max(0, args.lanes))
+    pcm = torch.stack([torch.from_numpy(synth.speech_like(5000 + i)) for i in range(n_chunks)]).cuda()
+    P = binding.default_params(language="en")
+    ses = [eng.new_session() for _ in range(n_chunks)]
+
+    def run(total):
+        pend = {}                              # slot (session + audio) -> (submit time, ticket)
+        res, lat = [], []
+        free = collections.deque(range(n_chunks))
+        submitted = 0
+
+        def collect(k):
+            t_sub, tk = pend.pop(k)
+            res.append((k, ses[k].wait(tk))); lat.append(time.perf_counter() - t_sub)
+            free.append(k)
+        while submitted < total or pend:
+            while free and submitted < total:
+                k = free.popleft()
+                pend[k] = (time.perf_counter(), ses[k].submit_device(pcm[k].data_ptr(), pcm.shape[1], P))
+                submitted += 1
+            done = [k for k, (_, tk) in pend.items() if ses[k].ready(tk)]      # whichever chunk finished, not the oldest: its slot is refilled at once
+            if done:
+                for k in done:
+                    collect(k)
+            elif pend:
+                time.sleep(2e-4)
+        return res, lat
+    first, _ = run(n_chunks)                   # warm-up: every chunk once (graph shapes, lazily sized buffers); also the reference results
+    ref = {k: tuple(int(t) for t in r["tokens"]) for k, r in first}
+    torch.cuda.synchronize()
+    t0 = eng.totals(); ts = time.perf_counter()
+    res, lat = run(rounds * n_chunks)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - ts; t1 = eng.totals()
+    same = all(tuple(int(t) for t in r["tokens"]) == ref[k] for k, r in res)
+    ntok = [len(r["tokens"]) for _, r in first]
+    nwin = [r["n_windows"] for _, r in first]
+    nfail = [r["n_fail"] for _, r in first]
+    d = {k: t1[k] - t0[k] for k in t0 if k != "n_lanes"}
+    eng.close()
+    return {"what": f"natural EOT with the reference's parameters (best_of 5, ladder 0.0..1.0, entropy 2.4, logprob -1.0) on {os.path.basename(path)} "
+                    f"(ggml_io.NATURAL); {n_chunks} distinct 30 s chunks kept in flight, {rounds * n_chunks} chunks timed after one warm-up round",
+            "value": round(rounds * n_chunks * CHUNK_SEC / dt, 2), "unit": "audio-sec/s", "p50_chunk_latency_ms": round(1e3 * float(np.median(lat)), 1),
+            "tokens_per_chunk": {"min": int(min(ntok)), "median": int(np.median(ntok)), "max": int(max(ntok))},
+            "windows_per_chunk": round(float(np.mean(nwin)), 2), "windows_at_temperature_0": round(1.0 - sum(nfail) / max(1, sum(nwin)), 3),
+            "distinct_streams": len(set(ref.values())), "chunks": n_chunks, "repeat_identical": same,
+            "decoder_passes": d["decoder_passes"], "rows_per_pass": round(d["decoder_rows"] / max(1, d["decoder_passes"]), 2),
+            "admitted_into_running_groups": d["admitted"], "windows_started_midway": d["started_midway"],
+            "phase_ms_total": {"encode_cross_kv": round(d["encode_ms"], 1), "decode": round(d["decode_ms"], 1)}}
+
+
 def algorithmic_work(hp, batch: int, n_steps: int, n_prompt: int):
     """FLOPs per chunk (SURVEY.md §8d conventions: 2*MAC, attention 2*T^2*d each for QK^T and AV) and decoder bytes per step."""
     T, d, L, dt, Lt, V = hp.n_audio_ctx, hp.n_audio_state, hp.n_audio_layer, hp.n_text_state, hp.n_text_layer, hp.n_vocab
@@ -182,17 +248,36 @@ def cpu_baseline_whisper_cpp():
     with wave.open(wav, "wb") as w:
         w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
         w.writeframes((np.clip(synth.speech_like(0), -1, 1) * 32767.0).astype("<i2").tobytes())
-    runs = {}
+    # The GPU side is measured warm, weights resident: whisper.cpp's own timing report is used (whisper_print_timings on stderr: "total time" minus
+    # "load time" = mel + encode + decode of the chunk); the wall time of the cold process (start + ~3 GB model load) is kept as a side note only.
+    import re
+    runs, walls, parsed = {}, {}, True
     for t in sorted({16, min(ncpu, 64)}):
         t0 = time.perf_counter()
-        r = subprocess.run([main_bin, "-m", model, "-f", wav, "-l", "en", "-t", str(t), "-bo", "5", "-np"], capture_output=True, text=True)
+        r = subprocess.run([main_bin, "-m", model, "-f", wav, "-l", "en", "-t", str(t), "-bo", "5"], capture_output=True, text=True)
         if r.returncode != 0:
             return None
-        runs[t] = time.perf_counter() - t0          # includes the model load, as one `whisper_full` call of a cold process does
+        walls[t] = time.perf_counter() - t0
+        tm = whisper_cpp_compute_seconds(r.stderr + "\n" + r.stdout)
+        if tm is None:
+            parsed = False
+            tm = walls[t]
+        runs[t] = tm
     best_t = min(runs, key=runs.get)
     return {"value": round(CHUNK_SEC / runs[best_t], 4), "unit": "audio-sec/s", "cores": best_t, "kind": "reference",
             "sample": "whisper.cpp CPU (" + os.path.basename(main_bin) + f", greedy best_of 5) on chunk 0 of the same synthetic PCM, weights {os.path.basename(model)}; "
-                      + "; ".join(f"-t {t}: {v:.1f} s per 30 s chunk" for t, v in sorted(runs.items())) + " (process start and model load included)"}
+                      + "; ".join(f"-t {t}: {v:.1f} s per 30 s chunk (cold process incl. model load: {walls[t]:.1f} s)" for t, v in sorted(runs.items()))
+                      + ("; whisper_print_timings total - load" if parsed else "; TIMING REPORT NOT FOUND: wall time of the cold process, model load included")}
+
+
+def whisper_cpp_compute_seconds(log: str):
+    """whisper_print_timings -> seconds spent on the audio (total time - load time), or None when the report is not in `log`."""
+    import re
+    tot = re.search(r"total time\s*=\s*([0-9.]+)\s*ms", log)
+    load = re.search(r"load time\s*=\s*([0-9.]+)\s*ms", log)
+    if not tot or not load:
+        return None
+    return max(1e-3, (float(tot.group(1)) - float(load.group(1))) / 1e3)
 
 
 def main():
@@ -214,6 +299,7 @@ def main():
     ap.add_argument("--no-steady", action="store_true", help="skip the steady-state estimate reported beside the headline")
     ap.add_argument("--headline-only", action="store_true", help="only the timed region (no steady-state, host-PCM, unloaded-latency or batch8_strict side measurements): "
                     "the counter passes of tools/gpu.sh pmc use it so that every decoder pass they count belongs to the benchmarked configuration")
+    ap.add_argument("--no-mode-n", action="store_true", help="skip the natural-EOT side measurement (`mode_n`)")
     ap.add_argument("--host-pcm", action="store_true", help="headline steps take host f32 PCM (H2D inside the timed region) instead of HBM-resident PCM")
     ap.add_argument("--dry-run", action="store_true", help="CPU test of the sharding/timing plumbing: stub workload, gloo backend")
     ap.add_argument("--dist-backend", default=None, help="override (default nccl on GPU); 'gloo' + SS_BENCH_DEVICE=0 lets several ranks share one GPU for testing")
@@ -484,6 +570,12 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": "decoder pass (as above)", "achieved": round(s_bytes / (s_pass_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(s_bytes / (s_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": s_bytes, "avg_launch_ms": round(s_pass_ms, 5),
                              "rows_per_launch": round(s_rows, 2)}}
+        if n_gpus == 1 and not args.headline_only and not args.no_mode_n and args.fixed_steps > 0 and "synthetic" in path:
+            try:
+                out["mode_n"] = mode_n_leg(args, local_rank_dev, {"f16": binding.DTYPE_F16, "bf16": binding.DTYPE_BF16, "fp8": binding.DTYPE_FP8}[args.dtype],
+                                           inflight * args.batch)
+            except Exception as e:   # a side measurement never takes the headline down
+                out["mode_n"] = {"value": None, "error": str(e)}
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(path, hp, n_steps_dec, n_prompt)

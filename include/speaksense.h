@@ -163,6 +163,8 @@ int ss_submit_ex(ss_session* s, const float* pcm, int32_t n_samples, const ss_pa
  * recorded on the ticket; results live on the session and are gone with it).  A ticket that is never waited for leaks its own memory (the copy of
  * the samples) and nothing else: the engine keeps no reference to it once the chunk is complete. */
 int ss_wait(ss_ticket* t);
+/* Non-blocking: 1 when the chunk is complete (ss_wait will not block), 0 while it is queued or running.  The ticket stays valid. */
+int ss_ticket_ready(const ss_ticket* t);
 
 /* ---- results of the session's last chunk (valid until its next transcribe/submit) -------------------- */
 int32_t ss_result_n_segments(const ss_session* s);
@@ -212,9 +214,9 @@ int ss_encode(ss_engine* e, const float* mel /* [n_mel][n_len] */, int32_t n_len
 int ss_session_set_encoder(ss_session* s, const float* enc /* [n_audio_ctx][n_audio_state] */);
 int ss_session_decode(ss_session* s, const int32_t* tokens, int32_t n_tokens, int32_t n_past, float* logits_out);
 /* The decoder PASS the batched engine runs, as a stage hook: cross-KV cache slot `window` (< max_batch, lane 0) is filled from an encoder
- * output, then ONE launch carries n_rows (1..64) token rows -- row i = token[i] at position pos[i] of self-KV slot slot[i]
+ * output, then ONE launch carries n_rows (1..128) token rows -- row i = token[i] at position pos[i] of self-KV slot slot[i]
  * (< max_batch * max_decoders) attending to cross-KV window cross[i]; rows of one slot must be at consecutive positions, earlier rows first.
- * The kernels are selected by the row count exactly as in ss_transcribe_batch (<= 16 rows: fused step; 17..64: multi-tile GEMVs; rows x
+ * The kernels are selected by the row count exactly as in ss_transcribe_batch (the GEMVs take 1 / 2 / 4 / 8 column tiles of 16 rows; rows x
  * heads >= 320: the unsplit cross-attention).  logits_out: [n_sample_rows][n_vocab] raw logits of the listed rows, before any rule. */
 int ss_engine_set_encoder_window(ss_engine* e, int32_t window, const float* enc /* [n_audio_ctx][n_audio_state] */);
 /* fp8 engines only (SS_ERR_UNSUPPORTED otherwise): the FIRST quantisation point of the path -- LayerNorm 1 of encoder block 0 for the window at

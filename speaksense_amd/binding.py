@@ -64,6 +64,7 @@ def lib():
         L.ss_transcribe.argtypes = [vp, f32p, i32, C.POINTER(Params)]
         L.ss_submit.argtypes = [vp, f32p, i32, C.POINTER(Params), C.POINTER(vp)]
         L.ss_wait.argtypes = [vp]
+        L.ss_ticket_ready.argtypes = [vp]
         L.ss_result_n_segments.argtypes = [vp]
         L.ss_result_segment_text.restype = C.c_char_p
         L.ss_result_segment_text.argtypes = [vp, i32]
@@ -393,6 +394,10 @@ class Session:
     def wait(self, ticket):
         _check(self.L.ss_wait(ticket))
         return self.result()
+
+    def ready(self, ticket) -> bool:
+        """Non-blocking: has the chunk behind `ticket` completed (wait() will return at once)?"""
+        return bool(self.L.ss_ticket_ready(ticket))
 
     def result(self):
         segs = []

@@ -56,7 +56,7 @@ int ss_engine_create(const char* path, const ss_engine_opts* opts, ss_engine** o
     if (opts) o = *opts;
     if (o.max_batch <= 0) o.max_batch = 8;
     if (o.max_decoders <= 0) o.max_decoders = 5;
-    if (o.max_batch * o.max_decoders > 64 * 8) return fail(SS_ERR_ARG, "ss_engine_create: max_batch*max_decoders too large");
+    if (o.max_batch * o.max_decoders > 128 * 8 || o.max_batch > 128) return fail(SS_ERR_ARG, "ss_engine_create: max_batch*max_decoders too large");
     SS_TRY
     if (o.dtype != SS_DTYPE_F16 && o.dtype != SS_DTYPE_BF16 && o.dtype != SS_DTYPE_FP8) return fail(SS_ERR_ARG, "ss_engine_create: unknown dtype");
     // SS_DTYPE_FP8 = the f16 engine with its encoder and cross-KV projections in e4m3
@@ -226,6 +226,7 @@ int ss_submit_ex(ss_session* s, const float* pcm, int32_t n_samples, const ss_pa
     *out = t;
     return SS_OK;
 }
+int ss_ticket_ready(const ss_ticket* t) { return t && t->job.done.load(std::memory_order_acquire) ? 1 : 0; }
 int ss_wait(ss_ticket* t) {
     if (!t) return fail(SS_ERR_ARG, "ss_wait: null ticket");
     // done already (also: the engine has been freed since, or the session has): neither is touched

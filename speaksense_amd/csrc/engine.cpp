@@ -180,13 +180,13 @@ struct EngineT : EngineBase {
     // Host staging for one decoder launch: control blocks, sampling-row indices and the uniform draws.  H2D copies from pinned memory read
     // their source when the copy EXECUTES, and the stream may be backlogged (encoder pass, earlier launches of the same round), so every
     // launch fills its own block of a ring and a block is only rewritten after the event recorded behind its copies has completed.
-    struct Stage { RowCtl ctl[128]; int rowidx[64]; double u[64]; };
+    struct Stage { RowCtl ctl[2 * kPartRows]; int rowidx[kPartRows]; double u[kPartRows]; };
     static constexpr int kStageRing = 16;
     Stage* stage_h = nullptr;      // pinned ring
     hipEvent_t stage_ev[kStageRing];
     bool stage_busy[kStageRing] = {};
     int stage_cur = 0;
-    RowCtl* ctl_h = nullptr;       // = stage_h[stage_cur].ctl  ([0,64) rows, [64,128) sampling rows)
+    RowCtl* ctl_h = nullptr;       // = stage_h[stage_cur].ctl  ([0, kPartRows) rows, [kPartRows, 2 kPartRows) sampling rows)
     int* rowidx_h = nullptr;       // = stage_h[stage_cur].rowidx
     void stage_acquire() {         // next free block of the ring becomes ctl_h / rowidx_h / u_h
         stage_cur = (stage_cur + 1) % kStageRing;
@@ -444,7 +444,7 @@ struct EngineT : EngineBase {
         cross.alloc((size_t)L * B * 2 * H * n_ctx * 64 * (fp8_enc ? 1 : 2));   // fp8 engine: e4m3 codes + one exponent byte per (key row, head)
         if (fp8_enc) cross_sc.alloc((size_t)L * B * 2 * H * n_ctx);
         kself.alloc((size_t)L * S * n_tctx * d * 2); vself.alloc((size_t)L * S * n_tctx * d * 2);
-        const int R = 64;  // rows per decode launch
+        const int R = kPartRows;  // rows per decode launch
         lnd.alloc((size_t)R * d * 2); qd.alloc((size_t)R * d * 2); attd.alloc((size_t)R * d * 2);
         ffd.alloc((size_t)R * 4 * d * 2); logits.alloc((size_t)R * n_vocab_pad * 4); probs.alloc((size_t)R * n_vocab_pad * 4);
         cscratch.alloc((size_t)R * H * 4 * 66 * 4); ctl_d.alloc(2 * R * sizeof(RowCtl));
@@ -578,7 +578,7 @@ struct EngineT : EngineBase {
         launch_gemm<T>(g, st);
     }
 
-    // ---- the decoder pass (1..64 rows): 11 launches per layer (10 from rows x heads >= direct_pairs on), see kernels_decode.hip / fused_body ----
+    // ---- the decoder pass (1..128 rows): 11 launches per layer (10 from rows x heads >= direct_pairs on), see kernels_decode.hip / fused_body ----
     struct Plan { int S, NW; };
     Plan pl_qkv, pl_dd, pl_fc1, pl_fc2, pl_logits;
     DBuf xa, xb, p1, pq, p2, p3;
@@ -621,7 +621,7 @@ struct EngineT : EngineBase {
         const int n_samp = (int)samp_rows.size();
         cnt_passes++; cnt_rows += M;
         if (!chained) {
-            SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(64 + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
+            SS_HIP(hipMemcpyAsync(ctl_d.p, ctl_h, (size_t)(kPartRows + n_samp) * sizeof(RowCtl), hipMemcpyHostToDevice, st));
             if (n_samp) {
                 memcpy(rowidx_h, samp_rows.data(), (size_t)n_samp * 4);
                 SS_HIP(hipMemcpyAsync(rowidx_d.p, rowidx_h, (size_t)n_samp * 4, hipMemcpyHostToDevice, st));
@@ -646,9 +646,9 @@ struct EngineT : EngineBase {
         if (n_samp == 0) return;
         const RowCtl* ctl = ctl_d.as<RowCtl>();
         step_parity ^= 1;
-        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + 64, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st,
+        launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl + kPartRows, n_samp, rc, samp_d.as<SampleOut>(), any_probs ? probs.as<float>() : nullptr, rules_scratch.as<float>(), st,
                             any_probs ? nullptr : ctl_d.as<RowCtl>(), rowidx_d.as<int>());
-        if (any_probs) draw_on_device(ctl + 64, n_samp);
+        if (any_probs) draw_on_device(ctl + kPartRows, n_samp);
         SS_HIP(hipMemcpyAsync(samp_hb[step_parity], samp_d.p, (size_t)n_samp * sizeof(SampleOut), hipMemcpyDeviceToHost, st));
         SS_HIP(hipEventRecord(ev_step[step_parity], st));
     }
@@ -745,7 +745,7 @@ struct EngineT : EngineBase {
     // One decoder launch over M rows described by ctl_h[0..M).  Rows may belong to the same decoder (a multi-token
     // prompt): K/V of every row are written to the cache before the attention kernels run, and each row attends to
     // cache positions <= its own, so causality holds without a mask.  The n_samp rows listed in samp_rows (with their
-    // rule state in ctl_h[64..64+n_samp)) get logits + rules; results land in samp_h[0..n_samp).
+    // rule state in ctl_h[kPartRows .. kPartRows + n_samp)) get logits + rules; results land in samp_h[0..n_samp).
     // the sampled rows' draws: u_h[k] was filled by round_rows (one generate_canonical per sampled row, in row order)
     void draw_on_device(const RowCtl* ctl_rows, int n_samp) {
         SS_HIP(hipMemcpyAsync(u_d.p, u_h, (size_t)n_samp * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1071,7 +1071,7 @@ struct EngineT : EngineBase {
                 RowCtl c{};
                 // a decoder slot is borrowed for this one row (position 0 of a free slot: nothing else uses it until the row has run)
                 c.token = vocab.token_sot; c.pos = 0; c.slot = free_dec[free_dec.size() - 1 - m]; c.cross = need[r0 + m]->cross; c.n_hist = 1;
-                ctl_h[m] = c; ctl_h[64 + m] = c;
+                ctl_h[m] = c; ctl_h[kPartRows + m] = c;
                 sr.push_back(m);
             }
             decoder_step(M, rc, sr, false);
@@ -1161,7 +1161,7 @@ struct EngineT : EngineBase {
 
     void round_rows(std::vector<RowRef>& decs_in, std::vector<JobState>& js, const RuleConsts& rc) {
         const Vocab& vocab = hm.vocab;
-        // expand decoders into rows (token, pos), position order within a decoder; split into launches of <= 64 rows
+        // expand decoders into rows (token, pos), position order within a decoder; split into launches of <= kPartRows rows
         std::vector<RowCtl> rows;
         std::vector<RowRef> refs;
         for (auto& dr : decs_in) {
@@ -1234,15 +1234,15 @@ struct EngineT : EngineBase {
             }
             // not usable (sampled attempt, prompt rows, other rules): it finishes in stream order and is ignored
         }
-        for (size_t r0 = 0; r0 < rows.size(); r0 += 64) {
-            const int M = (int)std::min<size_t>(64, rows.size() - r0);
+        for (size_t r0 = 0; r0 < rows.size(); r0 += kPartRows) {
+            const int M = (int)std::min<size_t>(kPartRows, rows.size() - r0);
             std::vector<int> samp_rows;
             bool any_probs = false;
             stage_acquire();   // this launch's own pinned block (ctl_h / rowidx_h / u_h)
             for (int m = 0; m < M; m++) {
                 ctl_h[m] = rows[r0 + m];
                 if (refs[r0 + m].sample) {
-                    ctl_h[64 + samp_rows.size()] = rows[r0 + m];
+                    ctl_h[kPartRows + samp_rows.size()] = rows[r0 + m];
                     if (rows[r0 + m].want_probs) {
                         // whisper_sample_token: dist(decoder.rng) -- decoder 0 draws from the generator the state carries, decoder j >= 1 from its
                         // own (whisper.cpp >= 1.5.0); SS_COMPAT_RNG_STATE: dist(state.rng), one draw per sampled decoder in decoder order
@@ -1426,7 +1426,7 @@ struct EngineT : EngineBase {
             RowCtl c{};
             c.token = tokens[i]; c.pos = n_past + i; c.slot = 0; c.cross = 0; c.n_hist = 1;
             stage_acquire();
-            ctl_h[0] = c; ctl_h[64] = c;
+            ctl_h[0] = c; ctl_h[kPartRows] = c;
             std::vector<int> sr;
             if (i == n - 1) sr.push_back(0);
             decoder_step(1, rc, sr, false);
@@ -1456,7 +1456,7 @@ struct EngineT : EngineBase {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
-        if (n < 1 || n > 64 || n_samp < 1 || n_samp > n) throw Error(SS_ERR_ARG, "decode_rows: 1..64 rows, 1..n sampling rows");
+        if (n < 1 || n > kPartRows || n_samp < 1 || n_samp > n) throw Error(SS_ERR_ARG, "decode_rows: 1..128 rows, 1..n sampling rows");
         for (int i = 0; i < n; i++)
             if (token[i] < 0 || token[i] >= n_vocab || pos[i] < 0 || pos[i] >= n_tctx || slot[i] < 0 || slot[i] >= S || crossw[i] < 0 || crossw[i] >= B)
                 throw Error(SS_ERR_ARG, "decode_rows: row " + std::to_string(i) + " out of range");
@@ -1471,7 +1471,7 @@ struct EngineT : EngineBase {
         std::vector<int> sr;
         for (int k = 0; k < n_samp; k++) {
             if (samp_rows[k] < 0 || samp_rows[k] >= n) { stage_release(); throw Error(SS_ERR_ARG, "decode_rows: sampling row out of range"); }
-            ctl_h[64 + k] = ctl_h[samp_rows[k]];
+            ctl_h[kPartRows + k] = ctl_h[samp_rows[k]];
             sr.push_back(samp_rows[k]);
         }
         decoder_step(n, rc, sr, false);

@@ -126,7 +126,8 @@ struct RowCtl {       // one per decode row; lives in pinned host memory mapped 
 };
 
 // Fused decode-step GEMV for M <= 16 rows (kernels_decode.hip): prologue + 16-row weight tiles x split-K + epilogue
-constexpr int kPartRows = 64;   // row stride of the split-K partial buffers [S][kPartRows][N]: a decoder pass carries up to 64 token rows
+constexpr int kPartRows = 128;  // most token rows ONE decoder pass carries (row stride of the split-K partial buffers [S][kPartRows][N]; the control blocks of a
+                                // pass are ctl[0, kPartRows) = its rows, ctl[kPartRows, 2 kPartRows) = its sampling rows).  Round 4: 64 -> 128 (CT = 8 column tiles)
 enum DecPro { PRO_LN = 0, PRO_T = 1 };   // PRO_LN: the descriptor of a dec_reduce_ln launch; PRO_T: a GEMV whose activations are T rows (Xt)
 enum DecEpi { DEPI_PART = 0, DEPI_QKV = 1, DEPI_GELU_T = 2, DEPI_LOGITS = 3 };
 struct DecGemvDesc {

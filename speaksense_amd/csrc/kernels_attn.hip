@@ -35,7 +35,7 @@ template <> struct MfmaA<f16> {
 
 // ---------------------------------------------------------------------------------------------
 // encoder flash attention, LDS-staged form: grid ceil(Tn / (64 QT)) * H * B workgroups of 256 threads; wave w owns 16 QT query rows.
-// The first form of this kernel (tools/experiments/r02_variants/kernels_attn.hip: enc_attn_kernel) let every wave pull its own K / V^T fragments from L2 in 32-key chunks: 8-B pieces of V^T rows and half lines of
+// The first form of this kernel (tools/experiments/r02_variants/r02_variants.diff: enc_attn_kernel) let every wave pull its own K / V^T fragments from L2 in 32-key chunks: 8-B pieces of V^T rows and half lines of
 // K rows, i.e. 3x the useful bytes through the CU's L1, re-read by every wave.  Here K and V^T tiles of 64 keys (whole 128-B lines)
 // are DMA'd global -> LDS once per workgroup (global_load_lds, 3-stage ring, one s_barrier per chunk) and shared by the four waves.
 //  * S^T = K Q^T with the K rows of a 32-key group permuted (MFMA row i of tile t <-> key (i>>2)*8 + (t&1)*4 + (i&3)), so the

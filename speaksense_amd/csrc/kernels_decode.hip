@@ -11,7 +11,7 @@
 //   dec_cross_attn_q(8)_kernel   cross-attention over the 1500 encoder positions with the q projection's reduction in its prologue
 // Split-K goes across workgroups (grid = N/16 x S) so that N = d projections still launch >= 256 workgroups; partials are summed in a fixed
 // order by the consumer, so results are run-to-run identical (no float atomics).
-// Variants measured slower and archived (tools/experiments/r02_variants/kernels_decode.hip): LayerNorm / flash-decoding-combine prologues inside the
+// Variants measured slower and archived (tools/experiments/r02_variants/r02_variants.diff): LayerNorm / flash-decoding-combine prologues inside the
 // GEMV, narrow output tiles without split-K, a residual-update epilogue, non-temporal weight loads (-1.2 %).
 #include "kernels.h"
 #include "wave_ops.h"
@@ -241,7 +241,8 @@ template <typename T, int EPI>
 static void launch_dg(const DecGemvDesc& g, int NW, hipStream_t st) {
     if (g.M <= 16) launch_dg3<T, EPI, 1>(g, NW, st);
     else if (g.M <= 32) launch_dg3<T, EPI, 2>(g, NW, st);
-    else launch_dg3<T, EPI, 4>(g, NW, st);
+    else if (g.M <= 64) launch_dg3<T, EPI, 4>(g, NW, st);
+    else launch_dg3<T, EPI, 8>(g, NW, st);     // 65..128 rows (round 4): the weight fragments still cross HBM once per pass
 }
 
 // choose split-K so the grid has >= ~256 workgroups; per-wave k must be a multiple of 32 and <= 320

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64) void logits_rules_pick_kernel(const float* __re
     if (ctl_upd) {
         // the row's control block for the NEXT step, exactly as the host derives it from this sample when it is accepted greedily
         // (engine.cpp round_rows / accept_sample): lets step t+1 be enqueued before the host has seen step t
-        RowCtl c = ctl_upd[64 + m];
+        RowCtl c = ctl_upd[kPartRows + m];
         const int nh = c.n_hist + 1;
         c.penult_ts = nh < 2 ? 1 : c.last_ts;
         c.last_ts = r.id >= rc.beg;
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(64) void logits_rules_pick_kernel(const float* __re
         c.token = r.id;
         c.pos += 1;
         if (rc.openai_ts ? r.id >= rc.beg : r.id > rc.beg) { c.has_ts = 1; c.ts_min = r.id - rc.beg; }
-        ctl_upd[64 + m] = c;
+        ctl_upd[kPartRows + m] = c;
         ctl_upd[row_of[m]] = c;
     }
 }

@@ -366,6 +366,14 @@ static int map_params(struct whisper_context* ctx, const struct whisper_full_par
     return SS_OK;
 }
 
+// whisper.cpp's to_timestamp(t, comma = false): t in centiseconds -> "HH:MM:SS.mmm"
+static void wcpp_timestamp(int64_t t, char* buf, size_t n) {
+    int64_t msec = t * 10;
+    const int64_t hr = msec / (1000 * 60 * 60); msec -= hr * (1000 * 60 * 60);
+    const int64_t mn = msec / (1000 * 60); msec -= mn * (1000 * 60);
+    const int64_t sec = msec / 1000; msec -= sec * 1000;
+    snprintf(buf, n, "%02d:%02d:%02d.%03d", (int)hr, (int)mn, (int)sec, (int)msec);
+}
 int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* state, struct whisper_full_params params, const float* samples,
                             int n_samples) {
     if (!ctx || !state) return -1;
@@ -375,7 +383,28 @@ int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* s
     ss_ticket* t = nullptr;
     rc = ss_submit(state->ses, samples, n_samples, &p, &t);
     if (rc != SS_OK) return rc;
-    return ss_wait(t);
+    rc = ss_wait(t);
+    // The reference switches whisper.cpp's own segment printing on (/root/reference/src/asr/whisper.rs:145-150: print_realtime, print_timestamps,
+    // print_progress all true), so a drop-in that stays silent changes what the service's stdout shows.  whisper_full_with_state prints each
+    // segment as its window is finalised -- "[%s --> %s]  %s\n" with to_timestamp() times under print_timestamps, the bare text otherwise; here the
+    // windows of a chunk complete inside a device batch, so the same lines appear when the call returns.  (print_progress reports whole
+    // percentages at window starts on stderr: a one-window chunk prints nothing there, and nothing is printed here.)
+    if (rc == SS_OK && params.print_realtime) {
+        const int n = ss_result_n_segments(state->ses);
+        for (int i = 0; i < n; i++) {
+            const char* text = ss_result_segment_text(state->ses, i);
+            if (params.print_timestamps) {
+                char a[32], b[32];
+                wcpp_timestamp(ss_result_segment_t0(state->ses, i), a, sizeof(a));
+                wcpp_timestamp(ss_result_segment_t1(state->ses, i), b, sizeof(b));
+                printf("[%s --> %s]  %s\n", a, b, text ? text : "");
+            } else {
+                printf("%s", text ? text : "");
+            }
+        }
+        fflush(stdout);
+    }
+    return rc;
 }
 int whisper_full(struct whisper_context* ctx, struct whisper_full_params params, const float* samples, int n_samples) {
     if (!ctx) return -1;

@@ -72,7 +72,7 @@ def bench_engine(request, large_v3_path):
     eng.close()
 
 
-def test_decoder_pass_32_and_64_rows_vs_oracle(bench_engine, large_v3_path, oracle_threads):
+def test_decoder_pass_32_64_and_128_rows_vs_oracle(bench_engine, large_v3_path, oracle_threads):
     """(i) One decoder pass of the benchmarked shape against the oracle.  4 (then 8) sequences x 8 prompt positions = 32 (64) rows in ONE launch;
     sequence s sits in self-KV slot 5 s and attends to cross-KV window s % 4, whose cache was filled from an encoder-output matrix that
     the oracle state of the same sequence gets too.  The logits of every sequence's last row are held to the per-step tolerance of the
@@ -90,11 +90,11 @@ def test_decoder_pass_32_and_64_rows_vs_oracle(bench_engine, large_v3_path, orac
         eng.set_encoder_window(w, encs[w])
     text = rng.integers(300, 40000, (8, 8))
     worst = {}
-    for n_seq in (4, 8):
+    for n_seq in (4, 8, 16):       # 32, 64 and (round 4: CT = 8 column tiles) 128 rows in one pass
         token, pos, slot, cross, samp = [], [], [], [], []
         seqs = []
         for s in range(n_seq):
-            toks = [om.sot, om.sot + 1 + s, om.transcribe] + [int(t) for t in text[s][:5]]
+            toks = [om.sot, om.sot + 1 + s, om.transcribe] + [int(t) for t in text[s % 8][:5]]
             seqs.append(toks)
             for i, t in enumerate(toks):
                 token.append(t); pos.append(i); slot.append(5 * s); cross.append(s % n_win)
@@ -102,7 +102,7 @@ def test_decoder_pass_32_and_64_rows_vs_oracle(bench_engine, large_v3_path, orac
         assert len(token) == 8 * n_seq
         got = eng.decode_rows(token, pos, slot, cross, samp)
         w_n = 0.0
-        for s in range(n_seq):
+        for s in (range(n_seq) if n_seq <= 8 else (0, 3, 7, 9, 12, 15)):     # the oracle costs seconds per sequence: a sample of the 128-row pass
             ost = om.new_state(omode)
             ost.set_encoder(encs[s % n_win])
             ref = ost.decode(seqs[s], 0)
@@ -119,12 +119,12 @@ def test_decoder_pass_32_and_64_rows_vs_oracle(bench_engine, large_v3_path, orac
     # changes the kernels and with them the accumulation order, not the arithmetic type -- the two passes differ by the f16 noise floor (measured
     # 1.85e-3 sigma, the distance each has from the oracle) and must stay within half the oracle tolerance
     s = 1
-    toks = [om.sot, om.sot + 1 + s, om.transcribe] + [int(t) for t in text[s][:5]]
+    toks = [om.sot, om.sot + 1 + s, om.transcribe] + [int(t) for t in text[s % 8][:5]]
     alone = eng.decode_rows(toks, list(range(8)), [5 * s] * 8, [s % n_win] * 8, [7])
     d = float(np.abs(alone[0] - got[s]).max()) / float(got[s].std())
     assert d < tol / 2, d
     report(f"large-v3 {which} decoder pass vs oracle at the benchmarked row counts (unsplit cross-attention, multi-tile GEMVs): worst max|logits - oracle| / std "
-           f"= {worst[32]:.2e} at 32 rows, {worst[64]:.2e} at 64 rows; 8-row pass vs 64-row pass {d:.2e}")
+           f"= {worst[32]:.2e} at 32 rows, {worst[64]:.2e} at 64 rows, {worst[128]:.2e} at 128 rows; 8-row pass vs 128-row pass {d:.2e}")
     om.close()
 
 
@@ -169,3 +169,52 @@ def test_bench_engine_32_row_passes_vs_oracle(bench_engine, large_v3_path, oracl
     report(f"large-v3 {which}, Engine(max_batch=32, n_lanes=3), 32 chunks async: {rows / passes:.1f} rows per decoder pass; {n_distinct} distinct token streams; {n_same}/32 chunks identical to "
            f"their single-chunk runs; chunks {replay} force-replayed on the oracle, largest near-tie margin {worst:.4f} (tolerance {gap_tol})")
     om.close()
+
+
+@pytest.fixture(scope="module")
+def large_v3_natural_path():
+    sys.path.insert(0, ROOT)
+    import bench
+    from speaksense_amd import ggml_io
+    path = bench.model_path_for("large-v3-natural")
+    if not os.path.exists(path):
+        ggml_io.write_model(path + ".tmp", "large-v3", seed=0, **ggml_io.NATURAL)
+        os.replace(path + ".tmp", path)
+    return path
+
+
+def test_natural_preset_32_chunks_distinct_streams_vs_oracle(large_v3_natural_path, oracle_threads):
+    """The whole path at full depth with the reference's REAL parameters (whisper.rs:131-173: best_of 5, temperature ladder, decode to EOT) on the
+    natural-EOT preset (ggml_io.NATURAL, what bench.py's `mode_n` runs): 32 different chunks through Engine(max_batch=32, n_lanes=3) must give
+    >= 24 DIFFERENT token streams (with the default synthetic weights 32 chunks fell into 5 attractors, so a cross-KV
+    slot mix-up between rows could hide behind coinciding streams), >= 90 % of the windows must stay at temperature 0, the transcript lengths
+    must spread, every chunk must equal its single-chunk run, and two chunks are replayed call by call on the oracle."""
+    from speaksense_amd import binding
+    from test_gpu_parity import check_trace_against_oracle
+    orc = oracle_threads
+    eng = binding.Engine(large_v3_natural_path, dtype=binding.DTYPE_F16, max_batch=32, n_lanes=3, batch_wait_us=500000)
+    P = binding.default_params(language="en")
+    pcms = [synth.speech_like(5000 + i) for i in range(32)]
+    ses = [eng.new_session() for _ in pcms]
+    tickets = [s.submit(p, P) for s, p in zip(ses, pcms)]
+    res = [s.wait(t) for s, t in zip(ses, tickets)]
+    lens = [len(r["tokens"]) for r in res]
+    n_win, n_fail = sum(r["n_windows"] for r in res), sum(r["n_fail"] for r in res)
+    streams = {tuple(int(t) for t in r["tokens"]) for r in res}
+    assert len(streams) >= 24, f"only {len(streams)} distinct token streams among 32 chunks"
+    assert n_fail <= 0.1 * n_win, f"{n_fail} fallbacks over {n_win} windows"
+    assert max(lens) - min(lens) >= 30 and min(lens) >= 2, lens
+    n_same = sum(list(eng.new_session().transcribe(p, P)["tokens"]) == list(r["tokens"]) for p, r in zip(pcms, res))
+    assert n_same >= 31, f"only {n_same}/32 chunks equal their single-chunk run"
+    om = orc.OracleModel(large_v3_natural_path)
+    order = sorted(range(32), key=lambda i: (res[i]["n_windows"], lens[i]))
+    picked = [i for i in order if lens[i] >= 8][:2]                  # the two cheapest non-trivial chunks for the CPU oracle (~1 min per window)
+    worst = 0.0
+    for i in picked:
+        fg, fs, wg, ws = check_trace_against_oracle(res[i], om, orc, orc.MODE_GGML_F16, pcms[i], orc.default_params(language="en"),
+                                                    f"large-v3 natural preset, chunk {i}", GAP_TOL_F16)
+        worst = max(worst, wg)
+    report(f"large-v3 natural preset, 32 chunks async on Engine(32, 3 lanes): {len(streams)} distinct streams, {n_win} windows, {n_fail} fallbacks, tokens per chunk "
+           f"{min(lens)}..{max(lens)} (median {int(np.median(lens))}), {n_same}/32 equal their single-chunk runs; chunks {picked} replayed call by call on the oracle, "
+           f"largest greedy margin {worst:.4f}")
+    om.close(); eng.close()

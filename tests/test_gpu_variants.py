@@ -159,7 +159,7 @@ class WCtxParams(C.Structure):
     _fields_ = [("use_gpu", C.c_bool)]
 
 
-def test_whisper_h_shim_matches_native_api(toy_ml_path, eng, monkeypatch):
+def test_whisper_h_shim_matches_native_api(toy_ml_path, eng, monkeypatch, capfd):
     """The call sequence of /root/reference/src/asr/whisper.rs (new -> create_state -> build_params -> full -> segment getters)."""
     from speaksense_amd import binding
     monkeypatch.setenv("SS_DTYPE", "f16")
@@ -201,11 +201,25 @@ def test_whisper_h_shim_matches_native_api(toy_ml_path, eng, monkeypatch):
     p.single_segment = False; p.no_context = True; p.audio_ctx = 0
     p.temperature_inc = 0.0   # keep this comparison deterministic (no sampled fallback)
     pcm = synth.speech_like(21)
+    capfd.readouterr()
     rc = L.whisper_full_with_state(ctx, st, p, pcm.ctypes.data_as(C.c_void_p), len(pcm))
     assert rc == 0
+    printed = capfd.readouterr().out
     ref = eng.new_session().transcribe(pcm, binding.default_params(language="zh", temperature_inc=0.0))
     n = L.whisper_full_n_segments_from_state(st)
     assert n == len(ref["segments"]) and n > 0
+    # print_realtime + print_timestamps (the reference sets both, whisper.rs:145-150): one line per segment in whisper.cpp's format
+    def ts(t):
+        ms = t * 10
+        return "%02d:%02d:%02d.%03d" % (ms // 3600000, ms // 60000 % 60, ms // 1000 % 60, ms % 1000)
+    want = "".join("[%s --> %s]  %s\n" % (ts(s["t0"]), ts(s["t1"]), s["text"].decode("utf-8", "replace")) for s in ref["segments"])
+    assert printed.encode("utf-8", "replace").decode("utf-8", "replace") == want, (printed[:200], want[:200])
+    p.print_timestamps = False
+    assert L.whisper_full_with_state(ctx, st, p, pcm.ctypes.data_as(C.c_void_p), len(pcm)) == 0
+    assert capfd.readouterr().out == "".join(s["text"].decode("utf-8", "replace") for s in ref["segments"])
+    p.print_realtime = False
+    assert L.whisper_full_with_state(ctx, st, p, pcm.ctypes.data_as(C.c_void_p), len(pcm)) == 0
+    assert capfd.readouterr().out == ""
     for i, s in enumerate(ref["segments"]):
         assert L.whisper_full_get_segment_text_from_state(st, i) == s["text"]
         assert L.whisper_full_get_segment_t0_from_state(st, i) == s["t0"]

@@ -52,4 +52,5 @@ def test_token_ids_identical_to_whisper_cpp_on_real_weights():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=3600)
     sys.stdout.write(r.stdout[-6000:])
     sys.stderr.write(r.stderr[-3000:])
-    assert r.returncode == 0, "the MI355X engine and whisper.cpp disagree beyond proven near ties (see the report above)"
+    assert r.returncode != 2, "the engine's DEFAULT behaviour does not match this whisper.cpp but another SS_COMPAT variant does (report above; DESIGN.md 2a)"
+    assert r.returncode == 0, "the MI355X engine and whisper.cpp disagree beyond proven near ties under every variant tried (see the report above)"
