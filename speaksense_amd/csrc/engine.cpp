@@ -259,6 +259,7 @@ struct EngineT : EngineBase {
         { const char* gv = getenv("SS_DECODE_GRAPH"); use_graph = !(gv && gv[0] == '0'); }     // 0: launch the step kernel by kernel instead of replaying its hipGraph
         { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }   // 0: wait for every step's samples before enqueuing the next step
         if (const char* sm = getenv("SS_CB_START_MIN")) cb_start_min = std::max(1, atoi(sm));
+        { const char* lf = getenv("SS_LN_FUSE"); ln_fuse = !(lf && lf[0] == '0'); }
         compat = donor ? donor->compat : resolve_compat(o.compat);
         if (!donor) {
             for (int i = 1; i < n_lanes_total; i++) { extra_lanes.emplace_back(new EngineT(path, o, this, i, n_lanes_total)); extra_lanes.back()->owner = this; }
@@ -658,9 +659,21 @@ struct EngineT : EngineBase {
         const long cb_stride = (long)2 * H * n_ctx * 64, cl_stride = (long)B * cb_stride;
         float* xcur = xa.as<float>(); float* xnext = xb.as<float>();
         const float* prev_parts = nullptr; int prev_np = 0; const float* prev_bias = nullptr;
+        // Few rows (the latency configuration: one chunk at a time): every residual-update + LayerNorm launch becomes the prologue of the GEMV that
+        // consumes it (kernels.h launch_dec_gemv_ln) -- 8 launches per layer instead of 11, one instead of two for the logits.
+        const bool lnf = ln_fuse && M <= kLnFuseRows && n_samp <= kLnFuseRows;
         for (int il = 0; il < L; il++) {
             const DecL& e = dec[il];
-            {   // x = [embed | x + b2 + sum P3]; LN1 (one wave per row) -> QKV GEMV, q scaled, K/V appended to the cache
+            if (lnf) {
+                DecGemvDesc g = dgd(PRO_LN, DEPI_QKV, e.wqkv, M, 3 * d, d, 1);
+                if (il == 0) { g.ctl = ctl; g.tok_emb = tok_emb; g.pos_emb = dec_pos; }
+                else { g.x_in = xcur; g.parts = prev_parts; g.n_parts = prev_np; g.bias_prev = prev_bias; }
+                g.x_out = xnext; g.ln_w = e.ln1w; g.ln_b = e.ln1b;
+                g.bias = e.bqkv; g.out = qd.p; g.ldo = d; g.scale = qscale;
+                g.ctl_rows = ctl; g.kcache = kself.as<T>() + il * layer_stride; g.vcache = vself.as<T>() + il * layer_stride; g.slot_stride = slot_stride;
+                launch_dec_gemv_ln<T>(g, pl_qkv.NW, st);
+                std::swap(xcur, xnext);
+            } else {   // x = [embed | x + b2 + sum P3]; LN1 (one wave per row) -> QKV GEMV, q scaled, K/V appended to the cache
                 DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
                 if (il == 0) { r.ctl = ctl; r.tok_emb = tok_emb; r.pos_emb = dec_pos; }
                 else { r.x_in = xcur; r.parts = prev_parts; r.n_parts = prev_np; r.bias_prev = prev_bias; }
@@ -679,13 +692,20 @@ struct EngineT : EngineBase {
             const bool direct = M * H >= direct_pairs;
             launch_dec_self_attention<T>(qd.as<T>(), kself.as<T>() + il * layer_stride, vself.as<T>() + il * layer_stride, slot_stride, d, H, ctl, M,
                                          attd.as<T>(), st);
-            const int n_qpart = pl_dd.S;
+            const int n_qpart = lnf ? 1 : pl_dd.S;
             {
                 {   // attention out-projection, split-K partials
                     DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wo, M, d, d, pl_dd.S);
                     g.Xt = attd.p; g.ldx = d; g.part_out = p1.as<float>();
                     launch_dec_gemv<T>(g, pl_dd.NW, st);
                 }
+                if (lnf) {   // x += bo + sum P1; LNc; cross query (one unsplit partial slot) in one launch
+                    DecGemvDesc g = dgd(PRO_LN, DEPI_PART, e.wcq, M, d, d, 1);
+                    g.x_in = xcur; g.x_out = xnext; g.parts = p1.as<float>(); g.n_parts = pl_dd.S; g.bias_prev = e.bo; g.ln_w = e.lncw; g.ln_b = e.lncb;
+                    g.part_out = pq.as<float>();
+                    launch_dec_gemv_ln<T>(g, pl_qkv.NW, st);
+                    std::swap(xcur, xnext);
+                } else {
                 // x += bo + sum P1; LNc -> cross query partials (reduced, biased and scaled inside the cross-attention kernel)
                 DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
                 r.x_in = xcur; r.x_out = xnext; r.parts = p1.as<float>(); r.n_parts = pl_dd.S; r.bias_prev = e.bo; r.ln_w = e.lncw; r.ln_b = e.lncb;
@@ -694,6 +714,7 @@ struct EngineT : EngineBase {
                 DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wcq, M, d, d, pl_dd.S);
                 g.Xt = lnd.p; g.ldx = d; g.part_out = pq.as<float>();
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
+                }
             }
             const T* kc = cross.as<T>() + il * cl_stride;
             if (fp8_enc) {   // e4m3 cross cache: the same two forms over codes + exponent bytes (half the bytes of the stream that bounds the pass)
@@ -715,7 +736,13 @@ struct EngineT : EngineBase {
                 g.Xt = attd.p; g.ldx = d; g.part_out = p2.as<float>();
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
             }
-            {   // x += bco + sum P2; LN2 -> FC1 + GELU
+            if (lnf) {   // x += bco + sum P2; LN2; FC1 + GELU in one launch
+                DecGemvDesc g = dgd(PRO_LN, DEPI_GELU_T, e.w1, M, 4 * d, d, 1);
+                g.x_in = xcur; g.x_out = xnext; g.parts = p2.as<float>(); g.n_parts = pl_dd.S; g.bias_prev = e.bco; g.ln_w = e.ln2w; g.ln_b = e.ln2b;
+                g.bias = e.b1; g.out = ffd.p; g.ldo = 4 * d;
+                launch_dec_gemv_ln<T>(g, pl_fc1.NW, st);
+                std::swap(xcur, xnext);
+            } else {   // x += bco + sum P2; LN2 -> FC1 + GELU
                 DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
                 r.x_in = xcur; r.x_out = xnext; r.parts = p2.as<float>(); r.n_parts = pl_dd.S; r.bias_prev = e.bco; r.ln_w = e.ln2w; r.ln_b = e.ln2b;
                 launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
@@ -732,6 +759,13 @@ struct EngineT : EngineBase {
             prev_parts = p3.as<float>(); prev_np = pl_fc2.S; prev_bias = e.b2;
         }
         if (n_samp == 0) return;
+        if (lnf) {
+            DecGemvDesc g = dgd(PRO_LN, DEPI_LOGITS, tok_emb, n_samp, n_vocab_pad, d, 1);
+            g.x_in = xcur; g.parts = prev_parts; g.n_parts = prev_np; g.bias_prev = prev_bias; g.ln_w = lnw; g.ln_b = lnb; g.row_idx = rowidx_d.as<int>();
+            g.out = logits.p; g.ldo = n_vocab_pad; g.n_valid = n_vocab;
+            launch_dec_gemv_ln<T>(g, pl_logits.NW, st);
+            return;
+        }
         {   // final LayerNorm once (gathering the sampling rows, folding FC2's bias + partials), then logits = x . tok_emb^T
             DecGemvDesc g = dgd(PRO_LN, DEPI_LOGITS, tok_emb, n_samp, n_vocab_pad, d, 1);
             g.x_in = xcur; g.parts = prev_parts; g.n_parts = prev_np; g.bias_prev = prev_bias; g.ln_w = lnw; g.ln_b = lnb; g.row_idx = rowidx_d.as<int>();
@@ -760,6 +794,7 @@ struct EngineT : EngineBase {
     DBuf samp_d, rowidx_d, rules_scratch;
     long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0, cnt_admitted = 0, cnt_midstart = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
     bool use_graph = true, chain_steps = true;
+    bool ln_fuse = true;      // SS_LN_FUSE=0: A/B switch of the LayerNorm-prologue launches for <= kLnFuseRows rows
     int cb_start_min = 4;     // SS_CB_START_MIN: windows that must be waiting before a running group pauses its decoders for their encoder pass
     static constexpr int direct_pairs = 320;   // (rows x heads) from which the cross-attention runs unsplit (large-v3: 16 rows; +2.3 % at 32-row passes, -12 % at 8)
 

@@ -150,6 +150,12 @@ void dec_gemv_plan(int N, int K, int* S_out, int* NW_out, bool whole_heads = fal
 template <typename T> void launch_dec_gemv(const DecGemvDesc& g, int NW, hipStream_t st);
 // stand-alone prologue: out T [M][K] = LayerNorm(x_in + bias_prev + sum parts) with optional row gather / x_out write-back
 template <typename T> void launch_dec_reduce_ln(const DecGemvDesc& g, T* out, hipStream_t st);
+// Few rows (M <= kLnFuseRows: the latency configuration, one chunk at a time): the residual update + LayerNorm of launch_dec_reduce_ln as the
+// PROLOGUE of the GEMV that consumes it -- one launch instead of two.  `g` carries both halves (x_in / parts / bias_prev / ln_w / ln_b / x_out /
+// ctl / row_idx AND W / N / K / epilogue fields); S == 1.  Every workgroup normalises the M rows itself (M x K f32 from L2: nothing at M <= 4;
+// at 32 rows x 320 workgroups it was 157 MB per launch, which is why the same fusion lost at the benchmark's row counts).
+constexpr int kLnFuseRows = 4;
+template <typename T> void launch_dec_gemv_ln(const DecGemvDesc& g, int NW, hipStream_t st);
 // cross-attention whose q comes as split-K partials: q = round_T((sum_p qpart[p] + qbias) * qscale); writes (m,l,o[64]) partials
 template <typename T>
 void launch_dec_cross_attention_q(const float* qpart, int n_qpart, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d, int H,

@@ -215,6 +215,71 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     }
 }
 
+// LayerNorm-prologue form for M <= 16 rows (dispatched for M <= kLnFuseRows): the weight fragments are requested FIRST, then the waves normalise
+// the rows into LDS (wave per row, ln_row) while those loads are in flight, then the B fragments come from LDS.  Workgroup (0, 0) also writes the
+// updated residual stream (x_out is the other half of a ping-pong pair, so the other workgroups still read the old rows).
+template <typename T, int EPI, int NFR, int NI>
+__global__ __launch_bounds__(256) void dec_gemv_ln_kernel(DecGemvDesc g) {
+    typedef typename MfmaD<T>::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem_d[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
+    const int frow = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kbeg = wave * (32 * NFR);
+    const int xld = g.K + 8;                                   // row stride in T elements: 16-B aligned rows, banks spread
+    T* xs = (T*)smem_d;                                        // [16][xld]
+    float* red = (float*)(smem_d + (size_t)16 * xld * sizeof(T));   // [NW][16][17]
+    const T* wp = (const T*)g.W + (long)(n0 + frow) * g.K + kbeg;
+    V8 wf[NFR];
+#pragma unroll
+    for (int f = 0; f < NFR; f++) wf[f] = SS_LDW((const V8*)(wp + frag_koff<NFR>(f, fg)));
+    for (int m = wave; m < 16; m += NW) {
+        if (m < g.M) ln_row<T, NI>(g, m, lane, blockIdx.x == 0, 0, g.K, xs + (long)m * xld);
+        else for (int c = lane * 8; c < g.K; c += 512) *(V8*)(xs + (long)m * xld + c) = V8{};      // unused MFMA columns: finite values
+    }
+    __syncthreads();
+    V8 xf[NFR];
+#pragma unroll
+    for (int f = 0; f < NFR; f++) xf[f] = *(const V8*)(xs + (long)frow * xld + kbeg + frag_koff<NFR>(f, fg));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int f = 0; f < NFR; f++) acc = MfmaD<T>::mma(wf[f], xf[f], acc);
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[(wave * 16 + frow) * 17 + fg * 4 + r] = acc[r];
+    __syncthreads();
+    for (int idx = tid; idx < 256; idx += blockDim.x) {
+        const int m = idx >> 4, nn = idx & 15, n = n0 + nn;
+        if (m < g.M && n < g.N) {
+            float v = 0.f;
+            for (int w = 0; w < NW; w++) v += red[(w * 16 + m) * 17 + nn];
+            dec_epilogue<T, EPI>(g, 0, m, n, v);
+        }
+    }
+}
+template <typename T, int EPI, int NFR>
+static void launch_dgl2(const DecGemvDesc& g, int NW, hipStream_t st) {
+    const size_t lds = (size_t)16 * (g.K + 8) * sizeof(T) + (size_t)NW * 16 * 17 * 4;
+    dim3 grid(g.N / 16, 1);
+    if (g.K <= 512) dec_gemv_ln_kernel<T, EPI, NFR, 2><<<grid, NW * 64, lds, st>>>(g);
+    else if (g.K <= 1280) dec_gemv_ln_kernel<T, EPI, NFR, 5><<<grid, NW * 64, lds, st>>>(g);
+    else dec_gemv_ln_kernel<T, EPI, NFR, 8><<<grid, NW * 64, lds, st>>>(g);
+    SS_LAUNCH_CHECK();
+}
+template <typename T, int EPI>
+static void launch_dgl(const DecGemvDesc& g, int NW, hipStream_t st) {
+    switch ((g.K / NW) / 32) {
+        case 1: launch_dgl2<T, EPI, 1>(g, NW, st); break;
+        case 2: launch_dgl2<T, EPI, 2>(g, NW, st); break;
+        case 3: launch_dgl2<T, EPI, 3>(g, NW, st); break;
+        case 4: launch_dgl2<T, EPI, 4>(g, NW, st); break;
+        case 5: launch_dgl2<T, EPI, 5>(g, NW, st); break;
+        case 6: launch_dgl2<T, EPI, 6>(g, NW, st); break;
+        case 8: launch_dgl2<T, EPI, 8>(g, NW, st); break;
+        case 10: launch_dgl2<T, EPI, 10>(g, NW, st); break;
+        default: throw Error(-1, "dec_gemv_ln: k per wave must be 32..320 (1-6, 8, 10 fragments)");
+    }
+}
+
 template <typename T, int EPI, int CT, int NFR>
 static void launch_dg4(const DecGemvDesc& g, int NW, hipStream_t st) {
     const size_t lds = (size_t)NW * CT * 16 * 17 * 4;
@@ -289,6 +354,21 @@ void launch_dec_gemv(const DecGemvDesc& g, int NW, hipStream_t st) {
         default: throw Error(-1, "dec_gemv: unsupported epilogue");
     }
 }
+template <typename T>
+void launch_dec_gemv_ln(const DecGemvDesc& g, int NW, hipStream_t st) {
+    if (NW < 1 || NW > 4 || (NW & (NW - 1))) throw Error(-1, "dec_gemv_ln: bad wave count");
+    if (g.M < 1 || g.M > 16 || g.N % 16 || g.S != 1 || g.K % NW || (g.K / NW) % 32 || g.K / NW > 320 || g.K > 2048 || g.K % 8 || g.n_parts > 4)
+        throw Error(-1, "dec_gemv_ln: bad shape");
+    switch (g.epi) {
+        case DEPI_PART: launch_dgl<T, DEPI_PART>(g, NW, st); break;
+        case DEPI_QKV: launch_dgl<T, DEPI_QKV>(g, NW, st); break;
+        case DEPI_GELU_T: launch_dgl<T, DEPI_GELU_T>(g, NW, st); break;
+        case DEPI_LOGITS: launch_dgl<T, DEPI_LOGITS>(g, NW, st); break;
+        default: throw Error(-1, "dec_gemv_ln: unsupported epilogue");
+    }
+}
+template void launch_dec_gemv_ln<bf16>(const DecGemvDesc&, int, hipStream_t);
+template void launch_dec_gemv_ln<f16>(const DecGemvDesc&, int, hipStream_t);
 template void launch_dec_gemv<bf16>(const DecGemvDesc&, int, hipStream_t);
 template void launch_dec_gemv<f16>(const DecGemvDesc&, int, hipStream_t);
 

@@ -79,6 +79,22 @@ def _write_wav(path, samples_f32, rate, channels=1):
 def test_rest_pipeline_end_to_end(wasr, tmp_path):
     """Config #1's plumbing (request JSON -> task config -> chunks -> result JSON) with the engine in the middle.  The reference's own test of
     this path (test_transcribe_processor, schedule/processors/transcribe.rs:248-304) asserts non-empty text and segments for a local WAV."""
+    _rest_pipeline(wasr, tmp_path)
+
+
+def test_rest_pipeline_end_to_end_tiny_en(tiny_en_path, tmp_path):
+    """BASELINE configs[0] as ONE test: the tiny.en shape (d = 384, 6 heads, 4 + 4 layers, 80 mels, English-only vocabulary) through the whole REST
+    pipeline -- request JSON, WAV, stream pre-processor, 481 280-sample chunks, batched engine, task result -- against the serial order and against
+    the CPU oracle transcribing the same chunks."""
+    from speaksense_amd import asr
+    e = asr.WhisperAsr(tiny_en_path, max_batch=4)
+    try:
+        _rest_pipeline(e, tmp_path)
+    finally:
+        e.engine.close()
+
+
+def _rest_pipeline(wasr, tmp_path):
     import json
     from oracle import binding as orc
     from oracle import preprocess_oracle as ppo
