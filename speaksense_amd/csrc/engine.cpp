@@ -260,6 +260,7 @@ struct EngineT : EngineBase {
         { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }   // 0: wait for every step's samples before enqueuing the next step
         if (const char* sm = getenv("SS_CB_START_MIN")) cb_start_min = std::max(1, atoi(sm));
         { const char* lf = getenv("SS_LN_FUSE"); ln_fuse = !(lf && lf[0] == '0'); }
+        if (const char* pf = getenv("SS_DEC_PREFETCH")) dec_prefetch = std::max(0, atoi(pf)) & ~7;
         compat = donor ? donor->compat : resolve_compat(o.compat);
         if (!donor) {
             for (int i = 1; i < n_lanes_total; i++) { extra_lanes.emplace_back(new EngineT(path, o, this, i, n_lanes_total)); extra_lanes.back()->owner = this; }
@@ -678,6 +679,7 @@ struct EngineT : EngineBase {
                 if (il == 0) { r.ctl = ctl; r.tok_emb = tok_emb; r.pos_emb = dec_pos; }
                 else { r.x_in = xcur; r.parts = prev_parts; r.n_parts = prev_np; r.bias_prev = prev_bias; }
                 r.x_out = xnext; r.ln_w = e.ln1w; r.ln_b = e.ln1b;
+                if (dec_prefetch) { r.pf_ptr = e.wqkv; r.pf_n16 = 3 * d / 16; r.pf_block_bytes = 16 * d * (int)sizeof(T); r.pf_wgs = dec_prefetch; }
                 launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
                 std::swap(xcur, xnext);
                 DecGemvDesc g = dgd(PRO_T, DEPI_QKV, e.wqkv, M, 3 * d, d, 1);
@@ -709,6 +711,7 @@ struct EngineT : EngineBase {
                 // x += bo + sum P1; LNc -> cross query partials (reduced, biased and scaled inside the cross-attention kernel)
                 DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
                 r.x_in = xcur; r.x_out = xnext; r.parts = p1.as<float>(); r.n_parts = pl_dd.S; r.bias_prev = e.bo; r.ln_w = e.lncw; r.ln_b = e.lncb;
+                if (dec_prefetch) { r.pf_ptr = e.wcq; r.pf_n16 = d / 16; r.pf_block_bytes = 16 * d * (int)sizeof(T); r.pf_wgs = dec_prefetch; }
                 launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
                 std::swap(xcur, xnext);
                 DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wcq, M, d, d, pl_dd.S);
@@ -745,6 +748,7 @@ struct EngineT : EngineBase {
             } else {   // x += bco + sum P2; LN2 -> FC1 + GELU
                 DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
                 r.x_in = xcur; r.x_out = xnext; r.parts = p2.as<float>(); r.n_parts = pl_dd.S; r.bias_prev = e.bco; r.ln_w = e.ln2w; r.ln_b = e.ln2b;
+                if (dec_prefetch) { r.pf_ptr = e.w1; r.pf_n16 = 4 * d / 16; r.pf_block_bytes = 16 * d * (int)sizeof(T); r.pf_wgs = dec_prefetch; }
                 launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
                 std::swap(xcur, xnext);
                 DecGemvDesc g = dgd(PRO_T, DEPI_GELU_T, e.w1, M, 4 * d, d, 1);
@@ -794,6 +798,7 @@ struct EngineT : EngineBase {
     DBuf samp_d, rowidx_d, rules_scratch;
     long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0, cnt_admitted = 0, cnt_midstart = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
     bool use_graph = true, chain_steps = true;
+    int dec_prefetch = 0;     // SS_DEC_PREFETCH=<workgroups> (experiment): the reduce + LayerNorm launches also warm the next GEMV's weights
     bool ln_fuse = true;      // SS_LN_FUSE=0: A/B switch of the LayerNorm-prologue launches for <= kLnFuseRows rows
     int cb_start_min = 4;     // SS_CB_START_MIN: windows that must be waiting before a running group pauses its decoders for their encoder pass
     static constexpr int direct_pairs = 320;   // (rows x heads) from which the cross-attention runs unsplit (large-v3: 16 rows; +2.3 % at 32-row passes, -12 % at 8)
