@@ -259,7 +259,7 @@ struct EngineT : EngineBase {
         { const char* gv = getenv("SS_DECODE_GRAPH"); use_graph = !(gv && gv[0] == '0'); }     // 0: launch the step kernel by kernel instead of replaying its hipGraph
         { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }   // 0: wait for every step's samples before enqueuing the next step
         if (const char* sm = getenv("SS_CB_START_MIN")) cb_start_min = std::max(1, atoi(sm));
-        if (const char* lf = getenv("SS_LN_FUSE")) ln_fuse = atoi(lf);   // 0: unfused (11 launches per layer), 1: LayerNorm prologues (9), 2 (default): + the cross block (7)
+        { const char* lf = getenv("SS_LN_FUSE"); ln_fuse = !(lf && lf[0] == '0'); }
         if (const char* pf = getenv("SS_DEC_PREFETCH")) dec_prefetch = std::max(0, atoi(pf)) & ~7;
         compat = donor ? donor->compat : resolve_compat(o.compat);
         if (!donor) {
@@ -663,7 +663,6 @@ struct EngineT : EngineBase {
         // Few rows (the latency configuration: one chunk at a time): every residual-update + LayerNorm launch becomes the prologue of the GEMV that
         // consumes it (kernels.h launch_dec_gemv_ln) -- 8 launches per layer instead of 11, one instead of two for the logits.
         const bool lnf = ln_fuse && M <= kLnFuseRows && n_samp <= kLnFuseRows;
-        const bool lnq = lnf && ln_fuse >= 2 && !fp8_enc && M * H < direct_pairs;   // + LNc / q inside the cross-attention, combine inside the out-projection: 7 launches per layer
         for (int il = 0; il < L; il++) {
             const DecL& e = dec[il];
             if (lnf) {
@@ -696,18 +695,13 @@ struct EngineT : EngineBase {
             launch_dec_self_attention<T>(qd.as<T>(), kself.as<T>() + il * layer_stride, vself.as<T>() + il * layer_stride, slot_stride, d, H, ctl, M,
                                          attd.as<T>(), st);
             const int n_qpart = lnf ? 1 : pl_dd.S;
-            DecGemvDesc lq{};
             {
                 {   // attention out-projection, split-K partials
                     DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wo, M, d, d, pl_dd.S);
                     g.Xt = attd.p; g.ldx = d; g.part_out = p1.as<float>();
                     launch_dec_gemv<T>(g, pl_dd.NW, st);
                 }
-                if (lnq) {   // x += bo + sum P1; LNc; this head's query rows -- all in the prologue of the cross-attention kernel below
-                    lq = dgd(PRO_LN, DEPI_PART, e.wcq, M, d, d, 1);
-                    lq.x_in = xcur; lq.x_out = xnext; lq.parts = p1.as<float>(); lq.n_parts = pl_dd.S; lq.bias_prev = e.bo; lq.ln_w = e.lncw; lq.ln_b = e.lncb;
-                    std::swap(xcur, xnext);
-                } else if (lnf) {   // x += bo + sum P1; LNc; cross query (one unsplit partial slot) in one launch
+                if (lnf) {   // x += bo + sum P1; LNc; cross query (one unsplit partial slot) in one launch
                     DecGemvDesc g = dgd(PRO_LN, DEPI_PART, e.wcq, M, d, d, 1);
                     g.x_in = xcur; g.x_out = xnext; g.parts = p1.as<float>(); g.n_parts = pl_dd.S; g.bias_prev = e.bo; g.ln_w = e.lncw; g.ln_b = e.lncb;
                     g.part_out = pq.as<float>();
@@ -732,8 +726,6 @@ struct EngineT : EngineBase {
                                                  cross_sc.as<unsigned char>() + il * (long)B * sc_b, cb_stride, sc_b, d, H, n_ctx, ctl, M,
                                                  direct ? nullptr : cscratch.as<float>(), attd.as<T>(), st);
                 if (!direct) launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
-            } else if (lnq) {   // key-split attention with LNc + q in its prologue; its combine is the prologue of the out-projection below
-                launch_dec_cross_attention_lnq<T>(lq, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M, cscratch.as<float>(), st);
             } else if (direct) {
                 launch_dec_cross_attention_direct<T>(pq.as<float>(), n_qpart, e.bcq, qscale, kc, kc + (long)H * n_ctx * 64, cb_stride, d, H, n_ctx, ctl, M,
                                                      attd.as<T>(), st);
@@ -742,18 +734,14 @@ struct EngineT : EngineBase {
                                                 cscratch.as<float>(), st);
                 launch_dec_cross_combine<T>(cscratch.as<float>(), d, H, M, attd.as<T>(), st);
             }
-            if (lnq) {   // combine of the key-split partials + cross out-projection (one unsplit partial slot)
-                DecGemvDesc g = dgd(PRO_COMBINE, DEPI_PART, e.wco, M, d, d, 1);
-                g.cross_parts = cscratch.as<float>(); g.n_heads = H; g.part_out = p2.as<float>();
-                launch_dec_gemv_ln<T>(g, pl_qkv.NW, st);
-            } else {   // cross out-projection, split-K partials
+            {   // cross out-projection, split-K partials
                 DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wco, M, d, d, pl_dd.S);
                 g.Xt = attd.p; g.ldx = d; g.part_out = p2.as<float>();
                 launch_dec_gemv<T>(g, pl_dd.NW, st);
             }
             if (lnf) {   // x += bco + sum P2; LN2; FC1 + GELU in one launch
                 DecGemvDesc g = dgd(PRO_LN, DEPI_GELU_T, e.w1, M, 4 * d, d, 1);
-                g.x_in = xcur; g.x_out = xnext; g.parts = p2.as<float>(); g.n_parts = lnq ? 1 : pl_dd.S; g.bias_prev = e.bco; g.ln_w = e.ln2w; g.ln_b = e.ln2b;
+                g.x_in = xcur; g.x_out = xnext; g.parts = p2.as<float>(); g.n_parts = pl_dd.S; g.bias_prev = e.bco; g.ln_w = e.ln2w; g.ln_b = e.ln2b;
                 g.bias = e.b1; g.out = ffd.p; g.ldo = 4 * d;
                 launch_dec_gemv_ln<T>(g, pl_fc1.NW, st);
                 std::swap(xcur, xnext);
@@ -811,7 +799,7 @@ struct EngineT : EngineBase {
     long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0, cnt_admitted = 0, cnt_midstart = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
     bool use_graph = true, chain_steps = true;
     int dec_prefetch = 0;     // SS_DEC_PREFETCH=<workgroups> (experiment): the reduce + LayerNorm launches also warm the next GEMV's weights
-    int ln_fuse = 2;      // SS_LN_FUSE: launches per decoder layer for <= kLnFuseRows rows -- 0: 11 (as for many rows), 1: 9 (LayerNorm prologues), 2: 7 (+ cross block)
+    bool ln_fuse = true;      // SS_LN_FUSE=0: A/B switch of the LayerNorm-prologue launches for <= kLnFuseRows rows
     int cb_start_min = 4;     // SS_CB_START_MIN: windows that must be waiting before a running group pauses its decoders for their encoder pass
     static constexpr int direct_pairs = 320;   // (rows x heads) from which the cross-attention runs unsplit (large-v3: 16 rows; +2.3 % at 32-row passes, -12 % at 8)
 

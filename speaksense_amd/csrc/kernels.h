@@ -128,7 +128,7 @@ struct RowCtl {       // one per decode row; lives in pinned host memory mapped 
 // Fused decode-step GEMV for M <= 16 rows (kernels_decode.hip): prologue + 16-row weight tiles x split-K + epilogue
 constexpr int kPartRows = 128;  // most token rows ONE decoder pass carries (row stride of the split-K partial buffers [S][kPartRows][N]; the control blocks of a
                                 // pass are ctl[0, kPartRows) = its rows, ctl[kPartRows, 2 kPartRows) = its sampling rows).  Round 4: 64 -> 128 (CT = 8 column tiles)
-enum DecPro { PRO_LN = 0, PRO_T = 1, PRO_COMBINE = 2 };   // PRO_LN: the descriptor of a dec_reduce_ln launch; PRO_T: a GEMV whose activations are T rows (Xt)
+enum DecPro { PRO_LN = 0, PRO_T = 1 };   // PRO_LN: the descriptor of a dec_reduce_ln launch; PRO_T: a GEMV whose activations are T rows (Xt)
 enum DecEpi { DEPI_PART = 0, DEPI_QKV = 1, DEPI_GELU_T = 2, DEPI_LOGITS = 3 };
 struct DecGemvDesc {
     int pro, epi;
@@ -148,8 +148,6 @@ struct DecGemvDesc {
     // dec_reduce_ln only (experiment SS_DEC_PREFETCH, VERDICT r03 #2c): extra workgroups of the launch read the weight matrix of the GEMV that comes
     // next ([pf_n16 row blocks of 16 rows][pf_row_bytes]) so that it finds its operands in L2 / the Infinity Cache instead of starting cold
     const void* pf_ptr; int pf_n16; int pf_block_bytes; int pf_wgs;
-    // launch_dec_gemv_ln with pro == PRO_COMBINE: the GEMV's activation rows are the flash-decoding combine of the cross-attention partials
-    const float* cross_parts; int n_heads;  // [M][H][4][66] (max, sum, o[64]) per key split
 };
 void dec_gemv_plan(int N, int K, int* S_out, int* NW_out, bool whole_heads = false);
 template <typename T> void launch_dec_gemv(const DecGemvDesc& g, int NW, hipStream_t st);
@@ -161,12 +159,6 @@ template <typename T> void launch_dec_reduce_ln(const DecGemvDesc& g, T* out, hi
 // at 32 rows x 320 workgroups it was 157 MB per launch, which is why the same fusion lost at the benchmark's row counts).
 constexpr int kLnFuseRows = 4;
 template <typename T> void launch_dec_gemv_ln(const DecGemvDesc& g, int NW, hipStream_t st);
-// The same idea one step further for the cross-attention block (few rows, f16 / bf16 cross cache): residual update + LayerNorm + THIS head's 64
-// rows of the query projection inside every (key split, head, row) workgroup of the attention kernel -- `lq` carries x_in / parts / bias_prev /
-// ln_w / ln_b / x_out and W = the query weight [d][d], K = d; qbias / qscale as in launch_dec_cross_attention_q.  Writes the split partials.
-template <typename T>
-void launch_dec_cross_attention_lnq(const DecGemvDesc& lq, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d, int H, int Tn,
-                                    const RowCtl* ctl, int M, float* scratch, hipStream_t st);
 // cross-attention whose q comes as split-K partials: q = round_T((sum_p qpart[p] + qbias) * qscale); writes (m,l,o[64]) partials
 template <typename T>
 void launch_dec_cross_attention_q(const float* qpart, int n_qpart, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d, int H,

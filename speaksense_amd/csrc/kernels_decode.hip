@@ -236,9 +236,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
 // LayerNorm-prologue form for M <= 16 rows (dispatched for M <= kLnFuseRows): the weight fragments are requested FIRST, then the waves normalise
 // the rows into LDS (wave per row, ln_row) while those loads are in flight, then the B fragments come from LDS.  Workgroup (0, 0) also writes the
 // updated residual stream (x_out is the other half of a ping-pong pair, so the other workgroups still read the old rows).
-// PRO = PRO_COMBINE: the rows are instead the flash-decoding combine of the cross-attention's key-split partials (what dec_cross_combine_kernel
-// writes for the unfused path): the cross out-projection then needs no combine launch in front of it.
-template <typename T, int EPI, int NFR, int NI, int PRO = PRO_LN>
+template <typename T, int EPI, int NFR, int NI>
 __global__ __launch_bounds__(256) void dec_gemv_ln_kernel(DecGemvDesc g) {
     typedef typename MfmaD<T>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
@@ -254,26 +252,8 @@ __global__ __launch_bounds__(256) void dec_gemv_ln_kernel(DecGemvDesc g) {
 #pragma unroll
     for (int f = 0; f < NFR; f++) wf[f] = SS_LDW((const V8*)(wp + frag_koff<NFR>(f, fg)));
     for (int m = wave; m < 16; m += NW) {
-        if (m >= g.M) { for (int c = lane * 8; c < g.K; c += 512) *(V8*)(xs + (long)m * xld + c) = V8{}; continue; }   // unused MFMA columns: finite values
-        if constexpr (PRO == PRO_COMBINE) {
-            for (int col = lane; col < g.K; col += 64) {
-                const int hh = col >> 6, jj = col & 63;
-                const float* part = g.cross_parts + (long)(m * g.n_heads + hh) * kCrossSplitD * kCrossPartD;
-                float mx = -1e30f;
-#pragma unroll
-                for (int sidx = 0; sidx < kCrossSplitD; sidx++) mx = fmaxf(mx, part[sidx * kCrossPartD]);
-                float num = 0.f, den = 0.f;
-#pragma unroll
-                for (int sidx = 0; sidx < kCrossSplitD; sidx++) {
-                    const float w = __expf(part[sidx * kCrossPartD] - mx);
-                    num += w * part[sidx * kCrossPartD + 2 + jj];
-                    den += w * part[sidx * kCrossPartD + 1];
-                }
-                xs[(long)m * xld + col] = (T)(num / den);
-            }
-        } else {
-            ln_row<T, NI>(g, m, lane, blockIdx.x == 0, 0, g.K, xs + (long)m * xld);
-        }
+        if (m < g.M) ln_row<T, NI>(g, m, lane, blockIdx.x == 0, 0, g.K, xs + (long)m * xld);
+        else for (int c = lane * 8; c < g.K; c += 512) *(V8*)(xs + (long)m * xld + c) = V8{};      // unused MFMA columns: finite values
     }
     __syncthreads();
     V8 xf[NFR];
@@ -298,10 +278,6 @@ template <typename T, int EPI, int NFR>
 static void launch_dgl2(const DecGemvDesc& g, int NW, hipStream_t st) {
     const size_t lds = (size_t)16 * (g.K + 8) * sizeof(T) + (size_t)NW * 16 * 17 * 4;
     dim3 grid(g.N / 16, 1);
-    if (g.pro == PRO_COMBINE) {
-        if constexpr (EPI == DEPI_PART) dec_gemv_ln_kernel<T, EPI, NFR, 2, PRO_COMBINE><<<grid, NW * 64, lds, st>>>(g);
-        else throw Error(-1, "dec_gemv_ln: the combine prologue feeds the cross out-projection only");
-    } else
     if (g.K <= 512) dec_gemv_ln_kernel<T, EPI, NFR, 2><<<grid, NW * 64, lds, st>>>(g);
     else if (g.K <= 1280) dec_gemv_ln_kernel<T, EPI, NFR, 5><<<grid, NW * 64, lds, st>>>(g);
     else dec_gemv_ln_kernel<T, EPI, NFR, 8><<<grid, NW * 64, lds, st>>>(g);
@@ -419,13 +395,37 @@ template void launch_dec_gemv<f16>(const DecGemvDesc&, int, hipStream_t);
 // cross-attention with the q projection's split-K reduction in its prologue
 // grid (4 key splits, H, M), 256 threads.  q = round_T((sum_s qpart[s][m][:] + bias) * scale)
 // ---------------------------------------------------------------------------------------------
-// the attention itself, shared by the kernels below: scores over this workgroup's key range, softmax weights in LDS, P.V, output or split partial
 template <typename T, int NSPLIT>
-__device__ __forceinline__ void cross_attn_body(const float (&qv)[8], const T* __restrict__ K, const T* __restrict__ V, int k_beg, int nk, int d, int H, int h, int m,
-                                                int sp, float* __restrict__ scratch, T* __restrict__ out_direct, float* s_sc, float* s_red, float (*s_o)[64]) {
+__global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __restrict__ qpart, int n_qpart, const float* __restrict__ qbias, float qscale,
+                                                               const T* __restrict__ kc, const T* __restrict__ vc, long b_stride, int d, int H, int Tn,
+                                                               const RowCtl* __restrict__ ctl, float* __restrict__ scratch, T* __restrict__ out_direct) {
     typedef typename MfmaD<T>::V8 V8;
+    __shared__ float s_sc[(NSPLIT == 1 ? 1536 : 512) + 128];
+    __shared__ float s_red[8];
+    __shared__ float s_o[4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 3, c = lane & 7;
+    const int sp = blockIdx.x, h = blockIdx.y, m = blockIdx.z;
+    const int per = (Tn + NSPLIT - 1) / NSPLIT;
+    const int k_beg = sp * per, k_end = min(Tn, k_beg + per), nk = k_end - k_beg;
+    const RowCtl rc = ctl[m];
+    const T* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
+    const T* V = vc + (long)rc.cross * b_stride + (long)h * Tn * 64;
+    float qv[8];
+    {
+        const int col = h * 64 + c * 8;
+        f32x4 a0 = *(const f32x4*)(qbias + col), a1 = *(const f32x4*)(qbias + col + 4);
+        f32x4 t0[4], t1[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {   // up to 4 partial slots, unused ones re-read slot 0 with weight 0
+            const float* pp = qpart + ((long)(p < n_qpart ? p : 0) * kPartRows + m) * d + col;
+            t0[p] = *(const f32x4*)pp; t1[p] = *(const f32x4*)(pp + 4);
+        }
+#pragma unroll
+        for (int p = 0; p < 4; p++) { const float w = p < n_qpart ? 1.f : 0.f; a0 += t0[p] * w; a1 += t1[p] * w; }
+#pragma unroll
+        for (int e = 0; e < 4; e++) { qv[e] = (float)(T)(a0[e] * qscale); qv[4 + e] = (float)(T)(a1[e] * qscale); }
+    }
     // phase 1: scores.  One wave-instruction reads 8 key rows x 128 B; 4 independent loads in flight per lane
     float mx = -1e30f;
     const int nit = (nk + 31) / 32;
@@ -498,81 +498,6 @@ __device__ __forceinline__ void cross_attn_body(const float (&qv)[8], const T* _
     }
 }
 
-template <typename T, int NSPLIT>
-__global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __restrict__ qpart, int n_qpart, const float* __restrict__ qbias, float qscale,
-                                                               const T* __restrict__ kc, const T* __restrict__ vc, long b_stride, int d, int H, int Tn,
-                                                               const RowCtl* __restrict__ ctl, float* __restrict__ scratch, T* __restrict__ out_direct) {
-    __shared__ float s_sc[(NSPLIT == 1 ? 1536 : 512) + 128];
-    __shared__ float s_red[8];
-    __shared__ float s_o[4][64];
-    const int lane = threadIdx.x & 63, c = lane & 7;
-    const int sp = blockIdx.x, h = blockIdx.y, m = blockIdx.z;
-    const int per = (Tn + NSPLIT - 1) / NSPLIT;
-    const int k_beg = sp * per, k_end = min(Tn, k_beg + per), nk = k_end - k_beg;
-    const RowCtl rc = ctl[m];
-    const T* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
-    const T* V = vc + (long)rc.cross * b_stride + (long)h * Tn * 64;
-    float qv[8];
-    {
-        const int col = h * 64 + c * 8;
-        f32x4 a0 = *(const f32x4*)(qbias + col), a1 = *(const f32x4*)(qbias + col + 4);
-        f32x4 t0[4], t1[4];
-#pragma unroll
-        for (int p = 0; p < 4; p++) {   // up to 4 partial slots, unused ones re-read slot 0 with weight 0
-            const float* pp = qpart + ((long)(p < n_qpart ? p : 0) * kPartRows + m) * d + col;
-            t0[p] = *(const f32x4*)pp; t1[p] = *(const f32x4*)(pp + 4);
-        }
-#pragma unroll
-        for (int p = 0; p < 4; p++) { const float w = p < n_qpart ? 1.f : 0.f; a0 += t0[p] * w; a1 += t1[p] * w; }
-#pragma unroll
-        for (int e = 0; e < 4; e++) { qv[e] = (float)(T)(a0[e] * qscale); qv[4 + e] = (float)(T)(a1[e] * qscale); }
-    }
-    cross_attn_body<T, NSPLIT>(qv, K, V, k_beg, nk, d, H, h, m, sp, scratch, out_direct, s_sc, s_red, s_o);
-}
-
-// Few rows (launch_dec_cross_attention_lnq): residual update + LayerNorm of the row and this head's slice of the query projection in the prologue.
-// Wave 0 normalises the row into LDS (ln_row; workgroup (0, 0, m) also writes the updated residual stream), then thread t computes a quarter of
-// the dot product of query row h*64 + (t >> 2) with it (16-B weight loads), the quarters meet by two DPP adds.
-template <typename T, int NSPLIT, int NI>
-__global__ __launch_bounds__(256) void dec_cross_attn_lnq_kernel(DecGemvDesc lq, const float* __restrict__ qbias, float qscale, const T* __restrict__ kc,
-                                                                 const T* __restrict__ vc, long b_stride, int d, int H, int Tn, const RowCtl* __restrict__ ctl,
-                                                                 float* __restrict__ scratch) {
-    typedef typename MfmaD<T>::V8 V8;
-    __shared__ float s_sc[512 + 128];
-    __shared__ float s_red[8];
-    __shared__ float s_o[4][64];
-    __shared__ __attribute__((aligned(16))) T s_ln[2048];
-    __shared__ float s_q[64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 7;
-    const int sp = blockIdx.x, h = blockIdx.y, m = blockIdx.z;
-    const int per = (Tn + NSPLIT - 1) / NSPLIT;
-    const int k_beg = sp * per, k_end = min(Tn, k_beg + per), nk = k_end - k_beg;
-    const RowCtl rc = ctl[m];
-    const T* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
-    const T* V = vc + (long)rc.cross * b_stride + (long)h * Tn * 64;
-    if (wave == 0) ln_row<T, NI>(lq, m, lane, sp == 0 && h == 0, 0, lq.K, s_ln);
-    __syncthreads();
-    {
-        const int j = tid >> 2, part = tid & 3, kq = lq.K >> 2;      // K % 32 == 0 is checked at launch
-        const T* wr = (const T*)lq.W + (long)(h * 64 + j) * lq.K + part * kq;
-        const T* xr = s_ln + part * kq;
-        float a = 0.f;
-        for (int k0 = 0; k0 < kq; k0 += 8) {
-            const V8 w8 = *(const V8*)(wr + k0), x8 = *(const V8*)(xr + k0);
-#pragma unroll
-            for (int e = 0; e < 8; e++) a += (float)w8[e] * (float)x8[e];
-        }
-        a += dpp_mov<kDppXor1>(a);
-        a += dpp_mov<kDppXor2>(a);
-        if (part == 0) s_q[j] = (float)(T)((a + qbias[h * 64 + j]) * qscale);
-    }
-    __syncthreads();
-    float qv[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) qv[e] = s_q[c * 8 + e];
-    cross_attn_body<T, NSPLIT>(qv, K, V, k_beg, nk, d, H, h, m, sp, scratch, (T*)nullptr, s_sc, s_red, s_o);
-}
-
 template <typename T>
 void launch_dec_cross_attention_direct(const float* qpart, int n_qpart, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d,
                                        int H, int Tn, const RowCtl* ctl, int M, T* out, hipStream_t st) {
@@ -592,21 +517,6 @@ void launch_dec_cross_attention_q(const float* qpart, int n_qpart, const float* 
     dim3 grid(kCrossSplitD, H, M);
     dec_cross_attn_q_kernel<T, kCrossSplitD><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch, nullptr); SS_LAUNCH_CHECK();
 }
-template <typename T>
-void launch_dec_cross_attention_lnq(const DecGemvDesc& lq, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d, int H, int Tn,
-                                    const RowCtl* ctl, int M, float* scratch, hipStream_t st) {
-    if ((Tn + kCrossSplitD - 1) / kCrossSplitD > 512 || lq.K != d || d > 2048 || d % 32 || M > kLnFuseRows || lq.n_parts > 4)
-        throw Error(-1, "cross attention (ln + q prologue): bad shape");
-    dim3 grid(kCrossSplitD, H, M);
-    if (d <= 512) dec_cross_attn_lnq_kernel<T, kCrossSplitD, 2><<<grid, 256, 0, st>>>(lq, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch);
-    else if (d <= 1280) dec_cross_attn_lnq_kernel<T, kCrossSplitD, 5><<<grid, 256, 0, st>>>(lq, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch);
-    else dec_cross_attn_lnq_kernel<T, kCrossSplitD, 8><<<grid, 256, 0, st>>>(lq, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch);
-    SS_LAUNCH_CHECK();
-}
-template void launch_dec_cross_attention_lnq<bf16>(const DecGemvDesc&, const float*, float, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int, float*,
-                                                   hipStream_t);
-template void launch_dec_cross_attention_lnq<f16>(const DecGemvDesc&, const float*, float, const f16*, const f16*, long, int, int, int, const RowCtl*, int, float*,
-                                                  hipStream_t);
 template void launch_dec_cross_attention_q<bf16>(const float*, int, const float*, float, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int,
                                                  float*, hipStream_t);
 template void launch_dec_cross_attention_q<f16>(const float*, int, const float*, float, const f16*, const f16*, long, int, int, int, const RowCtl*, int,

@@ -593,7 +593,7 @@ def test_lanes_under_concurrent_callers(toy_ml_path):
     eng.close()
 
 
-@pytest.mark.parametrize("env", [{"SS_DECODE_GRAPH": "0"}, {"SS_DECODE_CHAIN": "0"}, {"SS_DECODE_GRAPH": "0", "SS_DECODE_CHAIN": "0"}, {"SS_LN_FUSE": "0"}, {"SS_LN_FUSE": "1"}])
+@pytest.mark.parametrize("env", [{"SS_DECODE_GRAPH": "0"}, {"SS_DECODE_CHAIN": "0"}, {"SS_DECODE_GRAPH": "0", "SS_DECODE_CHAIN": "0"}, {"SS_LN_FUSE": "0"}])
 def test_decode_issue_modes(toy_ml_path, om, orc, monkeypatch, env):
     """The two switches left in the engine change how a decoder pass is ISSUED, not which kernels run: SS_DECODE_GRAPH=0 launches the pass kernel by
     kernel instead of replaying its captured hipGraph, SS_DECODE_CHAIN=0 waits for every step's samples before enqueuing the next step (no
