@@ -257,6 +257,7 @@ template void launch_enc_attention<f16>(const f16*, const f16*, long, const f16*
 template <typename T>
 __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__ q, const T* __restrict__ kcache, const T* __restrict__ vcache,
                                                            long slot_stride, int d, const RowCtl* __restrict__ ctl, T* __restrict__ out) {
+    __builtin_amdgcn_s_setprio(3);   // a chain kernel: see SS_CHAIN_PRIO_STMT in kernels_decode.hip
     typedef typename MfmaA<T>::V8 V8;
     __shared__ float s_p[448 + 64];
     const int lane = threadIdx.x, h = blockIdx.x, m = blockIdx.y;
@@ -350,6 +351,7 @@ constexpr int kCrossPart = 66;  // floats per partial: m, l, o[64]
 
 template <typename T>
 __global__ void dec_cross_combine_kernel(const float* __restrict__ scratch, int d, int H, T* __restrict__ out) {
+    __builtin_amdgcn_s_setprio(3);
     const int m = blockIdx.x;
     for (int col = threadIdx.x; col < d; col += blockDim.x) {
         const int h = col >> 6, j = col & 63;

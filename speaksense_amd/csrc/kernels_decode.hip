@@ -17,6 +17,16 @@
 #include "wave_ops.h"
 
 #define SS_LDW(p) (*(p))   // streamed-once operands (decoder weights, cross K/V): plain loads
+// The latency-bound chain kernels (GEMVs, reduce + LayerNorm, self-attention) raise their waves' issue priority: with several lanes in flight their
+// waves share SIMDs with another lane's streaming cross-attention (or encoder GEMM) waves, which have plenty of independent work to issue; the
+// chain wave's handful of instructions are on some lane's critical path.  A/B/A/B on one box (profiles/r04_l_chain_prio_ab.txt): 3 lanes x 32 rows
+// 3091 / 3095x -> 3133 / 3138x, pass 6.70 -> 6.57 ms; one lane alone: no change.  (-DSS_CROSS_PRIO=<n>: experiment, the same for the cross-attention.)
+#define SS_CHAIN_PRIO_STMT __builtin_amdgcn_s_setprio(3);
+#ifdef SS_CROSS_PRIO
+#define SS_CROSS_PRIO_STMT __builtin_amdgcn_s_setprio(SS_CROSS_PRIO);
+#else
+#define SS_CROSS_PRIO_STMT
+#endif
 
 
 namespace ss {
@@ -127,6 +137,7 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
 // for speed only) and so do the consumer's workgroups bx with bx % 8 == b % 8, whose operands are the 16-row blocks bx of the matrix.
 template <typename T, int NI>
 __global__ __launch_bounds__(64) void dec_reduce_ln_kernel(DecGemvDesc g, T* out) {
+    SS_CHAIN_PRIO_STMT
     const int M8 = (g.M + 7) & ~7;
     if ((int)blockIdx.x >= M8) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -183,6 +194,7 @@ template <int NFR> __device__ __forceinline__ int frag_koff(int f, int fg) {
 // fragments from HBM, CT x NFR activation fragments from L2 -- is issued before the first MFMA.  CT = column tiles of 16 token rows (1, 2, 4).
 template <typename T, int EPI, int CT, int NFR>
 __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
+    SS_CHAIN_PRIO_STMT
     typedef typename MfmaD<T>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
@@ -238,6 +250,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
 // updated residual stream (x_out is the other half of a ping-pong pair, so the other workgroups still read the old rows).
 template <typename T, int EPI, int NFR, int NI>
 __global__ __launch_bounds__(256) void dec_gemv_ln_kernel(DecGemvDesc g) {
+    SS_CHAIN_PRIO_STMT
     typedef typename MfmaD<T>::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
@@ -399,6 +412,7 @@ template <typename T, int NSPLIT>
 __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __restrict__ qpart, int n_qpart, const float* __restrict__ qbias, float qscale,
                                                                const T* __restrict__ kc, const T* __restrict__ vc, long b_stride, int d, int H, int Tn,
                                                                const RowCtl* __restrict__ ctl, float* __restrict__ scratch, T* __restrict__ out_direct) {
+    SS_CROSS_PRIO_STMT
     typedef typename MfmaD<T>::V8 V8;
     __shared__ float s_sc[(NSPLIT == 1 ? 1536 : 512) + 128];
     __shared__ float s_red[8];

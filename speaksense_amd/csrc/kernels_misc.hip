@@ -157,6 +157,7 @@ constexpr int kRuleSlices = 64, kRuleRec = 8;
 
 __global__ __launch_bounds__(256) void logits_rules_scan_kernel(const float* __restrict__ logits, long ld, const RowCtl* __restrict__ ctl, RuleConsts rc,
                                                                 float* __restrict__ scratch) {
+    __builtin_amdgcn_s_setprio(3);   // chain kernels outrank co-resident streaming waves (kernels_decode.hip SS_CHAIN_PRIO_STMT)
     __shared__ MaxIdx s_t[4], s_s[4];
     __shared__ float s_f[2][4];
     const int m = blockIdx.y, sl = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(64) void logits_rules_pick_kernel(const float* __re
                                                                RowCtl* __restrict__ ctl_upd, const int* __restrict__ row_of) {
     const int m = blockIdx.x;
     if (threadIdx.x != 0) return;
+    __builtin_amdgcn_s_setprio(3);
     const float* s = scratch + (long)m * kRuleSlices * kRuleRec;
     const int big = 0x7fffffff;
     float mall = kNegInf;

@@ -120,116 +120,118 @@ def test_soak_random_interleavings(toy_ml_path):
     from speaksense_amd import binding
     seconds = float(os.environ.get("SS_SOAK_SECONDS", "180"))
     eng = binding.Engine(toy_ml_path, max_batch=8, n_lanes=3)
-    lengths = [0.5, 1.0, 3.0, 7.5, 12.0, 29.9, 30.1, 44.0, 65.0]
-    audio = {(sd, ln): synth.speech_like(sd, int(16000 * ln)) for sd in (1, 2, 3) for ln in lengths}
-    variants = {
-        "greedy": dict(), "fixed": dict(fixed_steps=16), "no_ts": dict(no_timestamps=1), "single": dict(single_segment=1), "maxtok": dict(max_tokens=12),
-        "ladder": dict(temperature_inc=0.2), "offset": dict(offset_ms=1500), "bad_lang": dict(language="xx"), "bad_ctx": dict(audio_ctx=3000),
-        "bad_best": dict(best_of=9, temperature_inc=0.2), "detect": dict(language="auto"),
-    }
+    try:     # the engine is closed HERE whatever happens: an engine left to the garbage collector after a failed assertion is freed at an arbitrary later point
+        lengths = [0.5, 1.0, 3.0, 7.5, 12.0, 29.9, 30.1, 44.0, 65.0]
+        audio = {(sd, ln): synth.speech_like(sd, int(16000 * ln)) for sd in (1, 2, 3) for ln in lengths}
+        variants = {
+            "greedy": dict(), "fixed": dict(fixed_steps=16), "no_ts": dict(no_timestamps=1), "single": dict(single_segment=1), "maxtok": dict(max_tokens=12),
+            "ladder": dict(temperature_inc=0.2), "offset": dict(offset_ms=1500), "bad_lang": dict(language="xx"), "bad_ctx": dict(audio_ctx=3000),
+            "bad_best": dict(best_of=9, temperature_inc=0.2), "detect": dict(language="auto"),
+        }
 
-    def params(v):
-        kw = dict(language="en", temperature_inc=0.0)
-        kw.update(variants[v])
-        return binding.default_params(**kw)
-    serial = {}
-    serial_lock = threading.Lock()
+        def params(v):
+            kw = dict(language="en", temperature_inc=0.0)
+            kw.update(variants[v])
+            return binding.default_params(**kw)
+        serial = {}
+        serial_lock = threading.Lock()
 
-    def expected(k):
-        with serial_lock:
-            if k not in serial:
-                s = eng.new_session()
-                try:
-                    serial[k] = ("ok", _key(s.transcribe(audio[k[0]], params(k[1]))))
-                except binding.SpeakSenseError as e:
-                    serial[k] = ("err", e.code)
-                s.close()
-            return serial[k]
-    eng.new_session().transcribe(audio[(1, 30.1)], params("ladder"))      # warm every graph shape before the memory baseline
-    for k in [((1, 3.0), "greedy"), ((2, 65.0), "greedy"), ((3, 12.0), "ladder")]:
-        expected(k)
-    t_end = time.time() + seconds
-    t_start = time.time()
-    mem = {}          # free device memory at 25 / 50 / 75 % of the run: the lanes size their staging buffers lazily and fill their LRU of step graphs
-                      # (engine.cpp kMaxStepGraphs per lane) during the first part; what must not happen is growth that keeps going
-    stats = dict(chunks=0, refused=0, abandoned=0, freed_in_flight=0, checked=0)
-    errors = []
-    st_lock = threading.Lock()
-
-    def worker(wid):
-        rnd = random.Random(1000 + wid)
-        try:
-            while time.time() < t_end:
-                n_ses = rnd.randint(1, 5)
-                ses = [eng.new_session() for _ in range(n_ses)]
-                pending = []
-                for s in ses:
-                    for _ in range(rnd.randint(1, 2)):        # up to two tickets per session: they run in submission order
-                        k = ((rnd.choice((1, 2, 3)), rnd.choice(lengths)), rnd.choice(list(variants)))
-                        pending.append((s, s.submit(audio[k[0]], params(k[1])), k))
-                rnd.shuffle(pending)
-                last_of = {}
-                for s, t, k in pending:
-                    last_of[id(s)] = None
-                freed = set()
-                for s, t, k in pending:
-                    r = rnd.random()
-                    if id(s) in freed or r < 0.08:            # abandon the ticket (its session may already be gone)
-                        if id(s) in freed:
-                            code = eng.L.ss_wait(t)           # status only: the results went with the session
-                            exp = expected(k)
-                            assert (code == 0) == (exp[0] == "ok") or code == exp[1], (k, code, exp)
-                        else:
-                            with st_lock:
-                                stats["abandoned"] += 1
-                        continue
-                    if r < 0.18:                              # free the session with this (and maybe another) chunk in flight
-                        s.close(); freed.add(id(s))
-                        code = eng.L.ss_wait(t)
-                        with st_lock:
-                            stats["freed_in_flight"] += 1
-                        continue
-                    exp = expected(k)
+        def expected(k):
+            with serial_lock:
+                if k not in serial:
+                    s = eng.new_session()
                     try:
-                        got = ("ok", _key(s.wait(t)))
+                        serial[k] = ("ok", _key(s.transcribe(audio[k[0]], params(k[1]))))
                     except binding.SpeakSenseError as e:
-                        got = ("err", e.code)
-                    # a session with two tickets holds the results of whichever chunk ran last: only the status is comparable then
-                    two = sum(1 for s2, _, _ in pending if s2 is s) > 1
-                    if two:
-                        assert got[0] == exp[0], (k, got[0], exp[0])
-                    else:
-                        assert got == exp, (k, got, exp)
-                    with st_lock:
-                        stats["chunks"] += 1; stats["checked"] += not two; stats["refused"] += got[0] == "err"
-                for s in ses:
-                    if id(s) not in freed:
-                        s.close()
-        except BaseException as e:   # noqa: BLE001 -- reported by the main thread
-            errors.append((wid, repr(e)))
+                        serial[k] = ("err", e.code)
+                    s.close()
+                return serial[k]
+        eng.new_session().transcribe(audio[(1, 30.1)], params("ladder"))      # warm every graph shape before the memory baseline
+        for k in [((1, 3.0), "greedy"), ((2, 65.0), "greedy"), ((3, 12.0), "ladder")]:
+            expected(k)
+        t_end = time.time() + seconds
+        t_start = time.time()
+        mem = {}          # free device memory at 25 / 50 / 75 % of the run: the lanes size their staging buffers lazily and fill their LRU of step graphs
+                          # (engine.cpp kMaxStepGraphs per lane) during the first part; what must not happen is growth that keeps going
+        stats = dict(chunks=0, refused=0, abandoned=0, freed_in_flight=0, checked=0)
+        errors = []
+        st_lock = threading.Lock()
 
-    def poller():
-        while time.time() < t_end:
-            eng.totals(); eng.last_timing()
-            f = eng.mem_info()[0]
-            q = int(4 * (time.time() - t_start) / seconds)
-            if 1 <= q <= 3 and q not in mem:
-                mem[q] = f
-            time.sleep(0.005)
-    threads = [threading.Thread(target=worker, args=(w,)) for w in range(8)] + [threading.Thread(target=poller)]
-    for t in threads:
-        t.start()
-    for t in threads:
-        t.join(timeout=seconds + 240)
-        assert not t.is_alive(), "soak: a thread hung"
-    assert not errors, errors
-    free1, _ = eng.mem_info()
-    from conftest import report
-    q1, q2, q3 = (mem.get(i, free1) for i in (1, 2, 3))
-    report(f"soak {seconds:.0f} s, 8 threads: {stats}, device memory free at 25 / 50 / 75 / 100 % of the run: {q1 >> 20} / {q2 >> 20} / {q3 >> 20} / {free1 >> 20} MiB")
-    assert stats["chunks"] > 200 and stats["refused"] > 5 and stats["freed_in_flight"] > 5 and stats["abandoned"] > 5
-    # second half: at most 64 MiB (r04_g: 34 MiB between 40 % and 100 % of a 60 s run while the three lanes were still filling their graph LRUs) and
-    # not more than the first half took -- a leak grows linearly, a cache fills and stops
-    assert q2 - free1 < 64 << 20, f"device memory grew by {(q2 - free1) >> 20} MiB over the second half of the run"
-    assert (q2 - free1) <= max(16 << 20, 2 * (q1 - q2) + (16 << 20)), f"growth does not flatten: {(q1 - q2) >> 20} MiB in the second quarter, {(q2 - free1) >> 20} MiB in the second half"
-    eng.close()
+        def worker(wid):
+            rnd = random.Random(1000 + wid)
+            try:
+                while time.time() < t_end:
+                    n_ses = rnd.randint(1, 5)
+                    ses = [eng.new_session() for _ in range(n_ses)]
+                    pending = []
+                    for s in ses:
+                        for _ in range(rnd.randint(1, 2)):        # up to two tickets per session: they run in submission order
+                            k = ((rnd.choice((1, 2, 3)), rnd.choice(lengths)), rnd.choice(list(variants)))
+                            pending.append((s, s.submit(audio[k[0]], params(k[1])), k))
+                    rnd.shuffle(pending)
+                    last_of = {}
+                    for s, t, k in pending:
+                        last_of[id(s)] = None
+                    freed = set()
+                    for s, t, k in pending:
+                        r = rnd.random()
+                        if id(s) in freed or r < 0.08:            # abandon the ticket (its session may already be gone)
+                            if id(s) in freed:
+                                code = eng.L.ss_wait(t)           # status only: the results went with the session
+                                exp = expected(k)
+                                assert (code == 0) == (exp[0] == "ok") or code == exp[1], (k, code, exp)
+                            else:
+                                with st_lock:
+                                    stats["abandoned"] += 1
+                            continue
+                        if r < 0.18:                              # free the session with this (and maybe another) chunk in flight
+                            s.close(); freed.add(id(s))
+                            code = eng.L.ss_wait(t)
+                            with st_lock:
+                                stats["freed_in_flight"] += 1
+                            continue
+                        exp = expected(k)
+                        try:
+                            got = ("ok", _key(s.wait(t)))
+                        except binding.SpeakSenseError as e:
+                            got = ("err", e.code)
+                        # a session with two tickets holds the results of whichever chunk ran last: only the status is comparable then
+                        two = sum(1 for s2, _, _ in pending if s2 is s) > 1
+                        if two:
+                            assert got[0] == exp[0], (k, got[0], exp[0])
+                        else:
+                            assert got == exp, (k, got, exp)
+                        with st_lock:
+                            stats["chunks"] += 1; stats["checked"] += not two; stats["refused"] += got[0] == "err"
+                    for s in ses:
+                        if id(s) not in freed:
+                            s.close()
+            except BaseException as e:   # noqa: BLE001 -- reported by the main thread
+                errors.append((wid, repr(e)))
+
+        def poller():
+            while time.time() < t_end:
+                eng.totals(); eng.last_timing()
+                f = eng.mem_info()[0]
+                q = int(4 * (time.time() - t_start) / seconds)
+                if 1 <= q <= 3 and q not in mem:
+                    mem[q] = f
+                time.sleep(0.005)
+        threads = [threading.Thread(target=worker, args=(w,)) for w in range(8)] + [threading.Thread(target=poller)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=seconds + 240)
+            assert not t.is_alive(), "soak: a thread hung"
+        assert not errors, errors
+        free1, _ = eng.mem_info()
+        from conftest import report
+        q1, q2, q3 = (mem.get(i, free1) for i in (1, 2, 3))
+        report(f"soak {seconds:.0f} s, 8 threads: {stats}, device memory free at 25 / 50 / 75 / 100 % of the run: {q1 >> 20} / {q2 >> 20} / {q3 >> 20} / {free1 >> 20} MiB")
+        assert stats["chunks"] > 200 and stats["refused"] > 5 and stats["freed_in_flight"] > 5 and stats["abandoned"] > 5
+        # second half: at most 64 MiB (r04_g: 34 MiB between 40 % and 100 % of a 60 s run while the three lanes were still filling their graph LRUs) and
+        # not more than the first half took -- a leak grows linearly, a cache fills and stops
+        assert q2 - free1 < 64 << 20, f"device memory grew by {(q2 - free1) >> 20} MiB over the second half of the run"
+        assert (q2 - free1) <= max(16 << 20, 2 * (q1 - q2) + (16 << 20)), f"growth does not flatten: {(q1 - q2) >> 20} MiB in the second quarter, {(q2 - free1) >> 20} MiB in the second half"
+    finally:
+        eng.close()
