@@ -240,7 +240,7 @@ struct EngineT : EngineBase {
         if (fp8_enc && (da % 256 || d % 64)) throw Error(SS_ERR_UNSUPPORTED, "fp8: n_audio_state must be a multiple of 256 (k-step groups of the e4m3 GEMM)");
         if (d % 128 || da % 128) throw Error(SS_ERR_MODEL, "model: state size must be a multiple of 128");
         if (n_ctx % 4 || n_tctx > 448) throw Error(SS_ERR_MODEL, "model: unsupported context sizes");
-        create_lane_stream(lane_idx, n_lanes_total);
+        SS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         AllocStreamScope alloc_scope(st);
         for (auto& e : ev) SS_HIP(hipEventCreate(&e));
         for (auto& e : ev_step) SS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -260,26 +260,11 @@ struct EngineT : EngineBase {
         { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }   // 0: wait for every step's samples before enqueuing the next step
         if (const char* sm = getenv("SS_CB_START_MIN")) cb_start_min = std::max(1, atoi(sm));
         { const char* lf = getenv("SS_LN_FUSE"); ln_fuse = !(lf && lf[0] == '0'); }
-        if (const char* pf = getenv("SS_DEC_PREFETCH")) dec_prefetch = std::max(0, atoi(pf)) & ~7;
         compat = donor ? donor->compat : resolve_compat(o.compat);
         if (!donor) {
             for (int i = 1; i < n_lanes_total; i++) { extra_lanes.emplace_back(new EngineT(path, o, this, i, n_lanes_total)); extra_lanes.back()->owner = this; }
             start_worker();
         }
-    }
-    // SS_LANE_CUS=1 (experiment, VERDICT r03 #2a): confine every lane to its own CUs through a stream created with hipExtStreamCreateWithCUMask,
-    // so that one lane's latency-bound chain launches are not queued behind another lane's 248 MB cross-attention launch on the same CUs.
-    // What the mask can express on this driver was measured (tools/diag/cumask_probe.cpp, profiles/r04_b_cumask_probe.txt): the 256 user bits
-    // come in groups of 8, and CU c (0..31) of EVERY XCD is enabled iff any bit of group c is set -- a lane cannot be given whole XCDs, only the
-    // same slice of CUs in each of them.  Lane l gets CUs [32 l / n, 32 (l + 1) / n) of every XCD.  Unset: every lane may use the whole chip.
-    void create_lane_stream(int lane_idx, int n_lanes_total) {
-        const char* mode = getenv("SS_LANE_CUS");
-        if (!mode || !mode[0] || mode[0] == '0' || n_lanes_total < 2) { SS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); return; }
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int c0 = 32 * lane_idx / n_lanes_total, c1 = 32 * (lane_idx + 1) / n_lanes_total;
-        if (c1 <= c0) throw Error(SS_ERR_ARG, "SS_LANE_CUS: more lanes than CUs per XCD");
-        for (int c = c0; c < c1; c++) mask[c / 4] |= 0xffu << (8 * (c % 4));
-        SS_HIP(hipExtStreamCreateWithCUMask(&st, 8, mask));
     }
     ~EngineT() override {
         stop_worker();          // joins the workers of every lane (they live in lane 0); a lane itself has none
@@ -679,7 +664,6 @@ struct EngineT : EngineBase {
                 if (il == 0) { r.ctl = ctl; r.tok_emb = tok_emb; r.pos_emb = dec_pos; }
                 else { r.x_in = xcur; r.parts = prev_parts; r.n_parts = prev_np; r.bias_prev = prev_bias; }
                 r.x_out = xnext; r.ln_w = e.ln1w; r.ln_b = e.ln1b;
-                if (dec_prefetch) { r.pf_ptr = e.wqkv; r.pf_n16 = 3 * d / 16; r.pf_block_bytes = 16 * d * (int)sizeof(T); r.pf_wgs = dec_prefetch; }
                 launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
                 std::swap(xcur, xnext);
                 DecGemvDesc g = dgd(PRO_T, DEPI_QKV, e.wqkv, M, 3 * d, d, 1);
@@ -711,7 +695,6 @@ struct EngineT : EngineBase {
                 // x += bo + sum P1; LNc -> cross query partials (reduced, biased and scaled inside the cross-attention kernel)
                 DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
                 r.x_in = xcur; r.x_out = xnext; r.parts = p1.as<float>(); r.n_parts = pl_dd.S; r.bias_prev = e.bo; r.ln_w = e.lncw; r.ln_b = e.lncb;
-                if (dec_prefetch) { r.pf_ptr = e.wcq; r.pf_n16 = d / 16; r.pf_block_bytes = 16 * d * (int)sizeof(T); r.pf_wgs = dec_prefetch; }
                 launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
                 std::swap(xcur, xnext);
                 DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wcq, M, d, d, pl_dd.S);
@@ -748,7 +731,6 @@ struct EngineT : EngineBase {
             } else {   // x += bco + sum P2; LN2 -> FC1 + GELU
                 DecGemvDesc r = dgd(PRO_LN, DEPI_PART, nullptr, M, d, d, 1);
                 r.x_in = xcur; r.x_out = xnext; r.parts = p2.as<float>(); r.n_parts = pl_dd.S; r.bias_prev = e.bco; r.ln_w = e.ln2w; r.ln_b = e.ln2b;
-                if (dec_prefetch) { r.pf_ptr = e.w1; r.pf_n16 = 4 * d / 16; r.pf_block_bytes = 16 * d * (int)sizeof(T); r.pf_wgs = dec_prefetch; }
                 launch_dec_reduce_ln<T>(r, lnd.as<T>(), st);
                 std::swap(xcur, xnext);
                 DecGemvDesc g = dgd(PRO_T, DEPI_GELU_T, e.w1, M, 4 * d, d, 1);
@@ -798,7 +780,6 @@ struct EngineT : EngineBase {
     DBuf samp_d, rowidx_d, rules_scratch;
     long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0, cnt_admitted = 0, cnt_midstart = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
     bool use_graph = true, chain_steps = true;
-    int dec_prefetch = 0;     // SS_DEC_PREFETCH=<workgroups> (experiment): the reduce + LayerNorm launches also warm the next GEMV's weights
     bool ln_fuse = true;      // SS_LN_FUSE=0: A/B switch of the LayerNorm-prologue launches for <= kLnFuseRows rows
     int cb_start_min = 4;     // SS_CB_START_MIN: windows that must be waiting before a running group pauses its decoders for their encoder pass
     static constexpr int direct_pairs = 320;   // (rows x heads) from which the cross-attention runs unsplit (large-v3: 16 rows; +2.3 % at 32-row passes, -12 % at 8)

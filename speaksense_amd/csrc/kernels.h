@@ -145,9 +145,6 @@ struct DecGemvDesc {
     float* part_out;                        // DEPI_PART: [S][kPartRows][N]
     const RowCtl* ctl_rows; void* kcache; void* vcache; long slot_stride; int d;   // DEPI_QKV
     int gelu_f16_in;
-    // dec_reduce_ln only (experiment SS_DEC_PREFETCH, VERDICT r03 #2c): extra workgroups of the launch read the weight matrix of the GEMV that comes
-    // next ([pf_n16 row blocks of 16 rows][pf_row_bytes]) so that it finds its operands in L2 / the Infinity Cache instead of starting cold
-    const void* pf_ptr; int pf_n16; int pf_block_bytes; int pf_wgs;
 };
 void dec_gemv_plan(int N, int K, int* S_out, int* NW_out, bool whole_heads = false);
 template <typename T> void launch_dec_gemv(const DecGemvDesc& g, int NW, hipStream_t st);

@@ -133,28 +133,10 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
     }
 }
 
-// one wave per row.  Blocks >= round_up(M, 8) (only with g.pf_wgs > 0) warm the next GEMV's weights: block b sits on XCD b % 8 (observed placement, used
-// for speed only) and so do the consumer's workgroups bx with bx % 8 == b % 8, whose operands are the 16-row blocks bx of the matrix.
+// one wave per row
 template <typename T, int NI>
 __global__ __launch_bounds__(64) void dec_reduce_ln_kernel(DecGemvDesc g, T* out) {
     SS_CHAIN_PRIO_STMT
-    const int M8 = (g.M + 7) & ~7;
-    if ((int)blockIdx.x >= M8) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        const int xcd = blockIdx.x & 7, j = ((int)blockIdx.x - M8) >> 3, nj = g.pf_wgs >> 3;
-        // the loads are asynchronous: their destination must stay reserved until the wait below ("+v": one register quad, live across the whole
-        // loop -- with a fresh "=v" per load the compiler reused the quad for the next ADDRESS while the previous load was still in flight and
-        // the returning data overwrote it: memory aperture violations, r04_i)
-        u32x4 sink = {0u, 0u, 0u, 0u};
-        for (int bx = xcd + 8 * j; bx < g.pf_n16; bx += 8 * nj) {
-            const char* base = (const char*)g.pf_ptr + (long)bx * g.pf_block_bytes;
-            for (int off = threadIdx.x * 16; off < g.pf_block_bytes; off += 64 * 16)
-                asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(base + off) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
-        return;
-    }
-    if ((int)blockIdx.x >= g.M) return;
     ln_row<T, NI>(g, blockIdx.x, threadIdx.x, true, 0, g.K, out + (long)blockIdx.x * g.K);
 }
 
@@ -364,10 +346,9 @@ void dec_gemv_plan(int N, int K, int* S_out, int* NW_out, bool whole_heads) {
 template <typename T>
 void launch_dec_reduce_ln(const DecGemvDesc& g, T* out, hipStream_t st) {
     if (g.K > 2048 || g.n_parts > 4) throw Error(-1, "dec_reduce_ln: bad shape");
-    const int grid = g.pf_wgs > 0 && g.pf_ptr ? ((g.M + 7) & ~7) + (g.pf_wgs & ~7) : g.M;
-    if (g.K <= 512) { dec_reduce_ln_kernel<T, 2><<<grid, 64, 0, st>>>(g, out); SS_LAUNCH_CHECK(); }
-    else if (g.K <= 1280) { dec_reduce_ln_kernel<T, 5><<<grid, 64, 0, st>>>(g, out); SS_LAUNCH_CHECK(); }
-    else { dec_reduce_ln_kernel<T, 8><<<grid, 64, 0, st>>>(g, out); SS_LAUNCH_CHECK(); }
+    if (g.K <= 512) { dec_reduce_ln_kernel<T, 2><<<g.M, 64, 0, st>>>(g, out); SS_LAUNCH_CHECK(); }
+    else if (g.K <= 1280) { dec_reduce_ln_kernel<T, 5><<<g.M, 64, 0, st>>>(g, out); SS_LAUNCH_CHECK(); }
+    else { dec_reduce_ln_kernel<T, 8><<<g.M, 64, 0, st>>>(g, out); SS_LAUNCH_CHECK(); }
 }
 template void launch_dec_reduce_ln<bf16>(const DecGemvDesc&, bf16*, hipStream_t);
 template void launch_dec_reduce_ln<f16>(const DecGemvDesc&, f16*, hipStream_t);
