@@ -20,13 +20,9 @@
 // The latency-bound chain kernels (GEMVs, reduce + LayerNorm, self-attention) raise their waves' issue priority: with several lanes in flight their
 // waves share SIMDs with another lane's streaming cross-attention (or encoder GEMM) waves, which have plenty of independent work to issue; the
 // chain wave's handful of instructions are on some lane's critical path.  A/B/A/B on one box (profiles/r04_l_chain_prio_ab.txt): 3 lanes x 32 rows
-// 3091 / 3095x -> 3133 / 3138x, pass 6.70 -> 6.57 ms; one lane alone: no change.  (-DSS_CROSS_PRIO=<n>: experiment, the same for the cross-attention.)
+// 3091 / 3095x -> 3133 / 3138x, pass 6.70 -> 6.57 ms; one lane alone: no change.  (The cross-attention one level above the encoder GEMMs, s_setprio 1:
+// 3127 - 3137x against 3134 - 3149x, no gain, profiles/r04_m_cross_prio_ab.txt.)
 #define SS_CHAIN_PRIO_STMT __builtin_amdgcn_s_setprio(3);
-#ifdef SS_CROSS_PRIO
-#define SS_CROSS_PRIO_STMT __builtin_amdgcn_s_setprio(SS_CROSS_PRIO);
-#else
-#define SS_CROSS_PRIO_STMT
-#endif
 
 
 namespace ss {
@@ -393,7 +389,6 @@ template <typename T, int NSPLIT>
 __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __restrict__ qpart, int n_qpart, const float* __restrict__ qbias, float qscale,
                                                                const T* __restrict__ kc, const T* __restrict__ vc, long b_stride, int d, int H, int Tn,
                                                                const RowCtl* __restrict__ ctl, float* __restrict__ scratch, T* __restrict__ out_direct) {
-    SS_CROSS_PRIO_STMT
     typedef typename MfmaD<T>::V8 V8;
     __shared__ float s_sc[(NSPLIT == 1 ? 1536 : 512) + 128];
     __shared__ float s_red[8];
