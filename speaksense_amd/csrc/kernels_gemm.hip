@@ -575,6 +575,8 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     }  // tile loop
 }
 
+int g_gemm_cu_cap = 0;   // dev hook (tools/gemm_bench.cpp SS_GEMM_CUS): persistent workgroups of the 256 x 256 kernel on at most this many CUs (0 = all)
+
 template <typename T, int KIND>
 static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
     static std::atomic<uint64_t> attr128{0};
@@ -583,6 +585,7 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
         // 256 x 256 tiles, one persistent workgroup per CU (a multiple of 8 so the XCD of the remap is preserved).  Measured and archived under
         // tools/experiments/r02_variants/: two 128 x 256 workgroups per CU (-15..20 %), a start-time stagger of the workgroups (no change, r03_i: worse); static wave priorities (s_setprio 1 for waves 4-7: -5 %, for the staging waves 0-3: no change, r03_r); an 8-phase main loop (tools/experiments/r03_gemm_8phase/: correct, 860-890 against 1090 TF/s at 4096^3).
         int n_cu = device_cu_count() / 8 * 8;
+        if (g_gemm_cu_cap > 0 && n_cu > g_gemm_cu_cap) n_cu = g_gemm_cu_cap / 8 * 8;
         if (n_cu < 8) n_cu = 8;
         // f16-output kinds: half the waves do all the staging (main loop -9 %, their partners' stores drain unobserved); the f32 residual
         // kinds move 4x the epilogue bytes and measured 20 % slower that way (tools/gemm_bench.cpp)

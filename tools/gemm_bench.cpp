@@ -7,6 +7,7 @@
 #include <vector>
 #include "kernels.h"
 using namespace ss;
+namespace ss { extern int g_gemm_cu_cap; }
 
 __global__ void ref_gemm(const f16* A, const f16* W, const float* bias, float* C, int M, int N, int K) {
     int n = blockIdx.x * blockDim.x + threadIdx.x, m = blockIdx.y;
@@ -27,6 +28,7 @@ int main(int argc, char** argv) {
                       {12000, 81920, 1280, "crossKV"}, {4096, 4096, 4096, "sq4096"}, {8192, 8192, 8192, "sq8192"}};
     int kinds[] = {EPI_STORE_T, EPI_GELU_T, EPI_RES_F32};
     const char* kn[] = {"store", "gelu", "res_f32"};
+    if (getenv("SS_GEMM_CUS")) g_gemm_cu_cap = atoi(getenv("SS_GEMM_CUS"));   // how do the per-tile phases change when fewer CUs run tiles at once?
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (auto& s : shapes) {
