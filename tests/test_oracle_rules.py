@@ -157,3 +157,29 @@ def test_rng_topology_semantics(tmp_path):
     Pg = orc.default_params(language="en", temperature_inc=0.0)
     assert list(om.new_state(orc.MODE_GGML_F16).full(pcm, Pg)["trace"]) == list(om.new_state(orc.MODE_GGML_F16, compat=orc.COMPAT_RNG_STATE).full(pcm, Pg)["trace"])
     om.close()
+
+
+def test_natural_preset_behaves_like_a_transcriber_on_the_oracle(tmp_path):
+    """`ggml_io.NATURAL` (the synthetic weights behind bench.py's `mode_n` and the full-depth distinct-streams test): under whisper.cpp's FULL rules -- the
+    reference's parameters, ladder on -- the decoder must stay at temperature 0 (logprob and entropy checks pass), end with EOT or at the end of the
+    audio after a number of tokens that differs between audios, emit increasing timestamp pairs, and give a different stream for every audio.
+    Smallest shape the style supports (d = 256) here; tools/natural_preset_stats.py prints the same statistics for large-v3 on the GPU box."""
+    import numpy as np
+    from oracle import binding as orc
+    from speaksense_amd import ggml_io, synth
+    path = str(tmp_path / "toy256-natural.bin")
+    ggml_io.write_model(path, "toy256", seed=0, **ggml_io.NATURAL)
+    om = orc.OracleModel(path)
+    res = [om.new_state(orc.MODE_GGML_F16).full(synth.speech_like(100 + i), orc.default_params(language="en")) for i in range(6)]
+    n_win, n_fail = sum(r["n_encode"] for r in res), sum(r["n_fail"] for r in res)
+    lens = [len(r["tokens"]) for r in res]
+    assert n_fail <= 0.2 * n_win, (n_fail, n_win)
+    assert len({tuple(int(t) for t in r["tokens"]) for r in res}) == 6
+    assert max(lens) - min(lens) >= 10 and min(lens) >= 2, lens
+    for r in res:
+        ts = [int(t) - om.beg for t in r["tokens"] if t >= om.beg]
+        assert ts and ts[0] == 0                                    # the first window opens at <|0.00|>
+        assert all(s["t1"] >= s["t0"] for s in r["segments"])
+    with pytest.raises(ValueError):
+        ggml_io.write_model(str(tmp_path / "x.bin"), "toy", seed=0, **ggml_io.NATURAL)     # d = 128: no room for the control subspace
+    om.close()
