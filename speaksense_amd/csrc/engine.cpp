@@ -260,6 +260,7 @@ struct EngineT : EngineBase {
         { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }   // 0: wait for every step's samples before enqueuing the next step
         if (const char* sm = getenv("SS_CB_START_MIN")) cb_start_min = std::max(1, atoi(sm));
         { const char* lf = getenv("SS_LN_FUSE"); ln_fuse = !(lf && lf[0] == '0'); }
+        if (const char* lr = getenv("SS_LN_FUSE_ROWS")) ln_fuse_rows = std::min(16, std::max(1, atoi(lr)));
         compat = donor ? donor->compat : resolve_compat(o.compat);
         if (!donor) {
             for (int i = 1; i < n_lanes_total; i++) { extra_lanes.emplace_back(new EngineT(path, o, this, i, n_lanes_total)); extra_lanes.back()->owner = this; }
@@ -647,7 +648,7 @@ struct EngineT : EngineBase {
         const float* prev_parts = nullptr; int prev_np = 0; const float* prev_bias = nullptr;
         // Few rows (the latency configuration: one chunk at a time): every residual-update + LayerNorm launch becomes the prologue of the GEMV that
         // consumes it (kernels.h launch_dec_gemv_ln) -- 8 launches per layer instead of 11, one instead of two for the logits.
-        const bool lnf = ln_fuse && M <= kLnFuseRows && n_samp <= kLnFuseRows;
+        const bool lnf = ln_fuse && M <= ln_fuse_rows && n_samp <= ln_fuse_rows;
         for (int il = 0; il < L; il++) {
             const DecL& e = dec[il];
             if (lnf) {
@@ -780,6 +781,7 @@ struct EngineT : EngineBase {
     DBuf samp_d, rowidx_d, rules_scratch;
     long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0, cnt_admitted = 0, cnt_midstart = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
     bool use_graph = true, chain_steps = true;
+    int ln_fuse_rows = kLnFuseRows;   // (dev: SS_LN_FUSE_ROWS, <= 16, to re-measure where the fusion stops paying)
     bool ln_fuse = true;      // SS_LN_FUSE=0: A/B switch of the LayerNorm-prologue launches for <= kLnFuseRows rows
     int cb_start_min = 4;     // SS_CB_START_MIN: windows that must be waiting before a running group pauses its decoders for their encoder pass
     static constexpr int direct_pairs = 320;   // (rows x heads) from which the cross-attention runs unsplit (large-v3: 16 rows; +2.3 % at 32-row passes, -12 % at 8)
