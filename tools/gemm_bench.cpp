@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
                     pro += q[1] - q[0]; loop += q[2] - q[1]; epi += q[3] - q[2]; n++;
                     if (t > 0) { gap += q[0] - h[(b * 8 + t - 1) * 4 + 3]; ng++; }
                 }
-                printf("   trace %-8s: per tile (10 ns ticks) prologue %.0f  loop %.0f  epilogue %.0f  (tiles %d)\n", kn[ki], pro / n, loop / n, epi / n, n);
+                printf("   trace %-8s: per tile (s_memtime ticks = shader cycles) prologue %.0f  loop %.0f  epilogue %.0f  (tiles %d)\n", kn[ki], pro / n, loop / n, epi / n, n);
                 for (int b : {0, 100, 200}) { printf("     wg %3d:", b); for (int t = 0; t < 4; t++) { const long long* q = &h[(b * 8 + t) * 4]; if (q[3]) printf("  [%lld +%lld +%lld +%lld]", q[0] - tmin, q[1] - q[0], q[2] - q[1], q[3] - q[2]); } printf("\n"); }
             }
             hipFree(tr);
@@ -83,6 +83,12 @@ int main(int argc, char** argv) {
             hipMemcpy(a.data(), out, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), Cf, b.size() * 4, hipMemcpyDeviceToHost);
             double mx = 0, ref = 0; for (size_t i = 0; i < a.size(); i++) { mx = fmax(mx, fabs(a[i] - b[i])); ref = fmax(ref, fabs(b[i])); }
             printf("   check: max|diff| %.3e (max|ref| %.3f)\n", mx, ref);
+            g.kind = EPI_STORE_T;    // the 16-byte-store epilogue (lane regrouping by v_permlane16_swap)
+            launch_gemm<f16>(g, st); hipDeviceSynchronize();
+            std::vector<f16> h16((size_t)s.M * s.N);
+            hipMemcpy(h16.data(), out, h16.size() * 2, hipMemcpyDeviceToHost);
+            mx = 0; for (size_t i = 0; i < h16.size(); i++) mx = fmax(mx, fabs((float)h16[i] - b[i]));
+            printf("   check f16 out: max|diff| %.3e\n", mx);
             hipFree(Cf);
         }
         hipFree(A); hipFree(W); hipFree(bias); hipFree(out);
