@@ -301,6 +301,8 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="only the timed region (no steady-state, host-PCM, unloaded-latency or batch8_strict side measurements): "
                     "the counter passes of tools/gpu.sh pmc use it so that every decoder pass they count belongs to the benchmarked configuration")
     ap.add_argument("--no-mode-n", action="store_true", help="skip the natural-EOT side measurement (`mode_n`)")
+    ap.add_argument("--no-token-timestamps", action="store_true", help="A/B only: drop whisper.rs:160's token_timestamps(true) (signal energy on the device, "
+                    "its copy to the host and the per-segment host pass); the headline keeps the reference's setting")
     ap.add_argument("--host-pcm", action="store_true", help="headline steps take host f32 PCM (H2D inside the timed region) instead of HBM-resident PCM")
     ap.add_argument("--dry-run", action="store_true", help="CPU test of the sharding/timing plumbing: stub workload, gloo backend")
     ap.add_argument("--dist-backend", default=None, help="override (default nccl on GPU); 'gloo' + SS_BENCH_DEVICE=0 lets several ranks share one GPU for testing")
@@ -362,7 +364,7 @@ def main():
     # synthetic audio, one seed per global chunk id, uploaded before the timed region
     pcm = torch.stack([torch.from_numpy(synth.speech_like(cid)) for cid in my_chunks]).cuda()
     ptrs = [(pcm[i].data_ptr(), pcm.shape[1]) for i in range(len(my_chunks))]
-    P = binding.default_params(language="en", fixed_steps=args.fixed_steps)
+    P = binding.default_params(language="en", fixed_steps=args.fixed_steps, token_timestamps=0 if args.no_token_timestamps else 1)
     n_prompt = 3 if eng.n_vocab >= 51865 else 1
     tok_counts = []
 

@@ -96,8 +96,11 @@ typedef struct ss_params {
     int32_t detect_language;  /* 1 = only detect the language (result: ss_result_lang_id), no transcription */
     const int32_t* prompt_tokens;  /* prepended to the session's prompt_past (whisper_full_params.prompt_tokens); copied by the call */
     int32_t prompt_n_tokens;
-    int32_t reserved0;
+    int32_t token_timestamps; /* 1 (whisper.rs:160): whisper.cpp's token-level times for every segment's tokens (ss_result_segment_token_times); with
+                                 max_len = 0 (whisper.rs:167) they change neither the text nor the segment times */
     const char* initial_prompt;    /* used when prompt_tokens is NULL: tokenised with the model's vocabulary (whisper_tokenize) */
+    float thold_pt;           /* 0.01 (whisper.rs:170): a token's best-timestamp share must exceed this to pin its start time */
+    float thold_ptsum;        /* 0.01 (whisper.rs:171): and so must its total timestamp probability */
 } ss_params;
 
 void ss_default_params(ss_params* p);
@@ -174,6 +177,9 @@ int64_t ss_result_segment_t1(const ss_session* s, int32_t i);
 int32_t ss_result_segment_speaker_turn_next(const ss_session* s, int32_t i);
 int32_t ss_result_segment_n_tokens(const ss_session* s, int32_t i);     /* whisper_full_n_tokens: tokens of segment i (timestamp tokens included) */
 int ss_result_segment_token(const ss_session* s, int32_t i, int32_t k, int32_t* id, int32_t* tid, float out4[4] /* p, plog, pt, ptsum */);
+/* whisper_token_data.t0 / t1 / vlen of token k of segment i: token-level times in 10 ms units from whisper.cpp's whisper_exp_compute_token_level_timestamps
+ * (timestamp-token evidence, voice-length interpolation, signal-energy adjustment); -1 / -1 / 0 when ss_params.token_timestamps was 0 */
+int ss_result_segment_token_times(const ss_session* s, int32_t i, int32_t k, int64_t* t0, int64_t* t1, float* vlen);
 /* append src's segments to dst shifted by t_offset centiseconds, start times clamped to the previous end (the merge step of whisper_full_parallel) */
 int ss_result_append(ss_session* dst, const ss_session* src, int64_t t_offset);
 int32_t ss_result_n_tokens(const ss_session* s);                      /* accepted tokens over all windows */
@@ -207,6 +213,8 @@ int64_t ss_session_rng_draws_decoder(const ss_session* s, int32_t decoder);
 /* ---- per-stage hooks for parity tests (host f32 in / out; each runs the same device kernels) -------- */
 int32_t ss_mel_n_len(int32_t n_samples);
 int ss_log_mel(ss_engine* e, const float* pcm, int32_t n_samples, float* mel_out /* [n_mel][n_len] */, int32_t n_len);
+/* whisper.cpp get_signal_energy(pcm, n, 32), the per-sample signal the token-level timestamps consult (host in, host out; same kernel as the batch path) */
+int ss_signal_energy(ss_engine* e, const float* pcm, int32_t n_samples, float* energy_out /* [n_samples] */);
 int ss_encode(ss_engine* e, const float* mel /* [n_mel][n_len] */, int32_t n_len, int32_t seek,
               float* enc_out /* [n_audio_ctx][n_audio_state] */);
 /* Decoder hook on a session: set encoder output (computes cross-KV), then decode tokens at n_past with the

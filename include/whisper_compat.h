@@ -106,9 +106,9 @@ typedef struct whisper_token_data {
     float plog;         /* log probability of the token */
     float pt;           /* probability of the timestamp token */
     float ptsum;        /* sum of probabilities of all timestamp tokens */
-    int64_t t0;         /* token-level timestamps: not computed here (-1) */
+    int64_t t0;         /* token-level timestamps (whisper_full_params.token_timestamps), 10 ms units; -1 when the flag was off */
     int64_t t1;
-    float vlen;         /* voice length of the token: not computed (0) */
+    float vlen;         /* voice length of the token */
 } whisper_token_data;
 
 typedef struct whisper_model_loader {

@@ -31,6 +31,7 @@ class FullParams(C.Structure):
         ("audio_ctx", C.c_int32), ("translate", C.c_int32), ("fixed_steps", C.c_int32), ("language", C.c_char * 8),
         ("offset_ms", C.c_int32), ("duration_ms", C.c_int32), ("detect_language", C.c_int32), ("prompt_n_tokens", C.c_int32),
         ("prompt_tokens", C.c_void_p), ("initial_prompt", C.c_char_p),
+        ("token_timestamps", C.c_int32), ("thold_pt", C.c_float), ("thold_ptsum", C.c_float),
     ]
 
 
@@ -87,6 +88,12 @@ def lib():
         L.orc_segment_t1.restype = C.c_int64
         L.orc_segment_t1.argtypes = [C.c_void_p, C.c_int]
         L.orc_segment_speaker_turn_next.argtypes = [C.c_void_p, C.c_int]
+        L.orc_segment_n_tokens.argtypes = [C.c_void_p, C.c_int]
+        L.orc_segment_tokens.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_signal_energy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_token_times_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_float, C.c_float] + [C.c_void_p] * 3
+        L.orc_voice_length.restype = C.c_float
+        L.orc_voice_length.argtypes = [C.c_char_p]
         L.orc_n_tokens.argtypes = [C.c_void_p]
         L.orc_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_counters.argtypes = [C.c_void_p, C.c_void_p]
@@ -151,6 +158,23 @@ class OracleModel:
         n = self.L.orc_tokenize(self.h, b, _p(ids), len(ids))
         assert n >= 0
         return [int(x) for x in ids[:n]]
+
+    def token_times_chunk(self, pcm, segments, token_lists, thold_pt=0.01, thold_ptsum=0.01):
+        """Token-level timestamps of one chunk from GIVEN token data: `segments` = [(t0, t1)], `token_lists` = per segment dict(ids, tid, pt, ptsum)
+        (e.g. speaksense_amd.binding.Session.token_times()).  Returns per segment dict(t0, t1, vlen)."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        st0 = np.array([s[0] for s in segments], np.int64); st1 = np.array([s[1] for s in segments], np.int64)
+        nt = np.array([len(t["ids"]) for t in token_lists], np.int32)
+        cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(t[k], dt) for t in token_lists]) if token_lists else np.zeros(0, dt), dt)
+        ids, tid, pt, ps = cat("ids", np.int32), cat("tid", np.int32), cat("pt", np.float32), cat("ptsum", np.float32)
+        n = int(nt.sum())
+        o0, o1, ov = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.float32)
+        self.L.orc_token_times_chunk(self.h, _p(pcm), len(pcm), len(segments), _p(st0), _p(st1), _p(nt), _p(ids), _p(tid), _p(pt), _p(ps),
+                                     thold_pt, thold_ptsum, _p(o0), _p(o1), _p(ov))
+        out, at = [], 0
+        for k in nt:
+            out.append(dict(t0=o0[at:at + k].copy(), t1=o1[at:at + k].copy(), vlen=ov[at:at + k].copy())); at += k
+        return out
 
     def log_mel(self, pcm: np.ndarray) -> np.ndarray:
         pcm = np.ascontiguousarray(pcm, np.float32)
@@ -282,6 +306,12 @@ class OracleState:
         for i in range(self.L.orc_n_segments(self.h)):
             segs.append(dict(text=self.L.orc_segment_text(self.h, i), t0=self.L.orc_segment_t0(self.h, i),
                              t1=self.L.orc_segment_t1(self.h, i), speaker_turn_next=bool(self.L.orc_segment_speaker_turn_next(self.h, i))))
+            k = self.L.orc_segment_n_tokens(self.h, i)
+            tid, tt0, tt1, vl = np.zeros(k, np.int32), np.zeros(k, np.int64), np.zeros(k, np.int64), np.zeros(k, np.float32)
+            if k:
+                self.L.orc_segment_tokens(self.h, i, _p(tid), _p(tt0), _p(tt1), _p(vl))
+            # whisper_full_get_token_data per segment: ids, token-level t0 / t1 (10 ms units, -1 = not computed), voice length
+            segs[-1]["token_times"] = dict(ids=tid, t0=tt0, t1=tt1, vlen=vl)
         n = self.L.orc_n_tokens(self.h)
         ids = np.zeros(n, np.int32)
         plog = np.zeros(n, np.float32)
@@ -301,6 +331,19 @@ class OracleState:
         c = np.zeros(3, np.int32)
         self.L.orc_counters(self.h, _p(c))
         return dict(segments=segs, tokens=ids, plog=plog, n_encode=int(c[0]), n_decode=int(c[1]), n_fail=int(c[2]), **extra)
+
+
+def signal_energy(pcm: np.ndarray, hw: int = 32) -> np.ndarray:
+    """whisper.cpp get_signal_energy: mean |x| over a centred window of 2 hw + 1 samples (token-level timestamps)."""
+    pcm = np.ascontiguousarray(pcm, np.float32)
+    out = np.zeros(len(pcm), np.float32)
+    if len(pcm):
+        lib().orc_signal_energy(_p(pcm), len(pcm), hw, _p(out))
+    return out
+
+
+def voice_length(text: bytes) -> float:
+    return float(lib().orc_voice_length(text))
 
 
 def e4m3_round(x: np.ndarray) -> np.ndarray:

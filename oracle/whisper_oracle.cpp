@@ -616,7 +616,10 @@ void encode(const Model& m, const float* mel, int n_len, int seek, const Opts& o
 // ---------------------------------------------------------------------------------------------
 // decoder state (wcpp: whisper_state kv_cross / kv_self per decoder, whisper_build_graph_decoder)
 // ---------------------------------------------------------------------------------------------
-struct TokenData { int id = 0, tid = 0; float p = 0, plog = 0, pt = 0, ptsum = 0; };
+struct TokenData {
+    int id = 0, tid = 0; float p = 0, plog = 0, pt = 0, ptsum = 0;
+    int64_t t0 = -1, t1 = -1; float vlen = 0;   // wcpp whisper_token_data: token-level times (token_timestamps) in 10 ms units, voice length
+};
 struct Sequence {
     std::vector<TokenData> tokens;
     int result_len = 0;
@@ -647,6 +650,8 @@ struct FullParams {  // wcpp: whisper_full_params (fields the reference sets, wh
     int32_t prompt_n_tokens = 0;
     const int32_t* prompt_tokens = nullptr;
     const char* initial_prompt = nullptr;
+    int32_t token_timestamps = 1;   // whisper.rs:160 (whisper_full_default_params: false)
+    float thold_pt = 0.01f, thold_ptsum = 0.01f;   // whisper.rs:170-171 (= the defaults)
 };
 
 // Version-dependent behaviour of whisper.cpp that this restatement can follow either way (same values as SS_COMPAT_* in include/speaksense.h).
@@ -672,6 +677,8 @@ struct State {
     int compat = 0;                       // COMPAT_* flags: which upstream variant of a version-dependent behaviour is restated (ledger)
     int n_fail = 0, n_encode = 0, n_decode = 0;
     int lang_id = -1;                     // wcpp: whisper_full_lang_id
+    std::vector<float> energy;            // wcpp whisper_state::energy: PCM signal energy, one value per sample (token_timestamps)
+    int64_t t_beg = 0, t_last = 0; int tid_last = 0;   // wcpp whisper_state: carried from segment to segment of one call by the token-level timestamps
     // Test hook (not whisper.cpp): forced replay.  Greedy sampling step g takes forced[g] instead of the argmax and records
     // forced_gap[g] = logprob[argmax] - logprob[forced[g]] (0 when they coincide, +inf when a rule had suppressed the forced token).
     // A second implementation's token stream is thereby checked step by step against this one ON ITS OWN TRAJECTORY: every pick must be
@@ -913,6 +920,124 @@ void sequence_score(const FullParams& P, Sequence& q) {
     q.entropy = entropy;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Token-level timestamps: whisper.cpp's "experimental" whisper_exp_compute_token_level_timestamps, run on every new segment when
+// whisper_full_params.token_timestamps is set (the reference sets it, whisper.rs:160, with thold_pt = thold_ptsum = 0.01, whisper.rs:170-171, and
+// max_len = 0, so nothing is re-wrapped and neither text nor segment times change; whisper_token_data.t0 / t1 / vlen are what it produces).
+// Restated from whisper.cpp v1.5.4 (not in /root/reference; DESIGN.md section 2 ledger row 8): (1) timestamp-token evidence: a token whose
+// timestamp-probability mass (ptsum) and best-timestamp share (pt) pass the thresholds and whose best timestamp id (tid) advances pins
+// its own start and its predecessor's end to that time; (2) runs of tokens left without an end time split their interval in proportion to a
+// per-character "voice length"; (3) every text token's bounds are then moved to where the local signal energy crosses half its mean.
+// ---------------------------------------------------------------------------------------------
+std::vector<float> signal_energy(const float* x, int n, int hw) {   // wcpp get_signal_energy: mean |x| over a centred window of 2 hw + 1 samples
+    std::vector<float> e(n);
+    for (int i = 0; i < n; i++) {
+        float sum = 0;
+        for (int j = -hw; j <= hw; j++) if (i + j >= 0 && i + j < n) sum += fabsf(x[i + j]);
+        e[i] = sum / (2 * hw + 1);
+    }
+    return e;
+}
+float voice_length(const std::string& text) {   // wcpp voice_length
+    float r = 0.0f;
+    for (char c : text) {
+        if (c == ' ') r += 0.01f;
+        else if (c == ',') r += 2.00f;
+        else if (c == '.' || c == '!' || c == '?') r += 3.00f;
+        else if (c >= '0' && c <= '9') r += 3.00f;
+        else r += 1.00f;
+    }
+    return r;
+}
+int ts_to_sample(int64_t t, int n) { return std::max(0, std::min(n - 1, (int)((t * SAMPLE_RATE) / 100))); }
+int64_t sample_to_ts(int i) { return (100ll * i) / SAMPLE_RATE; }
+
+void token_level_timestamps(State& s, const Vocab& vocab, Segment& seg, float thold_pt, float thold_ptsum) {
+    auto& tk = seg.tokens;
+    const int n_samples = (int)s.energy.size(), n = (int)tk.size();
+    if (n_samples == 0 || n == 0) return;
+    const int64_t t0 = seg.t0, t1 = seg.t1;
+    if (n == 1) { tk[0].t0 = t0; tk[0].t1 = t1; return; }
+    for (int j = 0; j < n; j++) {
+        TokenData& t = tk[j];
+        if (j == 0) {
+            if (t.id == vocab.token_beg) {
+                tk[0].t0 = t0; tk[0].t1 = t0; tk[1].t0 = t0;
+                s.t_beg = t0; s.t_last = t0; s.tid_last = vocab.token_beg;
+            } else {
+                tk[0].t0 = s.t_last;
+            }
+        }
+        const int64_t tt = s.t_beg + 2 * (t.tid - vocab.token_beg);
+        t.vlen = voice_length(vocab.id_to_token[t.id]);
+        if (t.pt > thold_pt && t.ptsum > thold_ptsum && t.tid > s.tid_last && tt <= t1) {
+            if (j > 0) tk[j - 1].t1 = tt;
+            t.t0 = tt;
+            s.tid_last = t.tid;
+        }
+    }
+    tk[n - 2].t1 = t1; tk[n - 1].t0 = t1; tk[n - 1].t1 = t1;
+    s.t_last = t1;
+    // runs [p0, p1] that end at the next token with a known end: split their time in proportion to the voice lengths
+    for (int p0 = 0, p1 = 0;;) {
+        while (p1 < n && tk[p1].t1 < 0) p1++;
+        if (p1 >= n) p1--;
+        if (p1 > p0) {
+            double psum = 0.0;
+            for (int j = p0; j <= p1; j++) psum += tk[j].vlen;
+            const double dt = (double)(tk[p1].t1 - tk[p0].t0);
+            for (int j = p0 + 1; j <= p1; j++) {
+                const double ct = tk[j - 1].t0 + dt * tk[j - 1].vlen / psum;
+                tk[j - 1].t1 = (int64_t)ct; tk[j].t0 = (int64_t)ct;
+            }
+        }
+        p1++; p0 = p1;
+        if (p1 >= n) break;
+    }
+    for (int j = 0; j < n - 1; j++) {   // "fix up (just in case)"
+        if (tk[j].t1 < 0) tk[j + 1].t0 = tk[j].t1;
+        if (j > 0 && tk[j - 1].t1 > tk[j].t0) { tk[j].t0 = tk[j - 1].t1; tk[j].t1 = std::max(tk[j].t0, tk[j].t1); }
+    }
+    // voice activity: expand or contract every text token towards the samples where the energy crosses half its local mean
+    const int hw = SAMPLE_RATE / 8;
+    const std::vector<float>& en = s.energy;
+    for (int j = 0; j < n; j++) {
+        if (tk[j].id >= vocab.token_eot) continue;
+        int s0 = ts_to_sample(tk[j].t0, n_samples), s1 = ts_to_sample(tk[j].t1, n_samples);
+        const int ss0 = std::max(s0 - hw, 0), ss1 = std::min(s1 + hw, n_samples), ns = ss1 - ss0;
+        float sum = 0.0f;
+        for (int k = ss0; k < ss1; k++) sum += en[k];
+        const float thold = 0.5 * sum / ns;
+        {
+            int k = s0;
+            if (en[k] > thold && j > 0) {
+                while (k > 0 && en[k] > thold) k--;
+                tk[j].t0 = sample_to_ts(k);
+                if (tk[j].t0 < tk[j - 1].t1) tk[j].t0 = tk[j - 1].t1; else s0 = k;
+            } else {
+                while (en[k] < thold && k < s1) k++;
+                s0 = k;
+                tk[j].t0 = sample_to_ts(k);
+            }
+        }
+        {
+            int k = s1;
+            if (en[k] > thold) {
+                while (k < n_samples - 1 && en[k] > thold) k++;
+                tk[j].t1 = sample_to_ts(k);
+                // wcpp writes `j < ns - 1` here (ns = samples in the window, not tokens), i.e. practically always true, and then reads
+                // tokens[j + 1] -- past the end when the segment's last token is a text token.  Restated with the bound the read needs.
+                if (j + 1 < n && tk[j].t1 > tk[j + 1].t0) tk[j].t1 = tk[j + 1].t0; else s1 = k;
+            } else {
+                while (en[k] < thold && k > s0) k--;
+                s1 = k;
+                tk[j].t1 = sample_to_ts(k);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // whisper_full_with_state
 // ---------------------------------------------------------------------------------------------
@@ -920,6 +1045,10 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
     const Model& m = *s.m; const Vocab& vocab = m.vocab; const HParams& hp = m.hp;
     s.result_all.clear(); s.all_tokens.clear(); s.sampled_all.clear(); s.trace_rec.clear();
     s.n_encode = s.n_decode = s.n_fail = 0;
+    if (P.token_timestamps) {   // wcpp: reset at the top of every call, before the mel
+        s.t_beg = 0; s.t_last = 0; s.tid_last = 0;
+        if (n_samples > 0) s.energy = signal_energy(samples, n_samples, 32);
+    }
     if (n_samples > 0) {
         s.n_len = mel_n_len(n_samples); s.n_len_org = mel_n_len_org(n_samples);
         s.mel.resize((size_t)m.filt_n_mel * s.n_len);
@@ -1097,6 +1226,7 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
                         if (!text.empty()) {
                             s.result_all.push_back({t0, t1, text, {}, speaker_turn_next});
                             for (int j = i0; j <= i; j++) s.result_all.back().tokens.push_back(tokens_cur[j]);
+                            if (P.token_timestamps) token_level_timestamps(s, vocab, s.result_all.back(), P.thold_pt, P.thold_ptsum);
                         }
                         text = "";
                         while (i < (int)tokens_cur.size() && tokens_cur[i].id > vocab.token_beg) i++;
@@ -1107,6 +1237,7 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
                     const int64_t t1 = seek + seek_delta;
                     s.result_all.push_back({t0, t1, text, {}, speaker_turn_next});
                     for (int j = i0; j < (int)tokens_cur.size(); j++) s.result_all.back().tokens.push_back(tokens_cur[j]);
+                    if (P.token_timestamps) token_level_timestamps(s, vocab, s.result_all.back(), P.thold_pt, P.thold_ptsum);
                 }
             }
             seek += seek_delta;
@@ -1240,6 +1371,34 @@ const char* orc_segment_text(void* sp, int i) { return ((State*)sp)->result_all[
 int64_t orc_segment_t0(void* sp, int i) { return ((State*)sp)->result_all[i].t0; }
 int64_t orc_segment_t1(void* sp, int i) { return ((State*)sp)->result_all[i].t1; }
 int orc_segment_speaker_turn_next(void* sp, int i) { return ((State*)sp)->result_all[i].speaker_turn_next; }
+int orc_segment_n_tokens(void* sp, int i) { return (int)((State*)sp)->result_all[i].tokens.size(); }
+// whisper_full_get_token_data of segment i: ids, token-level times (10 ms units; -1 = not computed) and voice lengths
+void orc_segment_tokens(void* sp, int i, int32_t* ids, int64_t* t0, int64_t* t1, float* vlen) {
+    const auto& tk = ((State*)sp)->result_all[i].tokens;
+    for (size_t k = 0; k < tk.size(); k++) { ids[k] = tk[k].id; t0[k] = tk[k].t0; t1[k] = tk[k].t1; vlen[k] = tk[k].vlen; }
+}
+// Token-level timestamps of one chunk from GIVEN tokens (test entry): the segments' times and their tokens' (id, tid, pt, ptsum) as a second
+// implementation produced them, the chunk's PCM -> t0 / t1 / vlen per token.  Separates "the host pass is restated identically" from "both
+// sides sampled identical token data" (pt / ptsum / tid are f16-noisy across implementations; the pass thresholds them).
+int orc_token_times_chunk(void* mp, const float* pcm, int n_samples, int n_seg, const int64_t* seg_t0, const int64_t* seg_t1, const int32_t* seg_ntok,
+                          const int32_t* ids, const int32_t* tid, const float* pt, const float* ptsum, float thold_pt, float thold_ptsum,
+                          int64_t* t0_out, int64_t* t1_out, float* vlen_out) {
+    Model* m = (Model*)mp;
+    State s; s.m = m;
+    s.energy = signal_energy(pcm, n_samples, 32);
+    size_t at = 0;
+    for (int i = 0; i < n_seg; i++) {
+        Segment g{seg_t0[i], seg_t1[i], "", {}, false};
+        for (int k = 0; k < seg_ntok[i]; k++) { TokenData t; t.id = ids[at + k]; t.tid = tid[at + k]; t.pt = pt[at + k]; t.ptsum = ptsum[at + k]; g.tokens.push_back(t); }
+        token_level_timestamps(s, m->vocab, g, thold_pt, thold_ptsum);
+        for (int k = 0; k < seg_ntok[i]; k++) { t0_out[at + k] = g.tokens[k].t0; t1_out[at + k] = g.tokens[k].t1; vlen_out[at + k] = g.tokens[k].vlen; }
+        at += seg_ntok[i];
+    }
+    return 0;
+}
+// the two building blocks on their own (unit tests; the GPU signal-energy kernel is compared with the first)
+void orc_signal_energy(const float* x, int n, int hw, float* out) { const std::vector<float> e = signal_energy(x, n, hw); memcpy(out, e.data(), (size_t)n * 4); }
+float orc_voice_length(const char* text) { return voice_length(text); }
 int orc_n_tokens(void* sp) { return (int)((State*)sp)->all_tokens.size(); }
 void orc_tokens(void* sp, int32_t* ids, float* plog) {
     State* s = (State*)sp;

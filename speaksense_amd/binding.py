@@ -28,7 +28,8 @@ class Params(C.Structure):
                 ("print_special", C.c_int32), ("max_tokens", C.c_int32), ("audio_ctx", C.c_int32), ("translate", C.c_int32),
                 ("fixed_steps", C.c_int32), ("language", C.c_char * 8),
                 ("n_max_text_ctx", C.c_int32), ("offset_ms", C.c_int32), ("duration_ms", C.c_int32), ("detect_language", C.c_int32),
-                ("prompt_tokens", C.c_void_p), ("prompt_n_tokens", C.c_int32), ("reserved0", C.c_int32), ("initial_prompt", C.c_char_p)]
+                ("prompt_tokens", C.c_void_p), ("prompt_n_tokens", C.c_int32), ("token_timestamps", C.c_int32), ("initial_prompt", C.c_char_p),
+                ("thold_pt", C.c_float), ("thold_ptsum", C.c_float)]
 
 
 class DenoiseConfig(C.Structure):   # DenoiseConfig, /root/reference/src/audio/mod.rs:41-61
@@ -75,6 +76,7 @@ def lib():
         L.ss_result_segment_speaker_turn_next.argtypes = [vp, i32]
         L.ss_result_segment_n_tokens.argtypes = [vp, i32]
         L.ss_result_segment_token.argtypes = [vp, i32, i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_float)]
+        L.ss_result_segment_token_times.argtypes = [vp, i32, i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_float)]
         L.ss_result_n_tokens.argtypes = [vp]
         L.ss_result_tokens.argtypes = [vp, vp, vp]
         L.ss_result_n_sampled_tokens.argtypes = [vp]
@@ -94,6 +96,7 @@ def lib():
         L.ss_session_rng_draws_decoder.restype = C.c_int64
         L.ss_mel_n_len.argtypes = [i32]
         L.ss_log_mel.argtypes = [vp, f32p, i32, f32p, i32]
+        L.ss_signal_energy.argtypes = [vp, f32p, i32, f32p]
         L.ss_encode.argtypes = [vp, f32p, i32, i32, f32p]
         L.ss_session_set_encoder.argtypes = [vp, f32p]
         L.ss_session_decode.argtypes = [vp, vp, i32, i32, f32p]
@@ -232,6 +235,13 @@ class Engine:
         return Session(self)
 
     # ---- stage hooks ----
+    def signal_energy(self, pcm: np.ndarray) -> np.ndarray:
+        """whisper.cpp get_signal_energy(pcm, n, 32) on the device (token-level timestamps)."""
+        pcm = np.ascontiguousarray(pcm, np.float32)
+        out = np.zeros(len(pcm), np.float32)
+        _check(self.L.ss_signal_energy(self.h, _p(pcm), len(pcm), _p(out)))
+        return out
+
     def log_mel(self, pcm: np.ndarray) -> np.ndarray:
         pcm = np.ascontiguousarray(pcm, np.float32)
         n_len = self.L.ss_mel_n_len(len(pcm))
@@ -398,6 +408,21 @@ class Session:
     def ready(self, ticket) -> bool:
         """Non-blocking: has the chunk behind `ticket` completed (wait() will return at once)?"""
         return bool(self.L.ss_ticket_ready(ticket))
+
+    def token_times(self):
+        """whisper_full_get_token_data per segment: [dict(ids, t0, t1, vlen)], token-level times in 10 ms units (-1 when Params.token_timestamps was 0)."""
+        out = []
+        for i in range(self.L.ss_result_n_segments(self.h)):
+            k = self.L.ss_result_segment_n_tokens(self.h, i)
+            ids, tids, t0, t1, vl = np.zeros(k, np.int32), np.zeros(k, np.int32), np.zeros(k, np.int64), np.zeros(k, np.int64), np.zeros(k, np.float32)
+            pt, ptsum = np.zeros(k, np.float32), np.zeros(k, np.float32)
+            a, b, v, tid, tt, o4 = C.c_int64(), C.c_int64(), C.c_float(), C.c_int32(), C.c_int32(), (C.c_float * 4)()
+            for q in range(k):
+                _check(self.L.ss_result_segment_token(self.h, i, q, C.byref(tid), C.byref(tt), o4))
+                _check(self.L.ss_result_segment_token_times(self.h, i, q, C.byref(a), C.byref(b), C.byref(v)))
+                ids[q], tids[q], t0[q], t1[q], vl[q], pt[q], ptsum[q] = tid.value, tt.value, a.value, b.value, v.value, o4[2], o4[3]
+            out.append(dict(ids=ids, tid=tids, pt=pt, ptsum=ptsum, t0=t0, t1=t1, vlen=vl))
+        return out
 
     def result(self):
         segs = []

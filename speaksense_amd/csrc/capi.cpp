@@ -46,6 +46,7 @@ void ss_default_params(ss_params* p) {
     strcpy(p->language, "en");
     p->n_max_text_ctx = 16384; p->offset_ms = 0; p->duration_ms = 0; p->detect_language = 0;
     p->prompt_tokens = nullptr; p->prompt_n_tokens = 0; p->initial_prompt = nullptr;
+    p->token_timestamps = 1; p->thold_pt = 0.01f; p->thold_ptsum = 0.01f;   // whisper.rs:160,170-171
 }
 
 int ss_engine_create(const char* path, const ss_engine_opts* opts, ss_engine** out) {
@@ -258,6 +259,14 @@ int ss_result_segment_token(const ss_session* s, int32_t i, int32_t k, int32_t* 
     if (out4) { out4[0] = t.p; out4[1] = t.plog; out4[2] = t.pt; out4[3] = t.ptsum; }
     return SS_OK;
 }
+int ss_result_segment_token_times(const ss_session* s, int32_t i, int32_t k, int64_t* t0, int64_t* t1, float* vlen) {
+    if (!s || i < 0 || i >= (int)s->s.segments.size() || k < 0 || k >= (int)s->s.segments[i].tokens.size()) return fail(SS_ERR_ARG, "segment token times: out of range");
+    const TokenData& t = s->s.segments[i].tokens[k];
+    if (t0) *t0 = t.t0;
+    if (t1) *t1 = t.t1;
+    if (vlen) *vlen = t.vlen;
+    return SS_OK;
+}
 // whisper_full_parallel's merge: append src's segments to dst shifted by t_offset centiseconds, "make sure that segments are not overlapping"
 int ss_result_append(ss_session* dst, const ss_session* src, int64_t t_offset) {
     if (!dst || !src || dst == src) return fail(SS_ERR_ARG, "ss_result_append: bad argument");
@@ -308,6 +317,10 @@ int ss_session_rng_discard(ss_session* s, int64_t n) {
 }
 
 int32_t ss_mel_n_len(int32_t n_samples) { return mel_n_len(n_samples); }
+int ss_signal_energy(ss_engine* e, const float* pcm, int32_t n, float* out) {
+    if (!e || !pcm || !out || n <= 0) return fail(SS_ERR_ARG, "ss_signal_energy: bad argument");
+    SS_TRY e->e->signal_energy_host(pcm, n, out); return SS_OK; SS_CATCH
+}
 int ss_log_mel(ss_engine* e, const float* pcm, int32_t n, float* out, int32_t n_len) {
     if (!e || !pcm || !out || n <= 0) return fail(SS_ERR_ARG, "ss_log_mel: bad argument");
     SS_TRY e->e->log_mel_host(pcm, n, out, n_len); return SS_OK; SS_CATCH

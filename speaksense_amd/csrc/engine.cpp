@@ -75,6 +75,24 @@ struct DBuf {
     template <typename U> U* as() const { return (U*)p; }
 };
 
+// pinned, device-mapped host memory that only grows (per batch slot: the signal energy of the slot's chunk -- written by the kernel straight over
+// PCIe, read by the token-level timestamps on the host)
+struct HBuf {
+    void* p = nullptr; void* dev = nullptr; size_t bytes = 0;
+    void ensure(size_t n) {
+        if (n <= bytes) return;
+        free();
+        SS_HIP(hipHostMalloc(&p, n, hipHostMallocMapped)); bytes = n;
+        SS_HIP(hipHostGetDevicePointer(&dev, p, 0));
+    }
+    void free() { if (p) { (void)hipHostFree(p); p = nullptr; dev = nullptr; bytes = 0; } }
+    ~HBuf() { free(); }
+    HBuf() = default;
+    HBuf(const HBuf&) = delete;
+    HBuf& operator=(const HBuf&) = delete;
+    HBuf(HBuf&& o) noexcept : p(o.p), dev(o.dev), bytes(o.bytes) { o.p = nullptr; o.dev = nullptr; o.bytes = 0; }
+};
+
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // ss_engine_opts.compat, overridden by env SS_COMPAT: a number, or flag names joined by '+' / ',' ("rng_state", "openai_ts_rules"; "" or "v1.5" = 0)
@@ -129,7 +147,136 @@ struct JobState {
     std::vector<int> prompt_init;
     bool need_detect = false;   // language "auto": resolved after the first window's encoder pass
     bool has_window = false;    // a window of this chunk is encoded and decoding right now
+    const float* energy = nullptr; int n_energy = 0;   // token_timestamps: whisper_state::energy of this chunk (the slot's pinned host buffer, written by the device)
 };
+
+// ------------------------------------------------------------------------------------------------
+// whisper_exp_compute_token_level_timestamps (whisper.cpp v1.5.4, "experimental"; run on every new segment when whisper_full_params.token_timestamps
+// is set -- the reference sets it, /root/reference/src/asr/whisper.rs:160, thresholds :170-171).  Host arithmetic on ~100 tokens per window, as in
+// whisper.cpp; the per-sample signal energy it consults comes from the device (kernels_mel.hip signal_energy_kernel).  Three passes over the
+// segment's tokens: anchors from the timestamp distribution of each sampled token, proportional fill by "voice length", then the energy walk.
+// ------------------------------------------------------------------------------------------------
+static float token_voice_length(const std::string& text) {
+    float v = 0.0f;
+    for (const char c : text) {
+        switch (c) {
+            case ' ': v += 0.01f; break;
+            case ',': v += 2.00f; break;
+            case '.': case '!': case '?': v += 3.00f; break;
+            default: v += (c >= '0' && c <= '9') ? 3.00f : 1.00f;
+        }
+    }
+    return v;
+}
+static void token_level_times(Session& st, const Vocab& vocab, Segment& seg, const float* en, int n_samples, float thold_pt, float thold_ptsum) {
+    std::vector<TokenData>& tk = seg.tokens;
+    const int n = (int)tk.size();
+    if (n_samples <= 0 || n == 0) return;     // "no signal data available"
+    if (n == 1) { tk[0].t0 = seg.t0; tk[0].t1 = seg.t1; return; }
+    const auto to_sample = [n_samples](int64_t t) { return std::max(0, std::min(n_samples - 1, (int)((t * kSampleRate) / 100))); };
+    const auto to_time = [](int i) { return (int64_t)((100ll * i) / kSampleRate); };
+    // pass 1: anchors
+    if (tk[0].id == vocab.token_beg) {
+        tk[0].t0 = tk[0].t1 = tk[1].t0 = seg.t0;
+        st.t_beg = st.t_last = seg.t0; st.tid_last = vocab.token_beg;
+    } else {
+        tk[0].t0 = st.t_last;
+    }
+    for (int j = 0; j < n; j++) {
+        TokenData& t = tk[j];
+        t.vlen = token_voice_length(vocab.id_to_token[t.id]);
+        const int64_t when = st.t_beg + 2 * (int64_t)(t.tid - vocab.token_beg);
+        if (t.pt > thold_pt && t.ptsum > thold_ptsum && t.tid > st.tid_last && when <= seg.t1) {
+            if (j > 0) tk[j - 1].t1 = when;
+            t.t0 = when;
+            st.tid_last = t.tid;
+        }
+    }
+    tk[n - 2].t1 = seg.t1;
+    tk[n - 1].t0 = tk[n - 1].t1 = seg.t1;
+    st.t_last = seg.t1;
+    // pass 2: every maximal run first .. last whose members before `last` have no end time shares [t0(first), t1(last)] by voice length
+    for (int first = 0; first < n;) {
+        int last = first;
+        while (last < n && tk[last].t1 < 0) last++;
+        if (last >= n) last = n - 1;
+        if (last > first) {
+            double total = 0.0;
+            for (int j = first; j <= last; j++) total += tk[j].vlen;
+            const double span = (double)(tk[last].t1 - tk[first].t0);
+            for (int j = first; j < last; j++) {
+                const double cut = tk[j].t0 + span * tk[j].vlen / total;
+                tk[j].t1 = tk[j + 1].t0 = (int64_t)cut;
+            }
+        }
+        first = last + 1;
+    }
+    for (int j = 0; j + 1 < n; j++) {
+        if (tk[j].t1 < 0) tk[j + 1].t0 = tk[j].t1;
+        if (j > 0 && tk[j - 1].t1 > tk[j].t0) { tk[j].t0 = tk[j - 1].t1; tk[j].t1 = std::max(tk[j].t0, tk[j].t1); }
+    }
+    // pass 3: text tokens snap to where the signal energy crosses half its mean over the token +- 1/8 s.  The means first: a token's window depends
+    // only on its pass-2 times (the walk below changes token j alone, after its own mean was taken), and each mean is a left-to-right f32 sum of
+    // ~4 000 + duration samples -- a chain of dependent adds, ~5 us per token, ~0.5 ms per 30 s chunk on the lane's worker thread.  Four tokens'
+    // chains are interleaved so that the adder pipeline is shared; every chain keeps its own order, so the sums are whisper.cpp's bit for bit.
+    const int margin = kSampleRate / 8;
+    std::vector<int> wa(n), wb(n), wlo(n), whi(n), text_tok;
+    std::vector<float> mean_sum(n, 0.0f);
+    for (int j = 0; j < n; j++) {
+        if (tk[j].id >= vocab.token_eot) continue;
+        wa[j] = to_sample(tk[j].t0); wb[j] = to_sample(tk[j].t1);
+        wlo[j] = std::max(wa[j] - margin, 0); whi[j] = std::min(wb[j] + margin, n_samples);
+        text_tok.push_back(j);
+    }
+    {
+        size_t g = 0;
+        for (; g + 4 <= text_tok.size(); g += 4) {
+            const int j0 = text_tok[g], j1 = text_tok[g + 1], j2 = text_tok[g + 2], j3 = text_tok[g + 3];
+            const float *p0 = en + wlo[j0], *p1 = en + wlo[j1], *p2 = en + wlo[j2], *p3 = en + wlo[j3];
+            const int l0 = std::max(0, whi[j0] - wlo[j0]), l1 = std::max(0, whi[j1] - wlo[j1]), l2 = std::max(0, whi[j2] - wlo[j2]), l3 = std::max(0, whi[j3] - wlo[j3]);
+            const int common = std::min(std::min(l0, l1), std::min(l2, l3));
+            float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+            for (int k = 0; k < common; k++) { s0 += p0[k]; s1 += p1[k]; s2 += p2[k]; s3 += p3[k]; }
+            for (int k = common; k < l0; k++) s0 += p0[k];
+            for (int k = common; k < l1; k++) s1 += p1[k];
+            for (int k = common; k < l2; k++) s2 += p2[k];
+            for (int k = common; k < l3; k++) s3 += p3[k];
+            mean_sum[j0] = s0; mean_sum[j1] = s1; mean_sum[j2] = s2; mean_sum[j3] = s3;
+        }
+        for (; g < text_tok.size(); g++) {
+            const int j = text_tok[g];
+            float s = 0.0f;
+            for (int k = wlo[j]; k < whi[j]; k++) s += en[k];
+            mean_sum[j] = s;
+        }
+    }
+    for (int j = 0; j < n; j++) {
+        if (tk[j].id >= vocab.token_eot) continue;
+        int a = wa[j];
+        const int b = wb[j];
+        const float level = (float)(0.5 * mean_sum[j] / (whi[j] - wlo[j]));
+        int k = a;
+        if (en[k] > level && j > 0) {                       // voiced at the start: the token began earlier, but not before its predecessor ended
+            while (k > 0 && en[k] > level) k--;
+            tk[j].t0 = to_time(k);
+            if (tk[j].t0 < tk[j - 1].t1) tk[j].t0 = tk[j - 1].t1; else a = k;
+        } else {                                            // silent at the start: move in to the first voiced sample
+            while (en[k] < level && k < b) k++;
+            a = k; tk[j].t0 = to_time(k);
+        }
+        k = b;
+        if (en[k] > level) {                                // voiced at the end: extend, up to the next token's start
+            while (k < n_samples - 1 && en[k] > level) k++;
+            tk[j].t1 = to_time(k);
+            // whisper.cpp guards this read of tokens[j + 1] with `j < ns - 1` where ns is the SAMPLE count of the window (always true in practice) and
+            // so reads past the vector when the segment ends in a text token; the bound the read needs is used here (oracle: same decision)
+            if (j + 1 < n && tk[j].t1 > tk[j + 1].t0) tk[j].t1 = tk[j + 1].t0;
+        } else {                                            // silent at the end: move back to the last voiced sample
+            while (en[k] < level && k > a) k--;
+            tk[j].t1 = to_time(k);
+        }
+    }
+}
 
 static void sequence_score(const ss_params& P, Dec& q) {  // whisper_sequence_score
     if (q.result_len == 0) return;
@@ -172,6 +319,11 @@ struct EngineT : EngineBase {
 
     // ---- workspaces ----
     std::vector<DBuf> pcm_d, mel_d, fmax_d;  // per batch slot
+    // per batch slot, sized on first use: signal energy (token_timestamps) in pinned host memory the kernel writes directly.  A device buffer + a
+    // hipMemcpyAsync back cost ~0.3 ms of HOST time per chunk in the copy call (r04_x: -1.4 % on the headline); the 1.9 MB per 30 s chunk are
+    // instead stored over PCIe by the kernel itself, complete when the stream reaches the first decode step's synchronisation
+    std::vector<HBuf> energy_h;
+    bool energy_sized = false;
     DBuf x0, h1, x, ln, qk, vT, att, ff, encT, encF, cross, kself, vself;
     DBuf ln8, ln_sc, att8, att_sc, ff8, ff_sc;   // fp8 engine: quantised activations + their exponent bytes
     DBuf cross_sc;                               // fp8 engine: exponent bytes of the e4m3 cross cache, [L][B][kv][h][t]
@@ -413,7 +565,7 @@ struct EngineT : EngineBase {
     }
 
     void alloc_workspaces() {
-        pcm_d.resize(B); mel_d.resize(B); fmax_d.resize(B);
+        pcm_d.resize(B); mel_d.resize(B); fmax_d.resize(B); energy_h.resize(B);
         const size_t M = (size_t)B * n_ctx;
         x0.alloc(((size_t)B * (2 * n_ctx + 2) * n_mel + 256) * 2);
         h1.alloc(((size_t)B * (2 * n_ctx + 2) * da + 256) * 2);
@@ -840,6 +992,7 @@ struct EngineT : EngineBase {
             JobState q; q.job = j; q.slot = (int)i;
             j->status = 0;
             const ss_params& P = j->P;
+            if (P.token_timestamps) { s->t_beg = 0; s->t_last = 0; s->tid_last = 0; }   // reset at the top of every whisper_full_with_state call
             // What whisper_full_with_state has already done to the state by the time it checks audio_ctx ("overwrite audio_ctx, max allowed is
             // hparams.n_audio_ctx": return -5): decoders 1.. set up (their generators re-seeded), no_context applied, the prompt tokens prepended --
             // all of it only for a chunk of >= 1 s that is not a detect_language call (those return earlier).
@@ -892,6 +1045,21 @@ struct EngineT : EngineBase {
                 mel_d[i].ensure((size_t)n_mel * q.n_len * 4);
                 fmax_d[i].ensure((size_t)q.n_len * 4);
                 launch_log_mel(mt, dp, j->n_samples, mel_d[i].as<float>(), q.n_len, fmax_d[i].as<float>(), st);
+                if (P.token_timestamps) {   // "state->energy = get_signal_energy(samples, n_samples, 32)": on the device, then to the host for the per-segment pass
+                    const size_t eb = (size_t)j->n_samples * 4;
+                    if (!energy_sized) {   // first use on this lane: give EVERY slot room for a whole 30 s window now -- pinning host pages costs ~0.1 - 1 ms
+                                           // per buffer, and paid slot by slot it would be spread over the first max_batch chunks of a service's life
+                        const size_t first = std::max(eb, (size_t)kSampleRate * kChunkSec * 4);
+                        for (int b = 0; b < B; b++) energy_h[b].ensure(first);
+                        energy_sized = true;
+                    }
+                    if (eb > energy_h[i].bytes) {     // a longer chunk than this slot has seen: an earlier (refused) chunk's kernel may still be writing the old buffer
+                        SS_HIP(hipStreamSynchronize(st));
+                        energy_h[i].ensure(eb);
+                    }
+                    launch_signal_energy(dp, j->n_samples, (float*)energy_h[i].dev, st);
+                    q.energy = (const float*)energy_h[i].p; q.n_energy = j->n_samples;
+                }
                 q.seek_start = P.offset_ms / 10;
                 q.seek = q.seek_start; q.seek_end = P.duration_ms == 0 ? q.n_len_org : q.seek_start + P.duration_ms / 10;
                 q.alive = q.seek_end >= q.seek_start + 100;  // "if length of spectrogram is less than 1.0s, return"
@@ -1368,6 +1536,7 @@ struct EngineT : EngineBase {
                     if (!text.empty()) {
                         s->segments.push_back({t0, t1, text, speaker_turn_next, {}});
                         s->segments.back().tokens.assign(tk.begin() + i0, tk.begin() + i + 1);
+                        if (P.token_timestamps) token_level_times(*s, vocab, s->segments.back(), jq.energy, jq.n_energy, P.thold_pt, P.thold_ptsum);
                     }
                     text.clear();
                     while (i < (int)tk.size() && tk[i].id > vocab.token_beg) i++;
@@ -1380,6 +1549,7 @@ struct EngineT : EngineBase {
             if (!text.empty()) {
                 s->segments.push_back({t0, (int64_t)(seek + seek_delta), text, speaker_turn_next, {}});
                 s->segments.back().tokens.assign(tk.begin() + i0, tk.end());
+                if (P.token_timestamps) token_level_times(*s, vocab, s->segments.back(), jq.energy, jq.n_energy, P.thold_pt, P.thold_ptsum);
             }
         }
         jq.seek += seek_delta;
@@ -1399,6 +1569,18 @@ struct EngineT : EngineBase {
         launch_log_mel(mt, pcm_d[0].as<float>(), n, mel_d[0].as<float>(), n_len, fmax_d[0].as<float>(), st);
         SS_HIP(hipMemcpyAsync(out, mel_d[0].p, (size_t)n_mel * n_len * 4, hipMemcpyDeviceToHost, st));
         SS_HIP(hipStreamSynchronize(st));
+    }
+    void signal_energy_host(const float* pcm, int n, float* out) override {
+        std::lock_guard<std::mutex> lk(mu);
+        SS_HIP(hipSetDevice(opts.device));
+        AllocStreamScope alloc_scope(st);
+        pcm_d[0].ensure((size_t)n * 4);
+        SS_HIP(hipStreamSynchronize(st));
+        energy_h[0].ensure((size_t)n * 4);
+        SS_HIP(hipMemcpyAsync(pcm_d[0].p, pcm, (size_t)n * 4, hipMemcpyHostToDevice, st));
+        launch_signal_energy(pcm_d[0].as<float>(), n, (float*)energy_h[0].dev, st);
+        SS_HIP(hipStreamSynchronize(st));
+        memcpy(out, energy_h[0].p, (size_t)n * 4);
     }
     void encode_host(const float* mel, int n_len, int seek, float* enc_out) override {
         std::lock_guard<std::mutex> lk(mu);

@@ -16,7 +16,10 @@
 
 namespace ss {
 
-struct TokenData { int id = 0, tid = 0; float p = 0, plog = 0, pt = 0, ptsum = 0; };
+struct TokenData {
+    int id = 0, tid = 0; float p = 0, plog = 0, pt = 0, ptsum = 0;
+    int64_t t0 = -1, t1 = -1; float vlen = 0;   // whisper_token_data: token-level times (ss_params.token_timestamps; 10 ms units, -1 = not computed), voice length
+};
 struct Segment { int64_t t0, t1; std::string text; bool speaker_turn_next; std::vector<TokenData> tokens; };   // tokens: whisper_full_get_token_*
 
 // std::mt19937 that counts how often it was invoked: a session's sampling history is then summarised by one number, and a fresh session
@@ -43,6 +46,7 @@ struct Session {
     std::atomic<int> in_flight{0}; // chunks submitted (ss_submit) that the engine has not completed yet: they write into this session.  ss_pool_submit keeps
                                    // such a session on its engine; ss_session_free waits for 0.  Decremented by the engine under its qmu when the chunk is done
     int lang_id = -1;              // whisper_full_lang_id: language of the last chunk (given or detected)
+    int64_t t_beg = 0, t_last = 0; int tid_last = 0;   // whisper_state::t_beg / t_last / tid_last: carried from segment to segment of one chunk by the token-level timestamps
     CountingRng rng;  // the generator a state carries from call to call, seeded with 0 once, never reseeded: decoder 0's (whisper.cpp >= 1.5.0,
                       // whisper_init_state) or whisper_state::rng shared by all decoders (SS_COMPAT_RNG_STATE, <= 1.4.x)
     std::vector<CountingRng> rng_dec;   // [j - 1] = generator of decoder j >= 1: re-seeded with 0 by every chunk ("TAGS: WHISPER_DECODER_INIT" of
@@ -78,6 +82,7 @@ struct EngineBase {
     virtual void run_jobs(std::vector<Job*>& jobs) = 0;  // blocking, any count (grouped by max_batch); takes this lane's `mu`
     virtual void run_jobs_locked(std::vector<Job*>& jobs) = 0;   // caller holds `mu`
     virtual void log_mel_host(const float* pcm, int n, float* out, int n_len) = 0;
+    virtual void signal_energy_host(const float* pcm, int n, float* out) = 0;
     virtual void encode_host(const float* mel, int n_len, int seek, float* enc_out) = 0;
     virtual void set_encoder_host(const float* enc) = 0;
     virtual void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out) = 0;

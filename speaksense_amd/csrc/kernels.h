@@ -16,6 +16,7 @@ struct MelTables {       // device pointers, built once per engine
 };
 // pcm: device f32 [n_samples]; mel_out: device f32 [n_mel][n_len]; scratch: device f32 [>= 1 + 2048]
 void launch_log_mel(const MelTables& mt, const float* pcm, int n_samples, float* mel_out, int n_len, float* scratch, hipStream_t st);
+void launch_signal_energy(const float* pcm, int n_samples, float* energy, hipStream_t st);   // whisper.cpp get_signal_energy(.., 32): one value per sample
 // mel [n_mel][n_len] f32 -> time-major window x0[T2+2][n_mel] (rows 0 and T2+1 zero) in T, frames [seek, seek+T2)
 template <typename T>
 void launch_mel_window(const float* mel, int n_mel, int n_len, int seek, int T2, T* x0, hipStream_t st);

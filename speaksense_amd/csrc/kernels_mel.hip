@@ -156,7 +156,32 @@ __global__ __launch_bounds__(256) void mel_window_kernel(const float* __restrict
     }
 }
 
+// whisper.cpp get_signal_energy(samples, n, 32) (token-level timestamps, SURVEY.md section 8 a-8 / whisper.rs:160): e[i] = mean |x| over the centred
+// window [i - 32, i + 32] clipped to the signal, summed in f32 from left to right and divided by 65 -- the reference's order, so the values are the
+// CPU's bit for bit (terms outside the signal are skipped there; adding +0 to a non-negative sum is the same thing).
+constexpr int kEnergyHw = 32, kEnergyBlock = 256;
+__global__ __launch_bounds__(kEnergyBlock) void signal_energy_kernel(const float* __restrict__ x, int n, float* __restrict__ e) {
+    __shared__ float ax[kEnergyBlock + 2 * kEnergyHw];
+    const int i0 = blockIdx.x * kEnergyBlock;
+    for (int t = threadIdx.x; t < kEnergyBlock + 2 * kEnergyHw; t += kEnergyBlock) {
+        const int k = i0 - kEnergyHw + t;
+        ax[t] = (k >= 0 && k < n) ? fabsf(x[k]) : 0.0f;
+    }
+    __syncthreads();
+    const int i = i0 + threadIdx.x;
+    if (i >= n) return;
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j <= 2 * kEnergyHw; j++) sum = __fadd_rn(sum, ax[threadIdx.x + j]);
+    e[i] = __fdiv_rn(sum, (float)(2 * kEnergyHw + 1));
+}
+
 }  // namespace
+
+void launch_signal_energy(const float* pcm, int n_samples, float* energy, hipStream_t st) {
+    if (n_samples <= 0) return;
+    signal_energy_kernel<<<(n_samples + kEnergyBlock - 1) / kEnergyBlock, kEnergyBlock, 0, st>>>(pcm, n_samples, energy); SS_LAUNCH_CHECK();
+}
 
 void launch_log_mel(const MelTables& mt, const float* pcm, int n_samples, float* mel_out, int n_len, float* scratch, hipStream_t st) {
     // frames whose 400-sample window starts at or beyond the end of the audio (offset >= 200 + n) are all-zero

@@ -347,8 +347,8 @@ static int map_params(struct whisper_context* ctx, const struct whisper_full_par
     if (params.strategy != WHISPER_SAMPLING_GREEDY || params.speed_up || params.suppress_non_speech_tokens || params.n_grammar_rules > 0 ||
         params.logits_filter_callback || params.max_len > 0)
         return SS_ERR_UNSUPPORTED;
-    // callbacks would have to fire from inside the device batch.  token_timestamps / split_on_word (the reference sets both, whisper.rs:160-161)
-    // only act together with max_len > 0, refused above.
+    // callbacks would have to fire from inside the device batch.  split_on_word (the reference sets it, whisper.rs:161) only acts together with
+    // max_len > 0, refused above; token_timestamps (whisper.rs:160) is honoured: whisper_full_get_token_data(..).t0 / t1 / vlen.
     if (params.new_segment_callback || params.progress_callback || params.encoder_begin_callback || params.abort_callback) return SS_ERR_UNSUPPORTED;
     if (params.audio_ctx != 0 && params.audio_ctx != whisper_n_audio_ctx(ctx)) return SS_ERR_UNSUPPORTED;
     ss_default_params(&p);
@@ -358,6 +358,7 @@ static int map_params(struct whisper_context* ctx, const struct whisper_full_par
     p.no_context = params.no_context; p.single_segment = params.single_segment; p.no_timestamps = params.no_timestamps;
     p.suppress_blank = params.suppress_blank; p.tdrz_enable = params.tdrz_enable; p.print_special = params.print_special;
     p.max_tokens = params.max_tokens; p.audio_ctx = params.audio_ctx; p.translate = params.translate;
+    p.token_timestamps = params.token_timestamps; p.thold_pt = params.thold_pt; p.thold_ptsum = params.thold_ptsum;
     if (params.language) { strncpy(p.language, params.language, sizeof(p.language) - 1); p.language[sizeof(p.language) - 1] = 0; }
     else p.language[0] = 0;   // nullptr / "" / "auto": detect
     p.n_max_text_ctx = params.n_max_text_ctx; p.offset_ms = params.offset_ms; p.duration_ms = params.duration_ms;
@@ -459,7 +460,10 @@ whisper_token_data whisper_full_get_token_data_from_state(struct whisper_state* 
     memset(&d, 0, sizeof(d));
     d.t0 = d.t1 = -1;
     float f[4] = {0, 0, 0, 0};
-    if (state && ss_result_segment_token(state->ses, i, k, &d.id, &d.tid, f) == SS_OK) { d.p = f[0]; d.plog = f[1]; d.pt = f[2]; d.ptsum = f[3]; }
+    if (state && ss_result_segment_token(state->ses, i, k, &d.id, &d.tid, f) == SS_OK) {
+        d.p = f[0]; d.plog = f[1]; d.pt = f[2]; d.ptsum = f[3];
+        (void)ss_result_segment_token_times(state->ses, i, k, &d.t0, &d.t1, &d.vlen);
+    }
     return d;
 }
 whisper_token whisper_full_get_token_id_from_state(struct whisper_state* state, int i, int k) { return whisper_full_get_token_data_from_state(state, i, k).id; }

@@ -27,7 +27,8 @@ pub struct ss_params {
     pub suppress_blank: i32, pub tdrz_enable: i32, pub print_special: i32, pub max_tokens: i32, pub audio_ctx: i32,
     pub translate: i32, pub fixed_steps: i32, pub language: [u8; 8],
     pub n_max_text_ctx: i32, pub offset_ms: i32, pub duration_ms: i32, pub detect_language: i32,
-    pub prompt_tokens: *const i32, pub prompt_n_tokens: i32, pub reserved0: i32, pub initial_prompt: *const c_char,
+    pub prompt_tokens: *const i32, pub prompt_n_tokens: i32, pub token_timestamps: i32, pub initial_prompt: *const c_char,
+    pub thold_pt: f32, pub thold_ptsum: f32,
 }   // layout: tests/golden/abi_layout.txt (offsets checked against the C header by tests/test_host_cpu.py)
 unsafe impl Send for ss_params {}
 

@@ -54,6 +54,15 @@ def parse_whisper_json_full(j: dict):
     return ids, segs
 
 
+def parse_whisper_json_token_times(j: dict):
+    """-ojf output -> per segment [(id, t0_cs, t1_cs)]: main.cpp turns token_timestamps on for -ojf and writes every token's whisper_token_data.t0 / t1
+    as "offsets" in milliseconds (t * 10)."""
+    out = []
+    for s in j.get("transcription", []):
+        out.append([(int(t["id"]), int(t["offsets"]["from"]) // 10, int(t["offsets"]["to"]) // 10) for t in s.get("tokens", []) if "offsets" in t])
+    return out
+
+
 def run_whisper_cpp(main: str, model: str, wav: str, lang: str, threads: int, extra: list[str]):
     tmp = tempfile.mkdtemp()
     of = os.path.join(tmp, "out")
@@ -125,7 +134,16 @@ def compare(args, binding, compat, refs):
         k = first_divergence(ref_ids, got_ids[:len(ref_ids)] if len(got_ids) >= len(ref_ids) else got_ids)
         same_segs = [(a, b) for a, b, _ in ref_segs] == [(a, b) for a, b, _ in ses_segs] and [c for _, _, c in ref_segs] == [c for _, _, c in ses_segs]
         if k is None and same_segs:
-            print(f"OK    {wav}: {len(ref_ids)} tokens, {len(ref_segs)} segments identical")
+            # token-level timestamps (ledger row 8: restated from memory, this is its pin).  Reported, not part of the verdict:
+            # a token whose timestamp evidence (pt, ptsum) sits at a threshold may be anchored on one side only.
+            ses = eng.new_session()
+            ses.transcribe(pcm, P)
+            mine = [[(int(i), int(a), int(b)) for i, a, b in zip(g["ids"], g["t0"], g["t1"])] for g in ses.token_times()]
+            ses.close()
+            theirs = parse_whisper_json_token_times(ref)
+            n_tok = sum(len(g) for g in theirs)
+            n_same = sum(a == b for g, h in zip(mine, theirs) if len(g) == len(h) for a, b in zip(g, h))
+            print(f"OK    {wav}: {len(ref_ids)} tokens, {len(ref_segs)} segments identical; token-level (t0, t1): {n_same}/{n_tok} identical")
             continue
         print(f"DIFF  {wav}: first divergence at token {k}: whisper.cpp {ref_ids[k:k + 6] if k is not None else '-'} vs engine {got_ids[k:k + 6] if k is not None else '-'}; "
               f"segments {'identical' if same_segs else 'differ'}")
