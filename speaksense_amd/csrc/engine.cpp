@@ -323,7 +323,7 @@ struct EngineT : EngineBase {
     // hipMemcpyAsync back cost ~0.3 ms of HOST time per chunk in the copy call (r04_x: -1.4 % on the headline); the 1.9 MB per 30 s chunk are
     // instead stored over PCIe by the kernel itself, complete when the stream reaches the first decode step's synchronisation
     std::vector<HBuf> energy_h;
-    bool energy_sized = false;
+    bool energy_sized = false, mel_sized = false, pcm_sized = false;
     DBuf x0, h1, x, ln, qk, vT, att, ff, encT, encF, cross, kself, vself;
     DBuf ln8, ln_sc, att8, att_sc, ff8, ff_sc;   // fp8 engine: quantised activations + their exponent bytes
     DBuf cross_sc;                               // fp8 engine: exponent bytes of the e4m3 cross cache, [L][B][kv][h][t]
@@ -1038,9 +1038,21 @@ struct EngineT : EngineBase {
                 const float* dp;
                 if (j->pcm_on_device) dp = j->pcm;
                 else {
+                    if (!pcm_sized) {   // as mel_sized below, for callers that hand over host PCM
+                        for (int b = 0; b < B; b++) pcm_d[b].ensure(std::max((size_t)j->n_samples, (size_t)kSampleRate * kChunkSec) * 4);
+                        pcm_sized = true;
+                    }
                     pcm_d[i].ensure((size_t)j->n_samples * 4);
                     SS_HIP(hipMemcpyAsync(pcm_d[i].p, j->pcm, (size_t)j->n_samples * 4, hipMemcpyHostToDevice, st));
                     dp = pcm_d[i].as<float>();
+                }
+                if (!mel_sized) {
+                    // First chunk on this lane: size EVERY slot's staging buffers for a 30 s chunk now.  Sized slot by slot on first use, each
+                    // hipMalloc + zero fill + stream synchronisation (DBuf::alloc) stalls the lane once per slot -- spread over the first
+                    // max_batch chunks a lane sees, i.e. inside the timed region of a short benchmark and over the first minutes of a service.
+                    const int len30 = mel_n_len(kSampleRate * kChunkSec);
+                    for (int b = 0; b < B; b++) { mel_d[b].ensure((size_t)n_mel * std::max(q.n_len, len30) * 4); fmax_d[b].ensure((size_t)std::max(q.n_len, len30) * 4); }
+                    mel_sized = true;
                 }
                 mel_d[i].ensure((size_t)n_mel * q.n_len * 4);
                 fmax_d[i].ensure((size_t)q.n_len * 4);
