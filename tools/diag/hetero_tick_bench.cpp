@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef _Float16 f16;
@@ -164,6 +165,30 @@ int main(int argc, char** argv) {
     time_it("serial (one group, one stream)", 1, [&] { CK(hipGraphLaunch(g_serial0, st[0])); });
     time_it("two lanes (two groups, two streams)", 2, [&] { CK(hipGraphLaunch(g_serial0, st[0])); CK(hipGraphLaunch(g_serial1, st[1])); CK(hipStreamSynchronize(st[1])); });
     time_it("fused ticks (one group's chain + another's stream per launch)", 1, [&] { CK(hipGraphLaunch(g_fused, st[0])); });
+    // ---- which pairing costs what?  chain-only and stream-only passes, alone and against each other (r04_ab) ----
+    auto chain_pass = [&](int g) { for (int l = 0; l < L; l++) for (int s = 0; s < 10; s++) k_gemv<<<steps[s], 256, 0, st[g]>>>(wptr(g, l, s), X[g], out[g]); };
+    auto cross_pass = [&](int g) { for (int l = 0; l < L; l++) k_cross<<<M * H, 256, 0, st[g]>>>(kvptr(g, l), Q[g], part[g], 0, TN); };
+    hipGraphExec_t g_chain[2] = {capture(0, [&] { chain_pass(0); }), capture(1, [&] { chain_pass(1); })};
+    hipGraphExec_t g_cross[2] = {capture(0, [&] { cross_pass(0); }), capture(1, [&] { cross_pass(1); })};
+    hipEvent_t a0, a1, b0, b1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1)); CK(hipEventCreate(&b0)); CK(hipEventCreate(&b1));
+    auto pair = [&](const char* name, hipGraphExec_t ga, int ra, hipGraphExec_t gb, int rb) {   // ga x ra on stream 0 while gb x rb runs on stream 1 (rb = 0: alone)
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a0, st[0])); if (rb) CK(hipEventRecord(b0, st[1]));
+        for (int i = 0; i < std::max(ra, rb); i++) { if (i < ra) CK(hipGraphLaunch(ga, st[0])); if (i < rb) CK(hipGraphLaunch(gb, st[1])); }
+        CK(hipEventRecord(a1, st[0])); if (rb) CK(hipEventRecord(b1, st[1]));
+        CK(hipDeviceSynchronize());
+        float ma = 0, mb = 0; CK(hipEventElapsedTime(&ma, a0, a1)); if (rb) CK(hipEventElapsedTime(&mb, b0, b1));
+        printf("%-46s stream 0: %7.3f ms per pass (%5.1f us per layer)", name, ma / ra, 1e3 * ma / ra / L);
+        if (rb) printf("   stream 1: %7.3f ms per pass (%5.1f us per layer)", mb / rb, 1e3 * mb / rb / L);
+        printf("\n");
+    };
+    pair("chain alone", g_chain[0], reps, nullptr, 0);
+    pair("stream (cross-attention) alone", g_cross[0], reps, nullptr, 0);
+    pair("chain | chain", g_chain[0], reps, g_chain[1], reps);
+    pair("stream | stream", g_cross[0], reps, g_cross[1], reps);
+    // equal wall time on both sides: a chain pass is ~2 x a stream pass
+    pair("chain | stream (stream 1 runs 2 passes per chain pass)", g_chain[0], reps, g_cross[1], 2 * reps);
+    pair("full | full", g_serial0, reps, g_serial1, reps);
     // r04_r on MI355X: serial 3.475 ms (108.6 us per layer, 9.2 rows / ms -- the engine's real one-lane pass is 3.42 - 3.46 ms), two lanes 5.063 ms for two
     // groups (12.6 rows / ms), fused 3.897 ms for ONE group's worth (121.8 us per layer, 8.2 rows / ms): slower than serial.  A tenth of the key range
     // is 19 KB of K and 19 KB of V per (row, head) workgroup -- four dependent memory round trips and a barrier, i.e. as latency-bound as the chain
