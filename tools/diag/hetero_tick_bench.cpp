@@ -189,6 +189,15 @@ int main(int argc, char** argv) {
     // equal wall time on both sides: a chain pass is ~2 x a stream pass
     pair("chain | stream (stream 1 runs 2 passes per chain pass)", g_chain[0], reps, g_cross[1], 2 * reps);
     pair("full | full", g_serial0, reps, g_serial1, reps);
+    // ---- does limiting how many stream workgroups are resident per CU protect the other lane's chain?  (dynamic LDS as the limiter) ----
+    for (int dyn : {0, 40 << 10, 72 << 10, 120 << 10}) {
+        auto cross_lim = [&](int g) { for (int l = 0; l < L; l++) k_cross<<<M * H, 256, dyn, st[g]>>>(kvptr(g, l), Q[g], part[g], 0, TN); };
+        CK(hipFuncSetAttribute((const void*)k_cross, hipFuncAttributeMaxDynamicSharedMemorySize, 120 << 10));
+        hipGraphExec_t gl[2] = {capture(0, [&] { cross_lim(0); }), capture(1, [&] { cross_lim(1); })};
+        char nm[96];
+        snprintf(nm, sizeof nm, "stream alone, %3d KB dynamic LDS", dyn >> 10); pair(nm, gl[0], reps, nullptr, 0);
+        snprintf(nm, sizeof nm, "chain | stream, %3d KB dynamic LDS", dyn >> 10); pair(nm, g_chain[0], reps, gl[1], 2 * reps);
+    }
     // r04_r on MI355X: serial 3.475 ms (108.6 us per layer, 9.2 rows / ms -- the engine's real one-lane pass is 3.42 - 3.46 ms), two lanes 5.063 ms for two
     // groups (12.6 rows / ms), fused 3.897 ms for ONE group's worth (121.8 us per layer, 8.2 rows / ms): slower than serial.  A tenth of the key range
     // is 19 KB of K and 19 KB of V per (row, head) workgroup -- four dependent memory round trips and a barrier, i.e. as latency-bound as the chain
