@@ -575,6 +575,187 @@ __global__ __launch_bounds__(WM * 256, 2) void gemm256_kernel(GemmDesc g) {
     }  // tile loop
 }
 
+// ---------------------------------------------------------------------------------------------
+// The 256 x 256 tile with 64-deep stages (128-byte LDS rows).  Why: an LDS-DMA instruction occupies the CU's address path for ~28 cycles when
+// its 64 lanes fetch sixteen 64-byte rows (the TK = 32 layout above) and ~12 when they fetch eight 128-byte rows (tools/diag/dma_issue_bench.cpp,
+// profiles/r04_af_dma_issue_bench.txt) -- and that path is shared by all waves of the CU.  A 256 x 256 x 32 step needs 32 such instructions:
+// ~900 of the 1024 cycles its MFMAs take, which is why the TK = 32 main loop measures ~1500 cycles per step whatever the schedule.  With
+// 128-byte rows a 64-deep stage takes 64 instructions x 12 = ~790 of 2048 cycles.
+// Ring: 2 stages x 64 KB.  Stage s is consumed in two 32-deep halves (register sets A / B as above); the one barrier per stage sits between
+// them: by then every wave has read both halves of stage s into registers, so its buffer is refilled with stage s + 2 during the second half,
+// and stage s + 1 (issued one stage earlier) is waited for there.  Chunk c of row r sits at position c ^ ((r >> 1) & 7): with the row
+// parity selecting the bank half, every ds_read_b128 service group touches 16 distinct 16-byte slots (same swizzle as gemm_kernel).
+// ---------------------------------------------------------------------------------------------
+constexpr int TK2 = 64;
+template <typename T, int KIND>
+__global__ __launch_bounds__(512, 2) void gemm256k64_kernel(GemmDesc g) {
+    constexpr bool ST16 = KIND == EPI_STORE_T || KIND == EPI_GELU_T || KIND == EPI_CROSS_KV;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Mfma<T>::V8 V8;
+    constexpr int TM = 256, kStageBytes = (TM + TN) * TK2 * 2, RPP = 64, NP = (TM + TN) / RPP, NPX = TM / RPP;   // 64 KB per stage; a pass = 8 rows per wave, 64 per workgroup
+    constexpr bool SWAP = (KIND == EPI_VT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int nbn = g.N / TN, nbm = (g.M + TM - 1) / TM;
+    const T* __restrict__ A = (const T*)g.A;
+    const T* __restrict__ W = (const T*)g.W;
+    // Source offsets.  All eight waves stage (8 DMA instructions per thread and stage; the "half the waves stage" form of gemm256_kernel needs 16
+    // offsets per thread, which spilled inside the main loop).  A pass covers 64 consecutive rows of the stacked [X; W] stage, so a lane's
+    // swizzle term (row >> 1) & 7 does not depend on the pass.  X rows go through row_off (conv-stem batching) and the clamp to M - 1: one
+    // 32-bit offset per pass.  W rows are plain and always in range: ONE per-lane offset; the pass part (p - 4) * 64 * K elements is wave-uniform.
+    const int lrow = wave * 8 + (lane >> 3);
+    const int cpos = (lane & 7) ^ ((lrow >> 1) & 7);
+    unsigned sx[NPX], sw_lane = 0;
+    auto set_tile = [&](int m0, int n0) {
+#pragma unroll
+        for (int p = 0; p < NPX; p++) {
+            long m = m0 + p * RPP + lrow;
+            if (m > g.M - 1) m = g.M - 1;
+            sx[p] = (unsigned)((row_off(m, g.a_rows_per_batch, g.a_batch_stride, g.lda) + cpos * 8) * (long)sizeof(T));
+        }
+        sw_lane = (unsigned)(((long)(n0 + lrow) * g.K + cpos * 8) * (long)sizeof(T));
+    };
+    const int wave_off = wave * 8 * 128;
+    const unsigned wpass = (unsigned)g.K * (unsigned)sizeof(T);   // bytes per W row (wave-uniform)
+    // pass p (a compile-time constant) of the stage that starts at element k0, into the stage buffer at `base`
+#define SS_DMA(p, k0, base)                                                                                                              \
+    {                                                                                                                                    \
+        if constexpr ((p) < NPX) glds16<T>((const T*)((const char*)(A + (k0)) + sx[(p) < NPX ? (p) : 0]), (base) + (p) * (RPP * 128) + wave_off); \
+        else glds16<T>((const T*)((const char*)(W + (k0)) + (size_t)((((p) - NPX) * RPP) * wpass) + sw_lane), (base) + (p) * (RPP * 128) + wave_off); \
+    }
+    auto stage = [&](int buf, int k0) {
+        char* base = smem + buf * kStageBytes;
+        SS_DMA(0, k0, base) SS_DMA(1, k0, base) SS_DMA(2, k0, base) SS_DMA(3, k0, base)
+        SS_DMA(4, k0, base) SS_DMA(5, k0, base) SS_DMA(6, k0, base) SS_DMA(7, k0, base)
+    };
+    constexpr int OPS = NP;                    // DMA instructions a thread issues per stage
+    constexpr int kCarry = ST16 ? 12 : 24;     // as gemm256_kernel: output stores issued behind the early prologue that a wait may leave outstanding
+    bool pro_issued = false;
+    int carry = 0;
+    const int ns = g.K / TK2;
+    for (int vb = blockIdx.x; vb < nbn * nbm; vb += gridDim.x) {
+    int mb, nb;
+    tile_of_block(vb, nbm, nbn, &mb, &nb);
+    const int m0 = mb * TM, n0 = nb * TN;
+    long long* tr = g.trace ? g.trace + ((long)blockIdx.x * 8 + (vb - blockIdx.x) / gridDim.x) * 4 : nullptr;
+    if (tr && tid == 0) tr[0] = __builtin_amdgcn_s_memtime();
+    if (!pro_issued) {
+        __builtin_amdgcn_s_barrier();
+        set_tile(m0, n0);
+        carry = 0;
+        stage(0, 0);
+        stage(1, TK2);      // ns >= 2 is checked at launch
+    }
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fg = lane >> 4, swz = (frow >> 1) & 7;
+    const int fo0 = frow * 128 + ((fg ^ swz) * 16), fo1 = frow * 128 + (((4 + fg) ^ swz) * 16);   // this lane's chunk in the first / second 32-deep half
+    const int xrow = (wm * 128) * 128, wrow = TM * 128 + (wn * 64) * 128;
+
+    // Fragments: a quarter of a 32-deep half runs the 8 MFMAs of TWO row fragments (xf[2q], xf[2q + 1]) against all four column fragments.  The
+    // column fragments are therefore live for the whole half (two register sets, A / B), while a row fragment is dead once its quarter has
+    // issued and is reloaded with the next half's data, first used four quarters later: 32 + 32 fragment registers where a full double
+    // buffer (gemm256_kernel) holds 96, which is what lets the DMA offsets live beside 128 accumulators without spilling in the loop.
+    V8 wfA[4], wfB[4], xf[8];
+#define SS_MMA_X(WF, q)                                                                             \
+    _Pragma("unroll") for (int j = 0; j < 2; j++) {                                                 \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ni++) {                                          \
+            if (SWAP) acc[ni][2 * (q) + j] = Mfma<T>::mma(xf[2 * (q) + j], WF[ni], acc[ni][2 * (q) + j]); \
+            else acc[ni][2 * (q) + j] = Mfma<T>::mma(WF[ni], xf[2 * (q) + j], acc[ni][2 * (q) + j]);      \
+        }                                                                                           \
+    }
+    // a quarter: 8 MFMAs; optionally passes 2q and 2q + 1 of the DMA of stage `dma_k0` (measured: all eight passes in the first one or two
+    // quarters instead is within +-2 %, profiles/r04_ah_gemm_k64_dma_placement.txt); optionally the next half's fragments: one column fragment
+    // into the other set, this quarter's two row fragments
+#define SS_QUARTER(WC, WN, do_dma, dma_k0, do_read, fo, q)                                            \
+    {                                                                                                \
+        SS_MMA_X(WC, q)                                                                              \
+        if (do_dma) { SS_DMA(2 * (q), dma_k0, dbase) SS_DMA(2 * (q) + 1, dma_k0, dbase) }            \
+        if (do_read) {                                                                               \
+            WN[q] = *(const V8*)(rbase + wrow + (fo) + (q) * 16 * 128);                              \
+            xf[2 * (q)] = *(const V8*)(rbase + xrow + (fo) + (2 * (q)) * 16 * 128);                  \
+            xf[2 * (q) + 1] = *(const V8*)(rbase + xrow + (fo) + (2 * (q) + 1) * 16 * 128);          \
+        }                                                                                            \
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);                                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                           \
+        __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);                                           \
+    }
+#define SS_HALF(WC, WN, do_dma, dma_buf, dma_k0, do_read, rd_buf, fo)                                  \
+    {                                                                                                \
+        char* dbase = smem + (dma_buf) * kStageBytes;                                                \
+        const char* rbase = smem + (rd_buf) * kStageBytes;                                           \
+        SS_QUARTER(WC, WN, do_dma, dma_k0, do_read, fo, 0)                                            \
+        SS_QUARTER(WC, WN, do_dma, dma_k0, do_read, fo, 1)                                            \
+        SS_QUARTER(WC, WN, do_dma, dma_k0, do_read, fo, 2)                                            \
+        SS_QUARTER(WC, WN, do_dma, dma_k0, do_read, fo, 3)                                            \
+    }
+    // stage 0 has landed (stage 1 and, after an early prologue, the previous tile's last stores may stay in flight)
+    if (carry) wait_vmcnt<OPS + kCarry>(); else wait_vmcnt<OPS>();
+    __builtin_amdgcn_s_barrier();
+    {
+        const char* base = smem;
+#pragma unroll
+        for (int i = 0; i < 4; i++) wfA[i] = *(const V8*)(base + wrow + fo0 + i * 16 * 128);
+#pragma unroll
+        for (int i = 0; i < 8; i++) xf[i] = *(const V8*)(base + xrow + fo0 + i * 16 * 128);
+    }
+    if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memtime();
+    for (int s = 0; s < ns; s++) {
+        const int buf = s & 1;
+        // first half: k 0..31 of stage s from set A; set B and the row fragments <- its k 32..63
+        SS_HALF(wfA, wfB, false, 0, 0, true, buf, fo1)
+        const bool has_next = s + 1 < ns;
+        if (has_next) {
+            // stage s + 1 was issued a whole stage ago; nothing younger of this tile is in flight behind it
+            if (carry && s == 0) wait_vmcnt<kCarry>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of stage s have completed: its buffer may be overwritten once everybody is here
+            __builtin_amdgcn_s_barrier();
+        }
+        // second half: k 32..63 from set B; the buffer of stage s takes stage s + 2; set A and the row fragments <- k 0..31 of stage s + 1
+        const bool dma = s + 2 < ns;
+        SS_HALF(wfB, wfA, dma, buf, (s + 2) * TK2, has_next, buf ^ 1, fo0)
+    }
+#undef SS_HALF
+#undef SS_QUARTER
+#undef SS_MMA_X
+
+    if (tr && tid == 0) tr[2] = __builtin_amdgcn_s_memtime();
+    f32x4 bias_v[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ni++) {
+        bias_v[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+            if constexpr (SWAP) bias_v[ni][0] = g.bias[n0 + wn * 64 + ni * 16 + frow];
+            else bias_v[ni] = *(const f32x4*)(g.bias + n0 + wn * 64 + ni * 16 + fg * 4);
+        }
+        asm volatile("" : "+v"(bias_v[ni][0]), "+v"(bias_v[ni][1]), "+v"(bias_v[ni][2]), "+v"(bias_v[ni][3]));
+    }
+    pro_issued = false;
+    {
+        const int vbn = vb + gridDim.x;
+        if (vbn < nbn * nbm) {
+            int mbn, nbn2;
+            tile_of_block(vbn, nbm, nbn, &mbn, &nbn2);
+            __builtin_amdgcn_s_barrier();   // every wave has read its last fragments: both buffers are free
+            set_tile(mbn * TM, nbn2 * TN);
+            stage(0, 0);
+            stage(1, TK2);
+            carry = (m0 + TM <= g.M) ? kCarry : 0;
+            pro_issued = true;
+        }
+    }
+    epilogue256<T, KIND, ST16>(g, acc, bias_v, m0, n0, wm, wn, frow, fg);
+    if (tr && tid == 0) tr[3] = __builtin_amdgcn_s_memtime();
+    }  // tile loop
+#undef SS_DMA
+}
+
+int g_gemm_k64 = -1;     // env SS_GEMM_K64, read at the first launch: 0 = the 32-deep-stage main loop (gemm256_kernel; A/B reference), default 1
 int g_gemm_cu_cap = 0;   // dev hook (tools/gemm_bench.cpp SS_GEMM_CUS): persistent workgroups of the 256 x 256 kernel on at most this many CUs (0 = all)
 
 template <typename T, int KIND>
@@ -591,6 +772,13 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
         // kinds move 4x the epilogue bytes and measured 20 % slower that way (tools/gemm_bench.cpp)
         static constexpr bool dma4 = KIND == EPI_STORE_T || KIND == EPI_GELU_T || KIND == EPI_CROSS_KV;
         const int nwg = (g.N / TN) * ((g.M + G256<2>::TM - 1) / G256<2>::TM);
+        if (g_gemm_k64 < 0) { const char* e = getenv("SS_GEMM_K64"); g_gemm_k64 = e ? atoi(e) : 1; }
+        if (g_gemm_k64 && g.K % TK2 == 0 && g.K >= 2 * TK2) {
+            static std::atomic<uint64_t> attrk64{0};
+            once_per_device(attrk64, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256k64_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
+            gemm256k64_kernel<T, KIND><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();
+            return;
+        }
         static std::atomic<uint64_t> attr256{0};
         once_per_device(attr256, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm256_kernel<T, KIND, 2, dma4>, hipFuncAttributeMaxDynamicSharedMemorySize, G256<2>::kLds)); });
         gemm256_kernel<T, KIND, 2, dma4><<<nwg < n_cu ? nwg : n_cu, 512, G256<2>::kLds, st>>>(g); SS_LAUNCH_CHECK();

@@ -26,12 +26,15 @@ int main(int argc, char** argv) {
     struct Shape { int M, N, K; const char* name; };
     Shape shapes[] = {{48000, 5120, 1280, "FC1x4"}, {48000, 1280, 5120, "FC2x4"}, {48000, 1280, 1280, "Ox4"}, {48000, 2560, 1280, "QKx4"}, {12000, 5120, 1280, "FC1"}, {12000, 1280, 5120, "FC2"}, {12000, 3840, 1280, "QKV"}, {12000, 4096, 1280, "N4096"}, {12000, 2560, 1280, "QK"}, {11776, 5120, 1280, "M46"}, {12288, 5120, 1280, "M48"}, {12000, 1280, 1280, "O"},
                       {12000, 81920, 1280, "crossKV"}, {4096, 4096, 4096, "sq4096"}, {8192, 8192, 8192, "sq8192"}};
+    if (getenv("SS_GEMM_TINY")) { shapes[0] = {1024, 256, 128, "tiny2"}; shapes[1] = {1024, 256, 256, "tiny4"}; shapes[2] = {1024, 512, 1280, "tiny20"}; }
+    const int n_shapes = getenv("SS_GEMM_TINY") ? 3 : (int)(sizeof(shapes) / sizeof(shapes[0]));
     int kinds[] = {EPI_STORE_T, EPI_GELU_T, EPI_RES_F32};
     const char* kn[] = {"store", "gelu", "res_f32"};
     if (getenv("SS_GEMM_CUS")) g_gemm_cu_cap = atoi(getenv("SS_GEMM_CUS"));   // how do the per-tile phases change when fewer CUs run tiles at once?
     hipStream_t st; hipStreamCreate(&st);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (auto& s : shapes) {
+    for (int si = 0; si < n_shapes; si++) {
+        auto& s = shapes[si];
         f16 *A, *W; float *bias, *Cf; void* out;
         hipMalloc(&A, (size_t)s.M * s.K * 2); hipMalloc(&W, (size_t)s.N * s.K * 2); hipMalloc(&bias, s.N * 4);
         hipMalloc(&out, (size_t)s.M * s.N * 4);
@@ -81,8 +84,12 @@ int main(int argc, char** argv) {
             launch_gemm<f16>(g, st); hipDeviceSynchronize();
             std::vector<float> a((size_t)s.M * s.N), b((size_t)s.M * s.N);
             hipMemcpy(a.data(), out, a.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(b.data(), Cf, b.size() * 4, hipMemcpyDeviceToHost);
-            double mx = 0, ref = 0; for (size_t i = 0; i < a.size(); i++) { mx = fmax(mx, fabs(a[i] - b[i])); ref = fmax(ref, fabs(b[i])); }
-            printf("   check: max|diff| %.3e (max|ref| %.3f)\n", mx, ref);
+            double mx = 0, ref = 0; size_t bad = 0, first_bad = 0;
+            for (size_t i = 0; i < a.size(); i++) { if (!std::isfinite(a[i])) { if (!bad) first_bad = i; bad++; continue; } mx = fmax(mx, fabs(a[i] - b[i])); ref = fmax(ref, fabs(b[i])); }
+            printf("   check: max|diff| %.3e (max|ref| %.3f)%s\n", mx, ref, bad ? "  NON-FINITE OUTPUTS" : "");
+            if (bad) printf("   %zu non-finite outputs, first at row %zu column %zu\n", bad, first_bad / s.N, first_bad % s.N);
+            { size_t nbig = 0, fb = 0; for (size_t i = 0; i < a.size(); i++) if (std::isfinite(a[i]) && fabs(a[i] - b[i]) > 1e-2) { if (!nbig) fb = i; nbig++; }
+              if (nbig) printf("   %zu outputs off by more than 1e-2, first at row %zu column %zu: got %f want %f\n", nbig, fb / s.N, fb % s.N, a[fb], b[fb]); }
             g.kind = EPI_STORE_T;    // the 16-byte-store epilogue (lane regrouping by v_permlane16_swap)
             launch_gemm<f16>(g, st); hipDeviceSynchronize();
             std::vector<f16> h16((size_t)s.M * s.N);
