@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspeaksense_hip.so")
+LIB_PATH = os.environ.get("SS_LIB_PATH") or os.path.join(_HERE, "libspeaksense_hip.so")   # SS_LIB_PATH: A/B of two builds on one box (tools/experiments)
 _LIB = None
 
 DTYPE_BF16, DTYPE_F16, DTYPE_FP8 = 0, 1, 2   # FP8: the f16 engine with e4m3 encoder / cross-KV projections

@@ -444,6 +444,20 @@ struct EngineT : EngineBase {
     void put_f32(float*& ptr, const std::vector<float>& v) {
         size_t o = ar.take(v.size() * 4); memcpy(ar.host.data() + o, v.data(), v.size() * 4); reg(ptr, o);
     }
+    // a decode-step GEMV weight [N][K] in the fragment-major layout the GEMV kernels read (kernels.h dec_wpack_off); rows N .. N_alloc - 1 are zero
+    void put_T_packed(T*& ptr, const float* v, size_t N, size_t K, size_t N_alloc = 0) {
+        if (N_alloc < N) N_alloc = N;
+        if (N_alloc % 16 || K % 32) throw Error(SS_ERR_MODEL, "model: decoder weight shape not a multiple of 16 x 32");
+        size_t o = ar.take(N_alloc * K * 2);
+        uint16_t* dst = (uint16_t*)(ar.host.data() + o);
+        memset(dst, 0, N_alloc * K * 2);
+        for (size_t n = 0; n < N; n++)
+            for (size_t k = 0; k < K; k += 8) {
+                uint16_t* q = dst + dec_wpack_off((long)n, (int)k, (int)K);
+                for (int e = 0; e < 8; e++) q[e] = to_bits<T>(v[n * K + k + e]);
+            }
+        reg(ptr, o);
+    }
     void put_T(T*& ptr, const float* v, size_t n, size_t n_alloc = 0) {
         if (n_alloc < n) n_alloc = n;
         size_t o = ar.take(n_alloc * 2);
@@ -520,7 +534,7 @@ struct EngineT : EngineBase {
             put_proj(e.w2, e.w28, e.s2, W(p + "mlp.2.weight").data(), da, (size_t)4 * da); put_f32(e.b2, W(p + "mlp.2.bias"));
         }
         put_f32(lnpostw, W("encoder.ln_post.weight")); put_f32(lnpostb, W("encoder.ln_post.bias"));
-        put_T(tok_emb, W("decoder.token_embedding.weight").data(), (size_t)n_vocab * d, (size_t)n_vocab_pad * d);
+        put_T_packed(tok_emb, W("decoder.token_embedding.weight").data(), (size_t)n_vocab, (size_t)d, (size_t)n_vocab_pad);
         put_f32(dec_pos, W("decoder.positional_embedding"));
         dec.resize(L);
         std::vector<float> ckw, ckb;
@@ -529,15 +543,15 @@ struct EngineT : EngineBase {
             DecL& e = dec[i];
             put_f32(e.ln1w, W(p + "attn_ln.weight")); put_f32(e.ln1b, W(p + "attn_ln.bias"));
             auto wqkv = cat({&W(p + "attn.query.weight"), &W(p + "attn.key.weight"), &W(p + "attn.value.weight")});
-            put_T(e.wqkv, wqkv.data(), wqkv.size());
+            put_T_packed(e.wqkv, wqkv.data(), (size_t)3 * d, (size_t)d);
             put_f32(e.bqkv, cat({&W(p + "attn.query.bias"), &zeros_d, &W(p + "attn.value.bias")}));
-            put_T(e.wo, W(p + "attn.out.weight").data(), (size_t)d * d); put_f32(e.bo, W(p + "attn.out.bias"));
+            put_T_packed(e.wo, W(p + "attn.out.weight").data(), (size_t)d, (size_t)d); put_f32(e.bo, W(p + "attn.out.bias"));
             put_f32(e.lncw, W(p + "cross_attn_ln.weight")); put_f32(e.lncb, W(p + "cross_attn_ln.bias"));
-            put_T(e.wcq, W(p + "cross_attn.query.weight").data(), (size_t)d * d); put_f32(e.bcq, W(p + "cross_attn.query.bias"));
-            put_T(e.wco, W(p + "cross_attn.out.weight").data(), (size_t)d * d); put_f32(e.bco, W(p + "cross_attn.out.bias"));
+            put_T_packed(e.wcq, W(p + "cross_attn.query.weight").data(), (size_t)d, (size_t)d); put_f32(e.bcq, W(p + "cross_attn.query.bias"));
+            put_T_packed(e.wco, W(p + "cross_attn.out.weight").data(), (size_t)d, (size_t)d); put_f32(e.bco, W(p + "cross_attn.out.bias"));
             put_f32(e.ln2w, W(p + "mlp_ln.weight")); put_f32(e.ln2b, W(p + "mlp_ln.bias"));
-            put_T(e.w1, W(p + "mlp.0.weight").data(), (size_t)4 * d * d); put_f32(e.b1, W(p + "mlp.0.bias"));
-            put_T(e.w2, W(p + "mlp.2.weight").data(), (size_t)4 * d * d); put_f32(e.b2, W(p + "mlp.2.bias"));
+            put_T_packed(e.w1, W(p + "mlp.0.weight").data(), (size_t)4 * d, (size_t)d); put_f32(e.b1, W(p + "mlp.0.bias"));
+            put_T_packed(e.w2, W(p + "mlp.2.weight").data(), (size_t)d, (size_t)4 * d); put_f32(e.b2, W(p + "mlp.2.bias"));
             const auto& kw = W(p + "cross_attn.key.weight"); const auto& vw = W(p + "cross_attn.value.weight");
             ckw.insert(ckw.end(), kw.begin(), kw.end()); ckw.insert(ckw.end(), vw.begin(), vw.end());
             ckb.insert(ckb.end(), zeros_d.begin(), zeros_d.end());

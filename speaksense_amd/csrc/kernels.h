@@ -131,6 +131,16 @@ constexpr int kPartRows = 128;  // most token rows ONE decoder pass carries (row
                                 // pass are ctl[0, kPartRows) = its rows, ctl[kPartRows, 2 kPartRows) = its sampling rows).  Round 4: 64 -> 128 (CT = 8 column tiles)
 enum DecPro { PRO_LN = 0, PRO_T = 1 };   // PRO_LN: the descriptor of a dec_reduce_ln launch; PRO_T: a GEMV whose activations are T rows (Xt)
 enum DecEpi { DEPI_PART = 0, DEPI_QKV = 1, DEPI_GELU_T = 2, DEPI_LOGITS = 3 };
+// Layout of every weight matrix the decode-step GEMVs read ([N][K] in the file, N a multiple of 16, K of 32): FRAGMENT-MAJOR.  The 16 x 32 block
+// (rows 16 t .. 16 t + 15, columns 32 b .. 32 b + 31) -- one MFMA 16x16x32 A operand -- is one contiguous kilobyte in lane order: lane
+// l = (n % 16) + 16 ((k % 32) / 8) holds its 8 consecutive k.  A wave's weight-load instruction then reads 8 full 128-byte lines instead of 64 bytes
+// in each of 16 lines that lie a row pitch apart: ~2.7 x less time on the CU's address path per instruction (tools/diag/dma_issue_bench.cpp
+// measures the same effect for LDS-DMA) and sequential HBM bursts; the stand-in chain of tools/diag/hetero_tick_bench.cpp runs 7.5 % faster
+// for it (profiles/r04_ak_packed_weights_bench.txt).  The weights are constants: the engine packs them once at load.
+__host__ __device__ inline long dec_wpack_off(long n, int k, int K) {
+    return ((((n >> 4) * (K >> 5) + (k >> 5)) * 64) + (n & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7);
+}
+
 struct DecGemvDesc {
     int pro, epi;
     // PRO_LN: x = x_in (or tok/pos embedding when ctl != null) + bias_prev + sum_p parts[p]; optional write-back; LayerNorm
@@ -138,7 +148,7 @@ struct DecGemvDesc {
     const float* parts; int n_parts;        // [n_parts][kPartRows][K] f32 split-K partials of the previous projection
     const float* bias_prev;                 // [K] or null
     const float* ln_w; const float* ln_b;
-    const RowCtl* ctl; const void* tok_emb; const float* pos_emb;   // embedding prologue (layer 0)
+    const RowCtl* ctl; const void* tok_emb; const float* pos_emb;   // embedding prologue (layer 0); tok_emb in the decoder-weight layout below
     const int* row_idx;                     // optional row gather (final LayerNorm of the sampling rows)
     const void* Xt; long ldx;               // PRO_T: T [M][ldx]
     const void* W; int M, N, K, S;          // W: T [N][K]

@@ -71,12 +71,11 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
     for (int i = 0; i < NI; i++) { ww[i] = *(const f32x4*)(g.ln_w + cc[i]); bb[i] = *(const f32x4*)(g.ln_b + cc[i]); }
     if (g.ctl) {  // layer 0: token + positional embedding (replaces ggml get_rows + add)
         const RowCtl rc = g.ctl[r];
-        const T* te = (const T*)g.tok_emb + (long)rc.token * d;
         const float* pe = g.pos_emb + (long)rc.pos * d;
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             const f32x4 p4 = *(const f32x4*)(pe + cc[i]);
-            const T* t = te + cc[i];
+            const T* t = (const T*)g.tok_emb + dec_wpack_off(rc.token, cc[i], d);   // 4 consecutive k of a row stay contiguous in the fragment-major layout
             v[i] = (f32x4){(float)t[0] + p4[0], (float)t[1] + p4[1], (float)t[2] + p4[2], (float)t[3] + p4[3]};
         }
     } else {
@@ -160,11 +159,8 @@ __device__ __forceinline__ void dec_epilogue(const DecGemvDesc& g, int s, int m,
     }
 }
 
-// k offset (elements, within this wave's k range) of fragment f of a lane group fg: fragments come in pairs that cover 64 k, lane group fg
-// owning the 32 contiguous bytes [16 fg, 16 fg + 16) of a pair; an odd last fragment covers 32 k with 8 per lane group.  W and X use the same map.
-template <int NFR> __device__ __forceinline__ int frag_koff(int f, int fg) {
-    return (NFR & 1) && f == NFR - 1 ? (NFR / 2) * 64 + fg * 8 : (f >> 1) * 64 + fg * 16 + (f & 1) * 8;
-}
+// Fragment f of a wave covers k = kbeg + 32 f .. + 31, lane group fg its 8 consecutive k at 8 fg: the weights are stored fragment-major
+// (kernels.h dec_wpack_off: one contiguous kilobyte per fragment), the activations row-major.
 
 // NFR = 32-k fragments per wave (k per wave = 32 NFR <= 320), a template parameter: with a run-time count the loads sat behind branches and
 // hipcc put `s_waitcnt vmcnt(0)` between the weight loads, the activation loads of the first column tile and those of the second -- three
@@ -180,10 +176,10 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     const int n0 = blockIdx.x * 16, s = blockIdx.y;
     const int kbeg = s * (g.K / g.S) + wave * (32 * NFR);
     float* red = (float*)smem_d;   // [NW][CT*16][17]
-    const T* wp = (const T*)g.W + (long)(n0 + frow) * g.K + kbeg;      // N is a multiple of 16 (checked on the host): every weight row exists
+    const T* wp = (const T*)g.W + ((long)blockIdx.x * (g.K >> 5) + (kbeg >> 5)) * 512 + lane * 8;      // N is a multiple of 16 (checked on the host): every weight tile exists
     V8 wf[NFR];
 #pragma unroll
-    for (int f = 0; f < NFR; f++) wf[f] = SS_LDW((const V8*)(wp + frag_koff<NFR>(f, fg)));
+    for (int f = 0; f < NFR; f++) wf[f] = SS_LDW((const V8*)(wp + f * 512));
     // activations: B fragments straight from L2 into VGPRs (no LDS staging, no barrier before the MFMAs).  Token rows >= M read row 0: MFMA
     // columns are independent and never stored.  Two column tiles' loads are in flight at a time (CT = 4: 2 + 2, to stay under 168 VGPRs).
     f32x4 acc[CT];
@@ -196,7 +192,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
             const int m = (c0 + ct) * 16 + frow;
             const T* xg = (const T*)g.Xt + (long)(m < g.M ? m : 0) * g.ldx + kbeg;
 #pragma unroll
-            for (int f = 0; f < NFR; f++) xf[ct][f] = *(const V8*)(xg + frag_koff<NFR>(f, fg));
+            for (int f = 0; f < NFR; f++) xf[ct][f] = *(const V8*)(xg + f * 32 + fg * 8);
         }
         __builtin_amdgcn_sched_barrier(0);     // every load above is issued before the first MFMA below (left alone, hipcc trickles them in between the MFMAs to save registers)
 #pragma unroll
@@ -238,10 +234,10 @@ __global__ __launch_bounds__(256) void dec_gemv_ln_kernel(DecGemvDesc g) {
     const int xld = g.K + 8;                                   // row stride in T elements: 16-B aligned rows, banks spread
     T* xs = (T*)smem_d;                                        // [16][xld]
     float* red = (float*)(smem_d + (size_t)16 * xld * sizeof(T));   // [NW][16][17]
-    const T* wp = (const T*)g.W + (long)(n0 + frow) * g.K + kbeg;
+    const T* wp = (const T*)g.W + ((long)blockIdx.x * (g.K >> 5) + (kbeg >> 5)) * 512 + lane * 8;
     V8 wf[NFR];
 #pragma unroll
-    for (int f = 0; f < NFR; f++) wf[f] = SS_LDW((const V8*)(wp + frag_koff<NFR>(f, fg)));
+    for (int f = 0; f < NFR; f++) wf[f] = SS_LDW((const V8*)(wp + f * 512));
     for (int m = wave; m < 16; m += NW) {
         if (m < g.M) ln_row<T, NI>(g, m, lane, blockIdx.x == 0, 0, g.K, xs + (long)m * xld);
         else for (int c = lane * 8; c < g.K; c += 512) *(V8*)(xs + (long)m * xld + c) = V8{};      // unused MFMA columns: finite values
@@ -249,7 +245,7 @@ __global__ __launch_bounds__(256) void dec_gemv_ln_kernel(DecGemvDesc g) {
     __syncthreads();
     V8 xf[NFR];
 #pragma unroll
-    for (int f = 0; f < NFR; f++) xf[f] = *(const V8*)(xs + (long)frow * xld + kbeg + frag_koff<NFR>(f, fg));
+    for (int f = 0; f < NFR; f++) xf[f] = *(const V8*)(xs + (long)frow * xld + kbeg + f * 32 + fg * 8);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int f = 0; f < NFR; f++) acc = MfmaD<T>::mma(wf[f], xf[f], acc);

@@ -705,6 +705,9 @@ __global__ __launch_bounds__(512, 2) void gemm256k64_kernel(GemmDesc g) {
         for (int i = 0; i < 8; i++) xf[i] = *(const V8*)(base + xrow + fo0 + i * 16 * 128);
     }
     if (tr && tid == 0) tr[1] = __builtin_amdgcn_s_memtime();
+#ifdef SS_K64_WAITTRACE
+    long long wait_dma = 0, wait_bar = 0;
+#endif
     for (int s = 0; s < ns; s++) {
         const int buf = s & 1;
         // first half: k 0..31 of stage s from set A; set B and the row fragments <- its k 32..63
@@ -712,9 +715,18 @@ __global__ __launch_bounds__(512, 2) void gemm256k64_kernel(GemmDesc g) {
         const bool has_next = s + 1 < ns;
         if (has_next) {
             // stage s + 1 was issued a whole stage ago; nothing younger of this tile is in flight behind it
+#ifdef SS_K64_WAITTRACE
+            const long long w0 = __builtin_amdgcn_s_memtime();
+#endif
             if (carry && s == 0) wait_vmcnt<kCarry>(); else wait_vmcnt<0>();
+#ifdef SS_K64_WAITTRACE
+            const long long w1 = __builtin_amdgcn_s_memtime();
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my reads of stage s have completed: its buffer may be overwritten once everybody is here
             __builtin_amdgcn_s_barrier();
+#ifdef SS_K64_WAITTRACE
+            wait_dma += w1 - w0; wait_bar += __builtin_amdgcn_s_memtime() - w1;
+#endif
         }
         // second half: k 32..63 from set B; the buffer of stage s takes stage s + 2; set A and the row fragments <- k 0..31 of stage s + 1
         const bool dma = s + 2 < ns;
@@ -751,6 +763,9 @@ __global__ __launch_bounds__(512, 2) void gemm256k64_kernel(GemmDesc g) {
     }
     epilogue256<T, KIND, ST16>(g, acc, bias_v, m0, n0, wm, wn, frow, fg);
     if (tr && tid == 0) tr[3] = __builtin_amdgcn_s_memtime();
+#ifdef SS_K64_WAITTRACE
+    if (tr && tid == 0) { tr[0] = 0; tr[1] = wait_dma; tr[2] = wait_dma + wait_bar; tr[3] = tr[2]; }   // debug build: "prologue" = cycles in the vmcnt wait, "loop" = cycles in the barrier
+#endif
     }  // tile loop
 #undef SS_DMA
 }

@@ -234,20 +234,24 @@ def _same_result(got, ref, ctx, tid_slack_beg=None):
 
 @pytest.mark.parametrize("which", ["toy.en", "toy", "toy256"])
 def test_full_path_greedy_identical_tokens_f16(toy_en_path, toy_ml_path, toy256_path, orc, which):
-    """Pure greedy (temperature_inc = 0, no fallback ladder): f16 MFMA operands reproduce ggml's CPU arithmetic type,
-    so token ids, timestamps and segment texts must match the ggml-faithful oracle exactly.  Covers multi-window
-    chunks (seek advance + prompt_past conditioning), timestamp pairs, EOT and the no-timestamp path."""
+    """Pure greedy (temperature_inc = 0, no fallback ladder): f16 MFMA operands reproduce ggml's CPU arithmetic type, so token ids, timestamps and
+    segment texts match the ggml-faithful oracle exactly -- on at least five of the six audios per model; on the sixth a pick may differ where
+    the oracle's own top-2 margin is inside the f16 noise (random weights give a few such steps per hundred; which audio hits one moves with any
+    change of a kernel's summation order: r04, fragment-major decoder weights, toy256 seed 4), and then the engine's stream replayed on the oracle
+    must give the engine's windows, segments and timestamps.  Covers multi-window chunks (seek advance + prompt_past conditioning), timestamp
+    pairs, EOT and the no-timestamp path."""
     from speaksense_amd import binding
     path = {"toy.en": toy_en_path, "toy": toy_ml_path, "toy256": toy256_path}[which]
     om = orc.OracleModel(path)
     eng = _eng(path, binding.DTYPE_F16, max_batch=4)
-    n_multi = 0
+    n_multi = n_same = 0
     for seed in (3, 4, 5, 6, 7, 8):
         pcm = synth.speech_like(seed)
-        ref = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(language="en", temperature_inc=0.0))
         got = eng.new_session().transcribe(pcm, binding.default_params(language="en", temperature_inc=0.0))
-        _same_result(got, ref, f"{which} seed {seed}")
-        n_multi += ref["n_encode"] > 1
+        same, _ = check_against_oracle(got, om, orc, orc.MODE_GGML_F16, pcm, orc.default_params(language="en", temperature_inc=0.0), f"{which} seed {seed}", GAP_TOL_F16)
+        n_same += same
+        n_multi += got["n_encode"] > 1
+    assert n_same >= 5, f"{which}: only {n_same} of 6 audios give the oracle's ids (the rest are proven near ties, but that many is no longer noise)"
     if which == "toy":
         assert n_multi > 0, "fixture no longer exercises multi-window chunks"
     eng.close(); om.close()

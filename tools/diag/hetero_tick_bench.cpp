@@ -97,6 +97,71 @@ __device__ __forceinline__ void cross_part(int pair, int k0, int k1, const f16* 
     }
 }
 
+// the same with the weights pre-packed fragment-major: fragment (tile, k / 32) is ONE contiguous kilobyte in lane order, so a wave's load instruction
+// touches 8 full 128-byte lines instead of 64 bytes in each of 16 lines (rows 2560 bytes apart)
+__global__ __launch_bounds__(256) void k_gemv_packed(const f16* __restrict__ W, const f16* __restrict__ X, float* __restrict__ out) {
+    __shared__ float red[NW * 2 * 16 * 17];
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15, fg = lane >> 4;
+    const int kbeg = wave * (32 * NFR);
+    const f16* wp = W + ((long)tile * (D / 32) + kbeg / 32) * 512 + lane * 8;
+    f16x8 wf[NFR], xf[2][NFR];
+#pragma unroll
+    for (int f = 0; f < NFR; f++) wf[f] = *(const f16x8*)(wp + f * 512);
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int f = 0; f < NFR; f++) xf[ct][f] = *(const f16x8*)(X + (long)(ct * 16 + frow) * D + kbeg + f * 32 + fg * 8);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int f = 0; f < NFR; f++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f], xf[ct][f], acc[ct], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[((wave * 2 + ct) * 16 + frow) * 17 + fg * 4 + r] = acc[ct][r];
+    __syncthreads();
+    for (int idx = tid; idx < 512; idx += 256) {
+        const int m = idx >> 4, nn = idx & 15;
+        float v = 0.f;
+        for (int w = 0; w < NW; w++) v += red[((w * 2 + (m >> 4)) * 16 + (m & 15)) * 17 + nn];
+        out[(long)m * 5120 + tile * 16 + nn] = v;
+    }
+}
+// ... and with the 32 activation rows stored fragment-major as well (what a producer kernel would have to write)
+__global__ __launch_bounds__(256) void k_gemv_packed2(const f16* __restrict__ W, const f16* __restrict__ X, float* __restrict__ out) {
+    __shared__ float red[NW * 2 * 16 * 17];
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frow = lane & 15, fg = lane >> 4;
+    const int kbeg = wave * (32 * NFR);
+    const f16* wp = W + ((long)tile * (D / 32) + kbeg / 32) * 512 + lane * 8;
+    f16x8 wf[NFR], xf[2][NFR];
+#pragma unroll
+    for (int f = 0; f < NFR; f++) wf[f] = *(const f16x8*)(wp + f * 512);
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int f = 0; f < NFR; f++) xf[ct][f] = *(const f16x8*)(X + (((long)ct * (D / 32) + kbeg / 32 + f) * 64 + lane) * 8);   // activations fragment-major too
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int f = 0; f < NFR; f++) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[f], xf[ct][f], acc[ct], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[((wave * 2 + ct) * 16 + frow) * 17 + fg * 4 + r] = acc[ct][r];
+    __syncthreads();
+    for (int idx = tid; idx < 512; idx += 256) {
+        const int m = idx >> 4, nn = idx & 15;
+        float v = 0.f;
+        for (int w = 0; w < NW; w++) v += red[((w * 2 + (m >> 4)) * 16 + (m & 15)) * 17 + nn];
+        out[(long)m * 5120 + tile * 16 + nn] = v;
+    }
+}
 __global__ __launch_bounds__(256) void k_gemv(const f16* W, const f16* X, float* out) {
     __shared__ float red[NW * 2 * 16 * 17];
     gemv_part(blockIdx.x, W, X, out, red);
@@ -182,7 +247,16 @@ int main(int argc, char** argv) {
         if (rb) printf("   stream 1: %7.3f ms per pass (%5.1f us per layer)", mb / rb, 1e3 * mb / rb / L);
         printf("\n");
     };
+    auto chain_packed = [&](int g) { for (int l = 0; l < L; l++) for (int s = 0; s < 10; s++) k_gemv_packed<<<steps[s], 256, 0, st[g]>>>(wptr(g, l, s), X[g], out[g]); };
+    hipGraphExec_t g_chainp[2] = {capture(0, [&] { chain_packed(0); }), capture(1, [&] { chain_packed(1); })};
     pair("chain alone", g_chain[0], reps, nullptr, 0);
+    pair("chain alone, fragment-major weights", g_chainp[0], reps, nullptr, 0);
+    pair("chain | chain, fragment-major weights", g_chainp[0], reps, g_chainp[1], reps);
+    auto chain_packed2 = [&](int g) { for (int l = 0; l < L; l++) for (int s = 0; s < 10; s++) k_gemv_packed2<<<steps[s], 256, 0, st[g]>>>(wptr(g, l, s), X[g], out[g]); };
+    hipGraphExec_t g_chainq[2] = {capture(0, [&] { chain_packed2(0); }), capture(1, [&] { chain_packed2(1); })};
+    pair("chain alone, weights and activations fragment-major", g_chainq[0], reps, nullptr, 0);
+    pair("chain | chain, weights and activations fragment-major", g_chainq[0], reps, g_chainq[1], reps);
+    pair("chain (fragment-major) | stream", g_chainp[0], reps, g_cross[1], 2 * reps);
     pair("stream (cross-attention) alone", g_cross[0], reps, nullptr, 0);
     pair("chain | chain", g_chain[0], reps, g_chain[1], reps);
     pair("stream | stream", g_cross[0], reps, g_cross[1], reps);
