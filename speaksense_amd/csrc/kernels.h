@@ -137,6 +137,11 @@ enum DecEpi { DEPI_PART = 0, DEPI_QKV = 1, DEPI_GELU_T = 2, DEPI_LOGITS = 3 };
 // in each of 16 lines that lie a row pitch apart: ~2.7 x less time on the CU's address path per instruction (tools/diag/dma_issue_bench.cpp
 // measures the same effect for LDS-DMA) and sequential HBM bursts; the stand-in chain of tools/diag/hetero_tick_bench.cpp runs 7.5 % faster
 // for it (profiles/r04_ak_packed_weights_bench.txt).  The weights are constants: the engine packs them once at load.
+// The ACTIVATION rows a decode-step GEMV multiplies them with (the B operand: LayerNorm output, attention output, GELU output; <= 128 token rows)
+// use the same layout with n = token row: their producers (dec_reduce_ln, dec_self_attn, dec_cross_attn / combine, the GELU epilogue) store
+// through dec_wpack_off, and the GEMV's three times more numerous activation loads become contiguous kilobytes too (stand-in chain: 59.5 ->
+// 41.5 us per layer, same file).  Buffers hold a multiple of 16 rows; rows of a tile beyond M are stale but finite and feed MFMA columns
+// that are never stored.
 __host__ __device__ inline long dec_wpack_off(long n, int k, int K) {
     return ((((n >> 4) * (K >> 5) + (k >> 5)) * 64) + (n & 15) + 16 * ((k & 31) >> 3)) * 8 + (k & 7);
 }

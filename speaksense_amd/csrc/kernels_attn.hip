@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64) void dec_self_attn_kernel(const T* __restrict__
         V8 o;
 #pragma unroll
         for (int e = 0; e < 8; e++) o[e] = (T)(acc[e] * inv);
-        *(V8*)(out + (long)m * d + h * 64 + c * 8) = o;
+        *(V8*)(out + dec_wpack_off(m, h * 64 + c * 8, d)) = o;   // fragment-major (kernels.h): the out-projection GEMV's B operand
     }
 }
 
@@ -366,7 +366,7 @@ __global__ void dec_cross_combine_kernel(const float* __restrict__ scratch, int 
             num += w * part[s * kCrossPart + 2 + j];
             den += w * part[s * kCrossPart + 1];
         }
-        out[(long)m * d + col] = (T)(num / den);
+        out[dec_wpack_off(m, col, d)] = (T)(num / den);
     }
 }
 

@@ -55,8 +55,10 @@ constexpr int kCrossSplitD = 4, kCrossPartD = 66;
 // x = [x_in | tok+pos embedding] + bias_prev + sum_p parts[p]  (fixed order, branch-free: up to 4 partial slots, unused
 // slots re-read slot 0 with weight 0 so that every load is independent and in flight together), optional write-back,
 // LayerNorm over the full row, normalised columns [kbeg, kbeg+kslice) written to dst as T.  One wave per row.
+// pack_row >= 0: dst is the base of a fragment-major activation buffer (kernels.h dec_wpack_off) and this row is row pack_row of it;
+// pack_row < 0: dst points at a plain row (the LDS staging of dec_gemv_ln_kernel)
 template <typename T, int NI>
-__device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bool write_x, int kbeg, int kslice, T* dst) {
+__device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bool write_x, int kbeg, int kslice, T* dst, int pack_row = -1) {
     // NI float4 per lane cover the row (d <= NI*256); lanes past the end load a clamped (valid) address and are masked,
     // so no load sits behind a divergent branch: all of them are in flight together.
     const int d = g.K;
@@ -122,8 +124,9 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
     for (int i = 0; i < NI; i++) {
         const int c = cc[i];
         if (ok[i] && c >= kbeg && c < kbeg + kslice) {
+            T* q = pack_row >= 0 ? dst + dec_wpack_off(pack_row, c, d) : dst + (c - kbeg);   // c is a multiple of 4: the four stay contiguous either way
 #pragma unroll
-            for (int e = 0; e < 4; e++) dst[(c - kbeg) + e] = (T)(v[i][e] * rstd * ww[i][e] + bb[i][e]);
+            for (int e = 0; e < 4; e++) q[e] = (T)(v[i][e] * rstd * ww[i][e] + bb[i][e]);
         }
     }
 }
@@ -132,7 +135,7 @@ __device__ __forceinline__ void ln_row(const DecGemvDesc& g, int m, int lane, bo
 template <typename T, int NI>
 __global__ __launch_bounds__(64) void dec_reduce_ln_kernel(DecGemvDesc g, T* out) {
     SS_CHAIN_PRIO_STMT
-    ln_row<T, NI>(g, blockIdx.x, threadIdx.x, true, 0, g.K, out + (long)blockIdx.x * g.K);
+    ln_row<T, NI>(g, blockIdx.x, threadIdx.x, true, 0, g.K, out, blockIdx.x);
 }
 
 // one output (token row m, output column n, whole-slice sum v) of a decode GEMV
@@ -143,7 +146,7 @@ __device__ __forceinline__ void dec_epilogue(const DecGemvDesc& g, int s, int m,
     } else {
         if (g.bias) v += g.bias[n];
         if constexpr (EPI == DEPI_GELU_T) {
-            ((T*)g.out)[(long)m * g.ldo + n] = (T)gelu_tanh_d(gelu_in_round_d<T>(v, g.gelu_f16_in));
+            ((T*)g.out)[dec_wpack_off(m, n, g.ldo)] = (T)gelu_tanh_d(gelu_in_round_d<T>(v, g.gelu_f16_in));   // FC2's B operand: fragment-major
         } else if constexpr (EPI == DEPI_LOGITS) {
             if (n < g.n_valid) ((float*)g.out)[(long)m * g.ldo + n] = v;
         } else if constexpr (EPI == DEPI_QKV) {
@@ -180,8 +183,8 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     V8 wf[NFR];
 #pragma unroll
     for (int f = 0; f < NFR; f++) wf[f] = SS_LDW((const V8*)(wp + f * 512));
-    // activations: B fragments straight from L2 into VGPRs (no LDS staging, no barrier before the MFMAs).  Token rows >= M read row 0: MFMA
-    // columns are independent and never stored.  Two column tiles' loads are in flight at a time (CT = 4: 2 + 2, to stay under 168 VGPRs).
+    // activations: B fragments straight from L2 into VGPRs (no LDS staging, no barrier before the MFMAs), fragment-major like the weights:
+    // one contiguous kilobyte per load.  Token rows >= M hold stale finite values: MFMA columns are independent and never stored.  Two column tiles' loads are in flight at a time (CT = 4: 2 + 2, to stay under 168 VGPRs).
     f32x4 acc[CT];
 #pragma unroll
     for (int c0 = 0; c0 < CT; c0 += 2) {
@@ -189,10 +192,10 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
         V8 xf[CB][NFR];
 #pragma unroll
         for (int ct = 0; ct < CB; ct++) {
-            const int m = (c0 + ct) * 16 + frow;
-            const T* xg = (const T*)g.Xt + (long)(m < g.M ? m : 0) * g.ldx + kbeg;
+            const int mt = (c0 + ct) * 16 < g.M ? c0 + ct : 0;          // a column tile wholly beyond M reads tile 0: its MFMA columns are never stored
+            const T* xg = (const T*)g.Xt + (((long)mt * (g.ldx >> 5) + (kbeg >> 5)) * 64 + lane) * 8;
 #pragma unroll
-            for (int f = 0; f < NFR; f++) xf[ct][f] = *(const V8*)(xg + f * 32 + fg * 8);
+            for (int f = 0; f < NFR; f++) xf[ct][f] = *(const V8*)(xg + f * 512);
         }
         __builtin_amdgcn_sched_barrier(0);     // every load above is issued before the first MFMA below (left alone, hipcc trickles them in between the MFMAs to save registers)
 #pragma unroll
@@ -476,7 +479,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
     }
     __syncthreads();
     if constexpr (NSPLIT == 1) {
-        if (tid < 64) out_direct[(long)m * d + h * 64 + tid] = (T)((s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid]) / sum);
+        if (tid < 64) out_direct[dec_wpack_off(m, h * 64 + tid, d)] = (T)((s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid]) / sum);   // the out-projection's B operand
     } else {
         float* part = scratch + ((long)(m * H + h) * kCrossSplitD + sp) * kCrossPartD;
         if (tid < 64) part[2 + tid] = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
@@ -640,7 +643,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q8_kernel(const float* __r
     }
     __syncthreads();
     if constexpr (NSPLIT == 1) {
-        if (tid < 64) out_direct[(long)m * d + h * 64 + tid] = (T)((s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid]) / sum);
+        if (tid < 64) out_direct[dec_wpack_off(m, h * 64 + tid, d)] = (T)((s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid]) / sum);
     } else {
         float* part = scratch + ((long)(m * H + h) * kCrossSplitD + sp) * kCrossPartD;
         if (tid < 64) part[2 + tid] = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
