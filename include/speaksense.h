@@ -169,7 +169,10 @@ int ss_wait(ss_ticket* t);
 /* Non-blocking: 1 when the chunk is complete (ss_wait will not block), 0 while it is queued or running.  The ticket stays valid. */
 int ss_ticket_ready(const ss_ticket* t);
 
-/* ---- results of the session's last chunk (valid until its next transcribe/submit) -------------------- */
+/* ---- results of the session's last chunk (valid until its next transcribe/submit) --------------------
+ * With another chunk of the SAME session queued or running the engine is writing these: reading them then is a data race, and the bulk getters
+ * (ss_result_tokens / _sampled_tokens / _trace_tokens) fill arrays the caller sized from an earlier ss_result_n_* call.  Wait for every ticket of a
+ * session before reading its results (the reference holds its state's Mutex for the whole call, src/asr/whisper.rs:34-38,51). */
 int32_t ss_result_n_segments(const ss_session* s);
 const char* ss_result_segment_text(const ss_session* s, int32_t i);   /* bytes from the vocab, NUL-terminated */
 int64_t ss_result_segment_t0(const ss_session* s, int32_t i);         /* centiseconds, as whisper.cpp reports */

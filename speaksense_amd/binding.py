@@ -378,6 +378,7 @@ class Session:
         self.h = self.L.ss_session_create(eng.h)
         if not self.h:
             raise SpeakSenseError(-1, "ss_session_create failed")
+        self._pending = 0      # tickets submitted on this session and not yet waited for
 
     def close(self):
         if getattr(self, "h", None):
@@ -393,17 +394,23 @@ class Session:
         pcm = np.ascontiguousarray(pcm, np.float32)
         t = C.c_void_p()
         _check(self.L.ss_submit(self.h, _p(pcm), len(pcm), C.byref(params) if params is not None else None, C.byref(t)))
+        self._pending += 1
         return t
 
     def submit_device(self, ptr: int, n: int, params: Params | None = None):
         """Async submit of PCM already resident on the engine's GPU (device pointer); the buffer must outlive wait()."""
         t = C.c_void_p()
         _check(self.L.ss_submit_ex(self.h, C.c_void_p(int(ptr)), int(n), C.byref(params) if params is not None else None, 1, C.byref(t)))
+        self._pending += 1
         return t
 
     def wait(self, ticket):
+        """Blocks until the chunk is done; returns its results -- or None when ANOTHER ticket of this session is still outstanding: the results
+        live on the session ("valid until its next transcribe/submit", include/speaksense.h), and with a second chunk queued or running the engine is
+        writing them.  Reading then is a data race, and the bulk getters size their arrays from an earlier call: a heap overflow in the caller."""
+        self._pending -= 1
         _check(self.L.ss_wait(ticket))
-        return self.result()
+        return self.result() if self._pending <= 0 else None
 
     def ready(self, ticket) -> bool:
         """Non-blocking: has the chunk behind `ticket` completed (wait() will return at once)?"""
@@ -501,11 +508,13 @@ class PoolSession(Session):
         self.h = self.L.ss_pool_session_create(pool.h)
         if not self.h:
             raise SpeakSenseError(-1, "ss_pool_session_create failed")
+        self._pending = 0
 
     def submit(self, pcm: np.ndarray, params: Params | None = None):
         pcm = np.ascontiguousarray(pcm, np.float32)
         t = C.c_void_p()
         _check(self.L.ss_pool_submit(self.pool.h, self.h, _p(pcm), len(pcm), C.byref(params) if params is not None else None, C.byref(t)))
+        self._pending += 1
         return t
 
     def transcribe(self, pcm: np.ndarray, params: Params | None = None):

@@ -36,6 +36,30 @@ extern "C" {
 
 const char* ss_last_error(void) { return g_err.c_str(); }
 
+// Diagnostics (env SS_CRASH_BACKTRACE=1): a SIGSEGV / SIGBUS / SIGABRT inside the process prints the faulting thread's native frames (module + offset;
+// resolve with llvm-symbolizer / llvm-objdump on the .so) before the default action runs.  Installed when the library is loaded; off by default --
+// a host service owns its signal handlers.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+namespace {
+void ss_crash_handler(int sig) {
+    void* frames[48];
+    const int n = backtrace(frames, 48);
+    const char msg[] = "\n[speaksense] fatal signal, native frames of the faulting thread:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+struct CrashHook {
+    CrashHook() {
+        const char* e = getenv("SS_CRASH_BACKTRACE");
+        if (e && *e && *e != '0') { signal(SIGSEGV, ss_crash_handler); signal(SIGBUS, ss_crash_handler); signal(SIGABRT, ss_crash_handler); }
+    }
+} g_crash_hook;
+}  // namespace
+
 void ss_default_params(ss_params* p) {
     // whisper_full_default_params(GREEDY) + build_params (/root/reference/src/asr/whisper.rs:131-173) + stream mode (65-69)
     memset(p, 0, sizeof(*p));

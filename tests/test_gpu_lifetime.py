@@ -170,6 +170,7 @@ def test_soak_random_interleavings(toy_ml_path):
                           # (engine.cpp kMaxStepGraphs per lane) during the first part; what must not happen is growth that keeps going
         stats = dict(chunks=0, refused=0, abandoned=0, freed_in_flight=0, checked=0)
         errors = []
+        mismatches = []
         st_lock = threading.Lock()
 
         def worker(wid):
@@ -206,16 +207,24 @@ def test_soak_random_interleavings(toy_ml_path):
                                 stats["freed_in_flight"] += 1
                             continue
                         exp = expected(k)
+                        full = None
                         try:
-                            got = ("ok", _key(s.wait(t)))
+                            full = s.wait(t)            # None while the session's other ticket is outstanding: its results are being written
+                            got = ("ok", _key(full) if full is not None else None)
                         except binding.SpeakSenseError as e:
                             got = ("err", e.code)
-                        # a session with two tickets holds the results of whichever chunk ran last: only the status is comparable then
+                        # a session with two tickets holds the results of whichever chunk ran last, and may only be read once BOTH are done (the
+                        # results are "valid until the next submit": reading them with the other chunk in flight races with the engine -- this test
+                        # did, until r04, and corrupted its own heap about once in three 90 s runs): only the status is compared
                         two = sum(1 for s2, _, _ in pending if s2 is s) > 1
                         if two:
                             assert got[0] == exp[0], (k, got[0], exp[0])
-                        else:
-                            assert got == exp, (k, got, exp)
+                        elif got != exp:
+                            # same (audio, parameters), other batch-mates: the row count of a pass selects kernel variants and split-K plans, i.e. the
+                            # f32 summation order, and a pick inside the f16 noise of its runner-up may then differ.  Kept and PROVEN after the run.
+                            assert got[0] == exp[0] == "ok", (k, got[0], exp[0])
+                            with st_lock:
+                                mismatches.append((k, full))
                         with st_lock:
                             stats["chunks"] += 1; stats["checked"] += not two; stats["refused"] += got[0] == "err"
                     for s in ses:
@@ -239,6 +248,27 @@ def test_soak_random_interleavings(toy_ml_path):
             t.join(timeout=seconds + 240)
             assert not t.is_alive(), "soak: a thread hung"
         assert not errors, errors
+        if mismatches:
+            # every result that differs from the serial one must be a proven near tie: the engine's stream replayed on the oracle stays within the f16
+            # margin at every step and reproduces the engine's windows, segments and timestamps (tests/test_gpu_parity.py check_against_oracle)
+            from oracle import binding as orc
+            from test_gpu_parity import GAP_TOL_F16, check_against_oracle
+            om = orc.OracleModel(toy_ml_path)
+            seen = set()
+            for k, full in mismatches:
+                sig = (k, tuple(int(t) for t in full["tokens"]))
+                if sig in seen:
+                    continue
+                seen.add(sig)
+                kw = dict(language="en", temperature_inc=0.0)
+                kw.update(variants[k[1]])
+                if kw["temperature_inc"] > 0.0:
+                    continue      # a fallback chunk's sampled attempts depend on which attempt failed: covered by the trace-replay tests, not here
+                check_against_oracle(full, om, orc, orc.MODE_GGML_F16, audio[k[0]], orc.default_params(**kw), f"soak {k}", GAP_TOL_F16, replay_only=True)
+            om.close()
+            from conftest import report as _report
+            _report(f"soak: {len(mismatches)} of {stats['checked']} checked results differed from the serial run of the same chunk by a proven near tie ({len(seen)} distinct)")
+            assert len(mismatches) <= max(3, stats["checked"] // 50), (len(mismatches), stats["checked"])
         free1, _ = eng.mem_info()
         from conftest import report
         q1, q2, q3 = (mem.get(i, free1) for i in (1, 2, 3))
@@ -247,6 +277,8 @@ def test_soak_random_interleavings(toy_ml_path):
         # second half: at most 64 MiB (r04_g: 34 MiB between 40 % and 100 % of a 60 s run while the three lanes were still filling their graph LRUs) and
         # not more than the first half took -- a leak grows linearly, a cache fills and stops
         assert q2 - free1 < 64 << 20, f"device memory grew by {(q2 - free1) >> 20} MiB over the second half of the run"
-        assert (q2 - free1) <= max(16 << 20, 2 * (q1 - q2) + (16 << 20)), f"growth does not flatten: {(q1 - q2) >> 20} MiB in the second quarter, {(q2 - free1) >> 20} MiB in the second half"
+        # (hipMemGetInfo moves by +-30 MiB between two samples of a steady run -- graph LRU turnover, the runtime's own pools: r04_av, five 90 s runs --
+        # so quarter-to-quarter comparisons are noise; a leak of even one staging buffer per thousand chunks would be > 100 MiB over the second half)
+        assert (q1 - free1) < 96 << 20, f"device memory grew by {(q1 - free1) >> 20} MiB from 25 % of the run to its end"
     finally:
         eng.close()
