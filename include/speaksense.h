@@ -288,6 +288,10 @@ int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[6], i
 int ss_engine_lane_counters(const ss_engine* e, int32_t lane, int64_t out_cnt[6]);
 /* hipMemGetInfo on the engine's device: bytes free / total (leak checks of the soak test; a service's health endpoint) */
 int ss_engine_mem_info(const ss_engine* e, int64_t* free_bytes, int64_t* total_bytes);
+/* Element offset of entry (row n, column k) of a [N][K] matrix in the fragment-major layout the decode-step GEMVs read their weights and their
+ * activation rows in (kernels.h dec_wpack_off: the 16 x 32 block one MFMA 16x16x32 consumes is one contiguous kilobyte).  Host only, no GPU: the
+ * layout is a permutation of [0, N K) for N % 16 == 0, K % 32 == 0, which the CPU tests check.  Returns -1 on a bad argument. */
+int64_t ss_dec_weight_offset(int64_t n, int32_t k, int32_t K);
 /* average device time (ms) of `reps` launches of the dominant encoder GEMM (FC1: M=batch*1500, N=4d, K=d) on the
  * engine's stream, and its algorithmic FLOPs per launch: the roofline probe bench.py reports. */
 int ss_engine_probe_gemm(ss_engine* e, int32_t batch, int32_t reps, float* avg_ms, double* flops_per_launch);

@@ -341,6 +341,10 @@ int ss_session_rng_discard(ss_session* s, int64_t n) {
 }
 
 int32_t ss_mel_n_len(int32_t n_samples) { return mel_n_len(n_samples); }
+int64_t ss_dec_weight_offset(int64_t n, int32_t k, int32_t K) {
+    if (n < 0 || k < 0 || K <= 0 || k >= K || K % 32) return -1;
+    return dec_wpack_off(n, k, K);
+}
 int ss_signal_energy(ss_engine* e, const float* pcm, int32_t n, float* out) {
     if (!e || !pcm || !out || n <= 0) return fail(SS_ERR_ARG, "ss_signal_energy: bad argument");
     SS_TRY e->e->signal_energy_host(pcm, n, out); return SS_OK; SS_CATCH

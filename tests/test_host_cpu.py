@@ -298,3 +298,45 @@ def test_whisper_cpp_comparison_runner_parses_ojf(tmp_path):
         w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(x.tobytes())
     pcm = m.read_wav_16k_mono(p)
     assert pcm.dtype == np.float32 and len(pcm) == 16000 and abs(float(np.abs(pcm).max()) - 12000 / 32768) < 1e-3
+
+
+def test_decoder_weight_layout_is_a_permutation():
+    """The fragment-major layout the decode-step GEMVs read (kernels.h dec_wpack_off, exported as ss_dec_weight_offset): for N % 16 == 0 and
+    K % 32 == 0 every (row, column) maps to a distinct offset in [0, N K); the 16 x 32 block one MFMA 16x16x32 consumes is one contiguous
+    kilobyte (512 elements) in lane order, 8 consecutive k per lane; 4 consecutive k of a row stay contiguous (the embedding gather and the
+    LayerNorm store rely on it)."""
+    from speaksense_amd import binding
+    L = ctypes.CDLL(binding.LIB_PATH)
+    L.ss_dec_weight_offset.restype = ctypes.c_int64
+    L.ss_dec_weight_offset.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+    off = lambda n, k, K: int(L.ss_dec_weight_offset(n, k, K))
+    for N, K in ((16, 32), (48, 128), (32, 1280), (160, 384)):
+        seen = np.zeros(N * K, np.int32)
+        for n in range(N):
+            for k in range(K):
+                o = off(n, k, K)
+                assert 0 <= o < N * K
+                seen[o] += 1
+        assert (seen == 1).all(), (N, K)
+    K = 1280
+    for t, b in ((0, 0), (3, 7), (9, 39)):                       # fragment (tile t, 32-k block b) = elements [base, base + 512)
+        base = (t * (K // 32) + b) * 512
+        for lane in range(64):
+            n, kk = 16 * t + (lane & 15), 32 * b + 8 * (lane >> 4)
+            assert [off(n, kk + e, K) for e in range(8)] == list(range(base + 8 * lane, base + 8 * lane + 8))
+    assert off(5, 3, 100) == -1 and off(-1, 0, 32) == -1 and off(0, 32, 32) == -1     # K not a multiple of 32 / out of range
+
+
+def test_session_wait_withholds_results_while_another_ticket_is_outstanding():
+    """binding.Session bookkeeping (no GPU): results live on the session and are "valid until its next transcribe/submit" (include/speaksense.h); with
+    a second ticket outstanding wait() returns None instead of reading what the engine may be writing."""
+    from speaksense_amd import binding
+
+    class FakeLib:
+        def ss_wait(self, t): return 0
+    s = binding.Session.__new__(binding.Session)
+    s.L, s.h, s._pending = FakeLib(), 1, 0
+    s.result = lambda: {"tokens": [1, 2, 3]}
+    s._pending = 2                       # two tickets submitted
+    assert s.wait(object()) is None      # the other one is still outstanding
+    assert s.wait(object()) == {"tokens": [1, 2, 3]}
