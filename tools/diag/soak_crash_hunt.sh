@@ -1,7 +1,11 @@
-# the soak test, repeated, against a build of the host side with -D_GLIBCXX_ASSERTIONS (bounds-checked std::vector / std::string) and the library's crash
-# hook on: stops at the first run that dies of a signal and prints its native frames (dev tool, GPU box).  Build (dev container):
-#   for s in engine.cpp capi.cpp model.cpp whisper_compat.cpp: hipcc --offload-arch=gfx950 -O2 -g -std=c++17 -fPIC -D_GLIBCXX_ASSERTIONS -x hip -c ... -o /tmp/assert_obj/$s.o
-#   hipcc --offload-arch=gfx950 -shared -fPIC -o speaksense_amd/libspeaksense_hip_assert.so /tmp/assert_obj/*.o speaksense_amd/build/*.hip.o -lpthread
+# The soak test, repeated, with the library's crash hook on (SS_CRASH_BACKTRACE=1: native frames of the faulting thread on SIGSEGV / SIGBUS / SIGABRT):
+# stops at the first run that dies of a signal and prints its frames (dev tool, GPU box).
+#   gpurun --timeout 1200 -- 'bash tools/diag/soak_crash_hunt.sh'
+# To look for container overruns in the host side, point SS_LIB_PATH at a build of engine.cpp / capi.cpp / model.cpp / whisper_compat.cpp with
+# -D_GLIBCXX_ASSERTIONS (bounds-checked std::vector / std::string) linked with the product's kernels_*.hip.o:
+#   for s in engine.cpp capi.cpp model.cpp whisper_compat.cpp; do hipcc --offload-arch=gfx950 -O2 -g -std=c++17 -fPIC -D_GLIBCXX_ASSERTIONS -x hip -c speaksense_amd/csrc/$s -o /tmp/a/$s.o; done
+#   hipcc --offload-arch=gfx950 -shared -fPIC -o speaksense_amd/libspeaksense_hip_assert.so /tmp/a/*.o speaksense_amd/build/*.hip.o -lpthread
+# (ROCm's AddressSanitizer runtime intercepts HSA allocations and did not come up on this image; rocgdb changed the timing enough to hide the fault.)
 cd $GRAFT_REPO_ROOT
 export SS_SOAK_SECONDS=${SS_SOAK_SECONDS:-90} SS_CRASH_BACKTRACE=1
 for i in 1 2 3 4 5; do
