@@ -160,7 +160,7 @@ def mode_n_leg(args, device: int, dtype_code: int, n_chunks: int, rounds: int = 
             "tokens_per_chunk": {"min": int(min(ntok)), "median": int(np.median(ntok)), "max": int(max(ntok))},
             "windows_per_chunk": round(float(np.mean(nwin)), 2), "windows_at_temperature_0": round(1.0 - sum(nfail) / max(1, sum(nwin)), 3),
             "distinct_streams": len(set(ref.values())), "chunks": n_chunks,
-            "repeats_identical_to_first_run": f"{same}/{len(res)} (the row count of a pass selects the kernels: a pick inside the f16 noise of its runner-up may differ between compositions)",
+            "repeats_identical_to_first_run": f"{same}/{len(res)} (batch invariance: a row's bits do not depend on what shares its decoder pass, tests/test_gpu_batch_invariance.py)",
             "decoder_passes": d["decoder_passes"], "rows_per_pass": round(d["decoder_rows"] / max(1, d["decoder_passes"]), 2),
             "admitted_into_running_groups": d["admitted"], "windows_started_midway": d["started_midway"],
             "phase_ms_total": {"encode_cross_kv": round(d["encode_ms"], 1), "decode": round(d["decode_ms"], 1)}}

@@ -845,18 +845,18 @@ struct EngineT : EngineBase {
             const bool direct = M * H >= direct_pairs;
             launch_dec_self_attention<T>(qd.as<T>(), kself.as<T>() + il * layer_stride, vself.as<T>() + il * layer_stride, slot_stride, d, H, ctl, M,
                                          attd.as<T>(), st);
-            const int n_qpart = lnf ? 1 : pl_dd.S;
+            const int n_qpart = pl_dd.S;   // the same split-K plan whatever the row count: a row's q bits must not depend on the pass it rides in
             {
                 {   // attention out-projection, split-K partials
                     DecGemvDesc g = dgd(PRO_T, DEPI_PART, e.wo, M, d, d, pl_dd.S);
                     g.Xt = attd.p; g.ldx = d; g.part_out = p1.as<float>();
                     launch_dec_gemv<T>(g, pl_dd.NW, st);
                 }
-                if (lnf) {   // x += bo + sum P1; LNc; cross query (one unsplit partial slot) in one launch
-                    DecGemvDesc g = dgd(PRO_LN, DEPI_PART, e.wcq, M, d, d, 1);
+                if (lnf) {   // x += bo + sum P1; LNc; cross query (the S-way partials of the wide form) in one launch
+                    DecGemvDesc g = dgd(PRO_LN, DEPI_PART, e.wcq, M, d, d, pl_dd.S);
                     g.x_in = xcur; g.x_out = xnext; g.parts = p1.as<float>(); g.n_parts = pl_dd.S; g.bias_prev = e.bo; g.ln_w = e.lncw; g.ln_b = e.lncb;
                     g.part_out = pq.as<float>();
-                    launch_dec_gemv_ln<T>(g, pl_qkv.NW, st);
+                    launch_dec_gemv_ln<T>(g, pl_dd.NW, st);
                     std::swap(xcur, xnext);
                 } else {
                 // x += bo + sum P1; LNc -> cross query partials (reduced, biased and scaled inside the cross-attention kernel)

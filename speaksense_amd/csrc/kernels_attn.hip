@@ -342,39 +342,6 @@ void launch_dec_self_attention(const T* q, const T* kcache, const T* vcache, lon
 template void launch_dec_self_attention<bf16>(const bf16*, const bf16*, const bf16*, long, int, int, const RowCtl*, int, bf16*, hipStream_t);
 template void launch_dec_self_attention<f16>(const f16*, const f16*, const f16*, long, int, int, const RowCtl*, int, f16*, hipStream_t);
 
-// ---------------------------------------------------------------------------------------------
-// decoder cross-attention, second half: flash-decoding combine of the key-split partials (max, sum, o[64]) that dec_cross_attn_q_kernel
-// (kernels_decode.hip; grid (NSPLIT, H, M)) leaves in scratch
-// ---------------------------------------------------------------------------------------------
-constexpr int kCrossSplit = 4;
-constexpr int kCrossPart = 66;  // floats per partial: m, l, o[64]
-
-template <typename T>
-__global__ void dec_cross_combine_kernel(const float* __restrict__ scratch, int d, int H, T* __restrict__ out) {
-    __builtin_amdgcn_s_setprio(3);
-    const int m = blockIdx.x;
-    for (int col = threadIdx.x; col < d; col += blockDim.x) {
-        const int h = col >> 6, j = col & 63;
-        const float* part = scratch + (long)(m * H + h) * kCrossSplit * kCrossPart;
-        float mx = -1e30f;
-#pragma unroll
-        for (int s = 0; s < kCrossSplit; s++) mx = fmaxf(mx, part[s * kCrossPart]);
-        float num = 0.f, den = 0.f;
-#pragma unroll
-        for (int s = 0; s < kCrossSplit; s++) {
-            const float w = __expf(part[s * kCrossPart] - mx);
-            num += w * part[s * kCrossPart + 2 + j];
-            den += w * part[s * kCrossPart + 1];
-        }
-        out[dec_wpack_off(m, col, d)] = (T)(num / den);
-    }
-}
-
-template <typename T>
-void launch_dec_cross_combine(const float* scratch, int d, int H, int M, T* out, hipStream_t st) {
-    dec_cross_combine_kernel<T><<<M, 256, 0, st>>>(scratch, d, H, out); SS_LAUNCH_CHECK();
-}
-template void launch_dec_cross_combine<bf16>(const float*, int, int, int, bf16*, hipStream_t);
-template void launch_dec_cross_combine<f16>(const float*, int, int, int, f16*, hipStream_t);
+// (the flash-decoding combine of the cross-attention partials lives beside the kernel that produces them: kernels_decode.hip)
 
 }  // namespace ss

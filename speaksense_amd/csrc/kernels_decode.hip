@@ -225,6 +225,9 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
 // LayerNorm-prologue form for M <= 16 rows (dispatched for M <= kLnFuseRows): the weight fragments are requested FIRST, then the waves normalise
 // the rows into LDS (wave per row, ln_row) while those loads are in flight, then the B fragments come from LDS.  Workgroup (0, 0) also writes the
 // updated residual stream (x_out is the other half of a ping-pong pair, so the other workgroups still read the old rows).
+// The k ranges of the split-K slices and of the waves, and the order in which a column's wave sums are added, are those of dec_gemv_kernel for the
+// same (S, NW) plan: a row computed here (<= kLnFuseRows rows in the pass) has the bits it gets from the dec_reduce_ln + dec_gemv pair in a
+// wider pass (batch invariance, round 5; the engine therefore launches the cross-query projection with the S-way plan in both forms).
 template <typename T, int EPI, int NFR, int NI>
 __global__ __launch_bounds__(256) void dec_gemv_ln_kernel(DecGemvDesc g) {
     SS_CHAIN_PRIO_STMT
@@ -232,8 +235,8 @@ __global__ __launch_bounds__(256) void dec_gemv_ln_kernel(DecGemvDesc g) {
     extern __shared__ __attribute__((aligned(16))) char smem_d[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NW = blockDim.x >> 6;
     const int frow = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int kbeg = wave * (32 * NFR);
+    const int n0 = blockIdx.x * 16, s = blockIdx.y;            // s: split-K slice (DEPI_PART only), the same slices and wave ranges as dec_gemv_kernel
+    const int kbeg = s * (g.K / g.S) + wave * (32 * NFR);
     const int xld = g.K + 8;                                   // row stride in T elements: 16-B aligned rows, banks spread
     T* xs = (T*)smem_d;                                        // [16][xld]
     float* red = (float*)(smem_d + (size_t)16 * xld * sizeof(T));   // [NW][16][17]
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void dec_gemv_ln_kernel(DecGemvDesc g) {
 #pragma unroll
     for (int f = 0; f < NFR; f++) wf[f] = SS_LDW((const V8*)(wp + f * 512));
     for (int m = wave; m < 16; m += NW) {
-        if (m < g.M) ln_row<T, NI>(g, m, lane, blockIdx.x == 0, 0, g.K, xs + (long)m * xld);
+        if (m < g.M) ln_row<T, NI>(g, m, lane, blockIdx.x == 0 && blockIdx.y == 0, 0, g.K, xs + (long)m * xld);
         else for (int c = lane * 8; c < g.K; c += 512) *(V8*)(xs + (long)m * xld + c) = V8{};      // unused MFMA columns: finite values
     }
     __syncthreads();
@@ -260,14 +263,14 @@ __global__ __launch_bounds__(256) void dec_gemv_ln_kernel(DecGemvDesc g) {
         if (m < g.M && n < g.N) {
             float v = 0.f;
             for (int w = 0; w < NW; w++) v += red[(w * 16 + m) * 17 + nn];
-            dec_epilogue<T, EPI>(g, 0, m, n, v);
+            dec_epilogue<T, EPI>(g, s, m, n, v);
         }
     }
 }
 template <typename T, int EPI, int NFR>
 static void launch_dgl2(const DecGemvDesc& g, int NW, hipStream_t st) {
     const size_t lds = (size_t)16 * (g.K + 8) * sizeof(T) + (size_t)NW * 16 * 17 * 4;
-    dim3 grid(g.N / 16, 1);
+    dim3 grid(g.N / 16, g.S);
     if (g.K <= 512) dec_gemv_ln_kernel<T, EPI, NFR, 2><<<grid, NW * 64, lds, st>>>(g);
     else if (g.K <= 1280) dec_gemv_ln_kernel<T, EPI, NFR, 5><<<grid, NW * 64, lds, st>>>(g);
     else dec_gemv_ln_kernel<T, EPI, NFR, 8><<<grid, NW * 64, lds, st>>>(g);
@@ -275,7 +278,7 @@ static void launch_dgl2(const DecGemvDesc& g, int NW, hipStream_t st) {
 }
 template <typename T, int EPI>
 static void launch_dgl(const DecGemvDesc& g, int NW, hipStream_t st) {
-    switch ((g.K / NW) / 32) {
+    switch (((g.K / g.S) / NW) / 32) {
         case 1: launch_dgl2<T, EPI, 1>(g, NW, st); break;
         case 2: launch_dgl2<T, EPI, 2>(g, NW, st); break;
         case 3: launch_dgl2<T, EPI, 3>(g, NW, st); break;
@@ -365,8 +368,10 @@ void launch_dec_gemv(const DecGemvDesc& g, int NW, hipStream_t st) {
 template <typename T>
 void launch_dec_gemv_ln(const DecGemvDesc& g, int NW, hipStream_t st) {
     if (NW < 1 || NW > 4 || (NW & (NW - 1))) throw Error(-1, "dec_gemv_ln: bad wave count");
-    if (g.M < 1 || g.M > 16 || g.N % 16 || g.S != 1 || g.K % NW || (g.K / NW) % 32 || g.K / NW > 320 || g.K > 2048 || g.K % 8 || g.n_parts > 4)
+    if (g.M < 1 || g.M > 16 || g.N % 16 || g.S < 1 || g.K % g.S || (g.K / g.S) % NW || ((g.K / g.S) / NW) % 32 || (g.K / g.S) / NW > 320 || g.K > 2048 ||
+        g.K % 8 || g.n_parts > 4)
         throw Error(-1, "dec_gemv_ln: bad shape");
+    if (g.epi != DEPI_PART && g.S != 1) throw Error(-1, "dec_gemv_ln: direct epilogues need S == 1");
     switch (g.epi) {
         case DEPI_PART: launch_dgl<T, DEPI_PART>(g, NW, st); break;
         case DEPI_QKV: launch_dgl<T, DEPI_QKV>(g, NW, st); break;
@@ -381,22 +386,44 @@ template void launch_dec_gemv<bf16>(const DecGemvDesc&, int, hipStream_t);
 template void launch_dec_gemv<f16>(const DecGemvDesc&, int, hipStream_t);
 
 // ---------------------------------------------------------------------------------------------
-// cross-attention with the q projection's split-K reduction in its prologue
-// grid (4 key splits, H, M), 256 threads.  q = round_T((sum_s qpart[s][m][:] + bias) * scale)
+// cross-attention with the q projection's split-K reduction in its prologue.  q = round_T((sum_s qpart[s][m][:] + bias) * scale)
+//
+// BATCH INVARIANCE (round 5): the 1500 keys are ALWAYS walked as the same kCrossSplitD = 4 ranges, each with its own max / sum / o[64] computed
+// in one fixed operand order, and the four partials are ALWAYS merged by cross_combine() below.  NR = 1: grid (4, H, M), one range per
+// workgroup, partials through scratch, dec_cross_combine_kernel merges (few rows: the splits fill the chip).  NR = 4: grid (1, H, M), one
+// workgroup walks all four ranges and merges them itself (rows x heads >= 320: no partials, no combine launch).  Both forms execute the same
+// floating-point operations on the same operands in the same order, so a row's output bits do not depend on how many other rows share its
+// pass -- what state.full() guarantees per (state, audio) (/root/reference/src/asr/whisper.rs:75).  Rounds 2-4 ran the NR = 4 case as ONE
+// range (one max over 1500 keys): a different rounding of every p, i.e. results that depended on the batch.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NSPLIT>
+constexpr int kCrossRangeMax = 512;   // keys per range the LDS score buffer holds (n_audio_ctx <= 2048)
+
+__device__ __forceinline__ float cross_combine(const float mxs[kCrossSplitD], const float sums[kCrossSplitD], const float os[kCrossSplitD]) {
+    float mx = -1e30f;
+#pragma unroll
+    for (int s = 0; s < kCrossSplitD; s++) mx = fmaxf(mx, mxs[s]);
+    float num = 0.f, den = 0.f;
+#pragma unroll
+    for (int s = 0; s < kCrossSplitD; s++) {
+        const float w = __expf(mxs[s] - mx);
+        num = __builtin_fmaf(w, os[s], num);
+        den = __builtin_fmaf(w, sums[s], den);
+    }
+    return num / den;
+}
+
+template <typename T, int NR>
 __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __restrict__ qpart, int n_qpart, const float* __restrict__ qbias, float qscale,
                                                                const T* __restrict__ kc, const T* __restrict__ vc, long b_stride, int d, int H, int Tn,
                                                                const RowCtl* __restrict__ ctl, float* __restrict__ scratch, T* __restrict__ out_direct) {
     typedef typename MfmaD<T>::V8 V8;
-    __shared__ float s_sc[(NSPLIT == 1 ? 1536 : 512) + 128];
-    __shared__ float s_red[8];
-    __shared__ float s_o[4][64];
+    __shared__ float s_sc[NR * kCrossRangeMax];
+    __shared__ float s_red[2][NR][4];
+    __shared__ float s_o[NR][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 3, c = lane & 7;
-    const int sp = blockIdx.x, h = blockIdx.y, m = blockIdx.z;
-    const int per = (Tn + NSPLIT - 1) / NSPLIT;
-    const int k_beg = sp * per, k_end = min(Tn, k_beg + per), nk = k_end - k_beg;
+    const int h = blockIdx.y, m = blockIdx.z;
+    const int per = (Tn + kCrossSplitD - 1) / kCrossSplitD;
     const RowCtl rc = ctl[m];
     const T* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
     const T* V = vc + (long)rc.cross * b_stride + (long)h * Tn * 64;
@@ -416,83 +443,127 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
         for (int e = 0; e < 4; e++) { qv[e] = (float)(T)(a0[e] * qscale); qv[4 + e] = (float)(T)(a1[e] * qscale); }
     }
     // phase 1: scores.  One wave-instruction reads 8 key rows x 128 B; 4 independent loads in flight per lane
-    float mx = -1e30f;
-    const int nit = (nk + 31) / 32;
-    for (int it = 0; it < nit; it += 4) {
-        V8 kv[4];
-        int ii[4];
+    float mx[NR];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            ii[u] = (it + u) * 32 + wave * 8 + r;
-            kv[u] = SS_LDW((const V8*)(K + (long)(k_beg + (ii[u] < nk ? ii[u] : 0)) * 64 + c * 8));
-        }
+    for (int g = 0; g < NR; g++) {
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg, nit = (nk + 31) / 32;
+        float* sc = s_sc + g * kCrossRangeMax;
+        mx[g] = -1e30f;
+        for (int it = 0; it < nit; it += 4) {
+            V8 kv[4];
+            int ii[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            float a = 0.f;
+            for (int u = 0; u < 4; u++) {
+                ii[u] = (it + u) * 32 + wave * 8 + r;
+                kv[u] = SS_LDW((const V8*)(K + (long)(k_beg + (ii[u] < nk ? ii[u] : 0)) * 64 + c * 8));
+            }
 #pragma unroll
-            for (int e = 0; e < 8; e++) a += qv[e] * (float)kv[u][e];
-            a = sum_lanes8(a);
-            if (ii[u] < nk) {
-                if (c == 0) s_sc[ii[u]] = a;
-                mx = fmaxf(mx, a);
+            for (int u = 0; u < 4; u++) {
+                float a = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) a = __builtin_fmaf(qv[e], (float)kv[u][e], a);
+                a = sum_lanes8(a);
+                if (ii[u] < nk) {
+                    if (c == 0) sc[ii[u]] = a;
+                    mx[g] = fmaxf(mx[g], a);
+                }
             }
         }
     }
-    mx = wave_max(mx);
-    if (lane == 0) s_red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    float sum = 0.f;
-    for (int i = tid; i < nk; i += 256) {
-        const float p = (float)(T)__expf(s_sc[i] - mx);
-        s_sc[i] = p;
-        sum += p;
-    }
-    sum = wave_sum(sum);
-    if (lane == 0) s_red[4 + wave] = sum;
-    __syncthreads();
-    sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
-    // phase 2: o[c*8+e] += p[key] V[key][c*8+e]
-    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int it = 0; it < nit; it += 4) {
-        V8 vv[4];
-        float pw[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = (it + u) * 32 + wave * 8 + r;
-            const bool okk = i < nk;
-            vv[u] = SS_LDW((const V8*)(V + (long)(k_beg + (okk ? i : 0)) * 64 + c * 8));
-            pw[u] = okk ? s_sc[i] : 0.f;
+    for (int g = 0; g < NR; g++) {
+        mx[g] = wave_max(mx[g]);
+        if (lane == 0) s_red[0][g][wave] = mx[g];
+    }
+    __syncthreads();
+    float sum[NR];
+#pragma unroll
+    for (int g = 0; g < NR; g++) {
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg;
+        float* sc = s_sc + g * kCrossRangeMax;
+        mx[g] = fmaxf(fmaxf(s_red[0][g][0], s_red[0][g][1]), fmaxf(s_red[0][g][2], s_red[0][g][3]));
+        float sm = 0.f;
+        for (int i = tid; i < nk; i += 256) {
+            const float p = (float)(T)__expf(sc[i] - mx[g]);
+            sc[i] = p;
+            sm += p;
+        }
+        sm = wave_sum(sm);
+        if (lane == 0) s_red[1][g][wave] = sm;
+    }
+    __syncthreads();
+    // phase 2: o[c*8+e] += p[key] V[key][c*8+e]
+#pragma unroll
+    for (int g = 0; g < NR; g++) {
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg, nit = (nk + 31) / 32;
+        const float* sc = s_sc + g * kCrossRangeMax;
+        sum[g] = ((s_red[1][g][0] + s_red[1][g][1]) + s_red[1][g][2]) + s_red[1][g][3];
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int it = 0; it < nit; it += 4) {
+            V8 vv[4];
+            float pw[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = (it + u) * 32 + wave * 8 + r;
+                const bool okk = i < nk;
+                vv[u] = SS_LDW((const V8*)(V + (long)(k_beg + (okk ? i : 0)) * 64 + c * 8));
+                pw[u] = okk ? sc[i] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] = __builtin_fmaf(pw[u], (float)vv[u][e], acc[e]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++)
+        for (int e = 0; e < 8; e++) acc[e] = sum_stride8(acc[e]);
+        if (r == 0) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc[e] += pw[u] * (float)vv[u][e];
-    }
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        acc[e] = sum_stride8(acc[e]);
-    }
-    if (r == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) s_o[wave][c * 8 + e] = acc[e];
+            for (int e = 0; e < 8; e++) s_o[g][wave][c * 8 + e] = acc[e];
+        }
     }
     __syncthreads();
-    if constexpr (NSPLIT == 1) {
-        if (tid < 64) out_direct[dec_wpack_off(m, h * 64 + tid, d)] = (T)((s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid]) / sum);   // the out-projection's B operand
-    } else {
-        float* part = scratch + ((long)(m * H + h) * kCrossSplitD + sp) * kCrossPartD;
-        if (tid < 64) part[2 + tid] = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
-        if (tid == 0) { part[0] = mx; part[1] = sum; }
+    if (tid < 64) {
+        float os[NR];
+#pragma unroll
+        for (int g = 0; g < NR; g++) os[g] = ((s_o[g][0][tid] + s_o[g][1][tid]) + s_o[g][2][tid]) + s_o[g][3][tid];
+        if constexpr (NR == kCrossSplitD) {
+            out_direct[dec_wpack_off(m, h * 64 + tid, d)] = (T)cross_combine(mx, sum, os);   // the out-projection's B operand
+        } else {
+            static_assert(NR == 1, "one range per workgroup, or all of them");
+            float* part = scratch + ((long)(m * H + h) * kCrossSplitD + blockIdx.x) * kCrossPartD;
+            part[2 + tid] = os[0];
+            if (tid == 0) { part[0] = mx[0]; part[1] = sum[0]; }
+        }
     }
 }
+
+// flash-decoding combine of the key-split partials (max, sum, o[64]) the NR = 1 form leaves in scratch: out T [M][d], fragment-major
+template <typename T>
+__global__ void dec_cross_combine_kernel(const float* __restrict__ scratch, int d, int H, T* __restrict__ out) {
+    SS_CHAIN_PRIO_STMT
+    const int m = blockIdx.x;
+    for (int col = threadIdx.x; col < d; col += blockDim.x) {
+        const int h = col >> 6, j = col & 63;
+        const float* part = scratch + (long)(m * H + h) * kCrossSplitD * kCrossPartD;
+        float mxs[kCrossSplitD], sums[kCrossSplitD], os[kCrossSplitD];
+#pragma unroll
+        for (int s = 0; s < kCrossSplitD; s++) { mxs[s] = part[s * kCrossPartD]; sums[s] = part[s * kCrossPartD + 1]; os[s] = part[s * kCrossPartD + 2 + j]; }
+        out[dec_wpack_off(m, col, d)] = (T)cross_combine(mxs, sums, os);
+    }
+}
+template <typename T>
+void launch_dec_cross_combine(const float* scratch, int d, int H, int M, T* out, hipStream_t st) {
+    dec_cross_combine_kernel<T><<<M, 256, 0, st>>>(scratch, d, H, out); SS_LAUNCH_CHECK();
+}
+template void launch_dec_cross_combine<bf16>(const float*, int, int, int, bf16*, hipStream_t);
+template void launch_dec_cross_combine<f16>(const float*, int, int, int, f16*, hipStream_t);
 
 template <typename T>
 void launch_dec_cross_attention_direct(const float* qpart, int n_qpart, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d,
                                        int H, int Tn, const RowCtl* ctl, int M, T* out, hipStream_t st) {
-    if (Tn > 1536) throw Error(-1, "cross attention: n_audio_ctx too large");
+    if ((Tn + kCrossSplitD - 1) / kCrossSplitD > kCrossRangeMax) throw Error(-1, "cross attention: n_audio_ctx too large");
     dim3 grid(1, H, M);
-    dec_cross_attn_q_kernel<T, 1><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, nullptr, out); SS_LAUNCH_CHECK();
+    dec_cross_attn_q_kernel<T, kCrossSplitD><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, nullptr, out); SS_LAUNCH_CHECK();
 }
 template void launch_dec_cross_attention_direct<bf16>(const float*, int, const float*, float, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int,
                                                       bf16*, hipStream_t);
@@ -502,9 +573,9 @@ template void launch_dec_cross_attention_direct<f16>(const float*, int, const fl
 template <typename T>
 void launch_dec_cross_attention_q(const float* qpart, int n_qpart, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d, int H,
                                   int Tn, const RowCtl* ctl, int M, float* scratch, hipStream_t st) {
-    if ((Tn + kCrossSplitD - 1) / kCrossSplitD > 512) throw Error(-1, "cross attention: n_audio_ctx too large");
+    if ((Tn + kCrossSplitD - 1) / kCrossSplitD > kCrossRangeMax) throw Error(-1, "cross attention: n_audio_ctx too large");
     dim3 grid(kCrossSplitD, H, M);
-    dec_cross_attn_q_kernel<T, kCrossSplitD><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch, nullptr); SS_LAUNCH_CHECK();
+    dec_cross_attn_q_kernel<T, 1><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch, nullptr); SS_LAUNCH_CHECK();
 }
 template void launch_dec_cross_attention_q<bf16>(const float*, int, const float*, float, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int,
                                                  float*, hipStream_t);
@@ -517,20 +588,19 @@ template void launch_dec_cross_attention_q<f16>(const float*, int, const float*,
 // the exponent of a K row scales its score, the exponent of a V row is folded into its probability.  Arithmetic as the f16 kernel: q rounded
 // to T, scores and P.V accumulated in f32, p rounded to T.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NSPLIT>
+template <typename T, int NR>   // NR as in dec_cross_attn_q_kernel: the same four key ranges and the same combine whichever form runs
 __global__ __launch_bounds__(256) void dec_cross_attn_q8_kernel(const float* __restrict__ qpart, int n_qpart, const float* __restrict__ qbias, float qscale,
                                                                 const unsigned char* __restrict__ kc, const unsigned char* __restrict__ ksc, long b_stride,
                                                                 long sc_stride, int d, int H, int Tn, const RowCtl* __restrict__ ctl,
                                                                 float* __restrict__ scratch, T* __restrict__ out_direct) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    __shared__ float s_sc[(NSPLIT == 1 ? 1536 : 512) + 128];
-    __shared__ float s_red[8];
-    __shared__ float s_o[4][64];
+    __shared__ float s_sc[NR * kCrossRangeMax];
+    __shared__ float s_red[2][NR][4];
+    __shared__ float s_o[NR][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 2, c = lane & 3;            // 16 key rows x 4 chunks of 16 codes per wave-instruction
-    const int sp = blockIdx.x, h = blockIdx.y, m = blockIdx.z;
-    const int per = (Tn + NSPLIT - 1) / NSPLIT;
-    const int k_beg = sp * per, k_end = min(Tn, k_beg + per), nk = k_end - k_beg;
+    const int h = blockIdx.y, m = blockIdx.z;
+    const int per = (Tn + kCrossSplitD - 1) / kCrossSplitD;
     const RowCtl rc = ctl[m];
     // window layout: codes [kv][h][t][64], exponent bytes [kv][h][t]
     const unsigned char* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
@@ -556,112 +626,136 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q8_kernel(const float* __r
         float a = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            a += x[4 * j + 0] * __builtin_amdgcn_cvt_f32_fp8((int)w[j], 0);
-            a += x[4 * j + 1] * __builtin_amdgcn_cvt_f32_fp8((int)w[j], 1);
-            a += x[4 * j + 2] * __builtin_amdgcn_cvt_f32_fp8((int)w[j], 2);
-            a += x[4 * j + 3] * __builtin_amdgcn_cvt_f32_fp8((int)w[j], 3);
+            a = __builtin_fmaf(x[4 * j + 0], __builtin_amdgcn_cvt_f32_fp8((int)w[j], 0), a);
+            a = __builtin_fmaf(x[4 * j + 1], __builtin_amdgcn_cvt_f32_fp8((int)w[j], 1), a);
+            a = __builtin_fmaf(x[4 * j + 2], __builtin_amdgcn_cvt_f32_fp8((int)w[j], 2), a);
+            a = __builtin_fmaf(x[4 * j + 3], __builtin_amdgcn_cvt_f32_fp8((int)w[j], 3), a);
         }
         return a;
     };
-    // phase 1: scores
-    float mx = -1e30f;
-    const int nit = (nk + 63) / 64;                   // 64 keys per block iteration (4 waves x 16 rows)
-    for (int it = 0; it < nit; it += 4) {
-        u32x4 kw[4];
-        int ii[4];
-        unsigned char eb[4];
+    // phase 1: scores; 64 keys per block iteration (4 waves x 16 rows)
+    float mx[NR];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            ii[u] = (it + u) * 64 + wave * 16 + r;
-            const int kk = k_beg + (ii[u] < nk ? ii[u] : 0);
-            kw[u] = SS_LDW((const u32x4*)(K + (long)kk * 64 + c * 16));
-            eb[u] = KS[kk];
-        }
+    for (int g = 0; g < NR; g++) {
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg, nit = (nk + 63) / 64;
+        float* sc = s_sc + g * kCrossRangeMax;
+        mx[g] = -1e30f;
+        for (int it = 0; it < nit; it += 4) {
+            u32x4 kw[4];
+            int ii[4];
+            unsigned char eb[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            float a = dot16(kw[u], qv);
-            a += dpp_mov<kDppXor1>(a);
-            a += dpp_mov<kDppXor2>(a);
-            a *= __builtin_bit_cast(float, (unsigned)eb[u] << 23);
-            if (ii[u] < nk) {
-                if (c == 0) s_sc[ii[u]] = a;
-                mx = fmaxf(mx, a);
+            for (int u = 0; u < 4; u++) {
+                ii[u] = (it + u) * 64 + wave * 16 + r;
+                const int kk = k_beg + (ii[u] < nk ? ii[u] : 0);
+                kw[u] = SS_LDW((const u32x4*)(K + (long)kk * 64 + c * 16));
+                eb[u] = KS[kk];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                float a = dot16(kw[u], qv);
+                a += dpp_mov<kDppXor1>(a);
+                a += dpp_mov<kDppXor2>(a);
+                a *= __builtin_bit_cast(float, (unsigned)eb[u] << 23);
+                if (ii[u] < nk) {
+                    if (c == 0) sc[ii[u]] = a;
+                    mx[g] = fmaxf(mx[g], a);
+                }
             }
         }
     }
-    mx = wave_max(mx);
-    if (lane == 0) s_red[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-    float sum = 0.f;
-    for (int i = tid; i < nk; i += 256) {
-        const float p = (float)(T)__expf(s_sc[i] - mx);
-        s_sc[i] = p;
-        sum += p;
+#pragma unroll
+    for (int g = 0; g < NR; g++) {
+        mx[g] = wave_max(mx[g]);
+        if (lane == 0) s_red[0][g][wave] = mx[g];
     }
-    sum = wave_sum(sum);
-    if (lane == 0) s_red[4 + wave] = sum;
     __syncthreads();
-    sum = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    float sum[NR];
+#pragma unroll
+    for (int g = 0; g < NR; g++) {
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg;
+        float* sc = s_sc + g * kCrossRangeMax;
+        mx[g] = fmaxf(fmaxf(s_red[0][g][0], s_red[0][g][1]), fmaxf(s_red[0][g][2], s_red[0][g][3]));
+        float sm = 0.f;
+        for (int i = tid; i < nk; i += 256) {
+            const float p = (float)(T)__expf(sc[i] - mx[g]);
+            sc[i] = p;
+            sm += p;
+        }
+        sm = wave_sum(sm);
+        if (lane == 0) s_red[1][g][wave] = sm;
+    }
+    __syncthreads();
     // phase 2: o[c*16 + e] += p[key] * 2^(ev - 127) * code
-    float acc[16];
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0.f;
-    for (int it = 0; it < nit; it += 4) {
-        u32x4 vw[4];
-        float pw[4];
+    for (int g = 0; g < NR; g++) {
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg, nit = (nk + 63) / 64;
+        const float* sc = s_sc + g * kCrossRangeMax;
+        sum[g] = ((s_red[1][g][0] + s_red[1][g][1]) + s_red[1][g][2]) + s_red[1][g][3];
+        float acc[16];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int i = (it + u) * 64 + wave * 16 + r;
-            const bool okk = i < nk;
-            const int kk = k_beg + (okk ? i : 0);
-            vw[u] = SS_LDW((const u32x4*)(V + (long)kk * 64 + c * 16));
-            pw[u] = okk ? s_sc[i] * __builtin_bit_cast(float, (unsigned)VS[kk] << 23) : 0.f;
-        }
+        for (int e = 0; e < 16; e++) acc[e] = 0.f;
+        for (int it = 0; it < nit; it += 4) {
+            u32x4 vw[4];
+            float pw[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                acc[4 * j + 0] += pw[u] * __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 0);
-                acc[4 * j + 1] += pw[u] * __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 1);
-                acc[4 * j + 2] += pw[u] * __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 2);
-                acc[4 * j + 3] += pw[u] * __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 3);
+            for (int u = 0; u < 4; u++) {
+                const int i = (it + u) * 64 + wave * 16 + r;
+                const bool okk = i < nk;
+                const int kk = k_beg + (okk ? i : 0);
+                vw[u] = SS_LDW((const u32x4*)(V + (long)kk * 64 + c * 16));
+                pw[u] = okk ? sc[i] * __builtin_bit_cast(float, (unsigned)VS[kk] << 23) : 0.f;
             }
-    }
-    // sum over the 16 lanes that share lane & 3 (strides 4, 8, 16, 32)
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-        float a = acc[e];
-        a += dpp_mov<kDppRor4>(a);
-        a += dpp_mov<kDppRor8>(a);
-        a = rows_sum(a);
-        acc[e] = a;
-    }
-    if (r == 0) {
+            for (int u = 0; u < 4; u++)
 #pragma unroll
-        for (int e = 0; e < 16; e++) s_o[wave][c * 16 + e] = acc[e];
+                for (int j = 0; j < 4; j++) {
+                    acc[4 * j + 0] = __builtin_fmaf(pw[u], __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 0), acc[4 * j + 0]);
+                    acc[4 * j + 1] = __builtin_fmaf(pw[u], __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 1), acc[4 * j + 1]);
+                    acc[4 * j + 2] = __builtin_fmaf(pw[u], __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 2), acc[4 * j + 2]);
+                    acc[4 * j + 3] = __builtin_fmaf(pw[u], __builtin_amdgcn_cvt_f32_fp8((int)vw[u][j], 3), acc[4 * j + 3]);
+                }
+        }
+        // sum over the 16 lanes that share lane & 3 (strides 4, 8, 16, 32)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            float a = acc[e];
+            a += dpp_mov<kDppRor4>(a);
+            a += dpp_mov<kDppRor8>(a);
+            a = rows_sum(a);
+            acc[e] = a;
+        }
+        if (r == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) s_o[g][wave][c * 16 + e] = acc[e];
+        }
     }
     __syncthreads();
-    if constexpr (NSPLIT == 1) {
-        if (tid < 64) out_direct[dec_wpack_off(m, h * 64 + tid, d)] = (T)((s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid]) / sum);
-    } else {
-        float* part = scratch + ((long)(m * H + h) * kCrossSplitD + sp) * kCrossPartD;
-        if (tid < 64) part[2 + tid] = s_o[0][tid] + s_o[1][tid] + s_o[2][tid] + s_o[3][tid];
-        if (tid == 0) { part[0] = mx; part[1] = sum; }
+    if (tid < 64) {
+        float os[NR];
+#pragma unroll
+        for (int g = 0; g < NR; g++) os[g] = ((s_o[g][0][tid] + s_o[g][1][tid]) + s_o[g][2][tid]) + s_o[g][3][tid];
+        if constexpr (NR == kCrossSplitD) {
+            out_direct[dec_wpack_off(m, h * 64 + tid, d)] = (T)cross_combine(mx, sum, os);
+        } else {
+            static_assert(NR == 1, "one range per workgroup, or all of them");
+            float* part = scratch + ((long)(m * H + h) * kCrossSplitD + blockIdx.x) * kCrossPartD;
+            part[2 + tid] = os[0];
+            if (tid == 0) { part[0] = mx[0]; part[1] = sum[0]; }
+        }
     }
 }
 
 template <typename T>
 void launch_dec_cross_attention_f8(const float* qpart, int n_qpart, const float* qbias, float qscale, const unsigned char* kc, const unsigned char* ksc,
                                    long b_stride, long sc_stride, int d, int H, int Tn, const RowCtl* ctl, int M, float* scratch, T* out, hipStream_t st) {
+    if ((Tn + kCrossSplitD - 1) / kCrossSplitD > kCrossRangeMax) throw Error(-1, "cross attention: n_audio_ctx too large");
     if (scratch) {
-        if ((Tn + kCrossSplitD - 1) / kCrossSplitD > 512) throw Error(-1, "cross attention: n_audio_ctx too large");
         dim3 grid(kCrossSplitD, H, M);
-        dec_cross_attn_q8_kernel<T, kCrossSplitD><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, scratch, nullptr);
+        dec_cross_attn_q8_kernel<T, 1><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, scratch, nullptr);
     } else {
-        if (Tn > 1536) throw Error(-1, "cross attention: n_audio_ctx too large");
         dim3 grid(1, H, M);
-        dec_cross_attn_q8_kernel<T, 1><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, nullptr, out);
+        dec_cross_attn_q8_kernel<T, kCrossSplitD><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, nullptr, out);
     }
     SS_LAUNCH_CHECK();
 }

@@ -162,10 +162,9 @@ def test_bench_engine_32_row_passes_vs_oracle(bench_engine, large_v3_path, oracl
             n_same += 1
         else:
             differing.append(i)
-    # f16: a different row count only changes accumulation order, so a flip needs a tie at the 1e-4 sigma level; bf16 / e4m3 round coarser
-    assert n_same >= (31 if which == "f16" else 28), f"{which}: only {n_same}/32 chunks equal their single-chunk run"
-    replay = differing[:2] + [i for i in (3, 17) if i not in differing]
-    replay = replay[:max(N_REPLAY[which], len(differing[:2]))]
+    # batch invariance (round 5, tests/test_gpu_batch_invariance.py): a row's bits do not depend on the pass it rides in, so this is an equality
+    assert n_same == 32, f"{which}: only {n_same}/32 chunks equal their single-chunk run: {differing}"
+    replay = [3, 17][:N_REPLAY[which]]
     worst = 0.0
     for i in replay:
         _, gap = check_against_oracle(res[i], om, orc, omode, pcms[i], OP, f"large-v3 {which} bench config, chunk {i}", gap_tol, replay_only=True,
@@ -212,14 +211,10 @@ def test_natural_preset_32_chunks_distinct_streams_vs_oracle(large_v3_natural_pa
     singles = [eng.new_session().transcribe(p, P) for p in pcms]
     differing = [i for i in range(32) if list(singles[i]["tokens"]) != list(res[i]["tokens"])]
     n_same = 32 - len(differing)
-    # ~3 500 greedy picks at sigma(logits) = 16: a batched pass (CT = 2 column tiles, unsplit cross-attention) and a one-row pass (LayerNorm prologues,
-    # key-split cross-attention) round differently, so a pick whose top-2 margin is inside the f16 noise may differ (r04_g: 4 chunks of 32); each such
-    # chunk must still pass the call-by-call replay on the oracle below
-    assert n_same >= 24, f"only {n_same}/32 chunks equal their single-chunk run"
+    assert n_same == 32, f"only {n_same}/32 chunks equal their single-chunk run: {differing}"        # batch invariance (round 5)
     om = orc.OracleModel(large_v3_natural_path)
     order = sorted(range(32), key=lambda i: (res[i]["n_windows"], lens[i]))
     picked = [i for i in order if lens[i] >= 8][:2]                  # the two cheapest non-trivial chunks for the CPU oracle (~1 min per window)
-    picked += [i for i in order if i in differing and i not in picked][:1]     # + the cheapest chunk whose batched and single runs differ
     worst = 0.0
     for i in picked:
         fg, fs, wg, ws = check_trace_against_oracle(res[i], om, orc, orc.MODE_GGML_F16, pcms[i], orc.default_params(language="en"),

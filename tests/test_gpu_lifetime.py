@@ -128,12 +128,12 @@ def test_short_queue_is_levelled_over_idle_lanes(toy_ml_path):
 
 @pytest.mark.timeout(900)
 def test_soak_random_interleavings(toy_ml_path):
-    """~3 minutes (SS_SOAK_SECONDS, default 180): 8 threads submit chunks of random length (0.5 - 65 s) with random parameters -- refused ones included --
+    """SS_SOAK_SECONDS (default 60; tools/diag/soak_crash_hunt.sh runs 90 - 180): 8 threads submit chunks of random length (0.5 - 65 s) with random parameters -- refused ones included --
     wait for them in random order, abandon some tickets, free sessions at random points (also with chunks in flight), while a ninth thread polls the
     metrics entry points.  No hang (every thread finishes in time), device memory flat, and every result a thread did collect equals the
     serial result of the same (audio, parameters) on a fresh session."""
     from speaksense_amd import binding
-    seconds = float(os.environ.get("SS_SOAK_SECONDS", "180"))
+    seconds = float(os.environ.get("SS_SOAK_SECONDS", "60"))
     eng = binding.Engine(toy_ml_path, max_batch=8, n_lanes=3)
     try:     # the engine is closed HERE whatever happens: an engine left to the garbage collector after a failed assertion is freed at an arbitrary later point
         lengths = [0.5, 1.0, 3.0, 7.5, 12.0, 29.9, 30.1, 44.0, 65.0]
@@ -220,8 +220,7 @@ def test_soak_random_interleavings(toy_ml_path):
                         if two:
                             assert got[0] == exp[0], (k, got[0], exp[0])
                         elif got != exp:
-                            # same (audio, parameters), other batch-mates: the row count of a pass selects kernel variants and split-K plans, i.e. the
-                            # f32 summation order, and a pick inside the f16 noise of its runner-up may then differ.  Kept and PROVEN after the run.
+                            # same (audio, parameters), other batch-mates: must not happen (asserted after the run, with the count)
                             assert got[0] == exp[0] == "ok", (k, got[0], exp[0])
                             with st_lock:
                                 mismatches.append((k, full))
@@ -248,32 +247,13 @@ def test_soak_random_interleavings(toy_ml_path):
             t.join(timeout=seconds + 240)
             assert not t.is_alive(), "soak: a thread hung"
         assert not errors, errors
-        if mismatches:
-            # every result that differs from the serial one must be a proven near tie: the engine's stream replayed on the oracle stays within the f16
-            # margin at every step and reproduces the engine's windows, segments and timestamps (tests/test_gpu_parity.py check_against_oracle)
-            from oracle import binding as orc
-            from test_gpu_parity import GAP_TOL_F16, check_against_oracle
-            om = orc.OracleModel(toy_ml_path)
-            seen = set()
-            for k, full in mismatches:
-                sig = (k, tuple(int(t) for t in full["tokens"]))
-                if sig in seen:
-                    continue
-                seen.add(sig)
-                kw = dict(language="en", temperature_inc=0.0)
-                kw.update(variants[k[1]])
-                if kw["temperature_inc"] > 0.0:
-                    continue      # a fallback chunk's sampled attempts depend on which attempt failed: covered by the trace-replay tests, not here
-                check_against_oracle(full, om, orc, orc.MODE_GGML_F16, audio[k[0]], orc.default_params(**kw), f"soak {k}", GAP_TOL_F16, replay_only=True)
-            om.close()
-            from conftest import report as _report
-            _report(f"soak: {len(mismatches)} of {stats['checked']} checked results differed from the serial run of the same chunk by a proven near tie ({len(seen)} distinct)")
-            assert len(mismatches) <= max(3, stats["checked"] // 50), (len(mismatches), stats["checked"])
+        # batch invariance (round 5): the same (audio, parameters) gives the same result whatever shares its passes -- no near-tie allowance
+        assert not mismatches, f"soak: {len(mismatches)} of {stats['checked']} checked results differ from the serial run of the same chunk: {[k for k, _ in mismatches[:5]]}"
         free1, _ = eng.mem_info()
         from conftest import report
         q1, q2, q3 = (mem.get(i, free1) for i in (1, 2, 3))
         report(f"soak {seconds:.0f} s, 8 threads: {stats}, device memory free at 25 / 50 / 75 / 100 % of the run: {q1 >> 20} / {q2 >> 20} / {q3 >> 20} / {free1 >> 20} MiB")
-        assert stats["chunks"] > 200 and stats["refused"] > 5 and stats["freed_in_flight"] > 5 and stats["abandoned"] > 5
+        assert stats["chunks"] > seconds and stats["refused"] > 5 and stats["freed_in_flight"] > 5 and stats["abandoned"] > 5
         # second half: at most 64 MiB (r04_g: 34 MiB between 40 % and 100 % of a 60 s run while the three lanes were still filling their graph LRUs) and
         # not more than the first half took -- a leak grows linearly, a cache fills and stops
         assert q2 - free1 < 64 << 20, f"device memory grew by {(q2 - free1) >> 20} MiB over the second half of the run"
