@@ -241,6 +241,10 @@ int ss_engine_decode_rows(ss_engine* e, const int32_t* token, const int32_t* pos
  * hist: tokens sampled so far in this window.  out6: id, p, plog, tid, pt, ptsum. */
 int ss_process_logits(ss_engine* e, const float* raw_logits, const int32_t* hist, int32_t n_hist, int32_t has_ts,
                       int32_t seek_delta, const ss_params* params, float out6[6]);
+/* The same call, also returning the processed row: logprobs_out[n_vocab] = log-softmax over the ids the rules leave, -INFINITY where a rule masks
+ * the id (whisper_process_logits' `logprobs`).  tests/test_gpu_golden.py holds every mask bit to tests/golden/hf_rules_golden.npz. */
+int ss_process_logits_row(ss_engine* e, const float* raw_logits, const int32_t* hist, int32_t n_hist, int32_t has_ts,
+                          int32_t seek_delta, const ss_params* params, float out6[6], float* logprobs_out);
 
 /* ---- audio pre-stage (SURVEY.md §8f "next" #1) ------------------------------------------------------ */
 /* `denoise_audio(samples, &DenoiseConfig)` of /root/reference/src/audio/mod.rs:507-523 (the call the gRPC handler makes at

@@ -104,6 +104,7 @@ def lib():
         L.ss_engine_fp8_first_quant.argtypes = [vp, f32p, i32, i32, C.c_void_p, C.c_void_p]
         L.ss_engine_decode_rows.argtypes = [vp, vp, vp, vp, vp, i32, vp, i32, f32p]
         L.ss_process_logits.argtypes = [vp, f32p, vp, i32, i32, i32, C.POINTER(Params), f32p]
+        L.ss_process_logits_row.argtypes = [vp, f32p, vp, i32, i32, i32, C.POINTER(Params), f32p, f32p]
         L.ss_default_denoise_config.argtypes = [C.POINTER(DenoiseConfig)]
         L.ss_denoise_audio.argtypes = [vp, f32p, i32, C.POINTER(DenoiseConfig), i32, f32p, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.ss_resample_max_out.argtypes = [C.c_int64, i32]
@@ -279,13 +280,22 @@ class Engine:
         _check(self.L.ss_engine_decode_rows(self.h, _p(t), _p(p), _p(sl), _p(cr), len(t), _p(sr), len(sr), _p(out)))
         return out
 
-    def process_logits(self, raw, hist, has_ts: bool, seek_delta: int, params: Params | None = None):
+    def process_logits(self, raw, hist, has_ts: bool, seek_delta: int, params: Params | None = None, want_row: bool = False):
+        """want_row: also `logprobs` = the processed log-softmax row [n_vocab], -inf where a rule masks the id (ss_process_logits_row)."""
         raw = np.ascontiguousarray(raw, np.float32)
         h = np.ascontiguousarray(hist, np.int32)
         out = np.zeros(6, np.float32)
-        _check(self.L.ss_process_logits(self.h, _p(raw), _p(h), len(h), int(has_ts), seek_delta,
-                                        C.byref(params) if params is not None else None, _p(out)))
-        return dict(id=int(out[0]), p=float(out[1]), plog=float(out[2]), tid=int(out[3]), pt=float(out[4]), ptsum=float(out[5]))
+        pp = C.byref(params) if params is not None else None
+        row = None
+        if want_row:
+            row = np.empty(self.n_vocab, np.float32)
+            _check(self.L.ss_process_logits_row(self.h, _p(raw), _p(h), len(h), int(has_ts), seek_delta, pp, _p(out), _p(row)))
+        else:
+            _check(self.L.ss_process_logits(self.h, _p(raw), _p(h), len(h), int(has_ts), seek_delta, pp, _p(out)))
+        r = dict(id=int(out[0]), p=float(out[1]), plog=float(out[2]), tid=int(out[3]), pt=float(out[4]), ptsum=float(out[5]))
+        if want_row:
+            r["logprobs"] = row
+        return r
 
     def transcribe_batch(self, sessions, pcms, params: Params | None = None, device_ptrs=None):
         """pcms: list of np.float32 arrays (host), or with device_ptrs=[(ptr, n), ...] device buffers already in HBM."""

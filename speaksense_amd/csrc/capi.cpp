@@ -386,6 +386,13 @@ int ss_process_logits(ss_engine* e, const float* raw, const int32_t* hist, int32
     if (params) P = *params; else ss_default_params(&P);
     SS_TRY e->e->process_logits_host(raw, hist, n_hist, has_ts, seek_delta, P, out6); return SS_OK; SS_CATCH
 }
+int ss_process_logits_row(ss_engine* e, const float* raw, const int32_t* hist, int32_t n_hist, int32_t has_ts, int32_t seek_delta, const ss_params* params,
+                          float out6[6], float* logprobs_out) {
+    if (!e || !raw || !out6 || !logprobs_out || n_hist < 0 || (n_hist > 0 && !hist)) return fail(SS_ERR_ARG, "ss_process_logits_row: bad argument");
+    ss_params P;
+    if (params) P = *params; else ss_default_params(&P);
+    SS_TRY e->e->process_logits_host(raw, hist, n_hist, has_ts, seek_delta, P, out6, logprobs_out); return SS_OK; SS_CATCH
+}
 // last_ms / last_cnt describe the group that most recently FINISHED on any lane (a blocking call may have run on a lane other than 0);
 // each lane writes its own under its `mu`, the engine keeps which lane was last
 int ss_engine_last_timing(const ss_engine* e, float out_ms[4]) {

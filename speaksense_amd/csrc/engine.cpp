@@ -1710,7 +1710,8 @@ struct EngineT : EngineBase {
         SS_HIP(hipMemcpy2DAsync(logits_out, (size_t)n_vocab * 4, logits.p, (size_t)n_vocab_pad * 4, (size_t)n_vocab * 4, n_samp, hipMemcpyDeviceToHost, st));
         SS_HIP(hipStreamSynchronize(st));
     }
-    void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6]) override {
+    void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6],
+                             float* logprobs_out) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
@@ -1731,6 +1732,10 @@ struct EngineT : EngineBase {
         stage_release();
         launch_logits_rules(logits.as<float>(), n_vocab_pad, ctl_d.as<RowCtl>(), 1, rule_consts(P), samp_d.as<SampleOut>(), nullptr, rules_scratch.as<float>(), st);
         SS_HIP(hipMemcpyAsync(samp_h, samp_d.p, sizeof(SampleOut), hipMemcpyDeviceToHost, st));
+        if (logprobs_out) {   // the processed row itself (tests hold every mask bit to the golden vectors)
+            launch_logits_logprob_rows(logits.as<float>(), n_vocab_pad, ctl_d.as<RowCtl>(), 1, rule_consts(P), samp_d.as<SampleOut>(), probs.as<float>(), st);
+            SS_HIP(hipMemcpyAsync(logprobs_out, probs.p, (size_t)n_vocab * 4, hipMemcpyDeviceToHost, st));
+        }
         SS_HIP(hipStreamSynchronize(st));
         out6[0] = (float)samp_h[0].id; out6[1] = samp_h[0].p; out6[2] = samp_h[0].plog; out6[3] = (float)samp_h[0].tid;
         out6[4] = samp_h[0].pt; out6[5] = samp_h[0].ptsum;

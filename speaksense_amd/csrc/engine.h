@@ -90,7 +90,8 @@ struct EngineBase {
     virtual void fp8_first_quant_host(const float* mel, int n_len, int seek, uint8_t* codes, uint8_t* exps) = 0;
     virtual void decode_rows_host(const int32_t* token, const int32_t* pos, const int32_t* slot, const int32_t* cross, int n, const int32_t* samp_rows, int n_samp,
                                   float* logits_out) = 0;
-    virtual void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6]) = 0;
+    virtual void process_logits_host(const float* raw, const int32_t* hist, int n_hist, int has_ts, int seek_delta, const ss_params& P, float out6[6],
+                                     float* logprobs_out = nullptr) = 0;
     virtual void probe_gemm(int batch, int reps, float* avg_ms, double* flops) = 0;
     virtual void denoise_host(const float* pcm, int n, const ss_denoise_config& cfg, int force_type, float* out, int* noise_type, float* norm_var, float* ms) = 0;
     virtual void selftest_gemm(int M, int N, int K, int kind, float* max_err, float* max_ref) = 0;

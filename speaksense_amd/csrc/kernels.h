@@ -226,6 +226,9 @@ struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t pad[2]; };
 void launch_logits_rules(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, SampleOut* out, float* probs /* [M][ld] or null */,
                          float* scratch, hipStream_t st, RowCtl* ctl_upd = nullptr, const int* row_of = nullptr);
 
+// stage hook: after launch_logits_rules, the processed log-softmax rows (-inf where a rule masks the id), [M][ld]
+void launch_logits_logprob_rows(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, const SampleOut* picked, float* logprobs, hipStream_t st);
+
 // rows with ctl[m].want_probs: out[m].id / out[m].p <- the index std::discrete_distribution would return for the uniform draw u[m]
 void launch_sample_draw(const float* probs, long ld, int n_vocab, const RowCtl* ctl, int M, const double* u, SampleOut* out, hipStream_t st);
 

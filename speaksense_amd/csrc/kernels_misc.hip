@@ -263,6 +263,9 @@ __global__ __launch_bounds__(64) void logits_rules_pick_kernel(const float* __re
 }
 
 // t > 0 only: the full probability row for host-side sampling (probs = 0 where masked, text masked when a timestamp is forced)
+// LOGP (stage hook ss_process_logits_row): whisper_process_logits' `logprobs` row instead -- -inf where a rule masks the id (the "timestamp mass
+// beats every text token" rule included: it masks the text ids without renormalising), v - lse elsewhere
+template <bool LOGP>
 __global__ __launch_bounds__(256) void logits_probs_kernel(const float* __restrict__ logits, long ld, const RowCtl* __restrict__ ctl, RuleConsts rc,
                                                            const SampleOut* __restrict__ picked, float* __restrict__ probs) {
     const int m = blockIdx.y;
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(256) void logits_probs_kernel(const float* __restri
     for (int i = blockIdx.x * 256 + threadIdx.x; i < rc.n_vocab; i += gridDim.x * 256) {
         float v = masked_logit(i, logits[(long)m * ld + i], c, rc);
         if (force_ts && i < rc.beg) v = kNegInf;
+        if constexpr (LOGP) { probs[(long)m * ld + i] = v == kNegInf ? kNegInf : v - lse; continue; }
         probs[(long)m * ld + i] = v == kNegInf ? 0.0f : expf(v - lse);
     }
 }
@@ -327,7 +331,10 @@ void launch_logits_rules(const float* logits, long ld, const RowCtl* ctl, int M,
     if ((rc.n_vocab + kRuleSlices - 1) / kRuleSlices > 4 * 256) throw Error(-1, "logits rules: vocabulary too large for the slice plan");
     logits_rules_scan_kernel<<<dim3(kRuleSlices, M), 256, 0, st>>>(logits, ld, ctl, rc, scratch); SS_LAUNCH_CHECK();
     logits_rules_pick_kernel<<<M, 64, 0, st>>>(scratch, rc, out, ctl_upd, row_of); SS_LAUNCH_CHECK();
-    if (probs) { logits_probs_kernel<<<dim3(32, M), 256, 0, st>>>(logits, ld, ctl, rc, out, probs); SS_LAUNCH_CHECK(); }
+    if (probs) { logits_probs_kernel<false><<<dim3(32, M), 256, 0, st>>>(logits, ld, ctl, rc, out, probs); SS_LAUNCH_CHECK(); }
+}
+void launch_logits_logprob_rows(const float* logits, long ld, const RowCtl* ctl, int M, const RuleConsts& rc, const SampleOut* picked, float* logprobs, hipStream_t st) {
+    logits_probs_kernel<true><<<dim3(32, M), 256, 0, st>>>(logits, ld, ctl, rc, picked, logprobs); SS_LAUNCH_CHECK();
 }
 
 }  // namespace ss

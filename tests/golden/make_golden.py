@@ -210,8 +210,162 @@ def rules_fixture():
     print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
+# ------------------------------------------------------------------------------------------------------------------------------------
+# round 5: fixtures the HIP ENGINE can be held to directly (tests/test_gpu_golden.py), and a sequence-level one
+# ------------------------------------------------------------------------------------------------------------------------------------
+def hf_model_tanh(hp, tensors):
+    """HF Whisper with `activation_function="gelu_new"` -- the tanh form, ggml's formula (/root/reference/resources/ggml-metal.metal:262-277
+    kernel_gelu: 0.5 x (1 + tanh(sqrt(2/pi) x (1 + 0.044715 x^2)))) -- which is the only GELU the engine implements."""
+    cfg = WhisperConfig(vocab_size=hp.n_vocab, num_mel_bins=hp.n_mels, d_model=hp.n_audio_state, encoder_layers=hp.n_audio_layer,
+                        encoder_attention_heads=hp.n_audio_head, decoder_layers=hp.n_text_layer, decoder_attention_heads=hp.n_text_head,
+                        encoder_ffn_dim=4 * hp.n_audio_state, decoder_ffn_dim=4 * hp.n_text_state, max_source_positions=hp.n_audio_ctx,
+                        max_target_positions=hp.n_text_ctx, activation_function="gelu_new", dropout=0.0, attention_dropout=0.0,
+                        activation_dropout=0.0)
+    model = WhisperForConditionalGeneration(cfg).eval()
+    missing, unexpected = model.load_state_dict(ggml_to_hf_state(hp, tensors), strict=False)
+    assert not unexpected, unexpected
+    assert all("k_proj.bias" in m for m in missing) or not missing, missing
+    return model
+
+
+TANH_SHAPES = {"toy": 31, "tiny.en": 32, "wide2": 33}
+
+
+def tanh_fixture():
+    """hf_tanh_golden.npz: as shapes_fixture, with the tanh GELU, so that the same vectors apply to the oracle's default mode AND to the HIP
+    engine (f16 operands): sampled columns of the HF feature extractor's log-mel for both filterbanks (80 and 128 bins), encoder rows, and the
+    top-16 logits of every position of a prompt + text + timestamp sequence.  The encoder input is the oracle's whisper.cpp-style log-mel of
+    the seeded audio (frames [0, 3000)) rounded to f16; the tests recompute it."""
+    from oracle import binding as orc
+    out = {}
+    tmp = tempfile.mkdtemp()
+    for name, seed in TANH_SHAPES.items():
+        path = os.path.join(tmp, f"{name}.bin")
+        ggml_io.write_model(path, name, seed=seed)
+        hp, filt, vocab, tensors = ggml_io.read_model(path)
+        model = hf_model_tanh(hp, tensors)
+        om = orc.OracleModel(path)
+        pcm = synth.speech_like(SEED_AUDIO + 2)
+        mel = om.log_mel(pcm)[:, :3000].astype(np.float16).astype(np.float32)
+        multilingual = hp.n_vocab >= 51865
+        sot, beg = om.sot, om.beg
+        toks = ([sot, sot + 1 + 7, om.transcribe] if multilingual else [sot]) + [beg + 1, 4321, 707, 30999, 24, beg + 33, beg + 33, 11, 2600]
+        with torch.no_grad():
+            enc = model.model.encoder(torch.from_numpy(mel)[None]).last_hidden_state[0].numpy()
+            logits = model(encoder_outputs=(torch.from_numpy(enc)[None],), decoder_input_ids=torch.tensor([toks])).logits[0].numpy()
+        topk = np.argsort(-logits, axis=1)[:, :16].astype(np.int32)
+        k = name.replace(".", "_")
+        out[f"{k}_seed"] = seed
+        out[f"{k}_tokens"] = np.array(toks, np.int32)
+        out[f"{k}_n_prompt"] = 3 if multilingual else 1
+        out[f"{k}_enc"] = enc[ENC_ROWS].astype(np.float32)
+        out[f"{k}_enc_absmax"] = np.float32(np.abs(enc).max())
+        out[f"{k}_enc_rms"] = np.float32(np.sqrt((enc.astype(np.float64) ** 2).mean()))
+        out[f"{k}_topk"] = topk
+        out[f"{k}_topv"] = np.take_along_axis(logits, topk, axis=1).astype(np.float32)
+        out[f"{k}_logit_std"] = np.float32(logits.std())
+        if name in ("toy", "tiny.en"):     # 128 and 80 mel bins: the HF feature extractor on the same audio, sampled columns
+            fe = WhisperFeatureExtractor(feature_size=hp.n_mels)
+            hf_mel = fe(pcm, sampling_rate=16000, return_tensors="np")["input_features"][0].astype(np.float32)
+            out[f"{k}_hf_mel"] = hf_mel[:, 0:2990:13].astype(np.float32)
+        om.close()
+        print(name, "enc absmax", float(np.abs(enc).max()), "logit std", float(logits.std()))
+    out["seed_audio"] = SEED_AUDIO + 2
+    out["enc_rows"] = np.array(ENC_ROWS)
+    out["mel_cols"] = np.arange(0, 2990, 13)
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_tanh_golden.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
+# (preset, model seed, audio seed, ts_rate): ts_rate 24 = timestamps advance 7.68 s per pair and pass 29 s before EOT, so the window ends by
+# whisper.cpp's `seek + seek_delta + 100 >= seek_end` rule (on the FIRST timestamp of that pair) while HF decodes on
+GENERATE_CASES = [("toy256", 41, 3, 12.0), ("toy256", 42, 8, 12.0), ("tiny.en", 43, 4, 12.0), ("tiny.en", 44, 9, 12.0), ("wide2", 45, 5, 12.0),
+                  ("wide2", 46, 6, 12.0), ("toy256", 47, 10, 24.0), ("tiny.en", 48, 11, 24.0)]
+
+
+def window0_len(ids, beg, eot):
+    """How many of HF's ids whisper.cpp's decode loop samples before it ends the FIRST window (seek 0, seek_end 3000): EOT, or a timestamp
+    that brings seek_delta within 100 frames of the window's end (whisper_full_with_state: `has_ts && seek + seek_delta + 100 >= seek_end`)."""
+    has_ts, seek_delta = False, 3000
+    for i, t in enumerate(ids):
+        if t > beg:
+            seek_delta, has_ts = 2 * (t - beg), True
+        if t == eot or (has_ts and seek_delta + 100 >= 3000):
+            return i + 1
+    return len(ids)
+
+
+def generate_fixture():
+    """hf_generate_golden.npz: SEQUENCE level.  HF `WhisperForConditionalGeneration.generate(return_timestamps=True, do_sample=False)` -- OpenAI's
+    decoding rules as transformers implements them, greedy, KV-cached -- on seeded `natural`-style models (speaksense_amd.ggml_io.NATURAL: the
+    decoder emits text, increasing timestamp pairs and ends with EOT after an audio-dependent number of tokens) with whisper.cpp's suppress
+    lists (the parameters of /root/reference/src/asr/whisper.rs:131-173 at temperature 0).  Stored per case: every id of the FIRST 30 s window
+    (the raw result of that window: the tail after the last closed timestamp pair included), how many of them whisper.cpp's loop samples
+    before it ends the window, and the (start, end) of the window's segments in centiseconds as HF reports them.  The tests hold the oracle
+    (exact-f32 mode, COMPAT_OPENAI_TS_RULES) to identical ids and segment times, and the HIP engine to identical ids or a forced replay.
+    Later windows are not stored: HF zero-fills the log-mel past the audio, whisper.cpp continues in its own padded spectrogram."""
+    from transformers import GenerationConfig
+    from oracle import binding as orc
+    out = {}
+    tmp = tempfile.mkdtemp()
+    for ci, (name, seed, aseed, ts_rate) in enumerate(GENERATE_CASES):
+        path = os.path.join(tmp, f"{name}-{seed}.bin")
+        ggml_io.write_model(path, name, seed=seed, **dict(ggml_io.NATURAL, ts_rate=ts_rate))
+        hp, filt, vocab, tensors = ggml_io.read_model(path)
+        model = hf_model_tanh(hp, tensors)
+        om = orc.OracleModel(path)
+        pcm = synth.speech_like(aseed)
+        mel = om.log_mel(pcm)[:, :3000].astype(np.float32)
+        multilingual = hp.n_vocab >= 51865
+        eot, sot, beg = om.eot, om.sot, om.beg
+        n_lang = hp.n_vocab - 51765 - (1 if multilingual else 0)
+        prompt = [sot, sot + 1, om.transcribe] if multilingual else [sot]
+        suppress = [sot, om.nosp, om.solm, om.translate, om.transcribe, om.prev] + [sot + 1 + i for i in range(n_lang)]      # whisper_process_logits' list
+        gc = GenerationConfig(eos_token_id=eot, pad_token_id=eot, bos_token_id=eot, decoder_start_token_id=sot, no_timestamps_token_id=om.not_,
+                              max_initial_timestamp_index=50, suppress_tokens=suppress, begin_suppress_tokens=[220, eot], max_length=448,
+                              is_multilingual=multilingual, return_timestamps=True, do_sample=False, num_beams=1)
+        if multilingual:
+            gc.lang_to_id = {"<|en|>": sot + 1}
+            gc.task_to_id = {"transcribe": om.transcribe, "translate": om.translate}
+        model.generation_config = gc
+        with torch.no_grad():
+            res = model.generate(input_features=torch.from_numpy(mel)[None], decoder_input_ids=torch.tensor([prompt]), return_timestamps=True,
+                                 do_sample=False, num_beams=1, max_new_tokens=224, return_segments=True)
+        segs = res["segments"][0]
+        first = segs[0]["result"]
+        raw = first["sequences"] if isinstance(first, dict) else first
+        raw = [int(t) for t in (raw[0] if raw.dim() == 2 else raw)]
+        if raw[:len(prompt)] == prompt:
+            raw = raw[len(prompt):]
+        w0 = [sg for sg in segs if sg["result"] is segs[0]["result"]]
+        n0 = window0_len(raw, beg, eot)
+        k = f"c{ci}"
+        out[f"{k}_preset"], out[f"{k}_seed"], out[f"{k}_audio"], out[f"{k}_ts_rate"] = name, seed, aseed, ts_rate
+        out[f"{k}_ids"] = np.array(raw, np.int32)
+        out[f"{k}_n_window0"] = n0
+        out[f"{k}_seg_t0"] = np.array([round(100 * float(sg["start"])) for sg in w0], np.int64)
+        out[f"{k}_seg_t1"] = np.array([round(100 * float(sg["end"])) for sg in w0], np.int64)
+        # the generator checks what the CPU test will check, so that a fixture that cannot be met is never committed
+        ref = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES).full(pcm, orc.default_params(language="en", temperature_inc=0.0))
+        tr = [int(t) for t in ref["trace"]]
+        n_ts = sum(t >= beg for t in raw[:n0])
+        print(name, seed, aseed, "HF window 0:", len(raw), "ids,", n0, "sampled by whisper.cpp's loop,", n_ts, "timestamps,", len(w0), "segments; oracle trace",
+              len(tr), "equal prefix", tr[:n0] == raw[:n0], "segments", [(s["t0"], s["t1"]) for s in ref["segments"]][:len(w0)],
+              list(zip(out[f"{k}_seg_t0"].tolist(), out[f"{k}_seg_t1"].tolist())))
+        om.close()
+    out["n_cases"] = len(GENERATE_CASES)
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_generate_golden.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["toy", "shapes", "rules"]
+    which = sys.argv[1:] or ["toy", "shapes", "rules", "tanh", "generate"]
+    if "tanh" in which:
+        tanh_fixture()
+    if "generate" in which:
+        generate_fixture()
     if "toy" in which:
         main()
     if "shapes" in which:

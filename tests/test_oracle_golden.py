@@ -179,3 +179,77 @@ def test_process_logits_matches_openai_rules(tag, preset, variant, model_dir):
             n_cmp += len(keep)
     assert n_cmp > 400
     st.close(); om.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# round 5 fixtures: tanh GELU (the engine's and ggml's formula), and whole first windows of HF generate()
+# ------------------------------------------------------------------------------------------------------------------------------------
+TANH_GOLD = os.path.join(os.path.dirname(__file__), "golden", "hf_tanh_golden.npz")
+GENERATE_GOLD = os.path.join(os.path.dirname(__file__), "golden", "hf_generate_golden.npz")
+
+
+@pytest.mark.parametrize("name", ["toy", "tiny.en", "wide2"])
+def test_oracle_default_gelu_matches_hf_gelu_new(name, model_dir):
+    """The oracle in the mode every parity test uses (tanh GELU, ggml's formula) against HF Whisper with `activation_function="gelu_new"` on the
+    seeded toy / tiny.en / wide2 models: log-mel columns (both filterbanks), encoder rows, KV-cached per-step logits.  The SAME vectors are
+    applied to the HIP engine in tests/test_gpu_golden.py."""
+    g = np.load(TANH_GOLD)
+    k = name.replace(".", "_")
+    path = os.path.join(model_dir, f"tanh-{name}.bin")
+    ggml_io.write_model(path, name, seed=int(g[f"{k}_seed"]))
+    om = orc.OracleModel(path)
+    full = om.log_mel(synth.speech_like(int(g["seed_audio"])))
+    if f"{k}_hf_mel" in g:
+        a, b = full[:, g["mel_cols"]], g[f"{k}_hf_mel"]
+        above = (a > a.min() + 2e-3) & (b > b.min() + 2e-3)       # bins on the clamp floor: the two floors differ by ~1e-3 (test above)
+        assert above.mean() > 0.9 and np.abs(a - b)[above].max() < 2e-4
+    mel = np.zeros_like(full)
+    mel[:, :3000] = full[:, :3000].astype(np.float16).astype(np.float32)
+    enc = om.encode(mel, 0, orc.MODE_F32)
+    assert np.abs(enc[g["enc_rows"]] - g[f"{k}_enc"]).max() < 1e-3 * float(g[f"{k}_enc_absmax"])
+    st = om.new_state(orc.MODE_F32)
+    st.set_encoder(enc)
+    toks = [int(t) for t in g[f"{k}_tokens"]]
+    n_prompt = int(g[f"{k}_n_prompt"])
+    tol = 2e-3 * float(g[f"{k}_logit_std"])
+    lg = st.decode(toks[:n_prompt], 0)
+    assert np.abs(lg[g[f"{k}_topk"][n_prompt - 1]] - g[f"{k}_topv"][n_prompt - 1]).max() < tol
+    for i in range(n_prompt, len(toks)):
+        lg = st.decode(toks[i:i + 1], i)
+        assert np.abs(lg[g[f"{k}_topk"][i]] - g[f"{k}_topv"][i]).max() < tol, i
+        assert int(lg.argmax()) == int(g[f"{k}_topk"][i][0])
+    st.close(); om.close()
+
+
+def generate_cases():
+    g = np.load(GENERATE_GOLD)
+    return [dict(preset=str(g[f"c{i}_preset"]), seed=int(g[f"c{i}_seed"]), audio=int(g[f"c{i}_audio"]), ts_rate=float(g[f"c{i}_ts_rate"]),
+                 ids=[int(t) for t in g[f"c{i}_ids"]], n0=int(g[f"c{i}_n_window0"]), seg=list(zip(g[f"c{i}_seg_t0"].tolist(), g[f"c{i}_seg_t1"].tolist())))
+            for i in range(int(g["n_cases"]))]
+
+
+def generate_case_model(c, model_dir):
+    path = os.path.join(model_dir, f"gen-{c['preset']}-{c['seed']}.bin")
+    if not os.path.exists(path):
+        ggml_io.write_model(path, c["preset"], seed=c["seed"], **dict(ggml_io.NATURAL, ts_rate=c["ts_rate"]))
+    return path
+
+
+@pytest.mark.parametrize("ci", range(8))
+def test_oracle_full_matches_hf_generate_first_window(ci, model_dir):
+    """SEQUENCE level (tests/golden/make_golden.py generate_fixture): the oracle's whole whisper_full loop -- prompt, every logits rule, greedy
+    pick, the stopping rules (EOT; a timestamp within 1 s of the window's end), timestamp pairing into segments -- in exact-f32 mode with
+    COMPAT_OPENAI_TS_RULES against HF transformers' `generate(return_timestamps=True, do_sample=False)` on the same seeded model and audio, with
+    the parameters of /root/reference/src/asr/whisper.rs:131-173 at temperature 0: every id the loop samples in the first 30 s window must equal
+    HF's, and the window's segments must carry HF's (start, end).  Cases 6 and 7 end by the window-end rule 13 / 33 ids before HF's EOT."""
+    c = generate_cases()[ci]
+    om = orc.OracleModel(generate_case_model(c, model_dir))
+    res = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES).full(synth.speech_like(c["audio"]), orc.default_params(language="en", temperature_inc=0.0))
+    tr = [int(t) for t in res["trace"]]
+    n0 = c["n0"]
+    assert n0 >= 25 and sum(t >= om.beg for t in c["ids"][:n0]) >= 3, "fixture drifted: the window holds no timestamp pairs"
+    assert tr[:n0] == c["ids"][:n0], f"first difference at {next(i for i in range(n0) if i >= len(tr) or tr[i] != c['ids'][i])}"
+    assert len(tr) == n0 or res["n_encode"] > 1          # the loop ended the window exactly there (what follows belongs to the next window)
+    assert [(s["t0"], s["t1"]) for s in res["segments"]][:len(c["seg"])] == c["seg"]
+    assert res["n_fail"] == 0
+    om.close()
