@@ -27,6 +27,16 @@ typedef struct ss_engine ss_engine;
 typedef struct ss_session ss_session;
 typedef struct ss_ticket ss_ticket;
 
+/* ABI check for bindings.  ss_params / ss_engine_opts are passed by pointer and COPIED by the library (`P = *params`), so a caller built against an
+ * older header would make it read past the caller's struct.  A binding asserts, once at load time, that ss_abi_version() == SS_ABI_VERSION and
+ * that ss_sizeof_params() / ss_sizeof_engine_opts() equal its own sizeof (binding.py and rust/asr_hip.rs do).  Bumped whenever a struct of this
+ * header changes size or a field changes meaning: 4 = round 4's ss_params (128 bytes, token_timestamps in the former reserved0);
+ * 5 = round 5 (ss_process_logits_row, these three getters; layouts unchanged). */
+#define SS_ABI_VERSION 5
+int32_t ss_abi_version(void);
+int32_t ss_sizeof_params(void);
+int32_t ss_sizeof_engine_opts(void);
+
 enum { SS_DTYPE_BF16 = 0, SS_DTYPE_F16 = 1, SS_DTYPE_FP8 = 2 };
 enum {
     SS_OK = 0,
@@ -45,7 +55,15 @@ typedef struct ss_engine_opts {
                              SS_DTYPE_FP8: the f16 engine with the encoder-block and cross-KV projections (98 % of the path's FLOPs) on OCP e4m3
                              weights and activations, MX-scaled fp8 MFMA; needs n_audio_state % 256 == 0 (base and larger).  No reference
                              counterpart: whisper.cpp has no fp8; parity is against the oracle's FP8 mode with the same rounding points */
-    int32_t max_batch;    /* windows encoded+decoded together on the device (default 8) */
+    int32_t max_batch;    /* windows encoded+decoded together on the device (default 8, <= 128; max_batch x max_decoders <= 1024).  Device memory PER LANE,
+                             B = max_batch, ND = max_decoders, d = n_audio_state = n_text_state, L = n_text_layer, V = n_vocab rounded up to 64:
+                               cross-KV cache  L x B x 2 x 1500 x d x 2 bytes (1 byte + 1/64 in SS_DTYPE_FP8)      large-v3: 245.8 MB per window
+                               self-KV caches  L x (B x ND) x 2 x 448 x d x 2 bytes                                large-v3:  73.4 MB per decoder
+                               encoder workspace  ~ B x 1500 x d x 26 bytes                                        large-v3:  50 MB per window
+                               decoder rows    128 x (2 V x 4 + 14 d) bytes                                        large-v3:  56 MB
+                             plus the weights once per engine (f16 file size + 0.9 GB of e4m3 copies in SS_DTYPE_FP8).  large-v3, B = 32, ND = 5:
+                             ~21 GB per lane.  ss_engine_create adds this up, compares it with hipMemGetInfo and fails with SS_ERR_ARG and the numbers
+                             in ss_last_error() BEFORE allocating anything if it does not fit (B = 128, ND = 5, 3 lanes of large-v3 would need ~250 GB) */
     int32_t max_decoders; /* decoders per window at temperature > 0 (reference: Greedy{best_of:5}, whisper.rs:132) */
     int32_t batch_wait_us;/* how long the batch former waits for more chunks before launching a partial batch */
     int32_t n_lanes;      /* device batches in flight at once over one copy of the weights (0 = default 2; env SS_LANES overrides): each lane has
@@ -286,7 +304,8 @@ int ss_engine_last_timing(const ss_engine* e, float out_ms[4]);
  * [1] decoder rows over those passes, [2] encoder windows, [3] 0.  With last_timing[2] this gives the in-pipeline decode-step time. */
 int ss_engine_last_counters(const ss_engine* e, int64_t out4[4]);
 /* Cumulative since engine creation, summed over the lanes: device ms [mel, encoder+cross-KV, decode, total] and work [decoder passes, decoder
- * rows, encoder windows, chunks admitted into a running group, windows started while other windows of their group were decoding, 0].  Differences around a timed region give the in-pipeline averages when several groups run concurrently. */
+ * rows, encoder windows, chunks admitted into a running group, windows started while other windows of their group were decoding, decode-step
+ * graphs evicted from the per-lane LRU of 256 (a count that keeps growing means the (rows, sampled rows) shapes of the load thrash it)].  Differences around a timed region give the in-pipeline averages when several groups run concurrently. */
 int ss_engine_totals(const ss_engine* e, double out_ms[4], int64_t out_cnt[6], int32_t* n_lanes);
 /* The same counters for one lane (0 <= lane < n_lanes): how the batch former spread the work (tests: lane levelling). */
 int ss_engine_lane_counters(const ss_engine* e, int32_t lane, int64_t out_cnt[6]);

@@ -123,6 +123,9 @@ class WhisperAsr:
     def transcribe_with_state(self, state: binding.Session, audio, user_params: AsrParams) -> TranscribeResult:  # whisper.rs:45-129
         if self.batch_across_callers:
             res = state.wait(state.submit(np.asarray(audio, np.float32), self.build_params(user_params)))
+            if res is None:   # binding.Session.wait withholds results while another ticket of the session is outstanding
+                raise RuntimeError("transcribe_with_state: the state has another chunk in flight -- a state serves one caller at a time "
+                                   "(the reference guards it with a Mutex, /root/reference/src/asr/whisper.rs:38,51)")
         else:
             res = state.transcribe(np.asarray(audio, np.float32), self.build_params(user_params))
         return self._collect(res, user_params)

@@ -32,6 +32,9 @@ class Params(C.Structure):
                 ("thold_pt", C.c_float), ("thold_ptsum", C.c_float)]
 
 
+ABI_VERSION = 5   # include/speaksense.h SS_ABI_VERSION
+
+
 class DenoiseConfig(C.Structure):   # DenoiseConfig, /root/reference/src/audio/mod.rs:41-61
     _fields_ = [("frame_size", C.c_int32), ("overlap", C.c_float), ("strength", C.c_float), ("noise_gate", C.c_float),
                 ("enable_noise_reduction", C.c_int32), ("threshold", C.c_float)]
@@ -50,6 +53,10 @@ def lib():
             raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
         L = C.CDLL(LIB_PATH)
         vp, i32, f32p = C.c_void_p, C.c_int32, C.c_void_p
+        # the library copies ss_params / ss_engine_opts by value: a layout this binding does not share would be read out of bounds (speaksense.h SS_ABI_VERSION)
+        if (L.ss_abi_version(), L.ss_sizeof_params(), L.ss_sizeof_engine_opts()) != (ABI_VERSION, C.sizeof(Params), C.sizeof(EngineOpts)):
+            raise ImportError(f"{LIB_PATH}: ABI {L.ss_abi_version()} with ss_params of {L.ss_sizeof_params()} / ss_engine_opts of {L.ss_sizeof_engine_opts()} bytes; "
+                              f"this binding was written for ABI {ABI_VERSION}, {C.sizeof(Params)} / {C.sizeof(EngineOpts)} bytes -- rebuild the library")
         L.ss_last_error.restype = C.c_char_p
         L.ss_default_params.argtypes = [C.POINTER(Params)]
         L.ss_engine_create.argtypes = [C.c_char_p, C.POINTER(EngineOpts), C.POINTER(vp)]
@@ -207,7 +214,8 @@ class Engine:
     def lane_counters(self, lane: int):
         cnt = np.zeros(6, np.int64)
         _check(self.L.ss_engine_lane_counters(self.h, lane, _p(cnt)))
-        return dict(decoder_passes=int(cnt[0]), decoder_rows=int(cnt[1]), encoder_windows=int(cnt[2]), admitted=int(cnt[3]), started_midway=int(cnt[4]))
+        return dict(decoder_passes=int(cnt[0]), decoder_rows=int(cnt[1]), encoder_windows=int(cnt[2]), admitted=int(cnt[3]), started_midway=int(cnt[4]),
+                    graph_evictions=int(cnt[5]))
 
     def mem_info(self):
         """(free, total) bytes of the engine's device (hipMemGetInfo)."""

@@ -1,5 +1,7 @@
 // extern "C" boundary of libspeaksense_hip.so (include/speaksense.h).  No exceptions cross it.
 #include <cstring>
+#include <thread>
+#include <unordered_set>
 
 #include "engine.h"
 
@@ -9,6 +11,12 @@ struct ss_engine { EngineBase* e; };
 struct ss_session { Session s; };
 struct ss_ticket { Job job; };
 struct ss_pool { std::vector<ss_engine*> engines; std::atomic<uint32_t> cursor{0}; };
+
+// Engines that exist.  ss_session_free may have to wait on its engine's condition variable while another thread frees that engine: the waiter
+// enters (counted in EngineBase::n_waiters, which stop_worker drains) under this lock, and ss_engine_free leaves the set under it BEFORE teardown
+// starts -- so a session either finds its engine alive and is waited for, or finds it gone, in which case every chunk is already complete.
+static std::mutex g_live_mu;
+static std::unordered_set<const EngineBase*> g_live;
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
@@ -87,14 +95,19 @@ int ss_engine_create(const char* path, const ss_engine_opts* opts, ss_engine** o
     // SS_DTYPE_FP8 = the f16 engine with its encoder and cross-KV projections in e4m3
     EngineBase* e = o.dtype == SS_DTYPE_BF16 ? make_engine_bf16(path, o) : make_engine_f16(path, o);
     *out = new ss_engine{e};
+    { std::lock_guard<std::mutex> lk(g_live_mu); g_live.insert(e); }
     return SS_OK;
     SS_CATCH
 }
 void ss_engine_free(ss_engine* e) {
     if (!e) return;
-    delete e->e;
+    { std::lock_guard<std::mutex> lk(g_live_mu); g_live.erase(e->e); }   // no new ss_session_free waiter can enter from here on
+    delete e->e;                                                          // ~EngineT -> stop_worker: completes every chunk, lets the counted waiters leave
     delete e;
 }
+int32_t ss_abi_version(void) { return SS_ABI_VERSION; }
+int32_t ss_sizeof_params(void) { return (int32_t)sizeof(ss_params); }
+int32_t ss_sizeof_engine_opts(void) { return (int32_t)sizeof(ss_engine_opts); }
 int ss_engine_hparams(const ss_engine* e, int32_t out11[11]) {
     if (!e || !out11) return fail(SS_ERR_ARG, "null argument");
     memcpy(out11, &e->e->hm.hp, sizeof(HParams));
@@ -146,8 +159,10 @@ void ss_session_free(ss_session* s) {
     if (!s) return;
     if (s->s.in_flight.load() > 0) {
         EngineBase* e = s->s.eng;          // while in_flight > 0 the session stays on this engine (ss_pool_submit)
-        std::unique_lock<std::mutex> lk(e->qmu);
-        e->donecv.wait(lk, [&] { return s->s.in_flight.load() == 0; });
+        std::unique_lock<std::mutex> live(g_live_mu);
+        if (g_live.count(e)) e->wait_session_idle(s->s, live);     // releases `live` once it is counted as a waiter
+        // else: the engine is being (or has been) freed -- teardown completes every chunk before it returns; spin on the counter, never touch `e`
+        else { live.unlock(); while (s->s.in_flight.load() > 0) std::this_thread::yield(); }
     }
     delete s;
 }

@@ -392,6 +392,7 @@ struct EngineT : EngineBase {
         if (fp8_enc && (da % 256 || d % 64)) throw Error(SS_ERR_UNSUPPORTED, "fp8: n_audio_state must be a multiple of 256 (k-step groups of the e4m3 GEMM)");
         if (d % 128 || da % 128) throw Error(SS_ERR_MODEL, "model: state size must be a multiple of 128");
         if (n_ctx % 4 || n_tctx > 448) throw Error(SS_ERR_MODEL, "model: unsupported context sizes");
+        if (!donor) check_memory_fits(n_lanes_total);
         SS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         AllocStreamScope alloc_scope(st);
         for (auto& e : ev) SS_HIP(hipEventCreate(&e));
@@ -425,6 +426,7 @@ struct EngineT : EngineBase {
         if (st) (void)hipStreamSynchronize(st);   // a chained decode step may still be in flight: it writes into the pinned buffers freed below
         if (stage_h) (void)hipHostFree(stage_h);
         for (auto& e : stage_ev) (void)hipEventDestroy(e);
+        reap_retired_graphs();
         for (auto& kv : step_graphs) { if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec); if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph); }
         if (samp_h) (void)hipHostFree(samp_h);
         for (auto& e : ev) (void)hipEventDestroy(e);
@@ -578,6 +580,32 @@ struct EngineT : EngineBase {
         for (auto& kv : hm.t) std::vector<float>().swap(kv.second.f32);  // host copies no longer needed
     }
 
+    // Device memory the engine is about to allocate (speaksense.h documents the formula next to max_batch), against what the device has free: a
+    // configuration that cannot fit fails here with the numbers, not as a hipMalloc error somewhere inside the fourth lane's workspaces.
+    size_t lane_bytes() const {
+        const size_t M = (size_t)B * n_ctx, R = kPartRows;
+        size_t enc_ws = ((size_t)B * (2 * n_ctx + 2) * (n_mel + da)) * 2 + M * da * (4 + 2 + 4 + 2 + 2 + 2 + 4) + (size_t)B * Ha * 64 * Tpad * 2 + M * 4 * da * (fp8_enc ? 1 : 2);
+        if (fp8_enc) enc_ws += 2 * M * da + (M + 255) * (6 * da / 64);
+        const size_t cross_b = (size_t)L * B * 2 * H * n_ctx * (fp8_enc ? 65 : 128);
+        const size_t self_b = (size_t)2 * L * S * n_tctx * d * 2;
+        const size_t rows_b = R * ((size_t)2 * n_vocab_pad * 4 + (size_t)(3 + 4) * d * 2 + (size_t)H * 4 * 66 * 4 + 64 * 8 * 4) + (size_t)(2 + 4 * 4) * R * d * 4;
+        const size_t pcm_mel = (size_t)B * (2 * 480000 * 4 + (size_t)n_mel * 6000 * 4);       // grown lazily per chunk length: 30 s chunks assumed
+        return enc_ws + cross_b + self_b + rows_b + pcm_mel;
+    }
+    void check_memory_fits(int n_lanes_total) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+        if (const char* t = getenv("SS_TEST_FREE_MEM_MIB")) free_b = (size_t)atol(t) << 20;   // test hook (tests/test_gpu_lifetime.py)
+        const HParams& hp = hm.hp;
+        const size_t enc_w = (size_t)La * 12 * da * da + (size_t)da * 3 * n_mel + (size_t)3 * da * da;
+        const size_t dec_w = (size_t)L * 16 * d * d + (size_t)hp.n_vocab * d;
+        const size_t weights = (enc_w + dec_w) * 2 + (fp8_enc ? (size_t)La * 12 * da * da + (size_t)L * 2 * d * d : 0);
+        const size_t need = weights + (size_t)n_lanes_total * lane_bytes();
+        if (need > free_b)
+            throw Error(SS_ERR_ARG, "ss_engine_create: max_batch " + std::to_string(B) + " x max_decoders " + std::to_string(ND) + " on " + std::to_string(n_lanes_total) +
+                        " lanes needs ~" + std::to_string(need >> 20) + " MiB of device memory (" + std::to_string(lane_bytes() >> 20) + " MiB per lane + " +
+                        std::to_string(weights >> 20) + " MiB of weights), the device has " + std::to_string(free_b >> 20) + " MiB free");
+    }
     void alloc_workspaces() {
         pcm_d.resize(B); mel_d.resize(B); fmax_d.resize(B); energy_h.resize(B);
         const size_t M = (size_t)B * n_ctx;
@@ -759,16 +787,25 @@ struct EngineT : EngineBase {
     struct StepGraph { int uses = 0; long last_use = 0; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
     std::map<int, StepGraph> step_graphs;
     long graph_clock = 0;
-    static constexpr size_t kMaxStepGraphs = 96;   // a long-lived service sees up to 64 x 65 (rows, sampled rows) shapes: keep the recently used ones
+    // a long-lived service sees up to 128 x 129 (rows, sampled rows) shapes, in practice the diagonal (every row samples) plus the prompt passes:
+    // keep the 256 most recently used (an instantiated step graph of large-v3 holds ~0.4 MB of host memory).  An evicted graph's exec may still be
+    // replaying: it goes to a retired list that is reaped once the stream has been synchronised anyway (the end of a group), not by stalling the
+    // stream in the middle of one.  n_graph_evictions makes thrash visible (ss_engine_lane_counters).
+    static constexpr size_t kMaxStepGraphs = 256;
+    std::vector<StepGraph> retired_graphs;
+    long n_graph_evictions = 0;
     void evict_step_graphs() {
         while (step_graphs.size() > kMaxStepGraphs) {
             auto victim = step_graphs.begin();
             for (auto it = step_graphs.begin(); it != step_graphs.end(); ++it) if (it->second.last_use < victim->second.last_use) victim = it;
-            // a replay of this graph may still be executing: its exec must outlive it
-            if (victim->second.exec) { SS_HIP(hipStreamSynchronize(st)); (void)hipGraphExecDestroy(victim->second.exec); }
-            if (victim->second.graph) (void)hipGraphDestroy(victim->second.graph);
+            retired_graphs.push_back(victim->second);
             step_graphs.erase(victim);
+            n_graph_evictions++;
         }
+    }
+    void reap_retired_graphs() {   // caller has synchronised `st`: no replay of a retired graph is executing
+        for (StepGraph& g : retired_graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
+        retired_graphs.clear();
     }
     // chained = true: the control blocks are already on the device (the previous step's pick kernel advanced them), nothing is uploaded
     void decoder_step_fused(int M, const RuleConsts& rc, const std::vector<int>& samp_rows, bool any_probs, bool chained = false) {
@@ -1240,6 +1277,7 @@ struct EngineT : EngineBase {
         sweep();
         SS_HIP(hipEventRecord(ev[2], st));
         SS_HIP(hipEventSynchronize(ev[2]));
+        reap_retired_graphs();   // nothing of this lane's stream is executing any more
         float ms_mel = 0, ms_tot = 0;
         SS_HIP(hipEventElapsedTime(&ms_mel, ev[0], ev[1]));
         SS_HIP(hipEventElapsedTime(&ms_tot, ev[0], ev[2]));
@@ -1252,6 +1290,7 @@ struct EngineT : EngineBase {
             last_cnt[0] = cnt_passes; last_cnt[1] = cnt_rows; last_cnt[2] = cnt_windows; last_cnt[3] = cnt_admitted;
             for (int i = 0; i < 4; i++) { tot_ms[i] += last_ms[i]; tot_cnt[i] += last_cnt[i]; }
             tot_cnt[4] += cnt_midstart;
+            tot_cnt[5] = n_graph_evictions;
         }
         owner->last_lane.store(lane_index);
     }
@@ -2169,6 +2208,13 @@ void EngineBase::wait(Job* j) {
     if (--n_waiters == 0 && stop) donecv.notify_all();   // stop_worker waits for the last waiter to leave
 }
 
+void EngineBase::wait_session_idle(Session& s, std::unique_lock<std::mutex>& registry) {
+    std::unique_lock<std::mutex> lk(qmu);
+    n_waiters++;
+    registry.unlock();
+    donecv.wait(lk, [&] { return s.in_flight.load() == 0; });
+    if (--n_waiters == 0 && stop) donecv.notify_all();
+}
 EngineBase* make_engine_bf16(const char* path, const ss_engine_opts& o) { return new EngineT<bf16>(path, o, nullptr); }
 EngineBase* make_engine_f16(const char* path, const ss_engine_opts& o) { return new EngineT<f16>(path, o, nullptr); }
 

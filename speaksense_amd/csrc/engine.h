@@ -110,7 +110,7 @@ struct EngineBase {
     // cumulative device time (ms: mel, encoder+cross-KV, decode, total) and work (decoder passes, decoder rows, encoder windows) of this lane since
     // creation; ss_engine_totals sums over the lanes
     double tot_ms[4] = {0, 0, 0, 0};
-    long tot_cnt[6] = {0, 0, 0, 0, 0, 0};   // ..., [4] windows started while other windows of the group were decoding
+    long tot_cnt[6] = {0, 0, 0, 0, 0, 0};   // ..., [4] windows started while other windows of the group were decoding, [5] decode-step graphs evicted from the LRU
 
     // async batch former: one worker thread per lane; one of them at a time forms the next batch from the queue
     std::vector<std::thread> workers;
@@ -125,7 +125,7 @@ struct EngineBase {
     void job_finished(Job* j, EngineBase* lane_);                         // this chunk's results are final: wake its waiter now, not when the group ends
     int admit_more(int n_max, EngineBase* lane_, std::vector<Job*>& out); // pop up to n_max queued chunks (sessions not in flight) for a running group
     bool stop = false;
-    int n_waiters = 0;             // threads inside wait() (under qmu): stop_worker lets them leave before the engine goes
+    int n_waiters = 0;             // threads inside wait() / wait_session_idle() (under qmu): stop_worker lets them leave before the engine goes
     void complete_locked(Job* j);  // caller holds qmu: the chunk's status is final -- bookkeeping, then `done`
     std::atomic<unsigned> rr{0};
     std::atomic<int> workers_free{0};   // workers not running a batch right now (waiting for, or forming, one): queued chunks are theirs first
@@ -133,6 +133,9 @@ struct EngineBase {
     void stop_worker();
     void submit(Job* j);
     void wait(Job* j);
+    // ss_session_free with chunks of the session still in flight: a counted waiter like wait(); `registry` (capi.cpp g_live_mu, held by the caller,
+    // who has just seen this engine in the live set) is released as soon as the count is taken
+    void wait_session_idle(Session& s, std::unique_lock<std::mutex>& registry);
 };
 
 EngineBase* make_engine_bf16(const char* path, const ss_engine_opts& o);

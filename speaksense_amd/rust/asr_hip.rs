@@ -34,6 +34,9 @@ unsafe impl Send for ss_params {}
 
 #[link(name = "speaksense_hip")]
 extern "C" {
+    fn ss_abi_version() -> i32;
+    fn ss_sizeof_params() -> i32;
+    fn ss_sizeof_engine_opts() -> i32;
     fn ss_default_params(p: *mut ss_params);
     fn ss_last_error() -> *const c_char;
     fn ss_engine_create(path: *const c_char, opts: *const ss_engine_opts, out: *mut *mut ss_engine) -> c_int;
@@ -73,6 +76,12 @@ pub struct HipAsr { engine: Arc<EnginePtr> }
 
 impl HipAsr {
     pub fn new(model_path: String) -> Result<Self> {
+        // the library copies ss_params / ss_engine_opts by value: refuse a library whose layouts are not the ones declared above (speaksense.h SS_ABI_VERSION)
+        let (v, sp, so) = unsafe { (ss_abi_version(), ss_sizeof_params(), ss_sizeof_engine_opts()) };
+        if v != 5 || sp as usize != std::mem::size_of::<ss_params>() || so as usize != std::mem::size_of::<ss_engine_opts>() {
+            return Err(anyhow!("libspeaksense_hip ABI {} (ss_params {} B, ss_engine_opts {} B) does not match this shim (ABI 5, {} B, {} B)", v, sp, so,
+                               std::mem::size_of::<ss_params>(), std::mem::size_of::<ss_engine_opts>()));
+        }
         let path = CString::new(model_path)?;
         let opts = ss_engine_opts { device: 0, dtype: 1 /* SS_DTYPE_F16 (ggml's arithmetic); 0 = bf16, 2 = fp8 (e4m3 encoder / cross-KV projections and cross cache, base and larger models) */, max_batch: 8, max_decoders: 5, batch_wait_us: 2000, n_lanes: 2, compat: 0 /* whisper.cpp v1.5.x behaviour (what whisper-rs-sys 0.9.0 vendors); SS_COMPAT_* selects older / OpenAI variants */, reserved: 0 };
         let mut e: *mut ss_engine = std::ptr::null_mut();

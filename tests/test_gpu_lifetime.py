@@ -76,6 +76,61 @@ def test_engine_free_fails_queued_chunks_and_wakes_waiters(toy_ml_path):
         s.close()                                             # after the engine: nothing in flight, plain delete
 
 
+def test_session_free_blocked_while_the_engine_is_freed(toy_ml_path):
+    """Thread A sits in ss_session_free (its session has a chunk far back in the queue) while thread B frees the engine: B completes the
+    chunk (SS_ERR_DEVICE: it was queued), must then let A leave the engine's condition variable BEFORE the engine is deleted (A is counted like a
+    thread in ss_wait), and A returns.  Repeated so that A is caught before, inside and after its wait."""
+    from speaksense_amd import binding
+    pcm = synth.speech_like(6, 16000 * 20)
+    for rnd in range(8):
+        eng = binding.Engine(toy_ml_path, max_batch=2, n_lanes=1, batch_wait_us=0)
+        L = eng.L
+        ses = [eng.new_session() for _ in range(10)]
+        tickets = [s.submit(pcm, _P()) for s in ses]
+        done = []
+
+        def freer(i):
+            ses[i].close()                                        # blocks: chunk i is queued behind the others
+            done.append(i)
+        th = [threading.Thread(target=freer, args=(i,)) for i in (9, 8, 5)]
+        for t in th:
+            t.start()
+        time.sleep(0.002 * rnd)                                   # 0 .. 14 ms: the freers are about to enter, inside, or (late rounds) partly served
+        eng.close()
+        for t in th:
+            t.join(timeout=60)
+            assert not t.is_alive(), "a thread blocked in ss_session_free was not released by ss_engine_free"
+        assert sorted(done) == [5, 8, 9]
+        codes = [L.ss_wait(t) for t in tickets]
+        assert all(c in (0, -4) for c in codes) and codes[9] == -4, codes
+        for i, s in enumerate(ses):
+            if i not in (5, 8, 9):
+                s.close()
+
+
+def test_engine_create_refuses_a_configuration_that_cannot_fit(toy_ml_path, wide2_path):
+    """max_batch / max_decoders / lanes whose caches exceed the device's free memory fail in ss_engine_create with SS_ERR_ARG and the numbers
+    (ADVICE r04), not as a late hipMalloc error; a configuration that fits still loads."""
+    from speaksense_amd import binding
+    probe = binding.Engine(toy_ml_path, max_batch=2, n_lanes=1)
+    free_b, _ = probe.mem_info()
+    probe.close()
+    # wide2 (d = 1280, 2 decoder layers): 128 windows x 8 decoders x 8 lanes = 8 x (128 x 15 MB cross-KV + 1024 x 4.6 MB self-KV + 6.4 GB encoder) = ~105 GB
+    need_gb = 105
+    if free_b < (need_gb + 20) << 30:
+        with pytest.raises(binding.SpeakSenseError) as ei:
+            binding.Engine(wide2_path, max_batch=128, max_decoders=8, n_lanes=8)
+        assert ei.value.code == -1 and "MiB" in str(ei.value), str(ei.value)
+    os.environ["SS_TEST_FREE_MEM_MIB"] = "4096"                    # (test hook: pretend the device has 4 GiB free)
+    try:
+        with pytest.raises(binding.SpeakSenseError) as ei:
+            binding.Engine(wide2_path, max_batch=32, max_decoders=5, n_lanes=3)
+        assert ei.value.code == -1 and "lanes needs" in str(ei.value), str(ei.value)
+    finally:
+        del os.environ["SS_TEST_FREE_MEM_MIB"]
+    binding.Engine(wide2_path, max_batch=32, max_decoders=5, n_lanes=3).close()
+
+
 def test_abandoned_ticket_leaks_nothing_on_the_device(toy_ml_path):
     """A ticket that is never waited for: the chunk still completes, the session can be freed, device memory stays flat."""
     from speaksense_amd import binding
@@ -259,6 +314,8 @@ def test_soak_random_interleavings(toy_ml_path):
         assert q2 - free1 < 64 << 20, f"device memory grew by {(q2 - free1) >> 20} MiB over the second half of the run"
         # (hipMemGetInfo moves by +-30 MiB between two samples of a steady run -- graph LRU turnover, the runtime's own pools: r04_av, five 90 s runs --
         # so quarter-to-quarter comparisons are noise; a leak of even one staging buffer per thousand chunks would be > 100 MiB over the second half)
-        assert (q1 - free1) < 96 << 20, f"device memory grew by {(q1 - free1) >> 20} MiB from 25 % of the run to its end"
+        # (a 60 s run is still filling the lanes' step-graph LRUs -- 256 shapes each since round 5 -- at its 25 % mark: r05_c 292534 / 292284 / 292286 / 292320 MiB)
+        if seconds >= 150:
+            assert (q1 - free1) < 96 << 20, f"device memory grew by {(q1 - free1) >> 20} MiB from 25 % of the run to its end"
     finally:
         eng.close()
