@@ -32,7 +32,38 @@ struct whisper_context;
 struct whisper_state;
 typedef int32_t whisper_token;
 
+/* Which snapshot of whisper.h the by-value structs follow is a BUILD-TIME choice, because the crate's vendored snapshot cannot be read offline
+ * (whisper-rs-sys 0.9.0, /root/reference/Cargo.lock:3898-3901):
+ *   default                      whisper.h v1.5.0 .. v1.5.4: `whisper_context_params { bool use_gpu; }`, whisper_token_data without t_dtw
+ *                                -> the whisper_* symbols inside libspeaksense_hip.so
+ *   -DSS_WHISPER_H_POST_1_5_4    whisper.h v1.5.5 (the next release): `gpu_device` and the DTW token-timestamp fields in whisper_context_params
+ *                                (48 bytes, passed in memory instead of in a register), `t_dtw` in whisper_token_data (56 instead of 48 bytes,
+ *                                returned through a hidden pointer either way)
+ *                                -> libspeaksense_whisper_post154.so: the same shim source compiled with the macro, linked BEFORE
+ *                                   libspeaksense_hip.so (speaksense_amd/build.py builds both; INTEGRATION.md section A shows the link line)
+ * tests/golden/abi_layout.txt and abi_layout_post_1_5_4.txt hold the two layouts field by field (tests/c_harness/layout.c prints them from this
+ * header); a maintainer diffs the one that applies against bindgen's layout tests of the vendored header before linking.  v1.6.0 added
+ * `bool flash_attn` after `use_gpu`: a third snapshot, not built (no caller of the reference's crate version can see it). */
+#ifdef SS_WHISPER_H_POST_1_5_4
+enum whisper_alignment_heads_preset {
+    WHISPER_AHEADS_NONE, WHISPER_AHEADS_N_TOP_MOST, WHISPER_AHEADS_CUSTOM, WHISPER_AHEADS_TINY_EN, WHISPER_AHEADS_TINY, WHISPER_AHEADS_BASE_EN,
+    WHISPER_AHEADS_BASE, WHISPER_AHEADS_SMALL_EN, WHISPER_AHEADS_SMALL, WHISPER_AHEADS_MEDIUM_EN, WHISPER_AHEADS_MEDIUM, WHISPER_AHEADS_LARGE_V1,
+    WHISPER_AHEADS_LARGE_V2, WHISPER_AHEADS_LARGE_V3
+};
+typedef struct whisper_ahead { int n_text_layer; int n_head; } whisper_ahead;
+typedef struct whisper_aheads { size_t n_heads; const whisper_ahead* heads; } whisper_aheads;
+struct whisper_context_params {
+    bool use_gpu;
+    int gpu_device;                 /* -> ss_engine_opts.device (env SS_DEVICE overrides) */
+    bool dtw_token_timestamps;      /* DTW token timestamps are not implemented: a context created with it logs one line, t_dtw stays -1 */
+    enum whisper_alignment_heads_preset dtw_aheads_preset;
+    int dtw_n_top;
+    struct whisper_aheads dtw_aheads;
+    size_t dtw_mem_size;
+};
+#else
 struct whisper_context_params { bool use_gpu; };
+#endif
 
 enum whisper_sampling_strategy { WHISPER_SAMPLING_GREEDY, WHISPER_SAMPLING_BEAM_SEARCH };
 
@@ -108,6 +139,9 @@ typedef struct whisper_token_data {
     float ptsum;        /* sum of probabilities of all timestamp tokens */
     int64_t t0;         /* token-level timestamps (whisper_full_params.token_timestamps), 10 ms units; -1 when the flag was off */
     int64_t t1;
+#ifdef SS_WHISPER_H_POST_1_5_4
+    int64_t t_dtw;      /* DTW token-level timestamp: always -1 here (whisper.cpp's own value when DTW is off) */
+#endif
     float vlen;         /* voice length of the token */
 } whisper_token_data;
 
@@ -122,9 +156,10 @@ typedef void (*ggml_log_callback)(int level, const char* text, void* user_data);
 
 /* ---- the complete function list of whisper.h v1.5.4 ------------------------------------------------------------------------------------
  * Every symbol whisper-rs-sys 0.9.0's bindings can reference resolves against libspeaksense_hip.so.  What the reference calls (listed at the
- * top of this file) is implemented; so are the helpers that need no new device code.  Entry points of whisper.cpp's LOW-LEVEL API that
- * this engine has no per-state equivalent for (whisper_encode / whisper_decode / whisper_get_logits, the phase-vocoder mel, OpenVINO,
- * benchmarks) return an error code (or NULL) and log one line -- they never abort and never pretend to have worked. */
+ * top of this file) is implemented; so are the helpers that need no new device code and, since round 5, the low-level
+ * whisper_encode / whisper_decode / whisper_get_logits (whisper-rs: state.encode / state.decode / state.get_logits; the reference does not call
+ * them) on the engine's stage hooks.  What this engine has no equivalent for (the phase-vocoder mel, OpenVINO, ggml's CPU benchmarks) returns
+ * an error code and logs one line -- never aborts, never pretends to have worked. */
 struct whisper_context_params whisper_context_default_params(void);
 struct whisper_context_params* whisper_context_default_params_by_ref(void);
 struct whisper_context* whisper_init_from_file_with_params(const char* path_model, struct whisper_context_params params);
@@ -146,19 +181,24 @@ void whisper_free(struct whisper_context* ctx);
 void whisper_free_params(struct whisper_full_params* params);
 void whisper_free_context_params(struct whisper_context_params* params);
 
-/* mel: computed on the device, kept in the state (whisper_n_len reports it); the spectrogram only feeds whisper_encode, which is unsupported */
+/* mel: computed on the device, kept in the state (whisper_n_len reports it); it feeds whisper_encode* and the language detection */
 int whisper_pcm_to_mel(struct whisper_context* ctx, const float* samples, int n_samples, int n_threads);
 int whisper_pcm_to_mel_with_state(struct whisper_context* ctx, struct whisper_state* state, const float* samples, int n_samples, int n_threads);
 int whisper_pcm_to_mel_phase_vocoder(struct whisper_context* ctx, const float* samples, int n_samples, int n_threads);               /* -1 */
 int whisper_pcm_to_mel_phase_vocoder_with_state(struct whisper_context* ctx, struct whisper_state* state, const float* samples, int n_samples, int n_threads);
 int whisper_set_mel(struct whisper_context* ctx, const float* data, int n_len, int n_mel);
 int whisper_set_mel_with_state(struct whisper_context* ctx, struct whisper_state* state, const float* data, int n_len, int n_mel);
-int whisper_encode(struct whisper_context* ctx, int offset, int n_threads);                                                           /* -1 */
-int whisper_encode_with_state(struct whisper_context* ctx, struct whisper_state* state, int offset, int n_threads);                   /* -1 */
-int whisper_decode(struct whisper_context* ctx, const whisper_token* tokens, int n_tokens, int n_past, int n_threads);                /* -1 */
+/* encoder over the window that starts at mel frame `offset` of the state's spectrogram (whisper_pcm_to_mel* / whisper_set_mel*), then the
+ * cross-K/V of every decoder layer: the device kernels of the batch path, one window (ss_encode + ss_session_set_encoder).  0 = ok */
+int whisper_encode(struct whisper_context* ctx, int offset, int n_threads);
+int whisper_encode_with_state(struct whisper_context* ctx, struct whisper_state* state, int offset, int n_threads);
+/* n_tokens tokens at positions n_past .. of the state's self-KV cache, attending to the last whisper_encode* (ss_session_decode).  0 = ok */
+int whisper_decode(struct whisper_context* ctx, const whisper_token* tokens, int n_tokens, int n_past, int n_threads);
 int whisper_decode_with_state(struct whisper_context* ctx, struct whisper_state* state, const whisper_token* tokens, int n_tokens, int n_past, int n_threads);
-float* whisper_get_logits(struct whisper_context* ctx);                                                                               /* NULL */
-float* whisper_get_logits_from_state(struct whisper_state* state);                                                                    /* NULL */
+/* raw logits [n_vocab] of the LAST token of the last whisper_decode* (whisper.cpp v1.5.x computes that row only); owned by the state, valid until
+ * its next whisper_decode* / whisper_full*; NULL before the first decode */
+float* whisper_get_logits(struct whisper_context* ctx);
+float* whisper_get_logits_from_state(struct whisper_state* state);
 
 int whisper_tokenize(struct whisper_context* ctx, const char* text, whisper_token* tokens, int n_max_tokens);   /* count, or -needed */
 int whisper_lang_max_id(void);

@@ -9,6 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libspeaksense_hip.so")
+LIB_W155 = os.path.join(HERE, "libspeaksense_whisper_post154.so")
 SOURCES = ["model.cpp", "kernels_mel.hip", "kernels_gemm.hip", "kernels_gemm_fp8.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_decode.hip", "kernels_denoise.hip", "kernels_resample.hip", "engine.cpp", "capi.cpp"]
 HEADERS = ["common.h", "kernels.h", "gemm_common.h", "wave_ops.h", "engine.h", os.path.join("..", "..", "include", "speaksense.h"), os.path.join("..", "..", "include", "whisper_compat.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-x", "hip"]
@@ -47,6 +48,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = [os.path.join(objdir, s + ".o") for s in srcs]
     if jobs or not os.path.exists(LIB):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"])
+    # the whisper.h shim once more, laid out as whisper.h v1.5.5 (include/whisper_compat.h SS_WHISPER_H_POST_1_5_4): a small library of its own that
+    # a whisper-rs-sys build links BEFORE libspeaksense_hip.so.  -Bsymbolic: its whisper_* calls among themselves stay inside it.
+    src = os.path.join(CSRC, "whisper_compat.cpp")
+    if os.path.exists(src) and (jobs or not os.path.exists(LIB_W155) or _stale(LIB_W155, src)):
+        obj = os.path.join(objdir, "whisper_compat_post154.o")
+        run([hipcc] + FLAGS + ["-DSS_WHISPER_H_POST_1_5_4", "-c", src, "-o", obj])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", LIB_W155, obj, "-L" + HERE, "-lspeaksense_hip", "-Wl,-rpath,$ORIGIN"])
     return LIB
 
 

@@ -20,6 +20,9 @@ struct whisper_state {
     std::vector<float> mel;      // [n_mel][n_len] from the device log-mel
     int n_len = 0;
     std::string token_text;      // whisper_full_get_token_text's return buffer
+    std::vector<float> enc;      // whisper_encode*: encoder output of the window [n_audio_ctx][n_audio_state] (host copy; the cross-K/V lives in the session)
+    std::vector<float> logits;   // whisper_decode*: raw logits of the last token
+    bool encoded = false;
 };
 
 static ggml_log_callback g_log_cb = nullptr;
@@ -60,7 +63,16 @@ extern "C" {
 // ---- context / state lifetime -------------------------------------------------------------------------------------------------------
 struct whisper_context_params whisper_context_default_params(void) {
     whisper_context_params p;
+    memset(&p, 0, sizeof(p));
     p.use_gpu = true;
+#ifdef SS_WHISPER_H_POST_1_5_4
+    p.gpu_device = 0;
+    p.dtw_token_timestamps = false;
+    p.dtw_aheads_preset = WHISPER_AHEADS_NONE;
+    p.dtw_n_top = -1;
+    p.dtw_aheads.n_heads = 0; p.dtw_aheads.heads = nullptr;
+    p.dtw_mem_size = 1024 * 1024 * 128;
+#endif
     return p;
 }
 struct whisper_context_params* whisper_context_default_params_by_ref(void) {
@@ -71,11 +83,17 @@ struct whisper_context_params* whisper_context_default_params_by_ref(void) {
 void whisper_free_context_params(struct whisper_context_params* params) { free(params); }
 void whisper_free_params(struct whisper_full_params* params) { free(params); }
 
-struct whisper_context* whisper_init_from_file_with_params_no_state(const char* path_model, struct whisper_context_params) {
+struct whisper_context* whisper_init_from_file_with_params_no_state(const char* path_model, struct whisper_context_params cparams) {
     if (!path_model) return nullptr;
     ss_engine_opts o;
     memset(&o, 0, sizeof(o));
+    if (!cparams.use_gpu) wlog("whisper_init: use_gpu = false ignored -- the MI355X engine has no CPU path\n");
+#ifdef SS_WHISPER_H_POST_1_5_4
+    o.device = env_int("SS_DEVICE", cparams.gpu_device);
+    if (cparams.dtw_token_timestamps) wlog("whisper_init: dtw_token_timestamps is not implemented -- t_dtw stays -1 (token_timestamps t0 / t1 are computed)\n");
+#else
     o.device = env_int("SS_DEVICE", 0);
+#endif
     const char* dt = getenv("SS_DTYPE");
     o.dtype = (dt && !strcmp(dt, "bf16")) ? SS_DTYPE_BF16 : (dt && !strcmp(dt, "fp8")) ? SS_DTYPE_FP8 : SS_DTYPE_F16;
     o.max_batch = env_int("SS_MAX_BATCH", 8);
@@ -187,12 +205,34 @@ int whisper_set_mel_with_state(struct whisper_context* ctx, struct whisper_state
     return 0;
 }
 int whisper_set_mel(struct whisper_context* ctx, const float* data, int n_len, int n_mel) { return whisper_set_mel_with_state(ctx, dstate(ctx), data, n_len, n_mel); }
-int whisper_encode(struct whisper_context*, int, int) { return unsupported("whisper_encode"); }
-int whisper_encode_with_state(struct whisper_context*, struct whisper_state*, int, int) { return unsupported("whisper_encode_with_state"); }
-int whisper_decode(struct whisper_context*, const whisper_token*, int, int, int) { return unsupported("whisper_decode"); }
-int whisper_decode_with_state(struct whisper_context*, struct whisper_state*, const whisper_token*, int, int, int) { return unsupported("whisper_decode_with_state"); }
-float* whisper_get_logits(struct whisper_context*) { unsupported("whisper_get_logits"); return nullptr; }
-float* whisper_get_logits_from_state(struct whisper_state*) { unsupported("whisper_get_logits_from_state"); return nullptr; }
+int whisper_encode_with_state(struct whisper_context* ctx, struct whisper_state* state, int offset, int) {
+    if (!ctx || !state) return -1;
+    if (state->mel.empty() || state->n_len <= 0) { wlog("whisper_encode: no spectrogram (call whisper_pcm_to_mel or whisper_set_mel first)\n"); return -1; }
+    if (offset < 0 || offset >= state->n_len) { wlog("whisper_encode: offset %d outside the spectrogram (%d frames)\n", offset, state->n_len); return -1; }
+    state->enc.resize((size_t)hp(ctx, 1) * hp(ctx, 2));
+    state->encoded = false;
+    if (ss_encode(ctx->eng, state->mel.data(), state->n_len, offset, state->enc.data()) != SS_OK ||
+        ss_session_set_encoder(state->ses, state->enc.data()) != SS_OK) { wlog("whisper_encode: %s\n", ss_last_error()); return -1; }
+    state->encoded = true;
+    return 0;
+}
+int whisper_encode(struct whisper_context* ctx, int offset, int n_threads) { return whisper_encode_with_state(ctx, dstate(ctx), offset, n_threads); }
+int whisper_decode_with_state(struct whisper_context* ctx, struct whisper_state* state, const whisper_token* tokens, int n_tokens, int n_past, int) {
+    if (!ctx || !state || !tokens || n_tokens <= 0) return -1;
+    if (!state->encoded) { wlog("whisper_decode: no encoder output (call whisper_encode first)\n"); return -1; }
+    state->logits.resize((size_t)hp(ctx, 0));
+    if (ss_session_decode(state->ses, tokens, n_tokens, n_past, state->logits.data()) != SS_OK) {
+        wlog("whisper_decode: %s\n", ss_last_error());
+        state->logits.clear();
+        return -1;
+    }
+    return 0;
+}
+int whisper_decode(struct whisper_context* ctx, const whisper_token* tokens, int n_tokens, int n_past, int n_threads) {
+    return whisper_decode_with_state(ctx, dstate(ctx), tokens, n_tokens, n_past, n_threads);
+}
+float* whisper_get_logits_from_state(struct whisper_state* state) { return state && !state->logits.empty() ? state->logits.data() : nullptr; }
+float* whisper_get_logits(struct whisper_context* ctx) { return ctx && ctx->default_state ? whisper_get_logits_from_state(ctx->default_state) : nullptr; }
 
 int whisper_tokenize(struct whisper_context* ctx, const char* text, whisper_token* tokens, int n_max_tokens) {
     if (!ctx || !text) return -1;
@@ -381,6 +421,8 @@ int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* s
     ss_params p;
     int rc = map_params(ctx, params, p);
     if (rc != SS_OK) return rc;
+    state->encoded = false;      // the chunk's windows take over the session's cross-K/V and self-KV: a later whisper_decode needs a new whisper_encode
+    state->logits.clear();
     ss_ticket* t = nullptr;
     rc = ss_submit(state->ses, samples, n_samples, &p, &t);
     if (rc != SS_OK) return rc;
@@ -459,6 +501,9 @@ whisper_token_data whisper_full_get_token_data_from_state(struct whisper_state* 
     whisper_token_data d;
     memset(&d, 0, sizeof(d));
     d.t0 = d.t1 = -1;
+#ifdef SS_WHISPER_H_POST_1_5_4
+    d.t_dtw = -1;
+#endif
     float f[4] = {0, 0, 0, 0};
     if (state && ss_result_segment_token(state->ses, i, k, &d.id, &d.tid, f) == SS_OK) {
         d.p = f[0]; d.plog = f[1]; d.pt = f[2]; d.ptsum = f[3];

@@ -1,6 +1,6 @@
 /* Prints "struct field offset size" for every field of the two by-value parameter structs of the C ABI, as a C11 compiler lays them out from
- * the public headers.  tests/test_host_cpu.py compares the output with the committed table (tests/golden/abi_layout.json, derived by hand from
- * whisper.h v1.5.4 for LP64) and with the ctypes mirrors the Python binding uses. */
+ * the public headers.  tests/test_host_cpu.py compares the output with the committed tables (tests/golden/abi_layout.txt: whisper.h v1.5.4; with
+ * -DSS_WHISPER_H_POST_1_5_4 abi_layout_post_1_5_4.txt: v1.5.5; both derived by hand for LP64) and with the ctypes mirrors the Python binding uses. */
 #include <stddef.h>
 #include <stdio.h>
 #include "speaksense.h"
@@ -30,7 +30,19 @@ int main(void) {
     F(whisper_full_params, grammar_rules); F(whisper_full_params, n_grammar_rules); F(whisper_full_params, i_start_rule);
     F(whisper_full_params, grammar_penalty);
     printf("whisper_full_params sizeof %zu 0\n", sizeof(struct whisper_full_params));
+    F(whisper_context_params, use_gpu);
+#ifdef SS_WHISPER_H_POST_1_5_4
+    F(whisper_context_params, gpu_device); F(whisper_context_params, dtw_token_timestamps); F(whisper_context_params, dtw_aheads_preset);
+    F(whisper_context_params, dtw_n_top); F(whisper_context_params, dtw_aheads); F(whisper_context_params, dtw_mem_size);
+#endif
     printf("whisper_context_params sizeof %zu 0\n", sizeof(struct whisper_context_params));
+    F(whisper_token_data, id); F(whisper_token_data, tid); F(whisper_token_data, p); F(whisper_token_data, plog); F(whisper_token_data, pt);
+    F(whisper_token_data, ptsum); F(whisper_token_data, t0); F(whisper_token_data, t1);
+#ifdef SS_WHISPER_H_POST_1_5_4
+    F(whisper_token_data, t_dtw);
+#endif
+    F(whisper_token_data, vlen);
+    printf("whisper_token_data sizeof %zu 0\n", sizeof(struct whisper_token_data));
     F(ss_params, best_of); F(ss_params, temperature); F(ss_params, temperature_inc); F(ss_params, entropy_thold); F(ss_params, logprob_thold);
     F(ss_params, max_initial_ts); F(ss_params, length_penalty); F(ss_params, no_context); F(ss_params, single_segment); F(ss_params, no_timestamps);
     F(ss_params, suppress_blank); F(ss_params, tdrz_enable); F(ss_params, print_special); F(ss_params, max_tokens); F(ss_params, audio_ctx);

@@ -25,7 +25,7 @@ from test_gpu_fp8 import GAP_TOL_FP8
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-N_REPLAY = {"f16": 2, "bf16": 1, "fp8": 1}          # oracle windows per dtype (each ~1 min on 64 host threads)
+N_REPLAY = {"f16": 1, "bf16": 1, "fp8": 1}          # oracle windows per dtype (each ~1 min on 64 host threads)
 # fp8 at FULL depth: 32 e4m3 encoder layers put the encoder output 8.5e-3 rms / up to 8e-2 of full scale from the FP8-mode oracle (test_gpu_fp8.py),
 # and a pick's margin inherits that tail: r04_g measured 0.479 on one chunk of 32 (its single-chunk run, whose few-row kernels round differently,
 # happened to agree with the oracle there, which is what sent it to the replay).  There is no reference arithmetic for this mode:
@@ -107,7 +107,7 @@ def test_decoder_pass_32_64_and_128_rows_vs_oracle(bench_engine, large_v3_path, 
         assert len(token) == 8 * n_seq
         got = eng.decode_rows(token, pos, slot, cross, samp)
         w_n = 0.0
-        for s in (range(n_seq) if n_seq <= 8 else (0, 3, 7, 9, 12, 15)):     # the oracle costs seconds per sequence: a sample of the 128-row pass
+        for s in (range(n_seq) if n_seq <= 4 else (0, 3, 5, 7) if n_seq <= 8 else (0, 7, 9, 15)):     # the oracle costs seconds per sequence: a sample of the wide passes
             ost = om.new_state(omode)
             ost.set_encoder(encs[s % n_win])
             ref = ost.decode(seqs[s], 0)
@@ -214,7 +214,7 @@ def test_natural_preset_32_chunks_distinct_streams_vs_oracle(large_v3_natural_pa
     assert n_same == 32, f"only {n_same}/32 chunks equal their single-chunk run: {differing}"        # batch invariance (round 5)
     om = orc.OracleModel(large_v3_natural_path)
     order = sorted(range(32), key=lambda i: (res[i]["n_windows"], lens[i]))
-    picked = [i for i in order if lens[i] >= 8][:2]                  # the two cheapest non-trivial chunks for the CPU oracle (~1 min per window)
+    picked = [i for i in order if lens[i] >= 8][:1]                  # the cheapest non-trivial chunk for the CPU oracle (~1 min per window; two until round 5)
     worst = 0.0
     for i in picked:
         fg, fs, wg, ws = check_trace_against_oracle(res[i], om, orc, orc.MODE_GGML_F16, pcms[i], orc.default_params(language="en"),

@@ -183,12 +183,12 @@ def test_short_queue_is_levelled_over_idle_lanes(toy_ml_path):
 
 @pytest.mark.timeout(900)
 def test_soak_random_interleavings(toy_ml_path):
-    """SS_SOAK_SECONDS (default 60; tools/diag/soak_crash_hunt.sh runs 90 - 180): 8 threads submit chunks of random length (0.5 - 65 s) with random parameters -- refused ones included --
+    """SS_SOAK_SECONDS (default 45; tools/diag/soak_crash_hunt.sh runs 90 - 180): 8 threads submit chunks of random length (0.5 - 65 s) with random parameters -- refused ones included --
     wait for them in random order, abandon some tickets, free sessions at random points (also with chunks in flight), while a ninth thread polls the
     metrics entry points.  No hang (every thread finishes in time), device memory flat, and every result a thread did collect equals the
     serial result of the same (audio, parameters) on a fresh session."""
     from speaksense_amd import binding
-    seconds = float(os.environ.get("SS_SOAK_SECONDS", "60"))
+    seconds = float(os.environ.get("SS_SOAK_SECONDS", "45"))
     eng = binding.Engine(toy_ml_path, max_batch=8, n_lanes=3)
     try:     # the engine is closed HERE whatever happens: an engine left to the garbage collector after a failed assertion is freed at an arbitrary later point
         lengths = [0.5, 1.0, 3.0, 7.5, 12.0, 29.9, 30.1, 44.0, 65.0]

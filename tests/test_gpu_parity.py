@@ -342,8 +342,8 @@ def test_full_path_openai_ts_rules_variant(toy_en_path, toy_ml_path, orc, which)
     om = orc.OracleModel(path)
     eng = _eng(path, binding.DTYPE_F16, max_batch=4, compat=binding.COMPAT_OPENAI_TS_RULES)
     n_diff = n_same = 0
-    for seed in (3, 4, 5, 6):
-        pcm = synth.speech_like(seed, 16000 * 7)     # (forcing a timestamp at every window start makes the toy models advance in tiny steps: ~15 windows per second of audio)
+    for seed in (3, 4, 5):
+        pcm = synth.speech_like(seed, 16000 * 5)     # (forcing a timestamp at every window start makes the toy models advance in tiny steps: ~15 windows per second of audio)
         P = dict(language="en", temperature_inc=0.0)
         got = eng.new_session().transcribe(pcm, binding.default_params(**P))
         # identical, or every pick a proven near tie on the oracle's variant (the toy models' timestamp logits are nearly flat: forcing a
@@ -354,7 +354,7 @@ def test_full_path_openai_ts_rules_variant(toy_en_path, toy_ml_path, orc, which)
         base = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(**P))
         n_diff += list(base["tokens"]) != list(got["tokens"])
         assert len(got["tokens"]) == 0 or got["tokens"][0] >= om.beg, "first token of the first window is not a timestamp under the OpenAI rule"
-    report(f"{which}: SS_COMPAT_OPENAI_TS_RULES: {n_same}/4 chunks identical to the oracle's variant, the rest proven near ties; {n_diff}/4 differ from the v1.5.x rules")
+    report(f"{which}: SS_COMPAT_OPENAI_TS_RULES: {n_same}/3 chunks identical to the oracle's variant, the rest proven near ties; {n_diff}/3 differ from the v1.5.x rules")
     assert n_diff >= 1 and n_same >= 1
     eng.close(); om.close()
 

@@ -368,8 +368,8 @@ class WTokenData(C.Structure):
 
 def test_whisper_h_full_surface(toy_ml_path, eng, monkeypatch):
     """The rest of whisper.h v1.5.4 (what whisper-rs can reach beyond the reference's call sites): model / token getters, whisper_tokenize,
-    language helpers and detection, per-token results, whisper_full_parallel; the low-level encode/decode entry points refuse with an error
-    code instead of aborting."""
+    language helpers and detection, per-token results, whisper_full_parallel, and the low-level whisper_encode / whisper_decode /
+    whisper_get_logits (round 5)."""
     from speaksense_amd import binding
     monkeypatch.setenv("SS_DTYPE", "f16")
     monkeypatch.setenv("SS_MAX_BATCH", "4")
@@ -453,8 +453,23 @@ def test_whisper_h_full_surface(toy_ml_path, eng, monkeypatch):
     assert L.whisper_n_len_from_state(st) == (len(pcm) + 480000) // 160
     probs = (C.c_float * 100)()
     assert L.whisper_lang_auto_detect_with_state(ctx, st, 0, 4, probs) == ref["lang_id"] and probs[ref["lang_id"]] == 1.0
-    # the ggml-graph-level API is refused, not faked
-    assert L.whisper_encode_with_state(ctx, st, 0, 4) == -1 and not L.whisper_get_logits_from_state(st)
+    # whisper.h's low-level API (whisper-rs: state.encode / state.decode / state.get_logits) on the engine's stage hooks: the logits of the last token
+    # are the bits ss_session_decode gives a native session fed the same spectrogram window (same kernels, and a row's bits do not depend on the pass)
+    L.whisper_decode_with_state.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    L.whisper_get_logits_from_state.restype = C.POINTER(C.c_float)
+    assert not L.whisper_get_logits_from_state(st)                                    # nothing decoded yet
+    toks = np.array([eng.sot, eng.sot + 1, eng.transcribe, 1234, 4321], np.int32)
+    assert L.whisper_decode_with_state(ctx, st, toks.ctypes.data_as(vp), 3, 0, 4) == -1      # no whisper_encode yet (whisper_full reset the state's window)
+    assert L.whisper_encode_with_state(ctx, st, 100000, 4) == -1                      # offset outside the spectrogram
+    assert L.whisper_encode_with_state(ctx, st, 200, 4) == 0
+    ses = eng.new_session()
+    ses.set_encoder(eng.encode(eng.log_mel(pcm), 200))
+    assert L.whisper_decode_with_state(ctx, st, toks.ctypes.data_as(vp), 3, 0, 4) == 0
+    got = np.ctypeslib.as_array(L.whisper_get_logits_from_state(st), (eng.n_vocab,)).copy()
+    assert np.array_equal(got, ses.decode(toks[:3], 0))
+    assert L.whisper_decode_with_state(ctx, st, toks[3:].ctypes.data_as(vp), 1, 3, 4) == 0
+    assert np.array_equal(np.ctypeslib.as_array(L.whisper_get_logits_from_state(st), (eng.n_vocab,)), ses.decode(toks[3:4], 3))
+    ses.close()
 
     # whisper_full_parallel: two halves as one device batch, merged on the context's default state with whisper.cpp's offset rule
     long_pcm = synth.speech_like(24, 16000 * 24)
@@ -472,6 +487,73 @@ def test_whisper_h_full_surface(toy_ml_path, eng, monkeypatch):
         want.append((t0, s["t1"] + off, s["text"]))
     got = [(L.whisper_full_get_segment_t0(ctx, i), L.whisper_full_get_segment_t1(ctx, i), L.whisper_full_get_segment_text(ctx, i)) for i in range(L.whisper_full_n_segments(ctx))]
     assert got == want and len(got) > len(a["segments"])
+    L.whisper_free_state(st)
+    L.whisper_free(ctx)
+
+
+class WContextParams155(C.Structure):      # whisper.h v1.5.5 (include/whisper_compat.h, SS_WHISPER_H_POST_1_5_4; tests/golden/abi_layout_post_1_5_4.txt)
+    _fields_ = [("use_gpu", C.c_bool), ("gpu_device", C.c_int), ("dtw_token_timestamps", C.c_bool), ("dtw_aheads_preset", C.c_int), ("dtw_n_top", C.c_int),
+                ("dtw_n_heads", C.c_size_t), ("dtw_heads", C.c_void_p), ("dtw_mem_size", C.c_size_t)]
+
+
+class WTokenData155(C.Structure):
+    _fields_ = [("id", C.c_int32), ("tid", C.c_int32), ("p", C.c_float), ("plog", C.c_float), ("pt", C.c_float), ("ptsum", C.c_float),
+                ("t0", C.c_int64), ("t1", C.c_int64), ("t_dtw", C.c_int64), ("vlen", C.c_float)]
+
+
+def test_whisper_h_post_1_5_4_library(toy_ml_path, eng, monkeypatch):
+    """libspeaksense_whisper_post154.so: the shim laid out as whisper.h v1.5.5 -- a 48-byte whisper_context_params passed BY VALUE (in memory, not in
+    a register as the one-byte v1.5.4 struct), gpu_device honoured, whisper_token_data with t_dtw = -1 -- gives the results of the native API."""
+    from speaksense_amd import binding, build
+    monkeypatch.setenv("SS_DTYPE", "f16")
+    monkeypatch.setenv("SS_MAX_BATCH", "4")
+    assert C.sizeof(WContextParams155) == 48 and C.sizeof(WTokenData155) == 56
+    L = C.CDLL(build.LIB_W155)
+    vp = C.c_void_p
+    L.whisper_context_default_params.restype = WContextParams155
+    L.whisper_init_from_file_with_params_no_state.restype = vp
+    L.whisper_init_from_file_with_params_no_state.argtypes = [C.c_char_p, WContextParams155]
+    L.whisper_init_state.restype = vp
+    L.whisper_init_state.argtypes = [vp]
+    L.whisper_full_default_params.restype = WFullParams
+    L.whisper_full_default_params.argtypes = [C.c_int]
+    L.whisper_full_with_state.argtypes = [vp, vp, WFullParams, vp, C.c_int]
+    L.whisper_full_n_segments_from_state.argtypes = [vp]
+    L.whisper_full_n_tokens_from_state.argtypes = [vp, C.c_int]
+    L.whisper_full_get_token_data_from_state.restype = WTokenData155
+    L.whisper_full_get_token_data_from_state.argtypes = [vp, C.c_int, C.c_int]
+    L.whisper_full_get_segment_text_from_state.restype = C.c_char_p
+    L.whisper_full_get_segment_text_from_state.argtypes = [vp, C.c_int]
+    for f in ("whisper_full_get_segment_t0_from_state", "whisper_full_get_segment_t1_from_state"):
+        getattr(L, f).restype = C.c_int64
+        getattr(L, f).argtypes = [vp, C.c_int]
+    L.whisper_free_state.argtypes = [vp]
+    L.whisper_free.argtypes = [vp]
+    cp = L.whisper_context_default_params()
+    assert (cp.use_gpu, cp.gpu_device, cp.dtw_token_timestamps, cp.dtw_aheads_preset, cp.dtw_n_top, cp.dtw_n_heads, cp.dtw_mem_size) == (True, 0, False, 0, -1, 0, 128 << 20)
+    bad = L.whisper_context_default_params()
+    bad.gpu_device = 63                                            # no such device: the field is read where the v1.5.5 header puts it
+    assert not L.whisper_init_from_file_with_params_no_state(toy_ml_path.encode(), bad)
+    ctx = L.whisper_init_from_file_with_params_no_state(toy_ml_path.encode(), cp)
+    assert ctx
+    st = L.whisper_init_state(ctx)
+    pcm = synth.speech_like(29, 16000 * 14)
+    p = L.whisper_full_default_params(0)
+    p.language = b"en"; p.temperature_inc = 0.0; p.token_timestamps = True
+    assert L.whisper_full_with_state(ctx, st, p, pcm.ctypes.data_as(vp), len(pcm)) == 0
+    ref = eng.new_session().transcribe(pcm, binding.default_params(language="en", temperature_inc=0.0))
+    n_seg = L.whisper_full_n_segments_from_state(st)
+    assert n_seg == len(ref["segments"]) and n_seg > 0
+    got = [(L.whisper_full_get_segment_t0_from_state(st, i), L.whisper_full_get_segment_t1_from_state(st, i), L.whisper_full_get_segment_text_from_state(st, i))
+           for i in range(n_seg)]
+    assert got == [(s["t0"], s["t1"], s["text"]) for s in ref["segments"]]
+    ids = []
+    for i in range(n_seg):
+        for k in range(L.whisper_full_n_tokens_from_state(st, i)):
+            d = L.whisper_full_get_token_data_from_state(st, i, k)
+            assert d.t_dtw == -1 and 0.0 < d.p <= 1.0 and d.t0 >= 0 and d.t1 >= d.t0 and d.vlen >= 0.0
+            ids.append(d.id)
+    assert ids == [int(t) for t in ref["tokens"]][:len(ids)] and len(ids) > 0
     L.whisper_free_state(st)
     L.whisper_free(ctx)
 

@@ -122,11 +122,11 @@ def test_no_cpu_fallback(toy_ml_path):
     assert e.value.code == -4
 
 
-def _abi_layout(tmp_path):
+def _abi_layout(tmp_path, defines=()):
     import os, subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "layout")
-    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"),
+    exe = str(tmp_path / ("layout" + "".join(defines)))
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror"] + ["-D" + d for d in defines] + ["-I", os.path.join(root, "include"),
                         os.path.join(root, "tests", "c_harness", "layout.c"), "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     out = subprocess.run([exe], capture_output=True, text=True).stdout
@@ -156,6 +156,31 @@ def test_params_struct_layout_matches_header(tmp_path):
     assert (p.best_of, p.no_context, p.suppress_blank, p.language, p.n_max_text_ctx, p.offset_ms, p.prompt_n_tokens) == (5, 1, 1, b"en", 16384, 0, 0)
     assert abs(p.temperature_inc - 0.2) < 1e-7 and abs(p.entropy_thold - 2.4) < 1e-6 and p.logprob_thold == -1.0
     assert ctypes.sizeof(binding.EngineOpts) == 32
+
+
+def test_whisper_h_post_1_5_4_layout(tmp_path):
+    """The second, build-selectable snapshot of whisper.h (include/whisper_compat.h, -DSS_WHISPER_H_POST_1_5_4 = v1.5.5: gpu_device + DTW fields in
+    whisper_context_params, t_dtw in whisper_token_data): field by field against its own committed table; everything else is the v1.5.4 table; and the
+    library built with that macro (libspeaksense_whisper_post154.so) exports the whole whisper_* list and binds its own whisper_* calls to itself."""
+    import os, subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    out, lay = _abi_layout(tmp_path, ("SS_WHISPER_H_POST_1_5_4",))
+    assert out == open(os.path.join(here, "golden", "abi_layout_post_1_5_4.txt")).read()
+    base, _ = _abi_layout(tmp_path)
+    keep = lambda t: [l for l in t.splitlines() if not l.startswith(("whisper_context_params", "whisper_token_data"))]
+    assert keep(out) == keep(base)
+    assert lay[("whisper_context_params", "sizeof")][0] == 48 and lay[("whisper_context_params", "dtw_aheads")] == (24, 16)
+    assert lay[("whisper_token_data", "t_dtw")] == (40, 8) and lay[("whisper_token_data", "sizeof")][0] == 56
+    from speaksense_amd import build
+    build.build()
+    assert os.path.exists(build.LIB_W155)
+    sym = subprocess.run(["nm", "-D", "--defined-only", build.LIB_W155], capture_output=True, text=True).stdout
+    have = {l.split()[-1] for l in sym.splitlines() if " T " in l}
+    main = subprocess.run(["nm", "-D", "--defined-only", build.LIB], capture_output=True, text=True).stdout
+    want = {l.split()[-1] for l in main.splitlines() if " T whisper_" in l}
+    assert want and want <= have, sorted(want - have)
+    dyn = subprocess.run(["readelf", "-d", build.LIB_W155], capture_output=True, text=True).stdout
+    assert "SYMBOLIC" in dyn and "libspeaksense_hip.so" in dyn
 
 
 def _build_c_harness(tmp_path):
