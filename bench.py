@@ -149,6 +149,36 @@ def mode_n_leg(args, device: int, dtype_code: int, n_chunks: int, rounds: int = 
     torch.cuda.synchronize()
     dt = time.perf_counter() - ts; t1 = eng.totals()
     same = sum(tuple(int(t) for t in r["tokens"]) == ref[k] for k, r in res)
+    # the same engine with fewer chunks in flight: the latency a service would feel at lower load (Little's law: p50 ~ chunks in flight / rate)
+    points = [{"chunks_in_flight": n_chunks, "value": round(rounds * n_chunks * CHUNK_SEC / dt, 2), "p50_chunk_latency_ms": round(1e3 * float(np.median(lat)), 1)}]
+    for frac in (2, 3):
+        n_less = max(1, (n_chunks * 2 // 3) if frac == 2 else n_chunks // 3)
+        keep = list(range(n_less))
+
+        def run_less(total, keep=keep):
+            pend, lat2, free, submitted, n_same = {}, [], collections.deque(keep), 0, 0
+            while submitted < total or pend:
+                while free and submitted < total:
+                    k = free.popleft()
+                    pend[k] = (time.perf_counter(), ses[k].submit_device(pcm[k].data_ptr(), pcm.shape[1], P))
+                    submitted += 1
+                done = [k for k, (_, tk) in pend.items() if ses[k].ready(tk)]
+                for k in done:
+                    t_sub, tk = pend.pop(k)
+                    r = ses[k].wait(tk); lat2.append(time.perf_counter() - t_sub); free.append(k)
+                    n_same += tuple(int(t) for t in r["tokens"]) == ref[k]
+                if not done and pend:
+                    time.sleep(2e-4)
+            return lat2, n_same
+        torch.cuda.synchronize()
+        ts2 = time.perf_counter()
+        lat2, n_same2 = run_less(2 * n_less)
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - ts2
+        same += n_same2
+        points.append({"chunks_in_flight": n_less, "value": round(2 * n_less * CHUNK_SEC / dt2, 2), "p50_chunk_latency_ms": round(1e3 * float(np.median(lat2)), 1)})
+    n_checked = len(res) + sum(2 * p_["chunks_in_flight"] for p_ in points[1:])
+    under_1s = [p_ for p_ in points if p_["p50_chunk_latency_ms"] <= 1000.0]
     ntok = [len(r["tokens"]) for _, r in first]
     nwin = [r["n_windows"] for _, r in first]
     nfail = [r["n_fail"] for _, r in first]
@@ -160,7 +190,9 @@ def mode_n_leg(args, device: int, dtype_code: int, n_chunks: int, rounds: int = 
             "tokens_per_chunk": {"min": int(min(ntok)), "median": int(np.median(ntok)), "max": int(max(ntok))},
             "windows_per_chunk": round(float(np.mean(nwin)), 2), "windows_at_temperature_0": round(1.0 - sum(nfail) / max(1, sum(nwin)), 3),
             "distinct_streams": len(set(ref.values())), "chunks": n_chunks,
-            "repeats_identical_to_first_run": f"{same}/{len(res)} (batch invariance: a row's bits do not depend on what shares its decoder pass, tests/test_gpu_batch_invariance.py)",
+            "operating_points": points,
+            "best_at_p50_under_1s": max(under_1s, key=lambda p_: p_["value"]) if under_1s else None,
+            "repeats_identical_to_first_run": f"{same}/{n_checked} (batch invariance: a row's bits do not depend on what shares its decoder pass, tests/test_gpu_batch_invariance.py)",
             "decoder_passes": d["decoder_passes"], "rows_per_pass": round(d["decoder_rows"] / max(1, d["decoder_passes"]), 2),
             "admitted_into_running_groups": d["admitted"], "windows_started_midway": d["started_midway"],
             "phase_ms_total": {"encode_cross_kv": round(d["encode_ms"], 1), "decode": round(d["decode_ms"], 1)}}
@@ -523,6 +555,10 @@ def main():
                                    + (f"Mode F: 1 encoder window + {n_prompt}-token prompt + {args.fixed_steps} greedy steps, EOT suppressed (random weights: "
                                       "natural-EOT decoding would walk the fallback ladder on nearly every window)" if args.fixed_steps > 0
                                       else "Mode N: natural EOT, whisper.cpp fallback rules"),
+                       "arithmetic": ("fp8: e4m3 encoder / cross-KV projections and cross cache -- a throughput mode with NO reference arithmetic (whisper.cpp has no fp8; "
+                                      "parity is against the oracle's FP8 mode, near-tie margin 0.6 at full depth)" if args.dtype == "fp8" else
+                                      "bf16 operands (BASELINE's dtype; parity margin 0.25)" if args.dtype == "bf16" else
+                                      "f16 operands, f32 accumulate: ggml's own arithmetic type, the parity configuration"),
                        "weights": "seeded random, ggml legacy format" if "synthetic" in path else path,
                        "input": "host f32 PCM (H2D inside the timed region)" if args.host_pcm else "f32 PCM resident in HBM",
                        "chunks_per_step": n_gpus * args.batch, "parallelism": f"dp{n_gpus} (independent chunks, no collective)",
@@ -579,6 +615,14 @@ def main():
                                            inflight * args.batch)
             except Exception as e:   # a side measurement never takes the headline down
                 out["mode_n"] = {"value": None, "error": str(e)}
+        # what a service owner feels, in one place: the headline merges submissions into 32-row passes on 3 lanes, these do not hide behind it
+        mn = out.get("mode_n") or {}
+        out["service_view"] = {
+            "headline": {"value": out["value"], "p50_chunk_latency_ms": out["p50_chunk_latency_ms"]},
+            "batch8_strict": {k: out["batch8_strict"][k] for k in ("value", "p50_chunk_latency_ms")} if "batch8_strict" in out else None,
+            "one_chunk_unloaded_latency_ms": out["p50_chunk_latency_unloaded_ms"],
+            "mode_n_natural_eot": {"value": mn.get("value"), "p50_chunk_latency_ms": mn.get("p50_chunk_latency_ms")} if mn else None,
+            "mode_n_best_at_p50_under_1s": mn.get("best_at_p50_under_1s") if mn else None}
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(path, hp, n_steps_dec, n_prompt)

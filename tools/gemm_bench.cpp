@@ -38,7 +38,10 @@ int main(int argc, char** argv) {
         f16 *A, *W; float *bias, *Cf; void* out;
         hipMalloc(&A, (size_t)s.M * s.K * 2); hipMalloc(&W, (size_t)s.N * s.K * 2); hipMalloc(&bias, s.N * 4);
         hipMalloc(&out, (size_t)s.M * s.N * 4);
-        fill<<<1024, 256>>>(A, (size_t)s.M * s.K, 1, 1.0f); fill<<<1024, 256>>>(W, (size_t)s.N * s.K, 2, 0.05f);
+        // SS_GEMM_ZERO=1: all-zero operands -- the same instruction stream toggles far fewer bits, the chip's power management lets it clock higher
+        // (MI355X_MICROARCH.md "DVFS give-back"): the A/B that separates what the schedule loses from what the power budget takes
+        const float zs = getenv("SS_GEMM_ZERO") ? 0.0f : 1.0f;
+        fill<<<1024, 256>>>(A, (size_t)s.M * s.K, 1, 1.0f * zs); fill<<<1024, 256>>>(W, (size_t)s.N * s.K, 2, 0.05f * zs);
         hipMemset(bias, 0, s.N * 4); hipMemset(out, 0, (size_t)s.M * s.N * 4);
         for (int ki = 0; ki < 3; ki++) {
             GemmDesc g{};
@@ -58,7 +61,10 @@ int main(int argc, char** argv) {
                 GemmDesc g{};
                 g.A = A; g.lda = s.K; g.a_rows_per_batch = 0; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = kinds[ki]; g.bias = bias;
                 g.out = out; g.ldo = s.N; g.o_rows_per_batch = 0; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500; g.trace = tr; g.gelu_f16_in = 1;
-                launch_gemm<f16>(g, st); hipDeviceSynchronize();
+                hipEventRecord(e0, st);
+                launch_gemm<f16>(g, st);
+                hipEventRecord(e1, st); hipDeviceSynchronize();
+                float tms = 0; hipEventElapsedTime(&tms, e0, e1);
                 std::vector<long long> h(256 * 8 * 4);
                 hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost);
                 long long tmin = 1LL << 62;
@@ -71,6 +77,12 @@ int main(int argc, char** argv) {
                     if (t > 0) { gap += q[0] - h[(b * 8 + t - 1) * 4 + 3]; ng++; }
                 }
                 printf("   trace %-8s: per tile (s_memtime ticks = shader cycles) prologue %.0f  loop %.0f  epilogue %.0f  (tiles %d)\n", kn[ki], pro / n, loop / n, epi / n, n);
+                {   // effective shader clock of this launch: ticks a persistent workgroup spent from its first tile's start to its last tile's end / the launch's wall time
+                    double span = 0; int nb = 0;
+                    for (int b = 0; b < 256; b++) { long long a0 = h[(b * 8) * 4], z = 0; for (int t = 0; t < 8; t++) if (h[(b * 8 + t) * 4 + 3]) z = h[(b * 8 + t) * 4 + 3]; if (a0 && z) { span += (double)(z - a0); nb++; } }
+                    if (nb) printf("   clock %-8s: mean workgroup span %.0f ticks over a launch of %.3f ms (traced) => >= %.2f GHz effective shader clock; MFMA issue alone = %.0f ticks per tile at 16 cycles per 16x16x32\n",
+                                   kn[ki], span / nb, tms, span / nb / (tms * 1e6), (double)(s.K / 32) * 64 * 2 * 16);
+                }
                 for (int b : {0, 100, 200}) { printf("     wg %3d:", b); for (int t = 0; t < 4; t++) { const long long* q = &h[(b * 8 + t) * 4]; if (q[3]) printf("  [%lld +%lld +%lld +%lld]", q[0] - tmin, q[1] - q[0], q[2] - q[1], q[3] - q[2]); } printf("\n"); }
             }
             hipFree(tr);
