@@ -249,6 +249,9 @@ void whisper_log_set(ggml_log_callback log_callback, void* user_data);
 
 struct whisper_full_params* whisper_full_default_params_by_ref(enum whisper_sampling_strategy strategy);
 struct whisper_full_params whisper_full_default_params(enum whisper_sampling_strategy strategy);
+/* whisper_full_params callbacks fire at CHUNK granularity (a chunk's windows run inside a device batch shared with other states): abort_callback and
+ * encoder_begin_callback once before the chunk is submitted (true / false -> -6), progress_callback(100) and new_segment_callback(n_new = all
+ * segments of the call) once when it has completed.  logits_filter_callback and grammar rules are refused (-9). */
 int whisper_full(struct whisper_context* ctx, struct whisper_full_params params, const float* samples, int n_samples);
 int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* state, struct whisper_full_params params,
                             const float* samples, int n_samples);

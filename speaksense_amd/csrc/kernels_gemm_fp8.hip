@@ -42,6 +42,199 @@ __device__ __forceinline__ void blds4(Rsrc r, unsigned voff, int soff, char* lds
 struct Frag8 { i32x4 lo, hi; };
 __device__ __forceinline__ i32x8 frag_join(const Frag8& f) { return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
+// ---- shared by the two main-loop forms below: what happens to a wave's 64 n x 128 m accumulator block after the k loop -------------------------
+// per-column weight scale and bias, folded into the accumulators (128 FMAs) before the next tile's DMAs are queued (in-order vmcnt)
+// non-SWAP: register r of acc[ni][mi] is column n0 + wn*64 + ni*32 + 8 (r >> 2) + 4 kh + (r & 3), row m0 + wm*128 + mi*32 + l32
+// SWAP:     register r is ROW m0 + wm*128 + mi*32 + 8 (r >> 2) + 4 kh + (r & 3), column n0 + wn*64 + ni*32 + l32
+template <int KIND>
+__device__ __forceinline__ void f8_fold_scale_bias(const GemmF8Desc& g, f32x16 (&acc)[2][4], int n0, int wn, int l32, int kh) {
+    constexpr bool SWAP = (KIND == F8_VT);
+    {
+        f32x4 bias_v[2][4], ws_v[2][4];
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                if constexpr (SWAP) {
+                    const int n = n0 + wn * 64 + ni * 32 + l32;
+                    const float bn = g.bias ? g.bias[n] : 0.f, sn = g.w_scale[n];
+                    bias_v[ni][gq] = (f32x4){bn, bn, bn, bn};
+                    ws_v[ni][gq] = (f32x4){sn, sn, sn, sn};
+                } else {
+                    const int n = n0 + wn * 64 + ni * 32 + 8 * gq + 4 * kh;
+                    bias_v[ni][gq] = g.bias ? *(const f32x4*)(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    ws_v[ni][gq] = *(const f32x4*)(g.w_scale + n);
+                }
+            }
+        // folded into the accumulators here (128 FMAs): the 64 registers are free again before the residual prefetch of the epilogue needs them
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[ni][mi][r] = acc[ni][mi][r] * ws_v[ni][r >> 2][r & 3] + bias_v[ni][r >> 2][r & 3];
+    }
+}
+
+template <typename T, int KIND>
+__device__ __forceinline__ void f8_epilogue(const GemmF8Desc& g, f32x16 (&acc)[2][4], int m0, int n0, int wm, int wn, int l32, int kh) {
+    typedef typename Mfma<T>::V4 V4;
+    constexpr bool SWAP = (KIND == F8_VT);
+    if constexpr (KIND == F8_RES_F32) {
+        const float* __restrict__ resp = g.res;
+        float* __restrict__ outp = (float*)g.out;
+        auto src_of = [&](int mi, int ni, int gq) -> const float* {
+            long m = m0 + wm * 128 + mi * 32 + l32;
+            if (m > g.M - 1) m = g.M - 1;
+            return resp + m * g.ldo + n0 + wn * 64 + ni * 32 + 8 * gq + 4 * kh;
+        };
+        // the residual of half-row-group t+1 (32 rows x 32 columns of this wave) is loaded before half-row-group t is stored
+        f32x4 nxt[4];
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) nxt[gq] = *(const f32x4*)src_of(0, 0, gq);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int mi = t >> 1, ni = t & 1;
+            f32x4 cur[4];
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) cur[gq] = nxt[gq];
+            if (t + 1 < 8) {
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) nxt[gq] = *(const f32x4*)src_of((t + 1) >> 1, (t + 1) & 1, gq);
+            }
+            const long m = m0 + wm * 128 + mi * 32 + l32;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; r++) v[r] = acc[ni][mi][gq * 4 + r];
+                *(f32x4*)(outp + m * g.ldo + n0 + wn * 64 + ni * 32 + 8 * gq + 4 * kh) = cur[gq] + v;
+            }
+        }
+    } else if constexpr (KIND == F8_GELU_F8) {
+        unsigned ebytes = 0;
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) {
+            const long m = m0 + wm * 128 + mi * 32 + l32;
+            float v[2][4][4];
+            float amax = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {   // packed-f32 GELU (gemm_common.h gelu_tanh_pk): two elements per VALU instruction
+                        f32x2 t = {acc[ni][mi][gq * 4 + r], acc[ni][mi][gq * 4 + r + 1]};
+                        if (std::is_same<T, f16>::value && g.gelu_f16_in) t = gelu_tanh_pk<true>(t); else t = gelu_tanh_pk<false>(t);
+                        v[ni][gq][r] = t[0]; v[ni][gq][r + 1] = t[1];
+                        amax = fmaxf(amax, fmaxf(fabsf(t[0]), fabsf(t[1])));
+                    }
+            amax = swap32_max(amax);   // the other half of this row's 64 columns is in lane ^ 32
+            const int e = e8m0_for_amax(amax);
+            const float inv = pow2_neg_of_e8m0(e);
+            ebytes |= (unsigned)e << (8 * mi);
+            if (m < g.M) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++)
+                        *(unsigned*)((unsigned char*)g.out + m * g.ldo + n0 + wn * 64 + ni * 32 + 8 * gq + 4 * kh) =
+                            pack_e4m3x4(v[ni][gq][0] * inv, v[ni][gq][1] * inv, v[ni][gq][2] * inv, v[ni][gq][3] * inv);
+            }
+        }
+        // exponent bytes of rows (mi*32 + l32, mi = 0..3) of this wave's 128-row half: one dword per lane in the tiled layout
+        if (kh == 0) *(unsigned*)(g.out_scale + (long)((n0 + wn * 64) >> 6) * g.ld_osc + m0 + wm * 128 + l32 * 4) = ebytes;
+    } else if constexpr (KIND == F8_CROSS_KV8) {
+        // this wave's 64 columns are one head of one (layer, K|V): quantised per (key row, head) like the GELU output, K pre-scaled by dh^-1/4
+        const int H = g.d / 64;
+        const int nw = n0 + wn * 64;
+        const int l = nw / (2 * g.d), rem = nw % (2 * g.d), kv = rem / g.d, h = (rem % g.d) >> 6;
+        const float ksc = kv == 0 ? g.scale : 1.0f;
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) {
+            const long m = m0 + wm * 128 + mi * 32 + l32;
+            float v[2][4][4];
+            float amax = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { v[ni][gq][r] = acc[ni][mi][gq * 4 + r] * ksc; amax = fmaxf(amax, fabsf(v[ni][gq][r])); }
+            amax = swap32_max(amax);
+            const int e = e8m0_for_amax(amax);
+            const float inv = pow2_neg_of_e8m0(e);
+            if (m < g.M) {
+                int b = (int)(m / g.rows_per_batch);
+                const int t = (int)(m % g.rows_per_batch);
+                if (g.use_batch_map) b = g.batch_map[b];
+                const long row = (((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t;
+#pragma unroll
+                for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                    for (int gq = 0; gq < 4; gq++)
+                        *(unsigned*)((unsigned char*)g.out + row * 64 + ni * 32 + 8 * gq + 4 * kh) =
+                            pack_e4m3x4(v[ni][gq][0] * inv, v[ni][gq][1] * inv, v[ni][gq][2] * inv, v[ni][gq][3] * inv);
+                if (kh == 0) g.out_scale[row] = (unsigned char)e;
+            }
+        }
+    } else if constexpr (!SWAP) {
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++) {
+            const long m = m0 + wm * 128 + mi * 32 + l32;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < 2; ni++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const int n = n0 + wn * 64 + ni * 32 + 8 * gq + 4 * kh;
+                    f32x4 v;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) v[r] = acc[ni][mi][gq * 4 + r];
+                    if constexpr (KIND == F8_STORE_T) {
+                        V4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
+                        *(V4*)((T*)g.out + m * g.ldo + n) = o;
+                    } else if constexpr (KIND == F8_STORE_F32) {
+                        *(f32x4*)((float*)g.out + m * g.ldo + n) = v;
+                    } else if constexpr (KIND == F8_CROSS_KV) {
+                        const int H = g.d / 64;
+                        const int l = n / (2 * g.d), rem = n % (2 * g.d), kv = rem / g.d, hj = rem % g.d, h = hj >> 6, j = hj & 63;
+                        int b = (int)(m / g.rows_per_batch);
+                        const int t = (int)(m % g.rows_per_batch);
+                        if (g.use_batch_map) b = g.batch_map[b];
+                        const float sc = kv == 0 ? g.scale : 1.0f;
+                        V4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
+                        *(V4*)((T*)g.out + ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j) = o;
+                    }
+                }
+        }
+    } else {
+        const int H = g.d / 64;
+#pragma unroll
+        for (int ni = 0; ni < 2; ni++) {
+            const int n = n0 + wn * 64 + ni * 32 + l32;
+            const int h = n >> 6, j = n & 63;
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                for (int gq = 0; gq < 4; gq++) {
+                    const long m = m0 + wm * 128 + mi * 32 + 8 * gq + 4 * kh;
+                    if (m >= g.M) continue;
+                    const int bb = (int)(m / g.rows_per_batch), t = (int)(m % g.rows_per_batch);
+                    V4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) o[r] = (T)acc[ni][mi][gq * 4 + r];
+                    *(V4*)((T*)g.out + (((long)(bb * H + h) * 64 + j) * g.Tpad + t)) = o;
+                }
+        }
+    }
+}
+
 // 256 (m) x 256 (n) x 64 tile, 512 threads = 8 waves (4 n x 2 m), each wave 64 n x 128 m = 2 x 4 MFMA 32x32x64; one workgroup per CU, persistent.
 // LDS rows are 64 B; the 16-B chunk c of row r sits at chunk position c ^ ((r >> 2) & 3), which makes the ds_read_b128 of a fragment
 // (32 rows x one chunk per half-wave) conflict-free; the permutation is applied to the per-lane DMA source address.
@@ -212,34 +405,7 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(GemmF8Desc g) {
 #undef SS_QUARTER
 #undef SS_MMA1
 
-    // per-column weight scale and bias of this lane's output columns, loaded before the next tile's DMAs are queued (in-order vmcnt)
-    // non-SWAP: register r of acc[ni][mi] is column n0 + wn*64 + ni*32 + 8 (r >> 2) + 4 kh + (r & 3), row m0 + wm*128 + mi*32 + l32
-    // SWAP:     register r is ROW m0 + wm*128 + mi*32 + 8 (r >> 2) + 4 kh + (r & 3), column n0 + wn*64 + ni*32 + l32
-    {
-        f32x4 bias_v[2][4], ws_v[2][4];
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int gq = 0; gq < 4; gq++) {
-                if constexpr (SWAP) {
-                    const int n = n0 + wn * 64 + ni * 32 + l32;
-                    const float bn = g.bias ? g.bias[n] : 0.f, sn = g.w_scale[n];
-                    bias_v[ni][gq] = (f32x4){bn, bn, bn, bn};
-                    ws_v[ni][gq] = (f32x4){sn, sn, sn, sn};
-                } else {
-                    const int n = n0 + wn * 64 + ni * 32 + 8 * gq + 4 * kh;
-                    bias_v[ni][gq] = g.bias ? *(const f32x4*)(g.bias + n) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                    ws_v[ni][gq] = *(const f32x4*)(g.w_scale + n);
-                }
-            }
-        // folded into the accumulators here (128 FMAs): the 64 registers are free again before the residual prefetch of the epilogue needs them
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-            for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[ni][mi][r] = acc[ni][mi][r] * ws_v[ni][r >> 2][r & 3] + bias_v[ni][r >> 2][r & 3];
-    }
+    f8_fold_scale_bias<KIND>(g, acc, n0, wn, l32, kh);
     pro_issued = false;
     {
         const int vbn = vb + gridDim.x;
@@ -255,164 +421,208 @@ __global__ __launch_bounds__(512, 2) void gemm_f8_kernel(GemmF8Desc g) {
             pro_issued = true;
         }
     }
-    // ---------------- epilogue ----------------
-    if constexpr (KIND == F8_RES_F32) {
-        const float* __restrict__ resp = g.res;
-        float* __restrict__ outp = (float*)g.out;
-        auto src_of = [&](int mi, int ni, int gq) -> const float* {
-            long m = m0 + wm * 128 + mi * 32 + l32;
-            if (m > g.M - 1) m = g.M - 1;
-            return resp + m * g.ldo + n0 + wn * 64 + ni * 32 + 8 * gq + 4 * kh;
-        };
-        // the residual of half-row-group t+1 (32 rows x 32 columns of this wave) is loaded before half-row-group t is stored
-        f32x4 nxt[4];
-#pragma unroll
-        for (int gq = 0; gq < 4; gq++) nxt[gq] = *(const f32x4*)src_of(0, 0, gq);
-#pragma unroll
-        for (int t = 0; t < 8; t++) {
-            const int mi = t >> 1, ni = t & 1;
-            f32x4 cur[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; gq++) cur[gq] = nxt[gq];
-            if (t + 1 < 8) {
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++) nxt[gq] = *(const f32x4*)src_of((t + 1) >> 1, (t + 1) & 1, gq);
-            }
-            const long m = m0 + wm * 128 + mi * 32 + l32;
-            if (m >= g.M) continue;
-#pragma unroll
-            for (int gq = 0; gq < 4; gq++) {
-                f32x4 v;
-#pragma unroll
-                for (int r = 0; r < 4; r++) v[r] = acc[ni][mi][gq * 4 + r];
-                *(f32x4*)(outp + m * g.ldo + n0 + wn * 64 + ni * 32 + 8 * gq + 4 * kh) = cur[gq] + v;
-            }
-        }
-    } else if constexpr (KIND == F8_GELU_F8) {
-        unsigned ebytes = 0;
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++) {
-            const long m = m0 + wm * 128 + mi * 32 + l32;
-            float v[2][4][4];
-            float amax = 0.f;
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++)
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2) {   // packed-f32 GELU (gemm_common.h gelu_tanh_pk): two elements per VALU instruction
-                        f32x2 t = {acc[ni][mi][gq * 4 + r], acc[ni][mi][gq * 4 + r + 1]};
-                        if (std::is_same<T, f16>::value && g.gelu_f16_in) t = gelu_tanh_pk<true>(t); else t = gelu_tanh_pk<false>(t);
-                        v[ni][gq][r] = t[0]; v[ni][gq][r + 1] = t[1];
-                        amax = fmaxf(amax, fmaxf(fabsf(t[0]), fabsf(t[1])));
-                    }
-            amax = swap32_max(amax);   // the other half of this row's 64 columns is in lane ^ 32
-            const int e = e8m0_for_amax(amax);
-            const float inv = pow2_neg_of_e8m0(e);
-            ebytes |= (unsigned)e << (8 * mi);
-            if (m < g.M) {
-#pragma unroll
-                for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                    for (int gq = 0; gq < 4; gq++)
-                        *(unsigned*)((unsigned char*)g.out + m * g.ldo + n0 + wn * 64 + ni * 32 + 8 * gq + 4 * kh) =
-                            pack_e4m3x4(v[ni][gq][0] * inv, v[ni][gq][1] * inv, v[ni][gq][2] * inv, v[ni][gq][3] * inv);
-            }
-        }
-        // exponent bytes of rows (mi*32 + l32, mi = 0..3) of this wave's 128-row half: one dword per lane in the tiled layout
-        if (kh == 0) *(unsigned*)(g.out_scale + (long)((n0 + wn * 64) >> 6) * g.ld_osc + m0 + wm * 128 + l32 * 4) = ebytes;
-    } else if constexpr (KIND == F8_CROSS_KV8) {
-        // this wave's 64 columns are one head of one (layer, K|V): quantised per (key row, head) like the GELU output, K pre-scaled by dh^-1/4
-        const int H = g.d / 64;
-        const int nw = n0 + wn * 64;
-        const int l = nw / (2 * g.d), rem = nw % (2 * g.d), kv = rem / g.d, h = (rem % g.d) >> 6;
-        const float ksc = kv == 0 ? g.scale : 1.0f;
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++) {
-            const long m = m0 + wm * 128 + mi * 32 + l32;
-            float v[2][4][4];
-            float amax = 0.f;
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) { v[ni][gq][r] = acc[ni][mi][gq * 4 + r] * ksc; amax = fmaxf(amax, fabsf(v[ni][gq][r])); }
-            amax = swap32_max(amax);
-            const int e = e8m0_for_amax(amax);
-            const float inv = pow2_neg_of_e8m0(e);
-            if (m < g.M) {
-                int b = (int)(m / g.rows_per_batch);
-                const int t = (int)(m % g.rows_per_batch);
-                if (g.use_batch_map) b = g.batch_map[b];
-                const long row = (((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t;
-#pragma unroll
-                for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                    for (int gq = 0; gq < 4; gq++)
-                        *(unsigned*)((unsigned char*)g.out + row * 64 + ni * 32 + 8 * gq + 4 * kh) =
-                            pack_e4m3x4(v[ni][gq][0] * inv, v[ni][gq][1] * inv, v[ni][gq][2] * inv, v[ni][gq][3] * inv);
-                if (kh == 0) g.out_scale[row] = (unsigned char)e;
-            }
-        }
-    } else if constexpr (!SWAP) {
-#pragma unroll
-        for (int mi = 0; mi < 4; mi++) {
-            const long m = m0 + wm * 128 + mi * 32 + l32;
-            if (m >= g.M) continue;
-#pragma unroll
-            for (int ni = 0; ni < 2; ni++)
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const int n = n0 + wn * 64 + ni * 32 + 8 * gq + 4 * kh;
-                    f32x4 v;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) v[r] = acc[ni][mi][gq * 4 + r];
-                    if constexpr (KIND == F8_STORE_T) {
-                        V4 o;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * g.scale);
-                        *(V4*)((T*)g.out + m * g.ldo + n) = o;
-                    } else if constexpr (KIND == F8_STORE_F32) {
-                        *(f32x4*)((float*)g.out + m * g.ldo + n) = v;
-                    } else if constexpr (KIND == F8_CROSS_KV) {
-                        const int H = g.d / 64;
-                        const int l = n / (2 * g.d), rem = n % (2 * g.d), kv = rem / g.d, hj = rem % g.d, h = hj >> 6, j = hj & 63;
-                        int b = (int)(m / g.rows_per_batch);
-                        const int t = (int)(m % g.rows_per_batch);
-                        if (g.use_batch_map) b = g.batch_map[b];
-                        const float sc = kv == 0 ? g.scale : 1.0f;
-                        V4 o;
-#pragma unroll
-                        for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
-                        *(V4*)((T*)g.out + ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j) = o;
-                    }
-                }
-        }
-    } else {
-        const int H = g.d / 64;
-#pragma unroll
-        for (int ni = 0; ni < 2; ni++) {
-            const int n = n0 + wn * 64 + ni * 32 + l32;
-            const int h = n >> 6, j = n & 63;
-#pragma unroll
-            for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-                for (int gq = 0; gq < 4; gq++) {
-                    const long m = m0 + wm * 128 + mi * 32 + 8 * gq + 4 * kh;
-                    if (m >= g.M) continue;
-                    const int bb = (int)(m / g.rows_per_batch), t = (int)(m % g.rows_per_batch);
-                    V4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; r++) o[r] = (T)acc[ni][mi][gq * 4 + r];
-                    *(V4*)((T*)g.out + (((long)(bb * H + h) * 64 + j) * g.Tpad + t)) = o;
-                }
-        }
-    }
+    f8_epilogue<T, KIND>(g, acc, m0, n0, wm, wn, l32, kh);
     }  // tile loop
 #undef SS_DMA
 #undef SS_DMA_SC
 }
+
+// ---------------------------------------------------------------------------------------------
+// The same tile with 128-byte LDS rows (round 5): a stage is 128 e4m3 of k per row = TWO 64-k MFMA blocks, 2 x 64 KB ring.
+// Why: an LDS-DMA instruction whose 64 lanes fetch sixteen 64-byte rows holds the CU's address path for ~28 cycles, one that fetches eight
+// 128-byte rows for ~12 (tools/diag/dma_issue_bench.cpp, profiles/r04_af_dma_issue_bench.txt), and that path is shared by the 8 waves.  A 64-byte-row
+// stage above issues 40 of them (32 operand + 8 exponent-byte) = ~1100 cycles against the 1024 cycles its 16 e4m3 MFMAs per SIMD take: the main loop
+// was bound by the address path, not by the matrix pipe.  With 128-byte rows a stage issues 64 + 16 instructions for 2048 cycles of MFMA (~800 +).
+// Schedule as gemm256k64_kernel (kernels_gemm.hip): stage s is consumed in two halves (its two 64-k blocks; register sets A / B for the column
+// fragments, the row fragments refreshed in place a quarter at a time), ONE barrier per stage between them -- by then every wave holds both
+// halves of stage s in registers, so its buffer takes stage s + 2 during the second half while stage s + 1 (issued a whole stage earlier) has
+// landed.  Chunk c (16 B) of row r sits at position c ^ ((r >> 1) & 7): the 16 lanes of a ds_read_b128 service group (16 consecutive rows, one
+// logical chunk) touch 16 distinct slots of the 256-byte bank window.  Stages run in pairs so that every ring index is a compile-time constant
+// and each half is one basic block (see the notes in gemm_f8_kernel on what run-time flags do to this loop); K % 256 == 0 makes the pairs whole.
+// ---------------------------------------------------------------------------------------------
+constexpr int Q2K = 128;
+constexpr int kQ2Stage = (QTM + QTN) * Q2K;            // 64 KB
+constexpr int kQ2ScaleOff = 2 * kQ2Stage;              // exponent bytes behind the ring: [stage][wave][block][256]
+constexpr int kQ2Lds = kQ2ScaleOff + 2 * 8 * 2 * 256;  // 136 KB
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(512, 2) void gemm_f8k128_kernel(GemmF8Desc g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool SWAP = (KIND == F8_VT);
+    constexpr int NPX = 4, RPP = 64, OPS = 8 + 2;     // DMA instructions a thread issues per stage: 4 X passes + 4 W passes of 64 rows, 2 exponent-byte blocks
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 1, wm = wave & 1;
+    const int nbn = g.N / QTN, nbm = (g.M + QTM - 1) / QTM;
+    const Rsrc rA = make_rsrc(g.A, (long)g.M * g.lda), rW = make_rsrc(g.W, (long)g.N * g.K), rS = make_rsrc(g.a_scale, (long)g.ldsc * (g.K / QTK));
+    const int lrow = wave * 8 + (lane >> 3);              // row of a 64-row pass this lane stages (8 lanes x 16 B per 128-byte row)
+    const int cpos = (lane & 7) ^ ((lrow >> 1) & 7);      // the logical chunk that belongs at this lane's LDS position
+    unsigned sx[NPX], sw_lane = 0, sc_off = 0;
+    auto set_tile = [&](int m0, int n0) {
+#pragma unroll
+        for (int p = 0; p < NPX; p++) {
+            long m = m0 + p * RPP + lrow;
+            if (m > g.M - 1) m = g.M - 1;
+            sx[p] = (unsigned)(m * g.lda + cpos * 16);
+        }
+        sw_lane = (unsigned)((long)(n0 + lrow) * g.K + cpos * 16);
+        sc_off = (unsigned)(m0 + lane * 4);
+    };
+    const int wave_off = wave * 8 * 128;
+    const int wpass = RPP * g.K;                          // bytes between two W passes (wave-uniform: rides in the DMA's scalar offset)
+#define SS_DMA2(p, kt, base)                                                                                                      \
+    {                                                                                                                             \
+        if constexpr ((p) < NPX) blds16(rA, sx[(p) < NPX ? (p) : 0], (kt) * Q2K, (base) + (p) * (RPP * 128) + wave_off);           \
+        else blds16(rW, sw_lane, (kt) * Q2K + ((p) - NPX) * wpass, (base) + (p) * (RPP * 128) + wave_off);                         \
+    }
+#define SS_DMA2_SC(buf, kt, blk) blds4(rS, sc_off, ((kt) * 2 + (blk)) * (int)g.ldsc, smem + kQ2ScaleOff + (((buf) * 8 + wave) * 2 + (blk)) * 256)
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * kQ2Stage;
+        SS_DMA2(0, kt, base) SS_DMA2(1, kt, base) SS_DMA2(2, kt, base) SS_DMA2(3, kt, base)
+        SS_DMA2(4, kt, base) SS_DMA2(5, kt, base) SS_DMA2(6, kt, base) SS_DMA2(7, kt, base)
+        SS_DMA2_SC(buf, kt, 0); SS_DMA2_SC(buf, kt, 1);
+    };
+    constexpr int kCarry = 24;
+    bool pro_issued = false;
+    int carry = 0;
+    const int l32 = lane & 31, kh = lane >> 5;
+    const int swz = (l32 >> 1) & 7;
+    // per-lane LDS read bases: {X, W} x {block 0, block 1} x {first, second 16-byte chunk of the lane's 32 bytes}; the rest of an address is an immediate
+    const char* const xb00 = smem + (wm * 128) * 128 + l32 * 128 + (((2 * kh) ^ swz) * 16);
+    const char* const xb01 = smem + (wm * 128) * 128 + l32 * 128 + (((2 * kh + 1) ^ swz) * 16);
+    const char* const xb10 = smem + (wm * 128) * 128 + l32 * 128 + (((4 + 2 * kh) ^ swz) * 16);
+    const char* const xb11 = smem + (wm * 128) * 128 + l32 * 128 + (((5 + 2 * kh) ^ swz) * 16);
+    const char* const wb00 = smem + QTM * 128 + (wn * 64) * 128 + l32 * 128 + (((2 * kh) ^ swz) * 16);
+    const char* const wb01 = smem + QTM * 128 + (wn * 64) * 128 + l32 * 128 + (((2 * kh + 1) ^ swz) * 16);
+    const char* const wb10 = smem + QTM * 128 + (wn * 64) * 128 + l32 * 128 + (((4 + 2 * kh) ^ swz) * 16);
+    const char* const wb11 = smem + QTM * 128 + (wn * 64) * 128 + l32 * 128 + (((5 + 2 * kh) ^ swz) * 16);
+    const char* const scb = smem + kQ2ScaleOff + wave * 512 + wm * 128 + l32 * 4;
+    const int ns = g.K / Q2K;                              // even (K % 256 == 0, checked at launch), >= 2
+
+    for (int vb = blockIdx.x; vb < nbn * nbm; vb += gridDim.x) {
+    int mb, nb;
+    tile_of_block(vb, nbm, nbn, &mb, &nb);
+    const int m0 = mb * QTM, n0 = nb * QTN;
+    if (!pro_issued) {
+        __builtin_amdgcn_s_barrier();
+        set_tile(m0, n0);
+        carry = 0;
+        stage(0, 0);
+        stage(1, 1);
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    Frag8 wfA[2], wfB[2], xf[4];
+    int scA = 0, scB = 0;
+#define SS_MMA2(WF, SCV, ni, q)                                                                                                       \
+    {                                                                                                                                 \
+        const int sxp = ((SCV) >> (8 * (q))) & 0xff;                                                                                  \
+        if (SWAP) acc[ni][q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag_join(xf[q]), frag_join(WF[ni]), acc[ni][q], 0, 0, 0, sxp, 0, 127); \
+        else acc[ni][q] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(frag_join(WF[ni]), frag_join(xf[q]), acc[ni][q], 0, 0, 0, 127, 0, sxp);      \
+    }
+    // a quarter of a half: 2 MFMAs on xf[q]; optionally two operand DMAs of stage dma_kt (+ its two exponent-byte DMAs in the last quarter) into
+    // buffer DBUF; optionally the refresh of xf[q] and half a W fragment from block RBLK of buffer RBUF (the other register set)
+#define SS_Q2(WC, SCC, WN, SCN, DMA, DBUF, dma_kt, READ, RBUF, XB0, XB1, WB0, WB1, RBLK, q)                                              \
+    {                                                                                                                                 \
+        SS_MMA2(WC, SCC, 0, q)                                                                                                        \
+        SS_MMA2(WC, SCC, 1, q)                                                                                                        \
+        if constexpr (DMA) {                                                                                                          \
+            SS_DMA2(2 * (q), dma_kt, smem + (DBUF) * kQ2Stage) SS_DMA2(2 * (q) + 1, dma_kt, smem + (DBUF) * kQ2Stage)                   \
+            if constexpr ((q) == 3) { SS_DMA2_SC(DBUF, dma_kt, 0); SS_DMA2_SC(DBUF, dma_kt, 1); }                                      \
+        }                                                                                                                             \
+        if constexpr (READ) {                                                                                                         \
+            constexpr int ro = (RBUF) * kQ2Stage;                                                                                     \
+            xf[q].lo = *(const i32x4*)(XB0 + ro + (q) * 32 * 128);                                                                    \
+            xf[q].hi = *(const i32x4*)(XB1 + ro + (q) * 32 * 128);                                                                    \
+            if constexpr (((q) & 1) == 0) WN[(q) >> 1].lo = *(const i32x4*)(WB0 + ro + ((q) >> 1) * 32 * 128);                         \
+            else WN[(q) >> 1].hi = *(const i32x4*)(WB1 + ro + ((q) >> 1) * 32 * 128);                                                  \
+            if constexpr ((q) == 0) SCN = *(const int*)(scb + (RBUF) * (8 * 512) + (RBLK) * 256);                                      \
+        }                                                                                                                             \
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                                                                            \
+        if constexpr (DMA) __builtin_amdgcn_sched_group_barrier(0x020, (q) == 3 ? 4 : 2, 0);                                          \
+        if constexpr (READ) __builtin_amdgcn_sched_group_barrier(0x100, (q) == 0 ? 4 : 3, 0);                                         \
+    }
+    // first half of stage BUF: block 0 from set A; set B and the row fragments <- its block 1
+#define SS_H0(BUF)                                                                                                                     \
+    {                                                                                                                                 \
+        SS_Q2(wfA, scA, wfB, scB, false, 0, 0, true, BUF, xb10, xb11, wb10, wb11, 1, 0)                                                \
+        SS_Q2(wfA, scA, wfB, scB, false, 0, 0, true, BUF, xb10, xb11, wb10, wb11, 1, 1)                                                \
+        SS_Q2(wfA, scA, wfB, scB, false, 0, 0, true, BUF, xb10, xb11, wb10, wb11, 1, 2)                                                \
+        SS_Q2(wfA, scA, wfB, scB, false, 0, 0, true, BUF, xb10, xb11, wb10, wb11, 1, 3)                                                \
+    }
+    // second half: block 1 from set B; buffer BUF takes stage dma_kt; set A and the row fragments <- block 0 of the other buffer (stage s + 1)
+#define SS_H1(BUF, DMA, dma_kt, NEXT)                                                                                                  \
+    {                                                                                                                                 \
+        SS_Q2(wfB, scB, wfA, scA, DMA, BUF, dma_kt, NEXT, (BUF) ^ 1, xb00, xb01, wb00, wb01, 0, 0)                                      \
+        SS_Q2(wfB, scB, wfA, scA, DMA, BUF, dma_kt, NEXT, (BUF) ^ 1, xb00, xb01, wb00, wb01, 0, 1)                                      \
+        SS_Q2(wfB, scB, wfA, scA, DMA, BUF, dma_kt, NEXT, (BUF) ^ 1, xb00, xb01, wb00, wb01, 0, 2)                                      \
+        SS_Q2(wfB, scB, wfA, scA, DMA, BUF, dma_kt, NEXT, (BUF) ^ 1, xb00, xb01, wb00, wb01, 0, 3)                                      \
+    }
+    // between the halves: stage s + 1 has landed (nothing younger of this tile is in flight behind it; WAITN > 0 leaves the previous tile's
+    // stores in flight), my reads of stage s have completed, and everybody is here -> its buffer may be overwritten
+#define SS_MID(WAITN) { wait_vmcnt<(WAITN)>(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+#define SS_PAIR(CARRY)                                                                                                                 \
+    {                                                                                                                                 \
+        SS_H0(0) SS_MID((CARRY) ? kCarry : 0) SS_H1(0, true, s + 2, true)                                                             \
+        SS_H0(1) SS_MID(0) SS_H1(1, true, s + 3, true)                                                                                \
+    }
+
+    // prologue: stage 0 has landed (stage 1 and, after an early prologue, the previous tile's last stores stay in flight); block 0 -> set A
+    if (carry) wait_vmcnt<OPS + kCarry>(); else wait_vmcnt<OPS>();
+    __builtin_amdgcn_s_barrier();
+    {
+#pragma unroll
+        for (int i = 0; i < 2; i++) { wfA[i].lo = *(const i32x4*)(wb00 + i * 32 * 128); wfA[i].hi = *(const i32x4*)(wb01 + i * 32 * 128); }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { xf[i].lo = *(const i32x4*)(xb00 + i * 32 * 128); xf[i].hi = *(const i32x4*)(xb01 + i * 32 * 128); }
+        scA = *(const int*)scb;
+    }
+    int s = 0;
+    if (carry && ns > 2) { SS_PAIR(true) s = 2; }
+    for (; s + 3 < ns; s += 2) SS_PAIR(false)
+    {   // last pair (ONE unconditional block: a branch here lets LLVM sink the MFMAs below it and spill every fragment on the way): nothing left to
+        // stage, its second stage has no successor.  Its wait never leaves stores in flight (only matters when K = 256 and the tile was issued early)
+        SS_H0(0) SS_MID(0) SS_H1(0, false, 0, true)
+        SS_H0(1) SS_H1(1, false, 0, false)
+    }
+#undef SS_PAIR
+#undef SS_MID
+#undef SS_H1
+#undef SS_H0
+#undef SS_Q2
+#undef SS_MMA2
+    // the accumulators must exist HERE (see gemm_f8_kernel)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) asm volatile("" : "+v"(acc[i][j]));
+
+    f8_fold_scale_bias<KIND>(g, acc, n0, wn, l32, kh);
+    pro_issued = false;
+    {
+        const int vbn = vb + gridDim.x;
+        if (vbn < nbn * nbm) {
+            int mbn, nbn2;
+            tile_of_block(vbn, nbm, nbn, &mbn, &nbn2);
+            __builtin_amdgcn_s_barrier();   // every wave has read its last fragments: both buffers are free
+            set_tile(mbn * QTM, nbn2 * QTN);
+            stage(0, 0);
+            stage(1, 1);
+            carry = (m0 + QTM <= g.M) ? kCarry : 0;
+            pro_issued = true;
+        }
+    }
+    f8_epilogue<T, KIND>(g, acc, m0, n0, wm, wn, l32, kh);
+    }  // tile loop
+#undef SS_DMA2
+#undef SS_DMA2_SC
+}
+
+int g_f8_k128 = -1;   // env SS_F8_K128, read at the first launch: 0 = the 64-byte-row main loop (gemm_f8_kernel; A/B reference), default 1
 
 template <typename T, int KIND>
 static void launch_f8_kind(const GemmF8Desc& g, hipStream_t st) {
@@ -434,6 +644,13 @@ static void launch_f8_kind(const GemmF8Desc& g, hipStream_t st) {
 #undef SS_KO_CASE
     }
 #endif
+    if (g_f8_k128 < 0) { const char* e = getenv("SS_F8_K128"); g_f8_k128 = e ? atoi(e) : 1; }
+    if (g_f8_k128) {
+        static std::atomic<uint64_t> attr2{0};
+        once_per_device(attr2, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm_f8k128_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kQ2Lds)); });
+        gemm_f8k128_kernel<T, KIND><<<nwg < n_cu ? nwg : n_cu, 512, kQ2Lds, st>>>(g); SS_LAUNCH_CHECK();
+        return;
+    }
     gemm_f8_kernel<T, KIND><<<nwg < n_cu ? nwg : n_cu, 512, kQLds, st>>>(g); SS_LAUNCH_CHECK();
 }
 

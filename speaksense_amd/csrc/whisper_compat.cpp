@@ -387,9 +387,9 @@ static int map_params(struct whisper_context* ctx, const struct whisper_full_par
     if (params.strategy != WHISPER_SAMPLING_GREEDY || params.speed_up || params.suppress_non_speech_tokens || params.n_grammar_rules > 0 ||
         params.logits_filter_callback || params.max_len > 0)
         return SS_ERR_UNSUPPORTED;
-    // callbacks would have to fire from inside the device batch.  split_on_word (the reference sets it, whisper.rs:161) only acts together with
-    // max_len > 0, refused above; token_timestamps (whisper.rs:160) is honoured: whisper_full_get_token_data(..).t0 / t1 / vlen.
-    if (params.new_segment_callback || params.progress_callback || params.encoder_begin_callback || params.abort_callback) return SS_ERR_UNSUPPORTED;
+    // split_on_word (the reference sets it, whisper.rs:161) only acts together with max_len > 0, refused above; token_timestamps (whisper.rs:160) is
+    // honoured: whisper_full_get_token_data(..).t0 / t1 / vlen.  The four plain callbacks are honoured at CHUNK granularity (whisper_full_with_state
+    // below): the windows of a chunk complete inside a device batch shared with other states, so nothing can fire from inside it.
     if (params.audio_ctx != 0 && params.audio_ctx != whisper_n_audio_ctx(ctx)) return SS_ERR_UNSUPPORTED;
     ss_default_params(&p);
     p.best_of = params.greedy.best_of > 0 ? params.greedy.best_of : 1;
@@ -423,10 +423,25 @@ int whisper_full_with_state(struct whisper_context* ctx, struct whisper_state* s
     if (rc != SS_OK) return rc;
     state->encoded = false;      // the chunk's windows take over the session's cross-K/V and self-KV: a later whisper_decode needs a new whisper_encode
     state->logits.clear();
+    // Callbacks, at chunk granularity (whisper.cpp fires them per window from inside whisper_full; here a chunk's windows run inside a device batch):
+    //   abort_callback          polled once before the chunk is submitted: true -> the call returns -6 like a whisper_encode that was aborted
+    //   encoder_begin_callback  called once before the chunk is submitted: false -> -6 ("encoder_begin_callback returned false - aborting")
+    //   progress_callback       called with 100 when the chunk has completed (whisper.cpp: whole percentages at window starts)
+    //   new_segment_callback    called ONCE when the chunk has completed, n_new = all its segments (whisper.cpp: once per window with that window's)
+    if (params.abort_callback && params.abort_callback(params.abort_callback_user_data)) { wlog("whisper_full_with_state: aborted by abort_callback\n"); return -6; }
+    if (params.encoder_begin_callback && !params.encoder_begin_callback(ctx, state, params.encoder_begin_callback_user_data)) {
+        wlog("whisper_full_with_state: encoder_begin_callback returned false - aborting\n");
+        return -6;
+    }
     ss_ticket* t = nullptr;
     rc = ss_submit(state->ses, samples, n_samples, &p, &t);
     if (rc != SS_OK) return rc;
     rc = ss_wait(t);
+    if (rc == SS_OK) {
+        if (params.progress_callback) params.progress_callback(ctx, state, 100, params.progress_callback_user_data);
+        const int n_new = ss_result_n_segments(state->ses);
+        if (params.new_segment_callback && n_new > 0) params.new_segment_callback(ctx, state, n_new, params.new_segment_callback_user_data);
+    }
     // The reference switches whisper.cpp's own segment printing on (/root/reference/src/asr/whisper.rs:145-150: print_realtime, print_timestamps,
     // print_progress all true), so a drop-in that stays silent changes what the service's stdout shows.  whisper_full_with_state prints each
     // segment as its window is finalised -- "[%s --> %s]  %s\n" with to_timestamp() times under print_timestamps, the bare text otherwise; here the
@@ -485,6 +500,11 @@ int whisper_full_parallel(struct whisper_context* ctx, struct whisper_full_param
             ss_result_append(st0->ses, extra[i], 100 * ((int64_t)(i + 1) * per) / 16000 + offset_t);
     }
     for (ss_session* s : extra) ss_session_free(s);
+    if (ret == SS_OK) {   // callbacks as in whisper_full_with_state: once, on the merged result
+        if (params.progress_callback) params.progress_callback(ctx, st0, 100, params.progress_callback_user_data);
+        const int n_new = ss_result_n_segments(st0->ses);
+        if (params.new_segment_callback && n_new > 0) params.new_segment_callback(ctx, st0, n_new, params.new_segment_callback_user_data);
+    }
     return ret;
 }
 

@@ -67,3 +67,29 @@ def test_gemm_fp8_matches_reference(eng, M, N, K, kind):
     else:
         tol = (1.2e-3 if eng.dtype_name == "f16" else 9e-3) * ref
     assert err <= tol, f"max |diff| {err} vs max |ref| {ref}"
+
+
+def test_ab_reference_main_loops_match_reference(toy_ml_path):
+    """The two A/B switches that select the PREVIOUS main loops -- `SS_GEMM_K64=0` (f16 / bf16 GEMM with 32-deep stages) and `SS_F8_K128=0` (e4m3 GEMM
+    with 64-byte LDS rows) -- are read once per process, so they get a process of their own: the kernels they select must still pass the self-test
+    (DESIGN.md section 7a promises that every switch selects a tested path)."""
+    import os
+    import subprocess
+    import sys
+    code = f"""
+import sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from speaksense_amd import binding
+e = binding.Engine({toy_ml_path!r}, dtype=binding.DTYPE_F16, max_batch=1)
+for M, N, K, kind, tol in ((12000, 5120, 1280, 1, 1.2e-3), (12000, 1280, 5120, 2, 2e-5), (1500, 1280, 1280, 0, 1.2e-3)):
+    err, ref = e.selftest_gemm(M, N, K, kind)
+    assert ref > 0.5 and err <= tol * ref, ("f16", M, N, K, kind, err, ref)
+for M, N, K, kind, tol in ((12000, 5120, 1280, 5, 1e-4), (12000, 5120, 1280, 1, 1e-4), (12000, 1280, 5120, 2, 1e-4), (777, 256, 256, 5, 1e-4)):
+    err, ref, _ = e.selftest_gemm_ex(M, N, K, kind, fp8=True)
+    assert ref > 0.5 and err <= tol * ref, ("e4m3", M, N, K, kind, err, ref)
+e.close()
+print("ok")
+"""
+    env = dict(os.environ, SS_GEMM_K64="0", SS_F8_K128="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]

@@ -448,6 +448,28 @@ def test_whisper_h_full_surface(toy_ml_path, eng, monkeypatch):
             ids.append(d.id)
     assert ids == [int(t) for t in ref["tokens"]][:len(ids)] and len(ids) > 0      # segment tokens = the accepted stream (minus a trailing text-less tail)
 
+    # callbacks at chunk granularity: abort / encoder_begin before the chunk is submitted (-6 when they say stop), progress(100) and new_segment(all segments) after
+    seen = []
+    NEWSEG = C.CFUNCTYPE(None, vp, vp, C.c_int, vp)
+    PROG = C.CFUNCTYPE(None, vp, vp, C.c_int, vp)
+    ENCB = C.CFUNCTYPE(C.c_bool, vp, vp, vp)
+    ABORT = C.CFUNCTYPE(C.c_bool, vp)
+    cb_new = NEWSEG(lambda c, s_, n_new, ud: seen.append(("new", n_new, L.whisper_full_n_segments_from_state(s_))))
+    cb_prog = PROG(lambda c, s_, pr, ud: seen.append(("progress", pr)))
+    go = {"enc": True, "abort": False}
+    cb_enc = ENCB(lambda c, s_, ud: go["enc"])
+    cb_abort = ABORT(lambda ud: go["abort"])
+    pc = L.whisper_full_default_params(0)
+    pc.language = b"auto"; pc.temperature_inc = 0.0
+    pc.new_segment_callback = C.cast(cb_new, vp); pc.progress_callback = C.cast(cb_prog, vp)
+    pc.encoder_begin_callback = C.cast(cb_enc, vp); pc.abort_callback = C.cast(cb_abort, vp)
+    assert L.whisper_full_with_state(ctx, st, pc, pcm.ctypes.data_as(vp), len(pcm)) == 0
+    assert seen == [("progress", 100), ("new", n_seg, n_seg)]
+    go["enc"] = False
+    assert L.whisper_full_with_state(ctx, st, pc, pcm.ctypes.data_as(vp), len(pcm)) == -6
+    go["enc"], go["abort"] = True, True
+    assert L.whisper_full_with_state(ctx, st, pc, pcm.ctypes.data_as(vp), len(pcm)) == -6 and len(seen) == 2
+
     # language detection alone, on the samples given to pcm_to_mel
     assert L.whisper_pcm_to_mel_with_state(ctx, st, pcm.ctypes.data_as(vp), len(pcm), 4) == 0
     assert L.whisper_n_len_from_state(st) == (len(pcm) + 480000) // 160

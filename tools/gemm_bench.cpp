@@ -80,8 +80,8 @@ int main(int argc, char** argv) {
                 {   // effective shader clock of this launch: ticks a persistent workgroup spent from its first tile's start to its last tile's end / the launch's wall time
                     double span = 0; int nb = 0;
                     for (int b = 0; b < 256; b++) { long long a0 = h[(b * 8) * 4], z = 0; for (int t = 0; t < 8; t++) if (h[(b * 8 + t) * 4 + 3]) z = h[(b * 8 + t) * 4 + 3]; if (a0 && z) { span += (double)(z - a0); nb++; } }
-                    if (nb) printf("   clock %-8s: mean workgroup span %.0f ticks over a launch of %.3f ms (traced) => >= %.2f GHz effective shader clock; MFMA issue alone = %.0f ticks per tile at 16 cycles per 16x16x32\n",
-                                   kn[ki], span / nb, tms, span / nb / (tms * 1e6), (double)(s.K / 32) * 64 * 2 * 16);
+                    if (nb) printf("   clock %-8s: mean workgroup span %.0f ticks over a launch of %.3f ms (traced) => >= %.2f GHz effective shader clock; MFMA issue alone (2 waves x 32 MFMAs per SIMD and 32-deep k-step, 16 cycles each) = %.0f ticks per tile\n",
+                                   kn[ki], span / nb, tms, span / nb / (tms * 1e6), (double)(s.K / 32) * 32 * 2 * 16);
                 }
                 for (int b : {0, 100, 200}) { printf("     wg %3d:", b); for (int t = 0; t < 4; t++) { const long long* q = &h[(b * 8 + t) * 4]; if (q[3]) printf("  [%lld +%lld +%lld +%lld]", q[0] - tmin, q[1] - q[0], q[2] - q[1], q[3] - q[2]); } printf("\n"); }
             }
