@@ -55,6 +55,17 @@ int main(int argc, char** argv) {
             float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
             printf("%-8s M=%5d N=%5d K=%4d %-8s %8.3f ms  %7.1f TF/s\n", s.name, s.M, s.N, s.K, kn[ki], ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
         }
+        if (s.N == 1280 && s.K == 1280 && s.M % 1500 == 0) {   // the V projection of the encoder: V^T layout [b][h][64][Tpad] (EPI_VT), what enc_attn_lds_kernel reads
+            GemmDesc g{};
+            g.A = A; g.lda = s.K; g.W = W; g.M = s.M; g.N = s.N; g.K = s.K; g.kind = EPI_VT; g.bias = bias; g.out = out; g.ldo = s.N; g.scale = 1.0f;
+            g.rows_per_batch = 1500; g.d = 1280; g.Tpad = 1536; g.n_batch = s.M / 1500;
+            launch_gemm<f16>(g, st);
+            hipEventRecord(e0, st);
+            for (int i = 0; i < 10; i++) launch_gemm<f16>(g, st);
+            hipEventRecord(e1, st); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 10;
+            printf("%-8s M=%5d N=%5d K=%4d %-8s %8.3f ms  %7.1f TF/s\n", s.name, s.M, s.N, s.K, "v^T", ms, 2.0 * s.M * s.N * s.K / ms / 1e9);
+        }
         if (getenv("SS_TRACE") && s.N == 5120 && s.M == 12000) {   // per-tile phase breakdown of the gelu epilogue kernel
             long long* tr; hipMalloc(&tr, 256 * 8 * 4 * 8); hipMemset(tr, 0, 256 * 8 * 4 * 8);
             for (int ki = 0; ki < 3; ki++) {
