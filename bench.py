@@ -244,15 +244,18 @@ def cpu_baseline(path: str, hp, n_steps: int, n_prompt: int):
     om = orc.OracleModel(path)
     # full depth for the encoder and the cross-KV precompute (nothing extrapolated there); the decoder steps are identical in cost up to the
     # growing self-KV, so 8 timed steps stand for the prompt + n_steps positions
-    n_enc, n_cross, n_dec = hp.n_audio_layer, hp.n_text_layer, 8
+    n_enc, n_cross, n_dec = hp.n_audio_layer, hp.n_text_layer, 16
     os.environ.setdefault("OMP_PROC_BIND", "close")   # read when the OpenMP runtime starts: threads stay on their cores
-    runs = []
+    runs, parts = [], []
     for _ in range(2):      # two timed repeats of the same sample, the faster one is reported (the first also pages the 6 GB f32 model in)
         t = om.time_sample(synth.speech_like(0), orc.MODE_GGML_F16, n_enc, n_cross, n_dec, cores)
         runs.append(t["mel_s"] + t["stem_s"] + hp.n_audio_layer * t["enc_layer_s"] + hp.n_text_layer * t["cross_layer_s"] + (n_steps + n_prompt) * t["dec_step_s"])
+        parts.append({"mel": round(t["mel_s"], 3), "conv_stem": round(t["stem_s"], 3), "encoder_layers": round(hp.n_audio_layer * t["enc_layer_s"], 3),
+                      "cross_kv": round(hp.n_text_layer * t["cross_layer_s"], 3), "decoder_extrapolated": round((n_steps + n_prompt) * t["dec_step_s"], 3),
+                      "decoder_step_measured": round(t["dec_step_s"], 4)})
     om.close()
     chunk_s = min(runs)
-    return {"value": round(CHUNK_SEC / chunk_s, 4), "unit": "audio-sec/s", "cores": cores, "kind": "port",
+    return {"value": round(CHUNK_SEC / chunk_s, 4), "unit": "audio-sec/s", "cores": cores, "kind": "port", "breakdown_s": parts[runs.index(chunk_s)],
             "sample": f"1 chunk: log-mel + conv stem + {n_enc}/{hp.n_audio_layer} encoder layers + {n_cross}/{hp.n_text_layer} cross-KV layers + "
                       f"{n_dec} decode steps timed (nothing extrapolated in the encoder; the decoder share is EXTRAPOLATED from those {n_dec} steps to {n_steps + n_prompt} positions) "
                       f"(est. {chunk_s:.1f} s per 30 s chunk; two repeats: {runs[0]:.1f} / {runs[1]:.1f} s, faster one reported); "
