@@ -7,8 +7,10 @@
 // This file restates whisper.cpp v1.5.x's published algorithm from the call the reference makes at
 // /root/reference/src/asr/whisper.rs:75 (`state.full(params, &audio)`), with the parameters the reference
 // sets at whisper.rs:131-173 and the stream-mode overrides at whisper.rs:60-71.  Each function names the
-// whisper.cpp routine it restates (marked "wcpp:"; unverifiable offline).  The network arithmetic is
-// cross-checked against HF transformers' Whisper on seeded random weights (tests/golden/make_golden.py).
+// whisper.cpp routine it restates (marked "wcpp:"; unverifiable offline).  Pinned to the one independent
+// implementation the container has, HF transformers' Whisper on seeded weights (tests/golden/make_golden.py, tests/test_oracle_golden.py):
+// stages on seven shapes (erf and tanh GELU), OpenAI's decoding rules bit for bit under COMPAT_OPENAI_TS_RULES, and whole first windows
+// of HF generate() (ids and segment times, 8 cases).  HF is not the reference: the header stays "parity unpinned".
 //
 // Numerics modes (orc_opts.mode):
 //   0  F32      : f32 everywhere, exact tanh-GELU / expf (clean mathematical restatement)
