@@ -669,23 +669,13 @@ __global__ __launch_bounds__(512, 2) void gemm256k64_kernel(GemmDesc g) {
             else acc[ni][2 * (q) + j] = Mfma<T>::mma(WF[ni], xf[2 * (q) + j], acc[ni][2 * (q) + j]);      \
         }                                                                                           \
     }
-#ifdef SS_K64_DMA_STAGGER   // experiment (tools/gpu_r05_l.sh): the two waves of a SIMD (w, w + 4) issue their DMA in DIFFERENT quarters of the half-stage
-    const bool hi_grp = __builtin_amdgcn_readfirstlane(wave) >= 4;
-#define SS_QDMA(do_dma, dma_k0, q)                                                                                                          \
-    if (do_dma) {                                                                                                                           \
-        if ((q) < 2) { if (!hi_grp) { SS_DMA(4 * ((q) & 1), dma_k0, dbase) SS_DMA(4 * ((q) & 1) + 1, dma_k0, dbase) SS_DMA(4 * ((q) & 1) + 2, dma_k0, dbase) SS_DMA(4 * ((q) & 1) + 3, dma_k0, dbase) } } \
-        else { if (hi_grp) { SS_DMA(4 * ((q) & 1), dma_k0, dbase) SS_DMA(4 * ((q) & 1) + 1, dma_k0, dbase) SS_DMA(4 * ((q) & 1) + 2, dma_k0, dbase) SS_DMA(4 * ((q) & 1) + 3, dma_k0, dbase) } }       \
-    }
-#else
-#define SS_QDMA(do_dma, dma_k0, q) if (do_dma) { SS_DMA(2 * (q), dma_k0, dbase) SS_DMA(2 * (q) + 1, dma_k0, dbase) }
-#endif
     // a quarter: 8 MFMAs; optionally passes 2q and 2q + 1 of the DMA of stage `dma_k0` (measured: all eight passes in the first one or two
     // quarters instead is within +-2 %, profiles/r04_ah_gemm_k64_dma_placement.txt); optionally the next half's fragments: one column fragment
     // into the other set, this quarter's two row fragments
 #define SS_QUARTER(WC, WN, do_dma, dma_k0, do_read, fo, q)                                            \
     {                                                                                                \
         SS_MMA_X(WC, q)                                                                              \
-        SS_QDMA(do_dma, dma_k0, q)                                                                   \
+        if (do_dma) { SS_DMA(2 * (q), dma_k0, dbase) SS_DMA(2 * (q) + 1, dma_k0, dbase) }            \
         if (do_read) {                                                                               \
             WN[q] = *(const V8*)(rbase + wrow + (fo) + (q) * 16 * 128);                              \
             xf[2 * (q)] = *(const V8*)(rbase + xrow + (fo) + (2 * (q)) * 16 * 128);                  \
@@ -744,7 +734,6 @@ __global__ __launch_bounds__(512, 2) void gemm256k64_kernel(GemmDesc g) {
     }
 #undef SS_HALF
 #undef SS_QUARTER
-#undef SS_QDMA
 #undef SS_MMA_X
 
     if (tr && tid == 0) tr[2] = __builtin_amdgcn_s_memtime();
