@@ -15,8 +15,9 @@ struct ss_pool { std::vector<ss_engine*> engines; std::atomic<uint32_t> cursor{0
 // Engines that exist.  ss_session_free may have to wait on its engine's condition variable while another thread frees that engine: the waiter
 // enters (counted in EngineBase::n_waiters, which stop_worker drains) under this lock, and ss_engine_free leaves the set under it BEFORE teardown
 // starts -- so a session either finds its engine alive and is waited for, or finds it gone, in which case every chunk is already complete.
-static std::mutex g_live_mu;
-static std::unordered_set<const EngineBase*> g_live;
+// (heap-allocated and never destroyed: a host may free sessions from its own exit handlers, after this library's static destructors have run)
+static std::mutex& g_live_mu = *new std::mutex();
+static std::unordered_set<const EngineBase*>& g_live = *new std::unordered_set<const EngineBase*>();
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) { g_err = msg; return code; }
