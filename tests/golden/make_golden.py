@@ -304,7 +304,11 @@ def generate_fixture():
     (the raw result of that window: the tail after the last closed timestamp pair included), how many of them whisper.cpp's loop samples
     before it ends the window, and the (start, end) of the window's segments in centiseconds as HF reports them.  The tests hold the oracle
     (exact-f32 mode, COMPAT_OPENAI_TS_RULES) to identical ids and segment times, and the HIP engine to identical ids or a forced replay.
-    Later windows are not stored: HF zero-fills the log-mel past the audio, whisper.cpp continues in its own padded spectrogram."""
+    Later windows are not stored: HF zero-fills the log-mel past the audio, whisper.cpp continues in its own padded spectrogram.  (Tried in round 5 with
+    62 s of audio, whisper.cpp's padded mel as `input_features`, `language` / `task` arguments and `condition_on_prev_tokens=True` -- what whisper.cpp
+    does inside one call: window 0, the seek advance to 23.04 s and window 1's segment (23.12 s .. 49.92 s) agree with the oracle; window 2's first pick
+    does not, because HF / OpenAI condition on the tokens of the SEGMENTS -- without the closing timestamp of the last pair -- where whisper.cpp keeps
+    every token up to result_len: DESIGN.md section 2a row 11.)"""
     from transformers import GenerationConfig
     from oracle import binding as orc
     out = {}
