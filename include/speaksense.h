@@ -80,9 +80,13 @@ enum {
     SS_COMPAT_RNG_STATE = 1,       /* whisper.cpp <= v1.4.x: ONE std::mt19937(0) in whisper_state; the best_of decoders draw from it in decoder order.
                                       Default (flag clear, >= v1.5.0): every decoder owns a generator -- decoder 0's is seeded once per state and carried
                                       across calls, decoders 1.. are re-seeded with 0 by every whisper_full call */
-    SS_COMPAT_OPENAI_TS_RULES = 2  /* OpenAI's timestamp rules where whisper.cpp's differ: the first sampled token must be a timestamp (whisper.cpp only
+    SS_COMPAT_OPENAI_TS_RULES = 2, /* OpenAI's timestamp rules where whisper.cpp's differ: the first sampled token must be a timestamp (whisper.cpp only
                                       applies max_initial_ts); a timestamp may not repeat the last one unless a pair is open (`<=`; whisper.cpp `<`);
                                       <|0.00|> counts as a timestamp seen (whisper.cpp: id > token_beg) */
+    SS_COMPAT_OPENAI_HISTORY = 4   /* what a later window of ONE call is conditioned on ([prev] + history + [sot ..]; `no_context` only clears the history a call
+                                      starts with): OpenAI / HF take the tokens of the window's segments -- a window ending in a timestamp pair contributes
+                                      everything but the pair's second timestamp -- and at most 222 of them; whisper.cpp (default) every token up to
+                                      result_len, at most 224.  Exists so that multi-window sequences can be held to HF generate() */
 };
 
 /* The whisper_full_params fields the reference sets (whisper.rs:131-173) plus its per-request overrides

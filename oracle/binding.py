@@ -15,6 +15,7 @@ MODE_F32, MODE_GGML_F16, MODE_BF16, MODE_FP8 = 0, 1, 2, 3   # FP8: GGML_F16 + e4
 # SS_COMPAT_* in include/speaksense.h.
 COMPAT_RNG_STATE = 1         # <= v1.4.x: one std::mt19937(0) in whisper_state shared by all best_of decoders
 COMPAT_OPENAI_TS_RULES = 2   # OpenAI's timestamp rules where whisper.cpp's differ (forced first timestamp, `<=` monotonic rule, <|0.00|> counts)
+COMPAT_OPENAI_HISTORY = 4    # later windows of a call conditioned on the SEGMENTS' tokens (no closing timestamp of the last pair), <= 222 of them
 
 
 class OrcOpts(C.Structure):

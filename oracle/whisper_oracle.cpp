@@ -662,6 +662,9 @@ enum {
     COMPAT_RNG_STATE = 1,        // one std::mt19937(0) in whisper_state, drawn from by every best_of decoder in decoder order (wcpp <= 1.4.x)
     COMPAT_OPENAI_TS_RULES = 2,  // OpenAI's timestamp rules where whisper.cpp's differ: the first sampled token must be a timestamp; timestamps may
                                  // not repeat the last one unless a pair is open (`<=` instead of `<`); <|0.00|> counts as a timestamp seen
+    COMPAT_OPENAI_HISTORY = 4,   // what a later window of one call is conditioned on, OpenAI's way (transcribe.py all_tokens / HF condition_on_prev_tokens):
+                                 // the tokens of the window's SEGMENTS -- a window that ends in a timestamp pair contributes everything but the pair's
+                                 // second timestamp -- and at most n_text_ctx / 2 - 2 = 222 of them.  Default (wcpp): every token up to result_len, <= 224
 };
 
 struct State {
@@ -1127,7 +1130,7 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
             }
             prompt.clear();
             if (!s.prompt_past.empty() && t_cur < 0.5f && P.n_max_text_ctx > 0) {
-                int n_take = std::min(std::min((int)P.n_max_text_ctx, hp.n_text_ctx / 2), (int)s.prompt_past.size());
+                int n_take = std::min(std::min((int)P.n_max_text_ctx, hp.n_text_ctx / 2 - ((s.compat & COMPAT_OPENAI_HISTORY) ? 2 : 0)), (int)s.prompt_past.size());
                 prompt = {vocab.token_prev};
                 prompt.insert(prompt.begin() + 1, s.prompt_past.end() - n_take, s.prompt_past.end());
             }
@@ -1214,6 +1217,9 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
             s.prompt_past.clear();
             if (!prompt.empty() && prompt.front() == vocab.token_prev) s.prompt_past.insert(s.prompt_past.end(), prompt.begin() + 1, prompt.end() - prompt_init.size());
             for (int i = 0; i < result_len && i < (int)tokens_cur.size(); i++) s.prompt_past.push_back(tokens_cur[i].id);
+            if ((s.compat & COMPAT_OPENAI_HISTORY) && result_len >= 2 && result_len <= (int)tokens_cur.size() &&
+                tokens_cur[result_len - 1].id >= vocab.token_beg && tokens_cur[result_len - 2].id >= vocab.token_beg)
+                s.prompt_past.pop_back();   // the closing timestamp of the last segment belongs to no segment's token slice
             for (auto& t : tokens_cur) s.all_tokens.push_back(t);
             s.sampled_all.insert(s.sampled_all.end(), bd.sampled.begin(), bd.sampled.end());
             if (!tokens_cur.empty()) {

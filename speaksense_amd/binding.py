@@ -13,7 +13,7 @@ _LIB = None
 
 DTYPE_BF16, DTYPE_F16, DTYPE_FP8 = 0, 1, 2   # FP8: the f16 engine with e4m3 encoder / cross-KV projections
 # SS_COMPAT_* (include/speaksense.h): which variant of a whisper.cpp-version-dependent behaviour the engine reproduces; 0 = whisper.cpp v1.5.x
-COMPAT_RNG_STATE, COMPAT_OPENAI_TS_RULES = 1, 2
+COMPAT_RNG_STATE, COMPAT_OPENAI_TS_RULES, COMPAT_OPENAI_HISTORY = 1, 2, 4
 
 
 class EngineOpts(C.Structure):

@@ -110,6 +110,7 @@ static int resolve_compat(int from_opts) {
         const std::string name = s.substr(pos, end - pos);
         if (name == "rng_state") flags |= SS_COMPAT_RNG_STATE;
         else if (name == "openai_ts_rules") flags |= SS_COMPAT_OPENAI_TS_RULES;
+        else if (name == "openai_history") flags |= SS_COMPAT_OPENAI_HISTORY;
         else if (!name.empty()) throw Error(SS_ERR_ARG, "SS_COMPAT: unknown flag '" + name + "'");
         pos = end + 1;
     }
@@ -1360,7 +1361,7 @@ struct EngineT : EngineBase {
         JobState& jq = state_of(js, w.job);
         w.prompt.clear();
         if (!s->prompt_past.empty() && t_cur < 0.5f && P.n_max_text_ctx > 0) {
-            const int n_take = std::min(std::min((int)P.n_max_text_ctx, n_tctx / 2), (int)s->prompt_past.size());
+            const int n_take = std::min(std::min((int)P.n_max_text_ctx, n_tctx / 2 - ((compat & SS_COMPAT_OPENAI_HISTORY) ? 2 : 0)), (int)s->prompt_past.size());
             w.prompt.push_back(hm.vocab.token_prev);
             w.prompt.insert(w.prompt.end(), s->prompt_past.end() - n_take, s->prompt_past.end());
         }
@@ -1586,6 +1587,10 @@ struct EngineT : EngineBase {
             if (!w.prompt.empty() && w.prompt.front() == vocab.token_prev)
                 np.insert(np.end(), w.prompt.begin() + 1, w.prompt.end() - jq.prompt_init.size());
             for (int i = 0; i < bd.result_len && i < (int)tk.size(); i++) np.push_back(tk[i].id);
+            // SS_COMPAT_OPENAI_HISTORY: the closing timestamp of the window's last segment belongs to no segment's token slice (OpenAI / HF history)
+            if ((compat & SS_COMPAT_OPENAI_HISTORY) && bd.result_len >= 2 && bd.result_len <= (int)tk.size() && tk[bd.result_len - 1].id >= vocab.token_beg &&
+                tk[bd.result_len - 2].id >= vocab.token_beg)
+                np.pop_back();
             s->prompt_past.swap(np);
         }
         if (!tk.empty()) {

@@ -364,8 +364,109 @@ def generate_fixture():
     print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
+def wcpp_window(ids, beg, eot, seek, seek_end):
+    """whisper.cpp's decode loop over HF's ids of ONE window that starts at frame `seek`: (ids it samples before it ends the window, seek_delta, regular) --
+    regular = the window ends with EOT after at least one closed timestamp pair and nothing but that pair decides the advance (no single trailing
+    timestamp, no window-end cut): the case in which OpenAI's / HF's seek advance and whisper.cpp's coincide."""
+    has_ts, seek_delta, result_len, n = False, 3000, 0, len(ids)
+    for i, t in enumerate(ids):
+        if t > beg:
+            seek_delta, has_ts, result_len = 2 * (t - beg), True, i + 1
+        if t == eot or (has_ts and seek + seek_delta + 100 >= seek_end):
+            n = i + 1
+            break
+    kept = ids[:result_len]
+    regular = (n <= len(ids) and ids[n - 1] == eot and result_len >= 2 and kept[-1] >= beg and kept[-2] >= beg and kept[-1] == kept[-2] and
+               seek + seek_delta + 100 < seek_end)
+    return n, seek_delta, regular
+
+
+LONG_CANDIDATES = [("wide2", 46, 6), ("toy256", 41, 3), ("tiny.en", 44, 9), ("toy256", 47, 12), ("tiny.en", 48, 13), ("wide2", 45, 7), ("toy256", 49, 14), ("tiny.en", 50, 15)]
+LONG_SECONDS = 95
+
+
+def generate_long_fixture():
+    """hf_generate_long_golden.npz: the sequence-level fixture ACROSS window boundaries.  HF `generate(condition_on_prev_tokens=True)` -- inside one call
+    whisper.cpp always conditions window n + 1 on `[prev] + history` (`no_context` only clears what a call starts with) -- on 95 s of seeded audio, fed
+    whisper.cpp's own padded log-mel so that every window sees the frames whisper.cpp's seek loop sees.  Stored per case: for each of the leading REGULAR
+    windows (closed timestamp pair, EOT, no end-of-audio effect: where the two implementations' seek advance coincides; at least two) the ids HF sampled,
+    how many of them whisper.cpp's loop samples, and HF's absolute segment times.  The oracle meets them under COMPAT_OPENAI_TS_RULES | COMPAT_OPENAI_HISTORY
+    (the history flag covers the one token by which the two histories differ); the generator refuses to store a case it does
+    not meet.  What this pins beyond the first-window fixture: the seek advance, the `[prev] + history + [sot ..]` prompt of later windows, the per-window
+    reset of the rule state, absolute segment times."""
+    from transformers import GenerationConfig
+    from oracle import binding as orc
+    out, n_kept = {}, 0
+    tmp = tempfile.mkdtemp()
+    for name, seed, aseed in LONG_CANDIDATES:
+        path = os.path.join(tmp, f"{name}-{seed}.bin")
+        ggml_io.write_model(path, name, seed=seed, **ggml_io.NATURAL)
+        hp, filt, vocab, tensors = ggml_io.read_model(path)
+        model = hf_model_tanh(hp, tensors)
+        om = orc.OracleModel(path)
+        pcm = synth.speech_like(aseed, 16000 * LONG_SECONDS)
+        mel = om.log_mel(pcm).astype(np.float32)                 # [n_mel][n_len], n_len = (n + 480000) / 160: 30 s of clamp-floor frames behind the audio
+        seek_end = 1 + (len(pcm) + 200 - 400) // 160             # whisper.cpp's n_len_org
+        multilingual = hp.n_vocab >= 51865
+        eot, sot, beg = om.eot, om.sot, om.beg
+        n_lang = hp.n_vocab - 51765 - (1 if multilingual else 0)
+        init = [sot, sot + 1, om.transcribe] if multilingual else [sot]
+        suppress = [sot, om.nosp, om.solm, om.translate, om.transcribe, om.prev] + [sot + 1 + i for i in range(n_lang)]
+        gc = GenerationConfig(eos_token_id=eot, pad_token_id=eot, bos_token_id=eot, decoder_start_token_id=sot, no_timestamps_token_id=om.not_,
+                              max_initial_timestamp_index=50, suppress_tokens=suppress, begin_suppress_tokens=[220, eot], max_length=448,
+                              is_multilingual=multilingual, return_timestamps=True, do_sample=False, num_beams=1, prev_sot_token_id=om.prev)
+        if multilingual:
+            gc.lang_to_id = {"<|en|>": sot + 1}
+            gc.task_to_id = {"transcribe": om.transcribe, "translate": om.translate}
+        model.generation_config = gc
+        with torch.no_grad():
+            res = model.generate(input_features=torch.from_numpy(mel)[None], **(dict(language="en", task="transcribe") if multilingual else {}),
+                                 return_timestamps=True, do_sample=False, num_beams=1, max_new_tokens=224, return_segments=True, condition_on_prev_tokens=True)
+        wins = []
+        for sg in res["segments"][0]:
+            if not wins or sg["result"] is not wins[-1]["result"]:
+                r = sg["result"]["sequences"] if isinstance(sg["result"], dict) else sg["result"]
+                r = [int(t) for t in (r[0] if r.dim() == 2 else r)]
+                k0 = max(i for i in range(len(r) - len(init) + 1) if r[i:i + len(init)] == init) + len(init)      # the new ids follow the LAST [sot ..]
+                wins.append(dict(result=sg["result"], ids=r[k0:], seg=[]))
+            wins[-1]["seg"].append((round(100 * float(sg["start"])), round(100 * float(sg["end"]))))
+        seek, keep = 0, []
+        for w in wins:
+            n, seek_delta, regular = wcpp_window(w["ids"], beg, eot, seek, seek_end)
+            first_ts = next((t for t in w["ids"] if t >= beg), None)
+            consistent = first_ts is not None and w["seg"][0][0] == seek + 2 * (first_ts - beg)     # HF's own seek of this window is the one the rule gives
+            if not (regular and consistent and seek + 3000 + 100 < seek_end):
+                break
+            keep.append(dict(ids=w["ids"], n=n, seg=w["seg"], seek=seek))
+            seek += seek_delta
+        ref = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES | orc.COMPAT_OPENAI_HISTORY).full(pcm, orc.default_params(language="en", temperature_inc=0.0))
+        tr, pos, ok = [int(t) for t in ref["trace"]], 0, True
+        for w in keep:
+            ok = ok and tr[pos:pos + w["n"]] == w["ids"][:w["n"]]
+            pos += w["n"]
+        segs = [sg for w in keep for sg in w["seg"]]
+        ok = ok and [(s_["t0"], s_["t1"]) for s_ in ref["segments"]][:len(segs)] == segs
+        print(name, seed, aseed, "HF windows", len(wins), "regular leading windows", len(keep), [w["n"] for w in keep], "seeks", [w["seek"] for w in keep], "oracle equal:", ok)
+        om.close()
+        if len(keep) >= 2 and ok and n_kept < 3:
+            k = f"c{n_kept}"
+            out[f"{k}_preset"], out[f"{k}_seed"], out[f"{k}_audio"], out[f"{k}_n_windows"] = name, seed, aseed, len(keep)
+            for wi, w in enumerate(keep):
+                out[f"{k}_w{wi}_ids"] = np.array(w["ids"], np.int32)
+                out[f"{k}_w{wi}_n"] = w["n"]
+                out[f"{k}_w{wi}_seek"] = w["seek"]
+                out[f"{k}_w{wi}_seg"] = np.array(w["seg"], np.int64)
+            n_kept += 1
+    out["n_cases"], out["seconds"] = n_kept, LONG_SECONDS
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_generate_long_golden.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes,", n_kept, "cases")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["toy", "shapes", "rules", "tanh", "generate"]
+    which = sys.argv[1:] or ["toy", "shapes", "rules", "tanh", "generate", "generate_long"]
+    if "generate_long" in which:
+        generate_long_fixture()
     if "tanh" in which:
         tanh_fixture()
     if "generate" in which:

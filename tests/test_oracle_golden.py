@@ -253,3 +253,58 @@ def test_oracle_full_matches_hf_generate_first_window(ci, model_dir):
     assert [(s["t0"], s["t1"]) for s in res["segments"]][:len(c["seg"])] == c["seg"]
     assert res["n_fail"] == 0
     om.close()
+
+
+GENERATE_LONG_GOLD = os.path.join(os.path.dirname(__file__), "golden", "hf_generate_long_golden.npz")
+
+
+def generate_long_cases():
+    g = np.load(GENERATE_LONG_GOLD)
+    out = []
+    for i in range(int(g["n_cases"])):
+        wins = [dict(ids=[int(t) for t in g[f"c{i}_w{w}_ids"]], n=int(g[f"c{i}_w{w}_n"]), seek=int(g[f"c{i}_w{w}_seek"]),
+                     seg=[(int(a), int(b)) for a, b in g[f"c{i}_w{w}_seg"]]) for w in range(int(g[f"c{i}_n_windows"]))]
+        out.append(dict(preset=str(g[f"c{i}_preset"]), seed=int(g[f"c{i}_seed"]), audio=int(g[f"c{i}_audio"]), ts_rate=12.0, seconds=int(g["seconds"]), windows=wins))
+    return out
+
+
+def long_case_params(mod, c):
+    """Parameters for a long fixture case: `duration_ms` ends the call 2 s after the last stored window could end -- far enough that no stored window feels
+    it (whisper.cpp's window-end rule looks 1 s ahead), near enough that the 95 s of audio cost 3 - 4 windows instead of 7."""
+    last = c["windows"][-1]["seek"]
+    return mod.default_params(language="en", temperature_inc=0.0, duration_ms=10 * (last + 3000 + 200))
+
+
+def check_windows_against_hf(res, c, beg):
+    """The leading windows of a whisper_full result (oracle or engine) against the HF fixture: every id sampled in window w equals HF's, the windows' segments
+    carry HF's absolute times, and the seek advance implied by them is HF's.  Returns None, or a description of the first difference."""
+    tr, pos = [int(t) for t in res["trace"]], 0
+    for wi, w in enumerate(c["windows"]):
+        got = tr[pos:pos + w["n"]]
+        if got != w["ids"][:w["n"]]:
+            k = next((i for i in range(min(len(got), w["n"])) if got[i] != w["ids"][i]), min(len(got), w["n"]))
+            return f"window {wi} (seek {w['seek']}): sampled id {k} differs from HF's"
+        pos += w["n"]
+    segs = [sg for w in c["windows"] for sg in w["seg"]]
+    if [(s["t0"], s["t1"]) for s in res["segments"]][:len(segs)] != segs:
+        return "segment times differ from HF's"
+    if res["n_encode"] < len(c["windows"]):
+        return "fewer windows than HF"
+    return None
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_oracle_full_matches_hf_generate_across_windows(ci, model_dir):
+    """SEQUENCE level across window boundaries (make_golden.py generate_long_fixture): 95 s of audio, HF `generate(condition_on_prev_tokens=True)` fed
+    whisper.cpp's own padded log-mel.  Over the leading regular windows (2 - 3 per case) the oracle's whisper_full loop under COMPAT_OPENAI_TS_RULES |
+    COMPAT_OPENAI_HISTORY samples HF's ids, advances `seek` to HF's frame, conditions the next window on `[prev] + history + [sot ..]` as HF does
+    (otherwise the ids of window 1 would differ) and reports HF's absolute segment times.  /root/reference/src/asr/whisper.rs:75 with the parameters of
+    :131-173 at temperature 0; the two flags cover the documented differences between whisper.cpp and OpenAI."""
+    c = generate_long_cases()[ci]
+    om = orc.OracleModel(generate_case_model(c, model_dir))
+    pcm = synth.speech_like(c["audio"], 16000 * c["seconds"])
+    P = long_case_params(orc, c)
+    res = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES | orc.COMPAT_OPENAI_HISTORY).full(pcm, P)
+    assert len(c["windows"]) >= 2 and all(w["n"] >= 15 for w in c["windows"]) and c["windows"][1]["seek"] > 0
+    assert check_windows_against_hf(res, c, om.beg) is None, check_windows_against_hf(res, c, om.beg)
+    om.close()
