@@ -9,8 +9,9 @@
 // sets at whisper.rs:131-173 and the stream-mode overrides at whisper.rs:60-71.  Each function names the
 // whisper.cpp routine it restates (marked "wcpp:"; unverifiable offline).  Pinned to the one independent
 // implementation the container has, HF transformers' Whisper on seeded weights (tests/golden/make_golden.py, tests/test_oracle_golden.py):
-// stages on seven shapes (erf and tanh GELU), OpenAI's decoding rules bit for bit under COMPAT_OPENAI_TS_RULES, and whole first windows
-// of HF generate() (ids and segment times, 8 cases).  HF is not the reference: the header stays "parity unpinned".
+// stages on seven shapes (erf and tanh GELU), OpenAI's decoding rules bit for bit under COMPAT_OPENAI_TS_RULES, whole first windows of HF
+// generate() (ids and segment times, 8 cases) and 2 - 3 consecutive windows of 95 s calls under COMPAT_OPENAI_HISTORY as well (seek advance,
+// [prev] + history prompts, absolute times).  HF is not the reference: the header stays "parity unpinned".
 //
 // Numerics modes (orc_opts.mode):
 //   0  F32      : f32 everywhere, exact tanh-GELU / expf (clean mathematical restatement)
