@@ -264,6 +264,14 @@ def tanh_fixture():
         out[f"{k}_topk"] = topk
         out[f"{k}_topv"] = np.take_along_axis(logits, topk, axis=1).astype(np.float32)
         out[f"{k}_logit_std"] = np.float32(logits.std())
+        if multilingual:   # language detection as HF does it (WhisperGenerationMixin.detect_language): the [sot] step's logits over the language tokens
+            n_lang = hp.n_vocab - 51765 - 1
+            with torch.no_grad():
+                l0 = model(encoder_outputs=(torch.from_numpy(enc)[None],), decoder_input_ids=torch.tensor([[sot]])).logits[0, -1].numpy()
+            ll = l0[sot + 1: sot + 1 + n_lang]
+            order = np.argsort(-ll)
+            out[f"{k}_lang_id"] = int(order[0])
+            out[f"{k}_lang_margin"] = np.float32(ll[order[0]] - ll[order[1]])
         if name in ("toy", "tiny.en"):     # 128 and 80 mel bins: the HF feature extractor on the same audio, sampled columns
             fe = WhisperFeatureExtractor(feature_size=hp.n_mels)
             hf_mel = fe(pcm, sampling_rate=16000, return_tensors="np")["input_features"][0].astype(np.float32)

@@ -218,7 +218,11 @@ def test_oracle_default_gelu_matches_hf_gelu_new(name, model_dir):
         lg = st.decode(toks[i:i + 1], i)
         assert np.abs(lg[g[f"{k}_topk"][i]] - g[f"{k}_topv"][i]).max() < tol, i
         assert int(lg.argmax()) == int(g[f"{k}_topk"][i][0])
-    st.close(); om.close()
+    st.close()
+    if f"{k}_lang_id" in g:     # whisper_lang_auto_detect == HF detect_language: argmax of the [sot] step's logits over the language tokens
+        det = om.new_state(orc.MODE_F32).full(synth.speech_like(int(g["seed_audio"])), orc.default_params(language="en", detect_language=1))
+        assert det["lang_id"] == int(g[f"{k}_lang_id"]) and float(g[f"{k}_lang_margin"]) > 1.0
+    om.close()
 
 
 def generate_cases():
