@@ -253,9 +253,15 @@ def cpu_baseline(path: str, hp, n_steps: int, n_prompt: int):
         parts.append({"mel": round(t["mel_s"], 3), "conv_stem": round(t["stem_s"], 3), "encoder_layers": round(hp.n_audio_layer * t["enc_layer_s"], 3),
                       "cross_kv": round(hp.n_text_layer * t["cross_layer_s"], 3), "decoder_extrapolated": round((n_steps + n_prompt) * t["dec_step_s"], 3),
                       "decoder_step_measured": round(t["dec_step_s"], 4)})
+    # the reference runs whisper.cpp with n_threads = 16 (/root/reference/src/asr/whisper.rs:143): the same sample once more on 16 threads, reported beside `value`
+    t16 = None
+    if cores > 16:
+        t = om.time_sample(synth.speech_like(0), orc.MODE_GGML_F16, n_enc, n_cross, n_dec, 16)
+        t16 = t["mel_s"] + t["stem_s"] + hp.n_audio_layer * t["enc_layer_s"] + hp.n_text_layer * t["cross_layer_s"] + (n_steps + n_prompt) * t["dec_step_s"]
     om.close()
     chunk_s = min(runs)
     return {"value": round(CHUNK_SEC / chunk_s, 4), "unit": "audio-sec/s", "cores": cores, "kind": "port", "breakdown_s": parts[runs.index(chunk_s)],
+            "value_at_16_threads": round(CHUNK_SEC / t16, 4) if t16 else None,
             "sample": f"1 chunk: log-mel + conv stem + {n_enc}/{hp.n_audio_layer} encoder layers + {n_cross}/{hp.n_text_layer} cross-KV layers + "
                       f"{n_dec} decode steps timed (nothing extrapolated in the encoder; the decoder share is EXTRAPOLATED from those {n_dec} steps to {n_steps + n_prompt} positions) "
                       f"(est. {chunk_s:.1f} s per 30 s chunk; two repeats: {runs[0]:.1f} / {runs[1]:.1f} s, faster one reported); "
