@@ -258,14 +258,21 @@ def cpu_baseline(path: str, hp, n_steps: int, n_prompt: int):
     if cores > 16:
         t = om.time_sample(synth.speech_like(0), orc.MODE_GGML_F16, n_enc, n_cross, n_dec, 16)
         t16 = t["mel_s"] + t["stem_s"] + hp.n_audio_layer * t["enc_layer_s"] + hp.n_text_layer * t["cross_layer_s"] + (n_steps + n_prompt) * t["dec_step_s"]
+        parts.append({"mel": round(t["mel_s"], 3), "conv_stem": round(t["stem_s"], 3), "encoder_layers": round(hp.n_audio_layer * t["enc_layer_s"], 3),
+                      "cross_kv": round(hp.n_text_layer * t["cross_layer_s"], 3), "decoder_extrapolated": round((n_steps + n_prompt) * t["dec_step_s"], 3),
+                      "decoder_step_measured": round(t["dec_step_s"], 4)})
     om.close()
     chunk_s = min(runs)
-    return {"value": round(CHUNK_SEC / chunk_s, 4), "unit": "audio-sec/s", "cores": cores, "kind": "port", "breakdown_s": parts[runs.index(chunk_s)],
-            "value_at_16_threads": round(CHUNK_SEC / t16, 4) if t16 else None,
+    best_cores = cores
+    if t16 is not None and t16 < chunk_s:     # the launch-bound decoder steps of the port often run FASTER on 16 threads than on 64: report the better baseline
+        runs.append(t16)
+        chunk_s, best_cores = t16, 16
+    return {"value": round(CHUNK_SEC / chunk_s, 4), "unit": "audio-sec/s", "cores": best_cores, "kind": "port", "breakdown_s": parts[runs.index(chunk_s)],
+            "value_at_threads": {str(cores): round(CHUNK_SEC / min(runs[:2]), 4), "16": round(CHUNK_SEC / t16, 4) if t16 else None},
             "sample": f"1 chunk: log-mel + conv stem + {n_enc}/{hp.n_audio_layer} encoder layers + {n_cross}/{hp.n_text_layer} cross-KV layers + "
                       f"{n_dec} decode steps timed (nothing extrapolated in the encoder; the decoder share is EXTRAPOLATED from those {n_dec} steps to {n_steps + n_prompt} positions) "
                       f"(est. {chunk_s:.1f} s per 30 s chunk; two repeats: {runs[0]:.1f} / {runs[1]:.1f} s, faster one reported); "
-                      f"oracle/whisper_oracle.cpp ggml-f16 mode, {cores} OpenMP threads"}
+                      f"oracle/whisper_oracle.cpp ggml-f16 mode, {best_cores} OpenMP threads (the faster of {cores} and 16 = the reference's n_threads, whisper.rs:143)"}
 
 
 def cpu_baseline_whisper_cpp():

@@ -803,6 +803,8 @@ struct EngineT : EngineBase {
             step_graphs.erase(victim);
             n_graph_evictions++;
         }
+        // a group under continuous admission may run for hours: bound the retired list by paying the stream synchronisation once per 64 evictions
+        if (retired_graphs.size() >= 64) { SS_HIP(hipStreamSynchronize(st)); reap_retired_graphs(); }
     }
     void reap_retired_graphs() {   // caller has synchronised `st`: no replay of a retired graph is executing
         for (StepGraph& g : retired_graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
