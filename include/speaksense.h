@@ -250,7 +250,7 @@ int ss_session_decode(ss_session* s, const int32_t* tokens, int32_t n_tokens, in
  * output, then ONE launch carries n_rows (1..128) token rows -- row i = token[i] at position pos[i] of self-KV slot slot[i]
  * (< max_batch * max_decoders) attending to cross-KV window cross[i]; rows of one slot must be at consecutive positions, earlier rows first.
  * The kernels are selected by the row count exactly as in ss_transcribe_batch (the GEMVs take 1 / 2 / 4 / 8 column tiles of 16 rows; rows x
- * heads >= 320: the unsplit cross-attention).  logits_out: [n_sample_rows][n_vocab] raw logits of the listed rows, before any rule. */
+ * heads >= 320: the one-workgroup cross-attention; a row's logits are bit-identical whichever forms its pass selects).  logits_out: [n_sample_rows][n_vocab] raw logits of the listed rows, before any rule. */
 int ss_engine_set_encoder_window(ss_engine* e, int32_t window, const float* enc /* [n_audio_ctx][n_audio_state] */);
 /* fp8 engines only (SS_ERR_UNSUPPORTED otherwise): the FIRST quantisation point of the path -- LayerNorm 1 of encoder block 0 for the window at
  * `seek` of a log-mel spectrogram -- as the e4m3 projections read it: codes [n_audio_ctx][n_audio_state] and one E8M0 exponent byte per

@@ -990,7 +990,7 @@ struct EngineT : EngineBase {
     int ln_fuse_rows = kLnFuseRows;   // (dev: SS_LN_FUSE_ROWS, <= 16, to re-measure where the fusion stops paying)
     bool ln_fuse = true;      // SS_LN_FUSE=0: A/B switch of the LayerNorm-prologue launches for <= kLnFuseRows rows
     int cb_start_min = 4;     // SS_CB_START_MIN: windows that must be waiting before a running group pauses its decoders for their encoder pass
-    static constexpr int direct_pairs = 320;   // (rows x heads) from which the cross-attention runs unsplit (large-v3: 16 rows; +2.3 % at 32-row passes, -12 % at 8)
+    static constexpr int direct_pairs = 320;   // (rows x heads) from which the cross-attention runs as one workgroup per (row, head) (large-v3: 16 rows; +2.3 % at 32-row passes, -12 % at 8; same bits either way)
 
     RuleConsts rule_consts(const ss_params& P) {
         const Vocab& v = hm.vocab;
@@ -1727,7 +1727,7 @@ struct EngineT : EngineBase {
     }
     // stage hook: ONE decoder launch over n rows (the pass the batched engine runs: rows of different windows and slots side by side); raw logits
     // of the rows listed in samp_rows.  The kernels are chosen exactly as in run_group (decoder_step): <= 16 rows the fused step, 17..64 the
-    // multi-tile GEMVs, rows x heads >= direct_pairs the unsplit cross-attention.
+    // multi-tile GEMVs, rows x heads >= direct_pairs the one-workgroup cross-attention.
     void decode_rows_host(const int32_t* token, const int32_t* pos, const int32_t* slot, const int32_t* crossw, int n, const int32_t* samp_rows, int n_samp,
                           float* logits_out) override {
         std::lock_guard<std::mutex> lk(mu);

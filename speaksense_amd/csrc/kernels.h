@@ -190,7 +190,8 @@ void launch_enc_attention_f8(const T* q, const T* k, long ld, const T* vT, int T
 template <typename T>
 void launch_dec_self_attention(const T* q, const T* kcache, const T* vcache, long slot_stride, int d, int H, const RowCtl* ctl, int M, T* out, hipStream_t st);
 
-// unsplit variant: one workgroup per (row, head) writes the normalised output T [M][d] directly (no partials, no combine launch)
+// one-workgroup variant (NR = 4): one workgroup per (row, head) walks the SAME four key ranges, merges them with the combine kernel's expression and writes
+// the normalised output T [M][d] directly (no partials, no combine launch): bit-identical to launch_dec_cross_attention_q + launch_dec_cross_combine
 template <typename T>
 void launch_dec_cross_attention_direct(const float* qpart, int n_qpart, const float* qbias, float qscale, const T* kc, const T* vc, long b_stride, int d,
                                        int H, int Tn, const RowCtl* ctl, int M, T* out, hipStream_t st);

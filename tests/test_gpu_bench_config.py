@@ -2,8 +2,8 @@
 
 bench.py's default line runs `Engine(max_batch=32, n_lanes=3)` on the real large-v3 shape (BASELINE.json configs[2], SURVEY.md section 8d
 config #3; reference call site /root/reference/src/asr/whisper.rs:75).  At 27-32 rows per decoder pass the engine takes kernel paths no
-8-row test reaches: rows x heads >= 320 switches the cross-attention to its unsplit form (`dec_cross_attn_q_kernel<T,1>`, the fp8 engine's
-`dec_cross_attn_q8_kernel<T,1>`), and every projection runs through the multi-tile GEMVs (`dec_gemv_kernel<T,EPI,CT,NFR>` with CT = 2 column tiles for 17..32 rows,
+8-row test reaches: rows x heads >= 320 switches the cross-attention to its one-workgroup form (`dec_cross_attn_q_kernel<T,4>`, the fp8 engine's
+`dec_cross_attn_q8_kernel<T,4>`: the same four key ranges and combine as the split form, merged in-kernel), and every projection runs through the multi-tile GEMVs (`dec_gemv_kernel<T,EPI,CT,NFR>` with CT = 2 column tiles for 17..32 rows,
 CT = 4 for 33..64) -- together ~45 % of the benchmark's GPU time.  Two kinds of test, each for f16 / bf16 / fp8:
 
 (i)  stage: `ss_engine_decode_rows` -- ONE decoder pass over 32 and over 64 rows (sequences of 8 prompt positions each, attending to different
@@ -128,7 +128,7 @@ def test_decoder_pass_32_64_and_128_rows_vs_oracle(bench_engine, large_v3_path, 
     alone = eng.decode_rows(toks, list(range(8)), [5 * s] * 8, [s % n_win] * 8, [7])
     d = float(np.abs(alone[0] - got[s]).max()) / float(got[s].std())
     assert d < tol / 2, d
-    report(f"large-v3 {which} decoder pass vs oracle at the benchmarked row counts (unsplit cross-attention, multi-tile GEMVs): worst max|logits - oracle| / std "
+    report(f"large-v3 {which} decoder pass vs oracle at the benchmarked row counts (one-workgroup cross-attention, multi-tile GEMVs): worst max|logits - oracle| / std "
            f"= {worst[32]:.2e} at 32 rows, {worst[64]:.2e} at 64 rows, {worst[128]:.2e} at 128 rows; 8-row pass vs 128-row pass {d:.2e}")
     om.close()
 
