@@ -82,6 +82,7 @@ def test_session_free_blocked_while_the_engine_is_freed(toy_ml_path):
     thread in ss_wait), and A returns.  Repeated so that A is caught before, inside and after its wait."""
     from speaksense_amd import binding
     pcm = synth.speech_like(6, 16000 * 20)
+    n_failed_queued = 0
     for rnd in range(8):
         eng = binding.Engine(toy_ml_path, max_batch=2, n_lanes=1, batch_wait_us=0)
         L = eng.L
@@ -102,10 +103,12 @@ def test_session_free_blocked_while_the_engine_is_freed(toy_ml_path):
             assert not t.is_alive(), "a thread blocked in ss_session_free was not released by ss_engine_free"
         assert sorted(done) == [5, 8, 9]
         codes = [L.ss_wait(t) for t in tickets]
-        assert all(c in (0, -4) for c in codes) and codes[9] == -4, codes
+        assert all(c in (0, -4) for c in codes), codes
+        n_failed_queued += codes[9] == -4          # (a late round on a fast box may find chunk 9 already running: then it completes normally)
         for i, s in enumerate(ses):
             if i not in (5, 8, 9):
                 s.close()
+    assert n_failed_queued >= 2, "the engine was never freed while the freers' chunks were still queued: the test did not exercise the race"
 
 
 def test_engine_create_refuses_a_configuration_that_cannot_fit(toy_ml_path, wide2_path):
