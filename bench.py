@@ -119,63 +119,43 @@ def mode_n_leg(args, device: int, dtype_code: int, n_chunks: int, rounds: int = 
     P = binding.default_params(language="en")
     ses = [eng.new_session() for _ in range(n_chunks)]
 
-    def run(total):
+    def run(total, n_slots):
+        """`total` chunks through the first `n_slots` (session, audio) pairs, every pair refilled the moment its chunk completes"""
         pend = {}                              # slot (session + audio) -> (submit time, ticket)
         res, lat = [], []
-        free = collections.deque(range(n_chunks))
+        free = collections.deque(range(n_slots))
         submitted = 0
-
-        def collect(k):
-            t_sub, tk = pend.pop(k)
-            res.append((k, ses[k].wait(tk))); lat.append(time.perf_counter() - t_sub)
-            free.append(k)
         while submitted < total or pend:
             while free and submitted < total:
                 k = free.popleft()
                 pend[k] = (time.perf_counter(), ses[k].submit_device(pcm[k].data_ptr(), pcm.shape[1], P))
                 submitted += 1
             done = [k for k, (_, tk) in pend.items() if ses[k].ready(tk)]      # whichever chunk finished, not the oldest: its slot is refilled at once
-            if done:
-                for k in done:
-                    collect(k)
-            elif pend:
+            for k in done:
+                t_sub, tk = pend.pop(k)
+                res.append((k, ses[k].wait(tk))); lat.append(time.perf_counter() - t_sub)
+                free.append(k)
+            if not done and pend:
                 time.sleep(2e-4)
         return res, lat
-    first, _ = run(n_chunks)                   # warm-up: every chunk once (graph shapes, lazily sized buffers); also the reference results
+
+    def timed(total, n_slots):
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        res, lat = run(total, n_slots)
+        torch.cuda.synchronize()
+        return res, lat, time.perf_counter() - ts
+    first, _ = run(n_chunks, n_chunks)         # warm-up: every chunk once (graph shapes, lazily sized buffers); also the reference results
     ref = {k: tuple(int(t) for t in r["tokens"]) for k, r in first}
-    torch.cuda.synchronize()
-    t0 = eng.totals(); ts = time.perf_counter()
-    res, lat = run(rounds * n_chunks)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - ts; t1 = eng.totals()
+    t0 = eng.totals()
+    res, lat, dt = timed(rounds * n_chunks, n_chunks)
+    t1 = eng.totals()
     same = sum(tuple(int(t) for t in r["tokens"]) == ref[k] for k, r in res)
     # the same engine with fewer chunks in flight: the latency a service would feel at lower load (Little's law: p50 ~ chunks in flight / rate)
     points = [{"chunks_in_flight": n_chunks, "value": round(rounds * n_chunks * CHUNK_SEC / dt, 2), "p50_chunk_latency_ms": round(1e3 * float(np.median(lat)), 1)}]
-    for frac in (2, 3):
-        n_less = max(1, (n_chunks * 2 // 3) if frac == 2 else n_chunks // 3)
-        keep = list(range(n_less))
-
-        def run_less(total, keep=keep):
-            pend, lat2, free, submitted, n_same = {}, [], collections.deque(keep), 0, 0
-            while submitted < total or pend:
-                while free and submitted < total:
-                    k = free.popleft()
-                    pend[k] = (time.perf_counter(), ses[k].submit_device(pcm[k].data_ptr(), pcm.shape[1], P))
-                    submitted += 1
-                done = [k for k, (_, tk) in pend.items() if ses[k].ready(tk)]
-                for k in done:
-                    t_sub, tk = pend.pop(k)
-                    r = ses[k].wait(tk); lat2.append(time.perf_counter() - t_sub); free.append(k)
-                    n_same += tuple(int(t) for t in r["tokens"]) == ref[k]
-                if not done and pend:
-                    time.sleep(2e-4)
-            return lat2, n_same
-        torch.cuda.synchronize()
-        ts2 = time.perf_counter()
-        lat2, n_same2 = run_less(2 * n_less)
-        torch.cuda.synchronize()
-        dt2 = time.perf_counter() - ts2
-        same += n_same2
+    for n_less in (max(1, n_chunks * 2 // 3), max(1, n_chunks // 3)):
+        res2, lat2, dt2 = timed(2 * n_less, n_less)
+        same += sum(tuple(int(t) for t in r["tokens"]) == ref[k] for k, r in res2)
         points.append({"chunks_in_flight": n_less, "value": round(2 * n_less * CHUNK_SEC / dt2, 2), "p50_chunk_latency_ms": round(1e3 * float(np.median(lat2)), 1)})
     n_checked = len(res) + sum(2 * p_["chunks_in_flight"] for p_ in points[1:])
     under_1s = [p_ for p_ in points if p_["p50_chunk_latency_ms"] <= 1000.0]
