@@ -289,7 +289,10 @@ def tanh_fixture():
 # (preset, model seed, audio seed, ts_rate): ts_rate 24 = timestamps advance 7.68 s per pair and pass 29 s before EOT, so the window ends by
 # whisper.cpp's `seek + seek_delta + 100 >= seek_end` rule (on the FIRST timestamp of that pair) while HF decodes on
 GENERATE_CASES = [("toy256", 41, 3, 12.0), ("toy256", 42, 8, 12.0), ("tiny.en", 43, 4, 12.0), ("tiny.en", 44, 9, 12.0), ("wide2", 45, 5, 12.0),
-                  ("wide2", 46, 6, 12.0), ("toy256", 47, 10, 24.0), ("tiny.en", 48, 11, 24.0)]
+                  ("wide2", 46, 6, 12.0), ("toy256", 47, 10, 24.0), ("tiny.en", 48, 11, 24.0),
+                  # cases 8, 9 (round 5): another language token and the translate task in the prompt -- [sot, <|de|>, <|translate|>], [sot, <|fr|>, <|transcribe|>]
+                  ("toy256", 51, 16, 12.0, "de", True), ("wide2", 52, 17, 12.0, "fr", False)]
+LANG_INDEX = {"en": 0, "de": 2, "fr": 6}
 
 
 def window0_len(ids, beg, eot):
@@ -321,7 +324,9 @@ def generate_fixture():
     from oracle import binding as orc
     out = {}
     tmp = tempfile.mkdtemp()
-    for ci, (name, seed, aseed, ts_rate) in enumerate(GENERATE_CASES):
+    for ci, case in enumerate(GENERATE_CASES):
+        name, seed, aseed, ts_rate = case[:4]
+        lang, translate = (case[4], case[5]) if len(case) > 4 else ("en", False)
         path = os.path.join(tmp, f"{name}-{seed}.bin")
         ggml_io.write_model(path, name, seed=seed, **dict(ggml_io.NATURAL, ts_rate=ts_rate))
         hp, filt, vocab, tensors = ggml_io.read_model(path)
@@ -332,7 +337,7 @@ def generate_fixture():
         multilingual = hp.n_vocab >= 51865
         eot, sot, beg = om.eot, om.sot, om.beg
         n_lang = hp.n_vocab - 51765 - (1 if multilingual else 0)
-        prompt = [sot, sot + 1, om.transcribe] if multilingual else [sot]
+        prompt = [sot, sot + 1 + LANG_INDEX[lang], om.translate if translate else om.transcribe] if multilingual else [sot]
         suppress = [sot, om.nosp, om.solm, om.translate, om.transcribe, om.prev] + [sot + 1 + i for i in range(n_lang)]      # whisper_process_logits' list
         gc = GenerationConfig(eos_token_id=eot, pad_token_id=eot, bos_token_id=eot, decoder_start_token_id=sot, no_timestamps_token_id=om.not_,
                               max_initial_timestamp_index=50, suppress_tokens=suppress, begin_suppress_tokens=[220, eot], max_length=448,
@@ -354,12 +359,13 @@ def generate_fixture():
         n0 = window0_len(raw, beg, eot)
         k = f"c{ci}"
         out[f"{k}_preset"], out[f"{k}_seed"], out[f"{k}_audio"], out[f"{k}_ts_rate"] = name, seed, aseed, ts_rate
+        out[f"{k}_language"], out[f"{k}_translate"] = lang, int(translate)
         out[f"{k}_ids"] = np.array(raw, np.int32)
         out[f"{k}_n_window0"] = n0
         out[f"{k}_seg_t0"] = np.array([round(100 * float(sg["start"])) for sg in w0], np.int64)
         out[f"{k}_seg_t1"] = np.array([round(100 * float(sg["end"])) for sg in w0], np.int64)
         # the generator checks what the CPU test will check, so that a fixture that cannot be met is never committed
-        ref = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES).full(pcm, orc.default_params(language="en", temperature_inc=0.0))
+        ref = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES).full(pcm, orc.default_params(language=lang, translate=int(translate), temperature_inc=0.0))
         tr = [int(t) for t in ref["trace"]]
         n_ts = sum(t >= beg for t in raw[:n0])
         print(name, seed, aseed, "HF window 0:", len(raw), "ids,", n0, "sampled by whisper.cpp's loop,", n_ts, "timestamps,", len(w0), "segments; oracle trace",

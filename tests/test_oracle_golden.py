@@ -228,6 +228,7 @@ def test_oracle_default_gelu_matches_hf_gelu_new(name, model_dir):
 def generate_cases():
     g = np.load(GENERATE_GOLD)
     return [dict(preset=str(g[f"c{i}_preset"]), seed=int(g[f"c{i}_seed"]), audio=int(g[f"c{i}_audio"]), ts_rate=float(g[f"c{i}_ts_rate"]),
+                 language=str(g[f"c{i}_language"]), translate=int(g[f"c{i}_translate"]),
                  ids=[int(t) for t in g[f"c{i}_ids"]], n0=int(g[f"c{i}_n_window0"]), seg=list(zip(g[f"c{i}_seg_t0"].tolist(), g[f"c{i}_seg_t1"].tolist())))
             for i in range(int(g["n_cases"]))]
 
@@ -239,16 +240,18 @@ def generate_case_model(c, model_dir):
     return path
 
 
-@pytest.mark.parametrize("ci", range(8))
+@pytest.mark.parametrize("ci", range(10))
 def test_oracle_full_matches_hf_generate_first_window(ci, model_dir):
     """SEQUENCE level (tests/golden/make_golden.py generate_fixture): the oracle's whole whisper_full loop -- prompt, every logits rule, greedy
     pick, the stopping rules (EOT; a timestamp within 1 s of the window's end), timestamp pairing into segments -- in exact-f32 mode with
     COMPAT_OPENAI_TS_RULES against HF transformers' `generate(return_timestamps=True, do_sample=False)` on the same seeded model and audio, with
     the parameters of /root/reference/src/asr/whisper.rs:131-173 at temperature 0: every id the loop samples in the first 30 s window must equal
-    HF's, and the window's segments must carry HF's (start, end).  Cases 6 and 7 end by the window-end rule 13 / 33 ids before HF's EOT."""
+    HF's, and the window's segments must carry HF's (start, end).  Cases 6 and 7 end by the window-end rule 13 / 33 ids before HF's EOT; cases 8 and 9
+    put another language token and the translate task into the prompt ([sot, <|de|>, <|translate|>], [sot, <|fr|>, <|transcribe|>])."""
     c = generate_cases()[ci]
     om = orc.OracleModel(generate_case_model(c, model_dir))
-    res = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES).full(synth.speech_like(c["audio"]), orc.default_params(language="en", temperature_inc=0.0))
+    pcm = synth.speech_like(c["audio"])
+    res = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES).full(pcm, orc.default_params(language=c["language"], translate=c["translate"], temperature_inc=0.0))
     tr = [int(t) for t in res["trace"]]
     n0 = c["n0"]
     assert n0 >= 25 and sum(t >= om.beg for t in c["ids"][:n0]) >= 3, "fixture drifted: the window holds no timestamp pairs"
@@ -256,6 +259,9 @@ def test_oracle_full_matches_hf_generate_first_window(ci, model_dir):
     assert len(tr) == n0 or res["n_encode"] > 1          # the loop ended the window exactly there (what follows belongs to the next window)
     assert [(s["t0"], s["t1"]) for s in res["segments"]][:len(c["seg"])] == c["seg"]
     assert res["n_fail"] == 0
+    if ci == 8:     # the prompt matters on this fixture: the same audio with [sot, <|en|>, <|transcribe|>] gives another stream
+        other = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES).full(pcm, orc.default_params(language="en", temperature_inc=0.0))
+        assert [int(t) for t in other["trace"]][:n0] != c["ids"][:n0]
     om.close()
 
 
