@@ -378,6 +378,41 @@ def generate_fixture():
     print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
+def large_v3_fixture():
+    """hf_large_v3_golden.npz: the FULL-DEPTH shape (32 + 32 layers, d = 1280, 20 heads, 128 mels, 51 866 tokens) -- the seeded synthetic large-v3 model
+    bench.py and tests/test_gpu_large_v3.py use (`write_model("large-v3", seed=0)`), loaded into HF with the tanh GELU: encoder rows, per-step top-16
+    logits of a prompt + text + timestamp sequence, and the detected language.  ~10 minutes and ~20 GB of RAM on the build container's CPU; the tests
+    apply the vectors to the HIP engine directly (and to the oracle under -m gpu only: its f32 pass over this model takes minutes)."""
+    from oracle import binding as orc
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "large-v3.bin")
+    ggml_io.write_model(path, "large-v3", seed=0)
+    hp, filt, vocab, tensors = ggml_io.read_model(path)
+    model = hf_model_tanh(hp, tensors)
+    del tensors
+    om = orc.OracleModel(path)
+    pcm = synth.speech_like(SEED_AUDIO + 5)
+    mel = om.log_mel(pcm)[:, :3000].astype(np.float16).astype(np.float32)
+    sot, beg = om.sot, om.beg
+    toks = [sot, sot + 1, om.transcribe, beg, 4321, 707, 30999, 24, beg + 33, beg + 33, 11]
+    with torch.no_grad():
+        enc = model.model.encoder(torch.from_numpy(mel)[None]).last_hidden_state[0].numpy()
+        logits = model(encoder_outputs=(torch.from_numpy(enc)[None],), decoder_input_ids=torch.tensor([toks])).logits[0].numpy()
+        l0 = model(encoder_outputs=(torch.from_numpy(enc)[None],), decoder_input_ids=torch.tensor([[sot]])).logits[0, -1].numpy()
+    n_lang = hp.n_vocab - 51765 - 1
+    ll = l0[sot + 1: sot + 1 + n_lang]
+    order = np.argsort(-ll)
+    topk = np.argsort(-logits, axis=1)[:, :16].astype(np.int32)
+    out = dict(seed=0, seed_audio=SEED_AUDIO + 5, tokens=np.array(toks, np.int32), n_prompt=3, enc_rows=np.array(ENC_ROWS), enc=enc[ENC_ROWS].astype(np.float32),
+               enc_absmax=np.float32(np.abs(enc).max()), topk=topk, topv=np.take_along_axis(logits, topk, axis=1).astype(np.float32),
+               logit_std=np.float32(logits.std()), lang_id=int(order[0]), lang_margin=np.float32(ll[order[0]] - ll[order[1]]))
+    om.close()
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_large_v3_golden.npz")
+    np.savez_compressed(dst, **out)
+    print("large-v3: enc absmax", float(np.abs(enc).max()), "logit std", float(logits.std()), "lang", int(order[0]), "margin", float(ll[order[0]] - ll[order[1]]))
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
 def wcpp_window(ids, beg, eot, seek, seek_end):
     """whisper.cpp's decode loop over HF's ids of ONE window that starts at frame `seek`: (ids it samples before it ends the window, seek_delta, regular) --
     regular = the window ends with EOT after at least one closed timestamp pair and nothing but that pair decides the advance (no single trailing
@@ -481,6 +516,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["toy", "shapes", "rules", "tanh", "generate", "generate_long"]
     if "generate_long" in which:
         generate_long_fixture()
+    if "large_v3" in which:      # not part of the default list: ~10 minutes
+        large_v3_fixture()
     if "tanh" in which:
         tanh_fixture()
     if "generate" in which:

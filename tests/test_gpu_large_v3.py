@@ -154,3 +154,36 @@ def test_large_v3_bf16_forced_replay(large_v3_path):
         eng.close(); om.close()
     finally:
         orc.set_thread_cap(16)
+
+
+def test_large_v3_full_depth_matches_hf_golden(eng8):
+    """The HIP engine at FULL depth (32 + 32 layers) held DIRECTLY to HF transformers' Whisper on the same seeded large-v3 weights
+    (tests/golden/hf_large_v3_golden.npz, tanh GELU; made by tests/golden/make_golden.py large_v3 in the build container): encoder rows, the top-16 logits
+    of a prompt pass and 8 KV-cached steps, and the detected language -- no oracle in between.  Tolerances: the f16-operand bounds of the 2-layer
+    golden tests (tests/test_gpu_golden.py), i.e. no allowance for depth."""
+    from speaksense_amd import binding
+    from test_gpu_golden import ENC_TOL_F16, LOGIT_TOL_F16
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hf_large_v3_golden.npz"))
+    pcm = synth.speech_like(int(g["seed_audio"]))
+    full = eng8.log_mel(pcm)
+    mel = np.zeros_like(full)
+    mel[:, :3000] = full[:, :3000].astype(np.float16).astype(np.float32)
+    enc = eng8.encode(mel, 0)
+    enc_err = float(np.abs(enc[g["enc_rows"]] - g["enc"]).max()) / float(g["enc_absmax"])
+    assert enc_err < ENC_TOL_F16, enc_err
+    ses = eng8.new_session()
+    ses.set_encoder(enc)
+    toks = [int(t) for t in g["tokens"]]
+    n_prompt, sd, worst = int(g["n_prompt"]), float(g["logit_std"]), 0.0
+    steps = [(n_prompt - 1, ses.decode(toks[:n_prompt], 0))] + [(i, ses.decode(toks[i:i + 1], i)) for i in range(n_prompt, len(toks))]
+    for i, lg in steps:
+        e = float(np.abs(lg[g["topk"][i]] - g["topv"][i]).max()) / sd
+        worst = max(worst, e)
+        assert e < LOGIT_TOL_F16, (i, e)
+        if g["topv"][i][0] - g["topv"][i][1] > 2 * LOGIT_TOL_F16 * sd:
+            assert int(lg.argmax()) == int(g["topk"][i][0]), i
+    ses.close()
+    det = eng8.new_session().transcribe(pcm, binding.default_params(language="en", detect_language=1))
+    assert det["lang_id"] == int(g["lang_id"]) and float(g["lang_margin"]) > 1.0
+    report(f"HIP engine (f16) vs HF golden at FULL depth (large-v3, 32 + 32 layers): encoder rows {enc_err:.1e} of absmax (tol {ENC_TOL_F16}), top-16 logits over "
+           f"{len(steps)} steps {worst:.1e} sigma (tol {LOGIT_TOL_F16}), detected language {det['lang_id']} == HF's")
