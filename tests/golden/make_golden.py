@@ -413,6 +413,60 @@ def large_v3_fixture():
     print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
+def generate_large_v3_fixture(audio_seeds=(5003, 5010)):
+    """hf_generate_large_v3_golden.npz: the first-window sequence fixture at FULL depth -- HF `generate(return_timestamps=True, do_sample=False)` on the
+    natural-EOT synthetic large-v3 model bench.py's `mode_n` and tests/test_gpu_bench_config.py use (`write_model("large-v3", seed=0, **NATURAL)`).
+    Stored per audio: HF's ids of the first window, how many whisper.cpp's loop samples, HF's segment times.  The generator also runs the oracle (exact
+    f32, COMPAT_OPENAI_TS_RULES; minutes per case) and reports whether it equals HF; the CPU suite does not (too slow), the GPU suite holds the ENGINE
+    to the ids directly (tests/test_gpu_bench_config.py)."""
+    from transformers import GenerationConfig
+    from oracle import binding as orc
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "large-v3-natural.bin")
+    ggml_io.write_model(path, "large-v3", seed=0, **ggml_io.NATURAL)
+    hp, filt, vocab, tensors = ggml_io.read_model(path)
+    model = hf_model_tanh(hp, tensors)
+    del tensors
+    om = orc.OracleModel(path)
+    eot, sot, beg = om.eot, om.sot, om.beg
+    n_lang = hp.n_vocab - 51765 - 1
+    prompt = [sot, sot + 1, om.transcribe]
+    suppress = [sot, om.nosp, om.solm, om.translate, om.transcribe, om.prev] + [sot + 1 + i for i in range(n_lang)]
+    gc = GenerationConfig(eos_token_id=eot, pad_token_id=eot, bos_token_id=eot, decoder_start_token_id=sot, no_timestamps_token_id=om.not_,
+                          max_initial_timestamp_index=50, suppress_tokens=suppress, begin_suppress_tokens=[220, eot], max_length=448,
+                          is_multilingual=True, return_timestamps=True, do_sample=False, num_beams=1)
+    gc.lang_to_id = {"<|en|>": sot + 1}
+    gc.task_to_id = {"transcribe": om.transcribe, "translate": om.translate}
+    model.generation_config = gc
+    out = {"n_cases": len(audio_seeds)}
+    for ci, aseed in enumerate(audio_seeds):
+        pcm = synth.speech_like(aseed)
+        mel = om.log_mel(pcm)[:, :3000].astype(np.float32)
+        with torch.no_grad():
+            res = model.generate(input_features=torch.from_numpy(mel)[None], decoder_input_ids=torch.tensor([prompt]), return_timestamps=True,
+                                 do_sample=False, num_beams=1, max_new_tokens=224, return_segments=True)
+        segs = res["segments"][0]
+        first = segs[0]["result"]
+        raw = first["sequences"] if isinstance(first, dict) else first
+        raw = [int(t) for t in (raw[0] if raw.dim() == 2 else raw)]
+        if raw[:len(prompt)] == prompt:
+            raw = raw[len(prompt):]
+        w0 = [sg for sg in segs if sg["result"] is segs[0]["result"]]
+        n0 = window0_len(raw, beg, eot)
+        k = f"c{ci}"
+        out[f"{k}_audio"], out[f"{k}_ids"], out[f"{k}_n_window0"] = aseed, np.array(raw, np.int32), n0
+        out[f"{k}_seg_t0"] = np.array([round(100 * float(sg["start"])) for sg in w0], np.int64)
+        out[f"{k}_seg_t1"] = np.array([round(100 * float(sg["end"])) for sg in w0], np.int64)
+        ref = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES).full(pcm, orc.default_params(language="en", temperature_inc=0.0, duration_ms=30000))
+        tr = [int(t) for t in ref["trace"]]
+        print("large-v3 natural, audio", aseed, "HF window 0:", len(raw), "ids,", n0, "sampled by whisper.cpp's loop,", sum(t >= beg for t in raw[:n0]), "timestamps; oracle equal prefix:",
+              tr[:n0] == raw[:n0], "segments equal:", [(s_["t0"], s_["t1"]) for s_ in ref["segments"]][:len(w0)] == list(zip(out[f"{k}_seg_t0"].tolist(), out[f"{k}_seg_t1"].tolist())))
+    om.close()
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_generate_large_v3_golden.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
 def wcpp_window(ids, beg, eot, seek, seek_end):
     """whisper.cpp's decode loop over HF's ids of ONE window that starts at frame `seek`: (ids it samples before it ends the window, seek_delta, regular) --
     regular = the window ends with EOT after at least one closed timestamp pair and nothing but that pair decides the advance (no single trailing
@@ -516,8 +570,10 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["toy", "shapes", "rules", "tanh", "generate", "generate_long"]
     if "generate_long" in which:
         generate_long_fixture()
-    if "large_v3" in which:      # not part of the default list: ~10 minutes
+    if "large_v3" in which:      # not part of the default list: ~3 minutes
         large_v3_fixture()
+    if "generate_large_v3" in which:      # not part of the default list: ~15 minutes (two oracle windows at full depth in exact f32)
+        generate_large_v3_fixture()
     if "tanh" in which:
         tanh_fixture()
     if "generate" in which:

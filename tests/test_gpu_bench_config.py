@@ -224,3 +224,41 @@ def test_natural_preset_32_chunks_distinct_streams_vs_oracle(large_v3_natural_pa
            f"{min(lens)}..{max(lens)} (median {int(np.median(lens))}), {n_same}/32 equal their single-chunk runs; chunks {picked} replayed call by call on the oracle, "
            f"largest greedy margin {worst:.4f}")
     om.close(); eng.close()
+
+
+@pytest.mark.parametrize("which", ["f16", "bf16", "fp8"])
+def test_natural_preset_first_windows_match_hf_generate(which, large_v3_natural_path, oracle_threads):
+    """Sequence-level pin at FULL depth: HF transformers' `generate(return_timestamps=True, do_sample=False)` on this very model (32 + 32 layers, the
+    natural-EOT preset `mode_n` times), first window of two recordings (tests/golden/hf_generate_large_v3_golden.npz, written by
+    tests/golden/make_golden.py generate_large_v3, which also checked that the oracle in exact f32 equals HF id for id on both).  The engine's sampled
+    ids must equal HF's, with HF's segment times; a difference must be a near tie proven by forced replay on the oracle in the engine's arithmetic."""
+    from speaksense_amd import binding
+    orc = oracle_threads
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "hf_generate_large_v3_golden.npz"))
+    dtype, omode, gap_tol = {"f16": (binding.DTYPE_F16, orc.MODE_GGML_F16, GAP_TOL_F16), "bf16": (binding.DTYPE_BF16, orc.MODE_BF16, GAP_TOL_BF16),
+                             "fp8": (binding.DTYPE_FP8, orc.MODE_FP8, GAP_TOL_FP8_FULL_DEPTH)}[which]
+    eng = binding.Engine(large_v3_natural_path, dtype=dtype, max_batch=2, compat=binding.COMPAT_OPENAI_TS_RULES)
+    n_same, worst, lens = 0, 0.0, []
+    for ci in range(int(gold["n_cases"])):
+        k = f"c{ci}"
+        pcm = synth.speech_like(int(gold[f"{k}_audio"]))
+        ids, n0 = [int(t) for t in gold[f"{k}_ids"]], int(gold[f"{k}_n_window0"])
+        seg = list(zip(gold[f"{k}_seg_t0"].tolist(), gold[f"{k}_seg_t1"].tolist()))
+        got = eng.new_session().transcribe(pcm, binding.default_params(language="en", temperature_inc=0.0, duration_ms=30000))
+        tr = [int(t) for t in got["trace"]]
+        lens.append(n0)
+        if tr[:n0] == ids[:n0]:
+            n_same += 1
+            assert [(s["t0"], s["t1"]) for s in got["segments"]][:len(seg)] == seg
+            assert got["n_fail"] == 0
+        else:
+            om = orc.OracleModel(large_v3_natural_path)
+            _, w = check_against_oracle(got, om, orc, omode, pcm, orc.default_params(language="en", temperature_inc=0.0, duration_ms=30000),
+                                        f"HF generate at full depth, case {ci} ({which})", gap_tol, replay_only=True, compat=orc.COMPAT_OPENAI_TS_RULES)
+            worst = max(worst, w)
+            om.close()
+    if which == "f16":
+        assert n_same >= 1, "f16 differs from HF on both full-depth windows"
+    report(f"HIP engine ({which}) vs HF generate at FULL depth (large-v3 natural preset, first windows of {lens} ids): {n_same}/{len(lens)} identical id for id with HF's segment times"
+           + ("" if n_same == len(lens) else f"; the rest near-tie flips proven by forced replay, largest margin {worst:.4f}"))
+    eng.close()
