@@ -31,8 +31,9 @@ typedef struct ss_ticket ss_ticket;
  * older header would make it read past the caller's struct.  A binding asserts, once at load time, that ss_abi_version() == SS_ABI_VERSION and
  * that ss_sizeof_params() / ss_sizeof_engine_opts() equal its own sizeof (binding.py and rust/asr_hip.rs do).  Bumped whenever a struct of this
  * header changes size or a field changes meaning: 4 = round 4's ss_params (128 bytes, token_timestamps in the former reserved0);
- * 5 = round 5 (ss_process_logits_row, these three getters; layouts unchanged). */
-#define SS_ABI_VERSION 5
+ * 5 = round 5 (ss_process_logits_row, these three getters; layouts unchanged); 6 = ss_params grows by suppress_non_speech_tokens / max_len /
+ * split_on_word (144 bytes). */
+#define SS_ABI_VERSION 6
 int32_t ss_abi_version(void);
 int32_t ss_sizeof_params(void);
 int32_t ss_sizeof_engine_opts(void);
@@ -123,6 +124,11 @@ typedef struct ss_params {
     const char* initial_prompt;    /* used when prompt_tokens is NULL: tokenised with the model's vocabulary (whisper_tokenize) */
     float thold_pt;           /* 0.01 (whisper.rs:170): a token's best-timestamp share must exceed this to pin its start time */
     float thold_ptsum;        /* 0.01 (whisper.rs:171): and so must its total timestamp probability */
+    int32_t suppress_non_speech_tokens; /* 0 (whisper.rs:156): 1 = whisper.cpp's non_speech_tokens list (symbols, brackets, music notes; with and
+                                 without a leading space) and " -" / " '" are masked at every step, as far as the model's vocabulary has them */
+    int32_t max_len;          /* 0 (whisper.rs:167): > 0 = whisper_wrap_segment -- every segment is cut into pieces of at most max_len bytes of text at
+                                 token boundaries, the pieces' times taken from the token-level times (acts only with token_timestamps = 1) */
+    int32_t split_on_word;    /* 1 (whisper.rs:161): with max_len > 0, cut only before a token that starts with ' ' */
 } ss_params;
 
 void ss_default_params(ss_params* p);

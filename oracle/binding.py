@@ -33,6 +33,7 @@ class FullParams(C.Structure):
         ("offset_ms", C.c_int32), ("duration_ms", C.c_int32), ("detect_language", C.c_int32), ("prompt_n_tokens", C.c_int32),
         ("prompt_tokens", C.c_void_p), ("initial_prompt", C.c_char_p),
         ("token_timestamps", C.c_int32), ("thold_pt", C.c_float), ("thold_ptsum", C.c_float),
+        ("suppress_non_speech_tokens", C.c_int32), ("max_len", C.c_int32), ("split_on_word", C.c_int32),
     ]
 
 

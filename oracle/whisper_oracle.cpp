@@ -655,7 +655,17 @@ struct FullParams {  // wcpp: whisper_full_params (fields the reference sets, wh
     const char* initial_prompt = nullptr;
     int32_t token_timestamps = 1;   // whisper.rs:160 (whisper_full_default_params: false)
     float thold_pt = 0.01f, thold_ptsum = 0.01f;   // whisper.rs:170-171 (= the defaults)
+    int32_t suppress_non_speech_tokens = 0;   // whisper.rs:156 sets false (= the default)
+    int32_t max_len = 0, split_on_word = 0;   // whisper.rs:167 max_len 0 = segments are not wrapped; whisper.rs:161 split_on_word true (only acts with max_len > 0)
 };
+
+// wcpp: `static const std::vector<std::string> non_speech_tokens` (whisper.cpp v1.5.x, after openai/whisper tokenizer.py non_speech_tokens): with
+// suppress_non_speech_tokens every vocabulary entry equal to one of these symbols, or to " " + the symbol, is masked, and so are " -" and " '"
+// ("allow hyphens and single quotes between words, but not at the beginning of a word").  Restated from memory (parity unpinned, as the header says).
+const char* const kNonSpeechTokens[] = {
+    "\"", "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^", "_", "`", "{", "|", "}", "~", "\u300c", "\u300d", "\u300e", "\u300f",
+    "<<", ">>", "<<<", ">>>", "--", "---", "-(", "-[", "('", "(\"", "((", "))", "(((", ")))", "[[", "]]", "{{", "}}", "\u266a\u266a", "\u266a\u266a\u266a",
+    "\u2669", "\u266a", "\u266b", "\u266c", "\u266d", "\u266e", "\u266f"};
 
 // Version-dependent behaviour of whisper.cpp that this restatement can follow either way (same values as SS_COMPAT_* in include/speaksense.h).
 // Default 0 = what whisper.cpp v1.5.0 .. v1.5.4 does (the range whisper-rs-sys 0.9.0 vendors, /root/reference/Cargo.lock:3888-3907).
@@ -806,6 +816,17 @@ void process_logits(const State& s, Decoder& dec, const FullParams& P, const flo
     logits[vocab.token_transcribe] = -INFINITY;
     logits[vocab.token_prev] = -INFINITY;
     for (int i = 0; i < vocab.num_languages(); i++) logits[vocab.token_sot + 1 + i] = -INFINITY;
+    if (P.suppress_non_speech_tokens) {
+        for (const char* sym : kNonSpeechTokens)
+            for (const std::string& t : {std::string(sym), " " + std::string(sym)}) {
+                auto it = vocab.token_to_id.find(t);
+                if (it != vocab.token_to_id.end()) logits[it->second] = -INFINITY;
+            }
+        for (const char* t : {" -", " '"}) {
+            auto it = vocab.token_to_id.find(t);
+            if (it != vocab.token_to_id.end()) logits[it->second] = -INFINITY;
+        }
+    }
     if (P.fixed_steps > 0) logits[vocab.token_eot] = -INFINITY;  // Mode F only (not a whisper.cpp rule)
     {
         const bool last_was_timestamp = tokens_cur.size() > 0 && tokens_cur.back().id >= vocab.token_beg;
@@ -928,6 +949,36 @@ void sequence_score(const FullParams& P, Sequence& q) {
 
 
 // ---------------------------------------------------------------------------------------------
+// wcpp: whisper_wrap_segment + should_split_on_word -- "wrap the last segment to max_len characters", run after the token-level timestamps of every new
+// segment when whisper_full_params.max_len > 0 (inside the token_timestamps branch: without token times there is nothing to cut at).  Walks the
+// segment's tokens (ids >= eot carry no text and are skipped); when the next token would take the running length (bytes, strlen) past max_len -- and,
+// with split_on_word, the token starts a word (leading ' ') -- the segment ends at that token's t0 and a new one starts there with the remaining
+// tokens; the walk restarts on the new segment, whose first token is always taken.  Restated from memory (parity unpinned).
+int wrap_segment(State& s, const Vocab& vocab, int max_len, bool split_on_word) {
+    Segment segment = s.result_all.back();
+    int res = 1, acc = 0;
+    std::string text;
+    for (int i = 0; i < (int)segment.tokens.size(); i++) {
+        const TokenData& token = segment.tokens[i];
+        if (token.id >= vocab.token_eot) continue;
+        const std::string& txt = vocab.id_to_token[token.id];
+        const int cur = (int)strlen(txt.c_str());
+        if (acc + cur > max_len && i > 0 && (!split_on_word || txt.c_str()[0] == ' ')) {
+            Segment& back = s.result_all.back();
+            back.text = text; back.t1 = token.t0; back.tokens.resize(i); back.speaker_turn_next = false;
+            Segment next{token.t0, segment.t1, "", {}, segment.speaker_turn_next};
+            next.tokens.assign(segment.tokens.begin() + i, segment.tokens.end());
+            s.result_all.push_back(next);
+            acc = 0; text.clear();
+            segment = s.result_all.back();
+            i = -1;
+            res++;
+        } else { acc += cur; text += txt; }
+    }
+    s.result_all.back().text = text;
+    return res;
+}
+
 // Token-level timestamps: whisper.cpp's "experimental" whisper_exp_compute_token_level_timestamps, run on every new segment when
 // whisper_full_params.token_timestamps is set (the reference sets it, whisper.rs:160, with thold_pt = thold_ptsum = 0.01, whisper.rs:170-171, and
 // max_len = 0, so nothing is re-wrapped and neither text nor segment times change; whisper_token_data.t0 / t1 / vlen are what it produces).
@@ -1235,7 +1286,10 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
                         if (!text.empty()) {
                             s.result_all.push_back({t0, t1, text, {}, speaker_turn_next});
                             for (int j = i0; j <= i; j++) s.result_all.back().tokens.push_back(tokens_cur[j]);
-                            if (P.token_timestamps) token_level_timestamps(s, vocab, s.result_all.back(), P.thold_pt, P.thold_ptsum);
+                            if (P.token_timestamps) {
+                                token_level_timestamps(s, vocab, s.result_all.back(), P.thold_pt, P.thold_ptsum);
+                                if (P.max_len > 0) wrap_segment(s, vocab, P.max_len, P.split_on_word != 0);
+                            }
                         }
                         text = "";
                         while (i < (int)tokens_cur.size() && tokens_cur[i].id > vocab.token_beg) i++;
@@ -1246,7 +1300,10 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
                     const int64_t t1 = seek + seek_delta;
                     s.result_all.push_back({t0, t1, text, {}, speaker_turn_next});
                     for (int j = i0; j < (int)tokens_cur.size(); j++) s.result_all.back().tokens.push_back(tokens_cur[j]);
-                    if (P.token_timestamps) token_level_timestamps(s, vocab, s.result_all.back(), P.thold_pt, P.thold_ptsum);
+                    if (P.token_timestamps) {
+                        token_level_timestamps(s, vocab, s.result_all.back(), P.thold_pt, P.thold_ptsum);
+                        if (P.max_len > 0) wrap_segment(s, vocab, P.max_len, P.split_on_word != 0);
+                    }
                 }
             }
             seek += seek_delta;

@@ -29,10 +29,11 @@ class Params(C.Structure):
                 ("fixed_steps", C.c_int32), ("language", C.c_char * 8),
                 ("n_max_text_ctx", C.c_int32), ("offset_ms", C.c_int32), ("duration_ms", C.c_int32), ("detect_language", C.c_int32),
                 ("prompt_tokens", C.c_void_p), ("prompt_n_tokens", C.c_int32), ("token_timestamps", C.c_int32), ("initial_prompt", C.c_char_p),
-                ("thold_pt", C.c_float), ("thold_ptsum", C.c_float)]
+                ("thold_pt", C.c_float), ("thold_ptsum", C.c_float),
+                ("suppress_non_speech_tokens", C.c_int32), ("max_len", C.c_int32), ("split_on_word", C.c_int32)]
 
 
-ABI_VERSION = 5   # include/speaksense.h SS_ABI_VERSION
+ABI_VERSION = 6   # include/speaksense.h SS_ABI_VERSION
 
 
 class DenoiseConfig(C.Structure):   # DenoiseConfig, /root/reference/src/audio/mod.rs:41-61

@@ -80,6 +80,7 @@ void ss_default_params(ss_params* p) {
     p->n_max_text_ctx = 16384; p->offset_ms = 0; p->duration_ms = 0; p->detect_language = 0;
     p->prompt_tokens = nullptr; p->prompt_n_tokens = 0; p->initial_prompt = nullptr;
     p->token_timestamps = 1; p->thold_pt = 0.01f; p->thold_ptsum = 0.01f;   // whisper.rs:160,170-171
+    p->suppress_non_speech_tokens = 0; p->max_len = 0; p->split_on_word = 1;   // whisper.rs:156,167,161
 }
 
 int ss_engine_create(const char* path, const ss_engine_opts* opts, ss_engine** out) {

@@ -102,6 +102,9 @@ struct Vocab {
 };
 int lang_id(const char* code);  // -1 if unknown
 const char* lang_code(int id);   // nullptr if out of range
+// whisper.cpp's non_speech_tokens (whisper_full_params.suppress_non_speech_tokens): ids of the vocabulary entries equal to one of the listed symbols or
+// to ' ' + the symbol, plus " -" and " '"; ascending, without duplicates
+std::vector<int> non_speech_token_ids(const Vocab& vocab);
 std::vector<int> tokenize(const Vocab& vocab, const std::string& text);   // whisper.cpp's tokenize(): GPT-2 pre-split + greedy longest match
 
 // Host-side tensor as read from the file: f32 copy + the raw f16 payload when the file stored f16

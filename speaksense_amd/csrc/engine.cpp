@@ -632,6 +632,12 @@ struct EngineT : EngineBase {
         ffd.alloc((size_t)R * 4 * d * 2); logits.alloc((size_t)R * n_vocab_pad * 4); probs.alloc((size_t)R * n_vocab_pad * 4);
         cscratch.alloc((size_t)R * H * 4 * 66 * 4); ctl_d.alloc(2 * R * sizeof(RowCtl));
         samp_d.alloc(R * sizeof(SampleOut)); rowidx_d.alloc(R * 4); rules_scratch.alloc((size_t)R * 64 * 8 * 4);
+        {   // ss_params.suppress_non_speech_tokens: which ids of THIS vocabulary are on whisper.cpp's non-speech list, one bit per id
+            std::vector<uint32_t> m((n_vocab + 31) / 32, 0u);
+            for (int id : non_speech_token_ids(hm.vocab)) if (id < n_vocab) m[id >> 5] |= 1u << (id & 31);
+            ns_mask_d.alloc(m.size() * 4);
+            SS_HIP(hipMemcpy(ns_mask_d.p, m.data(), m.size() * 4, hipMemcpyHostToDevice));
+        }
         SS_HIP(hipHostMalloc((void**)&stage_h, kStageRing * sizeof(Stage), hipHostMallocDefault));
         memset(stage_h, 0, kStageRing * sizeof(Stage));
         for (auto& e : stage_ev) SS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -984,7 +990,7 @@ struct EngineT : EngineBase {
         decoder_step_fused(M, rc, samp_rows, any_probs);
         return step_parity;
     }
-    DBuf samp_d, rowidx_d, rules_scratch;
+    DBuf samp_d, rowidx_d, rules_scratch, ns_mask_d;
     long cnt_passes = 0, cnt_rows = 0, cnt_windows = 0, cnt_admitted = 0, cnt_midstart = 0;   // of the running group: decoder passes (one read of the decoder weights each), rows, windows
     bool use_graph = true, chain_steps = true;
     int ln_fuse_rows = kLnFuseRows;   // (dev: SS_LN_FUSE_ROWS, <= 16, to re-measure where the fusion stops paying)
@@ -1008,6 +1014,7 @@ struct EngineT : EngineBase {
         }
         rc.suppress_eot = P.fixed_steps > 0;
         rc.openai_ts = (compat & SS_COMPAT_OPENAI_TS_RULES) != 0;
+        rc.ns_mask = P.suppress_non_speech_tokens ? ns_mask_d.as<uint32_t>() : nullptr;
         return rc;
     }
 
@@ -1410,7 +1417,8 @@ struct EngineT : EngineBase {
             const ss_params& P0 = all[pos0].w->job->P;
             auto same = [&](const ss_params& a) {
                 return a.suppress_blank == P0.suppress_blank && a.no_timestamps == P0.no_timestamps && a.tdrz_enable == P0.tdrz_enable &&
-                       a.max_initial_ts == P0.max_initial_ts && (a.fixed_steps > 0) == (P0.fixed_steps > 0);
+                       a.max_initial_ts == P0.max_initial_ts && (a.fixed_steps > 0) == (P0.fixed_steps > 0) &&
+                       !a.suppress_non_speech_tokens == !P0.suppress_non_speech_tokens;
             };
             std::vector<RowRef> g;
             while (pos0 < all.size() && same(all[pos0].w->job->P)) g.push_back(all[pos0++]);
@@ -1572,6 +1580,34 @@ struct EngineT : EngineBase {
         if (done || q.i >= n_max) q.active = false;
     }
 
+    // whisper_wrap_segment (whisper.cpp v1.5.x; ss_params.max_len > 0, after the token-level times of a new segment): the LAST segment is cut wherever
+    // the next text token would take the piece past max_len bytes -- with split_on_word only before a token that opens a word (' ' first) -- at that
+    // token's t0.  Every piece but the last loses speaker_turn_next; ids >= eot carry no text and never start a piece unless they come first.
+    static void wrap_last_segment(Session& s, const Vocab& vocab, int max_len, bool split_on_word) {
+        size_t from = 0;           // first token of the piece being measured, as an index into the ORIGINAL token list
+        const Segment whole = s.segments.back();
+        const int n = (int)whole.tokens.size();
+        int acc = 0;
+        std::string text;
+        for (int i = 0; i < n; i++) {
+            const TokenData& tok = whole.tokens[i];
+            if (tok.id >= vocab.token_eot) continue;
+            const std::string& txt = vocab.id_to_token[tok.id];
+            const int cur = (int)strlen(txt.c_str());
+            const bool opens_word = !split_on_word || (!txt.empty() && txt[0] == ' ');
+            if (acc + cur > max_len && i > (int)from && opens_word) {
+                Segment& piece = s.segments.back();
+                piece.text = text; piece.t1 = tok.t0; piece.speaker_turn_next = false;
+                piece.tokens.assign(whole.tokens.begin() + from, whole.tokens.begin() + i);
+                s.segments.push_back({tok.t0, whole.t1, std::string(), whole.speaker_turn_next, {}});
+                s.segments.back().tokens.assign(whole.tokens.begin() + i, whole.tokens.end());
+                from = i; acc = 0; text.clear();
+            }
+            acc += cur; text += txt;
+        }
+        s.segments.back().text = text;
+    }
+
     void finalize_window(Window& w, std::vector<JobState>& js) {
         const Vocab& vocab = hm.vocab;
         const ss_params& P = w.job->P;
@@ -1608,7 +1644,10 @@ struct EngineT : EngineBase {
                     if (!text.empty()) {
                         s->segments.push_back({t0, t1, text, speaker_turn_next, {}});
                         s->segments.back().tokens.assign(tk.begin() + i0, tk.begin() + i + 1);
-                        if (P.token_timestamps) token_level_times(*s, vocab, s->segments.back(), jq.energy, jq.n_energy, P.thold_pt, P.thold_ptsum);
+                        if (P.token_timestamps) {
+                            token_level_times(*s, vocab, s->segments.back(), jq.energy, jq.n_energy, P.thold_pt, P.thold_ptsum);
+                            if (P.max_len > 0) wrap_last_segment(*s, vocab, P.max_len, P.split_on_word != 0);
+                        }
                     }
                     text.clear();
                     while (i < (int)tk.size() && tk[i].id > vocab.token_beg) i++;
@@ -1621,7 +1660,10 @@ struct EngineT : EngineBase {
             if (!text.empty()) {
                 s->segments.push_back({t0, (int64_t)(seek + seek_delta), text, speaker_turn_next, {}});
                 s->segments.back().tokens.assign(tk.begin() + i0, tk.end());
-                if (P.token_timestamps) token_level_times(*s, vocab, s->segments.back(), jq.energy, jq.n_energy, P.thold_pt, P.thold_ptsum);
+                if (P.token_timestamps) {
+                    token_level_times(*s, vocab, s->segments.back(), jq.energy, jq.n_energy, P.thold_pt, P.thold_ptsum);
+                    if (P.max_len > 0) wrap_last_segment(*s, vocab, P.max_len, P.split_on_word != 0);
+                }
             }
         }
         jq.seek += seek_delta;

@@ -219,7 +219,9 @@ struct RuleConsts {
     int32_t n_vocab, eot, sot, translate, transcribe, solm, prev, nosp, not_, beg, blank /* id of " " or -1 */, n_lang;
     int32_t suppress_blank, no_timestamps, tdrz_enable, max_initial_tid /* -1 = off */, suppress_eot /* Mode F */;
     int32_t openai_ts;   // SS_COMPAT_OPENAI_TS_RULES: RowCtl.has_ts / ts_min then mean "a timestamp (id >= beg) was sampled" / "the last one's index"
+    const uint32_t* ns_mask;   // ss_params.suppress_non_speech_tokens: device bitmask over the vocabulary (bit i of word i / 32), null = off
 };
+static_assert(sizeof(RuleConsts) == 18 * 4 + 8, "RuleConsts is compared with memcmp: no padding");
 struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t pad[2]; };
 // scratch: >= M * 64 * 8 floats
 // ctl_upd (optional): base of the step's device control blocks; the pick kernel then rewrites rows [64 + m] and [row_of[m]] into the

@@ -122,6 +122,7 @@ __device__ __forceinline__ float masked_logit(int i, float v, const RowCtl& c, c
     if (rc.no_timestamps && i >= rc.beg) kill = true;
     if (i > rc.sot && i <= rc.sot + rc.n_lang) kill = true;
     if (rc.suppress_eot && i == rc.eot) kill = true;
+    if (rc.ns_mask && ((rc.ns_mask[i >> 5] >> (i & 31)) & 1u)) kill = true;
     if (c.last_ts) {
         if (c.penult_ts) { if (i >= rc.beg) kill = true; }
         else if (i < rc.eot) kill = true;

@@ -5,6 +5,7 @@
 // files are supported; quantised files are rejected with SS_ERR_MODEL.
 #include "common.h"
 
+#include <algorithm>
 #include <cstring>
 
 namespace ss {
@@ -28,6 +29,28 @@ const char* lang_code(int id) { return id >= 0 && id < kNLang ? kLang[id] : null
 // (std::regex, classic locale: alpha/digit/space are ASCII classes, every byte >= 0x80 is "other"), then each word is cut greedily into the
 // longest vocabulary entries; a byte no entry starts with is skipped.  Written out by hand: the alternatives are tried in order at each position.
 static inline bool is_alpha_c(unsigned char c) { return (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z'); }
+// whisper_full_params.suppress_non_speech_tokens (whisper.cpp v1.5.x whisper_process_logits, list after openai/whisper tokenizer.py non_speech_tokens):
+// punctuation that annotates rather than transcribes, brackets and their runs, music notes; each with and without a leading space.  " -" and " '"
+// are on the list only with the space: hyphens and apostrophes stay allowed inside words.
+std::vector<int> non_speech_token_ids(const Vocab& vocab) {
+    static const char* const kSymbols[] = {
+        "\"", "#", "(", ")", "*", "+", "/", ":", ";", "<", "=", ">", "@", "[", "\\", "]", "^", "_", "`", "{", "|", "}", "~",
+        "\xe3\x80\x8c", "\xe3\x80\x8d", "\xe3\x80\x8e", "\xe3\x80\x8f",                       // corner brackets U+300C..U+300F
+        "<<", ">>", "<<<", ">>>", "--", "---", "-(", "-[", "('", "(\"", "((", "))", "(((", ")))", "[[", "]]", "{{", "}}",
+        "\xe2\x99\xaa\xe2\x99\xaa", "\xe2\x99\xaa\xe2\x99\xaa\xe2\x99\xaa",                 // two and three eighth notes
+        "\xe2\x99\xa9", "\xe2\x99\xaa", "\xe2\x99\xab", "\xe2\x99\xac", "\xe2\x99\xad", "\xe2\x99\xae", "\xe2\x99\xaf"};   // U+2669..U+266F
+    std::vector<int> ids;
+    auto take = [&](const std::string& t) {
+        auto it = vocab.token_to_id.find(t);
+        if (it != vocab.token_to_id.end()) ids.push_back(it->second);
+    };
+    for (const char* sym : kSymbols) { take(sym); take(std::string(" ") + sym); }
+    take(" -"); take(" '");
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    return ids;
+}
+
 static inline bool is_digit_c(unsigned char c) { return c >= '0' && c <= '9'; }
 static inline bool is_space_c(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13); }
 static inline bool is_other_c(unsigned char c) { return !is_alpha_c(c) && !is_digit_c(c) && !is_space_c(c); }

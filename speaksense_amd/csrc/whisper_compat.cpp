@@ -384,11 +384,11 @@ struct whisper_full_params* whisper_full_default_params_by_ref(enum whisper_samp
 // whisper_full_params -> ss_params; returns SS_OK or the refusal
 static int map_params(struct whisper_context* ctx, const struct whisper_full_params& params, ss_params& p) {
     // features of whisper_full this path does not implement are refused, never silently ignored
-    if (params.strategy != WHISPER_SAMPLING_GREEDY || params.speed_up || params.suppress_non_speech_tokens || params.n_grammar_rules > 0 ||
-        params.logits_filter_callback || params.max_len > 0)
+    if (params.strategy != WHISPER_SAMPLING_GREEDY || params.speed_up || params.n_grammar_rules > 0 || params.logits_filter_callback)
         return SS_ERR_UNSUPPORTED;
-    // split_on_word (the reference sets it, whisper.rs:161) only acts together with max_len > 0, refused above; token_timestamps (whisper.rs:160) is
-    // honoured: whisper_full_get_token_data(..).t0 / t1 / vlen.  The four plain callbacks are honoured at CHUNK granularity (whisper_full_with_state
+    // Honoured beyond what the reference sets: suppress_non_speech_tokens (whisper.rs:156 false), max_len + split_on_word (whisper.rs:167,161:
+    // whisper_wrap_segment; like whisper.cpp only together with token_timestamps), token_timestamps (whisper.rs:160:
+    // whisper_full_get_token_data(..).t0 / t1 / vlen).  The four plain callbacks are honoured at CHUNK granularity (whisper_full_with_state
     // below): the windows of a chunk complete inside a device batch shared with other states, so nothing can fire from inside it.
     if (params.audio_ctx != 0 && params.audio_ctx != whisper_n_audio_ctx(ctx)) return SS_ERR_UNSUPPORTED;
     ss_default_params(&p);
@@ -399,6 +399,7 @@ static int map_params(struct whisper_context* ctx, const struct whisper_full_par
     p.suppress_blank = params.suppress_blank; p.tdrz_enable = params.tdrz_enable; p.print_special = params.print_special;
     p.max_tokens = params.max_tokens; p.audio_ctx = params.audio_ctx; p.translate = params.translate;
     p.token_timestamps = params.token_timestamps; p.thold_pt = params.thold_pt; p.thold_ptsum = params.thold_ptsum;
+    p.suppress_non_speech_tokens = params.suppress_non_speech_tokens; p.max_len = params.max_len; p.split_on_word = params.split_on_word;
     if (params.language) { strncpy(p.language, params.language, sizeof(p.language) - 1); p.language[sizeof(p.language) - 1] = 0; }
     else p.language[0] = 0;   // nullptr / "" / "auto": detect
     p.n_max_text_ctx = params.n_max_text_ctx; p.offset_ms = params.offset_ms; p.duration_ms = params.duration_ms;

@@ -467,11 +467,12 @@ def synth_tensor(name: str, shape, hp: HParams, rng: np.random.Generator, logit_
 
 
 def write_model(path: str, hp: HParams | str, seed: int = 0, logit_gain: float = 9.0, tensors: dict | None = None,
-                ts_period: int = 12, eot_start: int = 40, ftype: int | str | None = None, **style_kw):
+                ts_period: int = 12, eot_start: int = 40, ftype: int | str | None = None, vocab_overrides: dict | None = None, **style_kw):
     """Write a ggml legacy whisper model. `tensors` (name -> ndarray in PyTorch layout) overrides the
     synthetic draw -- used by the HF cross-check to export a transformers model's weights.
     `ftype` ("q5_0", "q5_1", "q8_0", "q4_0", "q4_1" or the ggml number): what whisper.cpp's quantize tool produces from the f16 file -- every
-    2-D weight except the positional embeddings becomes block-quantised, the header's ftype says which type (+ 2000: GGML_QNT_VERSION 2)."""
+    2-D weight except the positional embeddings becomes block-quantised, the header's ftype says which type (+ 2000: GGML_QNT_VERSION 2).
+    `vocab_overrides` (id -> bytes): replaces entries of the synthetic vocabulary, e.g. to plant whisper.cpp's non-speech symbols (weights are unaffected)."""
     if isinstance(hp, str):
         hp = PRESETS[hp]
     if isinstance(ftype, str):
@@ -485,6 +486,8 @@ def write_model(path: str, hp: HParams | str, seed: int = 0, logit_gain: float =
     ctx = {"ts_period": ts_period, "eot_start": eot_start}
     ctx.update(style_kw)    # style="natural" and its knobs: NATURAL / natural_tensor
     vocab = synth_vocab(hp.n_vocab)
+    for i, t in (vocab_overrides or {}).items():
+        vocab[i] = t
     filt = mel_filters(hp.n_mels)
     with open(path, "wb") as f:
         f.write(struct.pack("<I", GGML_MAGIC))

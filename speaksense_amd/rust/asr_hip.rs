@@ -29,6 +29,7 @@ pub struct ss_params {
     pub n_max_text_ctx: i32, pub offset_ms: i32, pub duration_ms: i32, pub detect_language: i32,
     pub prompt_tokens: *const i32, pub prompt_n_tokens: i32, pub token_timestamps: i32, pub initial_prompt: *const c_char,
     pub thold_pt: f32, pub thold_ptsum: f32,
+    pub suppress_non_speech_tokens: i32, pub max_len: i32, pub split_on_word: i32,
 }   // layout: tests/golden/abi_layout.txt (offsets checked against the C header by tests/test_host_cpu.py)
 unsafe impl Send for ss_params {}
 
@@ -78,8 +79,8 @@ impl HipAsr {
     pub fn new(model_path: String) -> Result<Self> {
         // the library copies ss_params / ss_engine_opts by value: refuse a library whose layouts are not the ones declared above (speaksense.h SS_ABI_VERSION)
         let (v, sp, so) = unsafe { (ss_abi_version(), ss_sizeof_params(), ss_sizeof_engine_opts()) };
-        if v != 5 || sp as usize != std::mem::size_of::<ss_params>() || so as usize != std::mem::size_of::<ss_engine_opts>() {
-            return Err(anyhow!("libspeaksense_hip ABI {} (ss_params {} B, ss_engine_opts {} B) does not match this shim (ABI 5, {} B, {} B)", v, sp, so,
+        if v != 6 || sp as usize != std::mem::size_of::<ss_params>() || so as usize != std::mem::size_of::<ss_engine_opts>() {
+            return Err(anyhow!("libspeaksense_hip ABI {} (ss_params {} B, ss_engine_opts {} B) does not match this shim (ABI 6, {} B, {} B)", v, sp, so,
                                std::mem::size_of::<ss_params>(), std::mem::size_of::<ss_engine_opts>()));
         }
         let path = CString::new(model_path)?;

@@ -49,6 +49,7 @@ int main(void) {
     F(ss_params, translate); F(ss_params, fixed_steps); F(ss_params, language); F(ss_params, n_max_text_ctx); F(ss_params, offset_ms);
     F(ss_params, duration_ms); F(ss_params, detect_language); F(ss_params, prompt_tokens); F(ss_params, prompt_n_tokens); F(ss_params, token_timestamps);
     F(ss_params, initial_prompt); F(ss_params, thold_pt); F(ss_params, thold_ptsum);
+    F(ss_params, suppress_non_speech_tokens); F(ss_params, max_len); F(ss_params, split_on_word);
     printf("ss_params sizeof %zu 0\n", sizeof(struct ss_params));
     F(ss_engine_opts, device); F(ss_engine_opts, dtype); F(ss_engine_opts, max_batch); F(ss_engine_opts, max_decoders);
     F(ss_engine_opts, batch_wait_us); F(ss_engine_opts, n_lanes); F(ss_engine_opts, compat); F(ss_engine_opts, reserved);
