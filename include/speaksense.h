@@ -108,7 +108,10 @@ typedef struct ss_params {
     int32_t tdrz_enable;      /* AsrParams.speaker_diarization */
     int32_t print_special;    /* 0 */
     int32_t max_tokens;       /* 0 */
-    int32_t audio_ctx;        /* 0 = full (1500) */
+    int32_t audio_ctx;        /* 0 = full (n_audio_ctx = 1500; whisper.rs:144 passes 1500).  A smaller positive multiple of 4 shortens the encoder to the first
+                                 audio_ctx positions (whisper.cpp's exp_n_audio_ctx): 2 audio_ctx mel frames per window, that many cross-attention keys;
+                                 larger than the model's -> SS_ERR_AUDIO_CTX (-5, as whisper_full); other values and language detection with a
+                                 shortened context -> SS_ERR_UNSUPPORTED */
     int32_t translate;        /* 0 */
     int32_t fixed_steps;      /* bench Mode F: >0 = exactly this many greedy steps, EOT suppressed, no fallback */
     char language[8];         /* "en" default; AsrParams.language.  "auto" or "" = detect (whisper_lang_auto_detect on the first window) */

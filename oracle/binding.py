@@ -58,6 +58,7 @@ def lib():
         L.orc_token_str.argtypes = [C.c_void_p, C.c_int]
         L.orc_log_mel.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.orc_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(OrcOpts), C.c_void_p]
+        L.orc_encode_ctx.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(OrcOpts), C.c_int, C.c_void_p]
         L.orc_state_new.restype = C.c_void_p
         L.orc_state_new.argtypes = [C.c_void_p, C.POINTER(OrcOpts)]
         L.orc_state_free.argtypes = [C.c_void_p]
@@ -65,6 +66,7 @@ def lib():
         L.orc_state_rng_peek.restype = C.c_uint32
         L.orc_state_rng_peek.argtypes = [C.c_void_p, C.c_int]
         L.orc_state_set_encoder.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_state_set_encoder_ctx.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.orc_state_cross_kv.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.orc_process_logits.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(FullParams), C.c_void_p, C.c_void_p]
@@ -185,10 +187,15 @@ class OracleModel:
         self.L.orc_log_mel(self.h, _p(pcm), len(pcm), _p(out), n_len)
         return out
 
-    def encode(self, mel: np.ndarray, seek: int = 0, mode: int = MODE_F32, gelu_erf: int = 0) -> np.ndarray:
+    def encode(self, mel: np.ndarray, seek: int = 0, mode: int = MODE_F32, gelu_erf: int = 0, audio_ctx: int = 0) -> np.ndarray:
+        """audio_ctx > 0 (whisper_full_params.audio_ctx): only the first audio_ctx positions, [audio_ctx][n_audio_state]."""
         mel = np.ascontiguousarray(mel, np.float32)
-        out = np.empty((self.n_audio_ctx, self.n_audio_state), np.float32)
         o = OrcOpts(mode, gelu_erf, default_threads())
+        if audio_ctx > 0:
+            out = np.empty((audio_ctx, self.n_audio_state), np.float32)
+            self.L.orc_encode_ctx(self.h, _p(mel), mel.shape[1], seek, C.byref(o), int(audio_ctx), _p(out))
+            return out
+        out = np.empty((self.n_audio_ctx, self.n_audio_state), np.float32)
         self.L.orc_encode(self.h, _p(mel), mel.shape[1], seek, C.byref(o), _p(out))
         return out
 
@@ -249,7 +256,12 @@ class OracleState:
             self.h = None
 
     def set_encoder(self, enc: np.ndarray):
+        """enc: [n_audio_ctx][n_audio_state], or fewer rows = the output of a shortened context (whisper_full_params.audio_ctx)."""
         enc = np.ascontiguousarray(enc, np.float32)
+        if enc.shape[0] < self.m.n_audio_ctx:
+            if self.L.orc_state_set_encoder_ctx(self.h, _p(enc), int(enc.shape[0])) != 0:
+                raise RuntimeError("oracle: bad audio_ctx")
+            return
         self.L.orc_state_set_encoder(self.h, _p(enc))
 
     def cross_kv(self, il: int):

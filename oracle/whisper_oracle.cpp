@@ -540,10 +540,12 @@ void attend_row(const float* q, const float* Kc, const float* Vc, int ldkv, int 
 // encoder   (wcpp: whisper_build_graph_conv / _encoder / _cross)
 // ---------------------------------------------------------------------------------------------
 // mel: [n_mel][n_len]; window [seek, seek+2*n_ctx) zero-padded past n_len. enc_out: [n_ctx][d]
-void encode(const Model& m, const float* mel, int n_len, int seek, const Opts& o, float* enc_out, int max_layers = -1, double* t_split = nullptr) {
+// n_ctx_run (wcpp whisper_state::exp_n_audio_ctx, from whisper_full_params.audio_ctx): > 0 = the pass covers only the first n_ctx_run positions --
+// 2 n_ctx_run mel frames (the conv's zero padding then sits right behind them), that many rows of the positional embedding and of enc_out
+void encode(const Model& m, const float* mel, int n_len, int seek, const Opts& o, float* enc_out, int max_layers = -1, double* t_split = nullptr, int n_ctx_run = 0) {
     const double t_begin = omp_get_wtime();
     const HParams& hp = m.hp;
-    const int n_ctx = hp.n_audio_ctx, d = hp.n_audio_state, H = hp.n_audio_head, dh = d / H, n_mel = hp.n_mels;
+    const int n_ctx = n_ctx_run > 0 ? n_ctx_run : hp.n_audio_ctx, d = hp.n_audio_state, H = hp.n_audio_head, dh = d / H, n_mel = hp.n_mels;
     const int T2 = 2 * n_ctx;
     // time-major padded input [T2+2][n_mel]
     std::vector<float> x0((size_t)(T2 + 2) * n_mel, 0.0f);
@@ -693,6 +695,7 @@ struct State {
     int compat = 0;                       // COMPAT_* flags: which upstream variant of a version-dependent behaviour is restated (ledger)
     int n_fail = 0, n_encode = 0, n_decode = 0;
     int lang_id = -1;                     // wcpp: whisper_full_lang_id
+    int exp_n_audio_ctx = 0;              // wcpp whisper_state::exp_n_audio_ctx: whisper_full installs params.audio_ctx here AFTER the language detection; 0 = n_audio_ctx
     std::vector<float> energy;            // wcpp whisper_state::energy: PCM signal energy, one value per sample (token_timestamps)
     int64_t t_beg = 0, t_last = 0; int tid_last = 0;   // wcpp whisper_state: carried from segment to segment of one call by the token-level timestamps
     // Test hook (not whisper.cpp): forced replay.  Greedy sampling step g takes forced[g] instead of the argmax and records
@@ -709,9 +712,11 @@ struct State {
     float t_cur = 0.0f;                   // temperature of the running attempt   // per consumed entry: 0 greedy (gap = log-probability distance), 1 sampled (gap = CDF distance)
 };
 
+inline int audio_ctx_of(const State& s) { return s.exp_n_audio_ctx > 0 ? s.exp_n_audio_ctx : s.m->hp.n_audio_ctx; }
+
 void cross_kv(State& s, int max_layers = -1) {
     const Model& m = *s.m; const HParams& hp = m.hp;
-    const int n_ctx = hp.n_audio_ctx, d = hp.n_text_state, L = hp.n_text_layer, dh = d / hp.n_text_head;
+    const int n_ctx = audio_ctx_of(s), d = hp.n_text_state, L = hp.n_text_layer, dh = d / hp.n_text_head;
     const float kscale = powf((float)dh, -0.25f);
     s.ck.resize((size_t)L * n_ctx * d); s.cv.resize((size_t)L * n_ctx * d);
     const int Lrun = max_layers >= 0 ? std::min(max_layers, L) : L;
@@ -741,7 +746,7 @@ void cross_kv(State& s, int max_layers = -1) {
 // Decode n tokens for one decoder at positions [n_past, n_past+n); logits_out (n_vocab) for the LAST token.
 void decode(State& s, Decoder& dec, const int* tokens, int n, int n_past, float* logits_out) {
     const Model& m = *s.m; const HParams& hp = m.hp; const Opts& o = s.o;
-    const int d = hp.n_text_state, H = hp.n_text_head, dh = d / H, L = hp.n_text_layer, n_ctx = hp.n_text_ctx, n_actx = hp.n_audio_ctx;
+    const int d = hp.n_text_state, H = hp.n_text_head, dh = d / H, L = hp.n_text_layer, n_ctx = hp.n_text_ctx, n_actx = audio_ctx_of(s);
     const float qs = powf((float)dh, -0.25f);
     if (dec.k.empty()) { dec.k.assign((size_t)L * n_ctx * d, 0.f); dec.v.assign((size_t)L * n_ctx * d, 0.f); }
     std::vector<float> x((size_t)n * d), ln((size_t)n * d), q((size_t)n * d), kk((size_t)n * d), vv((size_t)n * d), att((size_t)n * d),
@@ -1117,7 +1122,7 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
     s.enc.resize((size_t)hp.n_audio_ctx * hp.n_audio_state);
     if (auto_lang && vocab.is_multilingual()) {   // wcpp: whisper_lang_auto_detect_with_state(ctx, state, 0, ...): window at offset 0, prompt [sot], argmax over the language tokens
         if (s.n_len_org <= 0) return -3;
-        encode(m, s.mel.data(), s.n_len, 0, s.o, s.enc.data());
+        encode(m, s.mel.data(), s.n_len, 0, s.o, s.enc.data(), -1, nullptr, s.exp_n_audio_ctx);   // still the PREVIOUS call's context (0 on a new state)
         cross_kv(s);
         std::vector<float> lgd(hp.n_vocab);
         s.decoders.resize(std::max<size_t>(1, s.decoders.size()));
@@ -1151,6 +1156,7 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
         }
     }
     if (P.audio_ctx > hp.n_audio_ctx) return -5;
+    s.exp_n_audio_ctx = P.audio_ctx;      // wcpp: "overwrite audio_ctx, max allowed is hparams.n_audio_ctx"
     std::vector<int> prompt_init = {vocab.token_sot};
     if (vocab.is_multilingual()) {
         const int lid = lang_id(language.c_str());
@@ -1165,7 +1171,7 @@ int full(State& s, const float* samples, int n_samples, const FullParams& P) {
     std::vector<float> lg(hp.n_vocab);
     while (true) {
         if (seek + 100 >= seek_end) break;
-        encode(m, s.mel.data(), s.n_len, seek, s.o, s.enc.data());
+        encode(m, s.mel.data(), s.n_len, seek, s.o, s.enc.data(), -1, nullptr, s.exp_n_audio_ctx);
         cross_kv(s); s.n_encode++;
         if (seek > seek_start && seek + 500 >= seek_end) s.prompt_past.clear();
         int best_decoder_id = 0;
@@ -1342,6 +1348,12 @@ int orc_encode(void* mp, const float* mel, int n_len, int seek, const orc_opts* 
     if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
     encode(*(Model*)mp, mel, n_len, seek, op, enc_out); return 0;
 }
+// the same over the first audio_ctx positions only (whisper_full_params.audio_ctx); enc_out: [audio_ctx][n_audio_state]
+int orc_encode_ctx(void* mp, const float* mel, int n_len, int seek, const orc_opts* o, int audio_ctx, float* enc_out) {
+    Opts op; op.fp8 = o->mode == 3; op.mode = op.fp8 ? 1 : o->mode; op.gelu_erf = o->gelu_erf;
+    if (o->n_threads > 0) omp_set_num_threads(o->n_threads);
+    encode(*(Model*)mp, mel, n_len, seek, op, enc_out, -1, nullptr, audio_ctx); return 0;
+}
 // FP8 mode: the activations at the FIRST quantisation point of the path (LayerNorm 1 of encoder block 0, as the e4m3 projections see them:
 // code x 2^s per element), for the test that counts how many e4m3 codes differ between the device and this restatement.  out: [n_ctx][n_audio_state]
 int orc_encode_fp8_first_quant(void* mp, const float* mel, int n_len, int seek, int n_threads, float* out) {
@@ -1371,7 +1383,15 @@ uint32_t orc_state_rng_peek(void* sp, int decoder) {
 }
 int orc_state_set_encoder(void* sp, const float* enc) {
     State* s = (State*)sp; const HParams& hp = s->m->hp;
+    s->exp_n_audio_ctx = 0;   // a full-context encoder output
     s->enc.assign(enc, enc + (size_t)hp.n_audio_ctx * hp.n_audio_state); cross_kv(*s); return 0;
+}
+// the same for an encoder output of a shortened context (whisper_full_params.audio_ctx): enc = [audio_ctx][n_audio_state]
+int orc_state_set_encoder_ctx(void* sp, const float* enc, int audio_ctx) {
+    State* s = (State*)sp; const HParams& hp = s->m->hp;
+    if (audio_ctx <= 0 || audio_ctx > hp.n_audio_ctx) return -5;
+    s->exp_n_audio_ctx = audio_ctx;
+    s->enc.assign(enc, enc + (size_t)audio_ctx * hp.n_audio_state); cross_kv(*s); return 0;
 }
 // cross KV of layer il: k,v [n_ctx][d]
 int orc_state_cross_kv(void* sp, int il, float* k, float* v) {

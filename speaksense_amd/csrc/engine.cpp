@@ -133,6 +133,7 @@ struct Dec {
 struct Window {
     Job* job = nullptr;
     int cross = 0;   // cross-KV index in this batch
+    int n_keys = 0;  // whisper_full_params.audio_ctx when it shortens the window (RowCtl.n_keys); 0 = the model's n_audio_ctx
     int it = 0;      // temperature ladder position
     bool pending = true;
     std::vector<float> temperatures;
@@ -387,6 +388,7 @@ struct EngineT : EngineBase {
         n_mel = hp.n_mels; n_ctx = hp.n_audio_ctx; n_tctx = hp.n_text_ctx; n_vocab = hp.n_vocab; n_vocab_pad = round_up(n_vocab, 64);
         K1 = round_up(3 * n_mel, 64);
         Tpad = round_up(n_ctx, 64);   // V^T rows padded (zero) to whole 64-key chunks for the LDS-staged attention kernel
+        nc = n_ctx; Tp = Tpad;
         qscale = powf(64.0f, -0.25f);
         dtype_is_f16 = sizeof(T) == 2 && std::is_same<T, f16>::value;
         fp8_enc = o.dtype == SS_DTYPE_FP8;
@@ -654,14 +656,25 @@ struct EngineT : EngineBase {
         GemmDesc g{};
         g.A = A; g.lda = lda; g.a_rows_per_batch = 0; g.a_batch_stride = 0;
         g.W = Wt; g.M = M; g.N = N; g.K = K; g.kind = kind; g.bias = bias; g.out = out; g.ldo = ldo;
-        g.o_rows_per_batch = 0; g.o_batch_stride = 0; g.scale = 1.0f; g.rows_per_batch = n_ctx; g.d = da; g.Tpad = Tpad;
+        g.o_rows_per_batch = 0; g.o_batch_stride = 0; g.scale = 1.0f; g.rows_per_batch = nc; g.d = da; g.Tpad = Tp; g.cache_rows = n_ctx;
         g.n_batch = B; g.gelu_f16_in = dtype_is_f16;
         return g;
+    }
+    // whisper_full_params.audio_ctx (whisper.cpp exp_n_audio_ctx): the encoder runs over the first `nc` positions of the window -- 2 nc mel frames, nc
+    // rows of the positional embedding, nc keys per cross-attention head (RowCtl.n_keys) -- in buffers laid out for nc; the cross-KV CACHE keeps the
+    // model's geometry (n_ctx key rows per slot and head), a shortened window fills the first nc of them.  A change of context moves the zero padding
+    // rows of the conv stem and the zero key columns of V^T, so both buffers are cleared.
+    int nc = 0, Tp = 0;      // context of the encoder pass being issued (set_context); n_ctx / Tpad unless a job shortens it
+    void set_context(int a) {
+        if (a == nc) return;
+        nc = a; Tp = round_up(a, 64);
+        SS_HIP(hipMemsetAsync(h1.p, 0, h1.bytes, st));
+        SS_HIP(hipMemsetAsync(vT.p, 0, vT.bytes, st));
     }
 
     // encoder over Wn windows whose time-major inputs are already in x0; leaves ln_post output in encT (and encF if want_f32)
     void encoder_pass(int Wn, bool want_f32) {
-        const int T2 = 2 * n_ctx, M = Wn * n_ctx;
+        const int T2 = 2 * nc, M = Wn * nc;
         {   // conv1 + GELU: implicit GEMM over overlapping rows of the padded time-major input
             GemmDesc g = gd(x0.p, n_mel, conv1w, Wn * T2, da, K1, EPI_GELU_T, conv1b, h1.as<T>() + da, da);
             g.a_rows_per_batch = T2; g.a_batch_stride = (long)(T2 + 2) * n_mel;
@@ -670,7 +683,7 @@ struct EngineT : EngineBase {
         }
         {   // conv2 (stride 2) + GELU + positional embedding -> f32 residual stream
             GemmDesc g = gd(h1.p, 2 * da, conv2w, M, da, 3 * da, EPI_GELU_POS_F32, conv2b, x.p, da);
-            g.a_rows_per_batch = n_ctx; g.a_batch_stride = (long)(T2 + 2) * da;
+            g.a_rows_per_batch = nc; g.a_batch_stride = (long)(T2 + 2) * da;
             g.pos = enc_pos;
             launch_gemm<T>(g, st);
         }
@@ -683,7 +696,7 @@ struct EngineT : EngineBase {
                 GemmDesc g = gd(ln.p, da, e.wqkv + (size_t)2 * da * da, M, da, da, EPI_VT, e.bqkv + 2 * da, vT.p, 0);
                 launch_gemm<T>(g, st);
             }
-            launch_enc_attention<T>(qk.as<T>(), qk.as<T>() + da, 2 * da, vT.as<T>(), Tpad, att.as<T>(), da, Wn, Ha, n_ctx, st);
+            launch_enc_attention<T>(qk.as<T>(), qk.as<T>() + da, 2 * da, vT.as<T>(), Tp, att.as<T>(), da, Wn, Ha, nc, st);
             {
                 GemmDesc g = gd(att.p, da, e.wo, M, da, da, EPI_RES_F32, e.bo, x.p, da);
                 g.res = x.as<float>();
@@ -707,12 +720,12 @@ struct EngineT : EngineBase {
         GemmF8Desc g{};
         g.A = (const unsigned char*)A8; g.lda = lda; g.a_scale = (const unsigned char*)Asc; g.ldsc = Mpad; g.W = W8; g.w_scale = Ws;
         g.M = M; g.N = N; g.K = K; g.kind = kind; g.bias = bias; g.out = out; g.ldo = ldo; g.scale = 1.0f;
-        g.rows_per_batch = n_ctx; g.d = da; g.Tpad = Tpad; g.n_batch = B; g.gelu_f16_in = dtype_is_f16;
+        g.rows_per_batch = nc; g.d = da; g.Tpad = Tp; g.n_batch = B; g.gelu_f16_in = dtype_is_f16; g.cache_rows = n_ctx;
         return g;
     }
     uint8_t *tap8_codes = nullptr, *tap8_sc = nullptr;   // host buffers of the running fp8_first_quant_host call
     void encoder_layers_f8(int Wn, bool want_f32) {
-        const int M = Wn * n_ctx;
+        const int M = Wn * nc;
         for (int il = 0; il < La; il++) {
             const EncL& e = enc[il];
             launch_layernorm_f8(x.as<float>(), e.ln1w, e.ln1b, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, M, da, st);
@@ -722,7 +735,7 @@ struct EngineT : EngineBase {
             }
             launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8, e.sqkv, M, 2 * da, da, F8_STORE_T, e.bqkv, qk.p, 2 * da), st);
             launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8 + (size_t)2 * da * da, e.sqkv + 2 * da, M, da, da, F8_VT, e.bqkv + 2 * da, vT.p, 0), st);
-            launch_enc_attention_f8<T>(qk.as<T>(), qk.as<T>() + da, 2 * da, vT.as<T>(), Tpad, att8.as<unsigned char>(), da, att_sc.as<unsigned char>(), Mpad, Wn, Ha, n_ctx, st);
+            launch_enc_attention_f8<T>(qk.as<T>(), qk.as<T>() + da, 2 * da, vT.as<T>(), Tp, att8.as<unsigned char>(), da, att_sc.as<unsigned char>(), Mpad, Wn, Ha, nc, st);
             {
                 GemmF8Desc g = gd8(att8.p, att_sc.p, da, e.wo8, e.so, M, da, da, F8_RES_F32, e.bo, x.p, da);
                 g.res = x.as<float>();
@@ -747,8 +760,8 @@ struct EngineT : EngineBase {
     // cmap (optional): window k of this pass writes the cross-KV cache slot cmap[k] (windows of a running group keep their slots)
     void cross_kv_pass(int Wn, const int* cmap = nullptr) {
         if (fp8_enc) {
-            GemmF8Desc g = gd8(ln8.p, ln_sc.p, da, crosskv_w8, crosskv_s, Wn * n_ctx, L * 2 * d, da, F8_CROSS_KV8, crosskv_b, cross.p, 0);
-            g.scale = qscale; g.d = d; g.rows_per_batch = n_ctx; g.n_batch = B; g.out_scale = cross_sc.as<unsigned char>();
+            GemmF8Desc g = gd8(ln8.p, ln_sc.p, da, crosskv_w8, crosskv_s, Wn * nc, L * 2 * d, da, F8_CROSS_KV8, crosskv_b, cross.p, 0);
+            g.scale = qscale; g.d = d; g.rows_per_batch = nc; g.n_batch = B; g.out_scale = cross_sc.as<unsigned char>();
             if (cmap) {
                 if (Wn > (int)sizeof(g.batch_map)) throw Error(-1, "internal: cross-KV slot map too small");
                 g.use_batch_map = 1;
@@ -757,8 +770,8 @@ struct EngineT : EngineBase {
             launch_gemm_f8<T>(g, st);
             return;
         }
-        GemmDesc g = gd(encT.p, da, crosskv_w, Wn * n_ctx, L * 2 * d, da, EPI_CROSS_KV, crosskv_b, cross.p, 0);
-        g.scale = qscale; g.d = d; g.rows_per_batch = n_ctx; g.n_batch = B;
+        GemmDesc g = gd(encT.p, da, crosskv_w, Wn * nc, L * 2 * d, da, EPI_CROSS_KV, crosskv_b, cross.p, 0);
+        g.scale = qscale; g.d = d; g.rows_per_batch = nc; g.n_batch = B;
         if (cmap) {
             if (Wn > (int)sizeof(g.batch_map)) throw Error(-1, "internal: cross-KV slot map too small");
             g.use_batch_map = 1;
@@ -1071,8 +1084,13 @@ struct EngineT : EngineBase {
                 if (P.best_of <= ND && P.offset_ms >= 0 && P.duration_ms >= 0 && j->n_samples > 0 && s1 >= s0 + 100 && !P.detect_language) touch_context();
                 return q;
             }
-            if (P.audio_ctx != 0 && P.audio_ctx != n_ctx) {   // the reference only ever passes 1500 or 0 (whisper.rs:144,68); a shortened encoder context is not built
-                j->status = SS_ERR_UNSUPPORTED; j->err = "audio_ctx must be 0 or the model's n_audio_ctx"; return q;
+            if (P.audio_ctx != 0 && P.audio_ctx != n_ctx) {   // the reference passes 1500 or 0 (whisper.rs:144,68); a whisper-rs caller may shorten the context
+                // the V^T epilogue stores 4 consecutive positions per lane and the cross-attention walks 4 equal key ranges: multiples of 4 only
+                if (P.audio_ctx < 0 || P.audio_ctx % 4) { j->status = SS_ERR_UNSUPPORTED; j->err = "audio_ctx must be a positive multiple of 4 (or 0 = the model's n_audio_ctx)"; return q; }
+                // whisper.cpp detects the language BEFORE it installs params.audio_ctx in the state (the pass runs on whatever the previous call left there)
+                if (P.language[0] == 0 || !strcmp(P.language, "auto") || P.detect_language) {
+                    j->status = SS_ERR_UNSUPPORTED; j->err = "language detection together with a shortened audio_ctx"; return q;
+                }
             }
             if (P.best_of > ND) { j->status = SS_ERR_ARG; j->err = "best_of exceeds the engine's max_decoders"; return q; }
             if (P.offset_ms < 0 || P.duration_ms < 0) { j->status = SS_ERR_ARG; j->err = "negative offset_ms / duration_ms"; return q; }
@@ -1225,20 +1243,25 @@ struct EngineT : EngineBase {
                 const bool others_running = !active.empty();
                 std::vector<Window*> fresh;
                 std::vector<int> cmap;
+                auto ctx_of = [&](const JobState& q) { const int a = q.job->P.audio_ctx; return a > 0 && a < n_ctx ? a : n_ctx; };
+                const int pass_ctx = ctx_of(*need.front());      // one context per encoder pass; chunks that ask for another wait for the next pass
+                set_context(pass_ctx);
                 for (JobState* qp : need) {
                     if (free_cross.empty()) break;
                     JobState& q = *qp;
+                    if (ctx_of(q) != pass_ctx) continue;
                     active.emplace_back();
                     Window& w = active.back();
                     w.job = q.job; w.cross = free_cross.back(); free_cross.pop_back();
+                    w.n_keys = pass_ctx == n_ctx ? 0 : pass_ctx;
                     const ss_params& P = q.job->P;
                     if (P.fixed_steps > 0) w.temperatures = {0.0f};
                     else if (P.temperature_inc > 0.0f) for (float t = P.temperature; t < 1.0f + 1e-6f; t += P.temperature_inc) w.temperatures.push_back(t);
                     else w.temperatures = {P.temperature};
                     // "if there is a very short audio segment left to process, we remove any past prompt"
                     if (q.seek > q.seek_start && q.seek + 500 >= q.seek_end) q.job->sess->prompt_past.clear();
-                    launch_mel_window<T>(mel_d[q.slot].template as<float>(), n_mel, q.n_len, q.seek, 2 * n_ctx,
-                                         x0.as<T>() + (size_t)fresh.size() * (2 * n_ctx + 2) * n_mel, st);
+                    launch_mel_window<T>(mel_d[q.slot].template as<float>(), n_mel, q.n_len, q.seek, 2 * nc,
+                                         x0.as<T>() + (size_t)fresh.size() * (2 * nc + 2) * n_mel, st);
                     q.has_window = true;
                     cmap.push_back(w.cross);
                     fresh.push_back(&w);
@@ -1439,7 +1462,7 @@ struct EngineT : EngineBase {
                 RowCtl c{};
                 const int p = q.n_fed + k;
                 c.token = p < n_prompt ? w->prompt[p] : q.tokens.back().id;
-                c.pos = p; c.slot = q.slot; c.cross = w->cross;
+                c.pos = p; c.slot = q.slot; c.cross = w->cross; c.n_keys = w->n_keys;
                 const bool last = k == n_feed - 1;
                 if (last) {
                     c.n_hist = (int)q.tokens.size();
@@ -1700,6 +1723,7 @@ struct EngineT : EngineBase {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
+        set_context(n_ctx);   // stage hooks always run the full context
         mel_d[0].ensure((size_t)n_mel * n_len * 4);
         SS_HIP(hipMemcpyAsync(mel_d[0].p, mel, (size_t)n_mel * n_len * 4, hipMemcpyHostToDevice, st));
         launch_mel_window<T>(mel_d[0].as<float>(), n_mel, n_len, seek, 2 * n_ctx, x0.as<T>(), st);
@@ -1712,6 +1736,7 @@ struct EngineT : EngineBase {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
+        set_context(n_ctx);   // stage hooks always run the full context
         mel_d[0].ensure((size_t)n_mel * n_len * 4);
         SS_HIP(hipMemcpyAsync(mel_d[0].p, mel, (size_t)n_mel * n_len * 4, hipMemcpyHostToDevice, st));
         launch_mel_window<T>(mel_d[0].as<float>(), n_mel, n_len, seek, 2 * n_ctx, x0.as<T>(), st);
@@ -1729,6 +1754,7 @@ struct EngineT : EngineBase {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
+        set_context(n_ctx);   // stage hooks always run the full context
         SS_HIP(hipMemcpyAsync(encF.p, encv, (size_t)n_ctx * da * 4, hipMemcpyHostToDevice, st));
         launch_f32_to_T<T>(encF.as<float>(), encT.as<T>(), (size_t)n_ctx * da, st);
         if (fp8_enc) launch_quantize_f8<T>(encT.as<T>(), da, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, n_ctx, da, st);
@@ -1760,6 +1786,7 @@ struct EngineT : EngineBase {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
+        set_context(n_ctx);   // stage hooks always run the full context
         if (window < 0 || window >= B) throw Error(SS_ERR_ARG, "set_encoder_window: window outside the engine's batch");
         SS_HIP(hipMemcpyAsync(encF.p, encv, (size_t)n_ctx * da * 4, hipMemcpyHostToDevice, st));
         launch_f32_to_T<T>(encF.as<float>(), encT.as<T>(), (size_t)n_ctx * da, st);
@@ -2036,6 +2063,7 @@ struct EngineT : EngineBase {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
+        set_context(n_ctx);
         if (batch < 1 || batch > B) throw Error(SS_ERR_ARG, "probe_gemm: batch out of range");
         const int M = batch * n_ctx;
         if (fp8_enc) {   // the same projection on the e4m3 kernel (GELU output quantised in the epilogue)

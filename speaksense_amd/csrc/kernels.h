@@ -50,6 +50,7 @@ struct GemmDesc {
     int gelu_f16_in;          // f16 engines: gelu(f16(x)) like ggml's table (no-op for bf16)
     int use_batch_map;        // EPI_CROSS_KV: window b of this launch writes cache slot batch_map[b] instead of b
     unsigned char batch_map[128];
+    int cache_rows;           // EPI_CROSS_KV: key rows per (slot, head) of the CACHE (n_audio_ctx); 0 = rows_per_batch.  Differs when whisper_full_params.audio_ctx shortens the pass
     long long* trace;         // dev tool (tools/gemm_bench.cpp): per workgroup and tile {start, loop start, loop end, stores issued} s_memtime stamps; null in the product
 };
 template <typename T> void launch_gemm(const GemmDesc& g, hipStream_t st);
@@ -89,6 +90,7 @@ struct GemmF8Desc {
     float scale;
     int rows_per_batch, d, Tpad, n_batch, gelu_f16_in;
     int use_batch_map; unsigned char batch_map[128];
+    int cache_rows;           // as in GemmDesc
 };
 template <typename T> void launch_gemm_f8(const GemmF8Desc& g, hipStream_t st);
 // LayerNorm with quantised output (one wave per row), and plain quantisation of a T matrix (attention output): e4m3 + exponent bytes
@@ -123,7 +125,7 @@ struct RowCtl {       // one per decode row; lives in pinned host memory mapped 
     int32_t has_ts, ts_min;       // decoder.has_ts, seek_delta/2   (RuleConsts.openai_ts: any id >= beg sampled so far, index of the last such id)
     float temperature;
     int32_t want_probs;           // t > 0: also write the full probability row
-    int32_t pad;
+    int32_t n_keys;               // cross-attention keys of this row's window (whisper_full_params.audio_ctx); 0 = the kernel's Tn (n_audio_ctx)
 };
 
 // Fused decode-step GEMV for M <= 16 rows (kernels_decode.hip): prologue + 16-row weight tiles x split-K + epilogue

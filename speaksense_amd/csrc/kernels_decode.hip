@@ -423,8 +423,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 3, c = lane & 7;
     const int h = blockIdx.y, m = blockIdx.z;
-    const int per = (Tn + kCrossSplitD - 1) / kCrossSplitD;
     const RowCtl rc = ctl[m];
+    const int nkeys = rc.n_keys > 0 ? rc.n_keys : Tn;      // whisper_full_params.audio_ctx: the window's keys are the first nkeys rows of its cache slot
+    const int per = (nkeys + kCrossSplitD - 1) / kCrossSplitD;
     const T* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
     const T* V = vc + (long)rc.cross * b_stride + (long)h * Tn * 64;
     float qv[8];
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
     float mx[NR];
 #pragma unroll
     for (int g = 0; g < NR; g++) {
-        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg, nit = (nk + 31) / 32;
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = max(0, min(nkeys, k_beg + per) - k_beg), nit = (nk + 31) / 32;
         float* sc = s_sc + g * kCrossRangeMax;
         mx[g] = -1e30f;
         for (int it = 0; it < nit; it += 4) {
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
     float sum[NR];
 #pragma unroll
     for (int g = 0; g < NR; g++) {
-        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg;
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = max(0, min(nkeys, k_beg + per) - k_beg);
         float* sc = s_sc + g * kCrossRangeMax;
         mx[g] = fmaxf(fmaxf(s_red[0][g][0], s_red[0][g][1]), fmaxf(s_red[0][g][2], s_red[0][g][3]));
         float sm = 0.f;
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
     // phase 2: o[c*8+e] += p[key] V[key][c*8+e]
 #pragma unroll
     for (int g = 0; g < NR; g++) {
-        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg, nit = (nk + 31) / 32;
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = max(0, min(nkeys, k_beg + per) - k_beg), nit = (nk + 31) / 32;
         const float* sc = s_sc + g * kCrossRangeMax;
         sum[g] = ((s_red[1][g][0] + s_red[1][g][1]) + s_red[1][g][2]) + s_red[1][g][3];
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -600,8 +601,9 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q8_kernel(const float* __r
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane >> 2, c = lane & 3;            // 16 key rows x 4 chunks of 16 codes per wave-instruction
     const int h = blockIdx.y, m = blockIdx.z;
-    const int per = (Tn + kCrossSplitD - 1) / kCrossSplitD;
     const RowCtl rc = ctl[m];
+    const int nkeys = rc.n_keys > 0 ? rc.n_keys : Tn;
+    const int per = (nkeys + kCrossSplitD - 1) / kCrossSplitD;
     // window layout: codes [kv][h][t][64], exponent bytes [kv][h][t]
     const unsigned char* K = kc + (long)rc.cross * b_stride + (long)h * Tn * 64;
     const unsigned char* V = K + (long)H * Tn * 64;
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q8_kernel(const float* __r
     float mx[NR];
 #pragma unroll
     for (int g = 0; g < NR; g++) {
-        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg, nit = (nk + 63) / 64;
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = max(0, min(nkeys, k_beg + per) - k_beg), nit = (nk + 63) / 64;
         float* sc = s_sc + g * kCrossRangeMax;
         mx[g] = -1e30f;
         for (int it = 0; it < nit; it += 4) {
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q8_kernel(const float* __r
     float sum[NR];
 #pragma unroll
     for (int g = 0; g < NR; g++) {
-        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg;
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = max(0, min(nkeys, k_beg + per) - k_beg);
         float* sc = s_sc + g * kCrossRangeMax;
         mx[g] = fmaxf(fmaxf(s_red[0][g][0], s_red[0][g][1]), fmaxf(s_red[0][g][2], s_red[0][g][3]));
         float sm = 0.f;
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q8_kernel(const float* __r
     // phase 2: o[c*16 + e] += p[key] * 2^(ev - 127) * code
 #pragma unroll
     for (int g = 0; g < NR; g++) {
-        const int k_beg = (blockIdx.x * NR + g) * per, nk = min(Tn, k_beg + per) - k_beg, nit = (nk + 63) / 64;
+        const int k_beg = (blockIdx.x * NR + g) * per, nk = max(0, min(nkeys, k_beg + per) - k_beg), nit = (nk + 63) / 64;
         const float* sc = s_sc + g * kCrossRangeMax;
         sum[g] = ((s_red[1][g][0] + s_red[1][g][1]) + s_red[1][g][2]) + s_red[1][g][3];
         float acc[16];

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
                     V4 o;
 #pragma unroll
                     for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
-                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j;
+                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.cache_rows + t) * 64 + j;
                     *(V4*)((T*)g.out + off) = o;
                 }
             }
@@ -266,7 +266,7 @@ __device__ __forceinline__ void epilogue256(const GemmDesc& g, f32x4 (&acc)[4][8
                     int b = (int)(m / g.rows_per_batch);
                     const int t = (int)(m % g.rows_per_batch);
                     if (g.use_batch_map) b = g.batch_map[b];
-                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j;
+                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.cache_rows + t) * 64 + j;
                     *(u32x4*)((T*)g.out + off) = o16;
                 } else {
                     *(u32x4*)((T*)g.out + orow + n) = o16;
@@ -312,7 +312,7 @@ __device__ __forceinline__ void epilogue256(const GemmDesc& g, f32x4 (&acc)[4][8
                     V4 o;
 #pragma unroll
                     for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
-                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j;
+                    const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.cache_rows + t) * 64 + j;
                     *(V4*)((T*)g.out + off) = o;
                 }
             }
@@ -804,7 +804,9 @@ static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
 }
 
 template <typename T>
-void launch_gemm(const GemmDesc& g, hipStream_t st) {
+void launch_gemm(const GemmDesc& g_in, hipStream_t st) {
+    GemmDesc g = g_in;
+    if (g.cache_rows <= 0) g.cache_rows = g.rows_per_batch;
     if (g.N % BN || g.K % BK || g.M <= 0) throw Error(-1, "gemm: N must be a multiple of 128 and K of 64");
     switch (g.kind) {
         case EPI_STORE_T: launch_gemm_kind<T, EPI_STORE_T>(g, st); break;

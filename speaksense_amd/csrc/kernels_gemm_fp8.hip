@@ -169,7 +169,7 @@ __device__ __forceinline__ void f8_epilogue(const GemmF8Desc& g, f32x16 (&acc)[2
                 int b = (int)(m / g.rows_per_batch);
                 const int t = (int)(m % g.rows_per_batch);
                 if (g.use_batch_map) b = g.batch_map[b];
-                const long row = (((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t;
+                const long row = (((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.cache_rows + t;
 #pragma unroll
                 for (int ni = 0; ni < 2; ni++)
 #pragma unroll
@@ -209,7 +209,7 @@ __device__ __forceinline__ void f8_epilogue(const GemmF8Desc& g, f32x16 (&acc)[2
                         V4 o;
 #pragma unroll
                         for (int r = 0; r < 4; r++) o[r] = (T)(v[r] * sc);
-                        *(V4*)((T*)g.out + ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.rows_per_batch + t) * 64 + j) = o;
+                        *(V4*)((T*)g.out + ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.cache_rows + t) * 64 + j) = o;
                     }
                 }
         }
@@ -655,7 +655,9 @@ static void launch_f8_kind(const GemmF8Desc& g, hipStream_t st) {
 }
 
 template <typename T>
-void launch_gemm_f8(const GemmF8Desc& g, hipStream_t st) {
+void launch_gemm_f8(const GemmF8Desc& g_in, hipStream_t st) {
+    GemmF8Desc g = g_in;
+    if (g.cache_rows <= 0) g.cache_rows = g.rows_per_batch;
     if (g.M <= 0 || g.N % QTN || g.K % (QNST * QTK) || g.lda % 16 || g.ldsc % 256 || g.ldsc < ((g.M + 255) & ~255))
         throw Error(-1, "fp8 gemm: N and K must be multiples of 256, lda of 16, and the exponent-byte pitch a multiple of 256 >= M");
     if ((long)g.M * g.lda >= (1L << 32) || (long)g.N * g.K >= (1L << 32)) throw Error(-1, "fp8 gemm: operand larger than 4 GiB");

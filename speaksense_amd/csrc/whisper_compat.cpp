@@ -390,7 +390,6 @@ static int map_params(struct whisper_context* ctx, const struct whisper_full_par
     // whisper_wrap_segment; like whisper.cpp only together with token_timestamps), token_timestamps (whisper.rs:160:
     // whisper_full_get_token_data(..).t0 / t1 / vlen).  The four plain callbacks are honoured at CHUNK granularity (whisper_full_with_state
     // below): the windows of a chunk complete inside a device batch shared with other states, so nothing can fire from inside it.
-    if (params.audio_ctx != 0 && params.audio_ctx != whisper_n_audio_ctx(ctx)) return SS_ERR_UNSUPPORTED;
     ss_default_params(&p);
     p.best_of = params.greedy.best_of > 0 ? params.greedy.best_of : 1;
     p.temperature = params.temperature; p.temperature_inc = params.temperature_inc; p.entropy_thold = params.entropy_thold;

@@ -378,6 +378,86 @@ def generate_fixture():
     print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
+# (preset, model seed, audio seed, audio_ctx): shortened encoder contexts, multiples of 4 (the engine's restriction), none a multiple of 64
+AUDIO_CTX_CASES = [("tiny.en", 61, 21, 752), ("toy256", 62, 22, 500), ("wide2", 63, 23, 1000)]
+
+
+def audio_ctx_fixture():
+    """hf_audio_ctx_golden.npz: `whisper_full_params.audio_ctx` < n_audio_ctx (whisper.cpp's exp_n_audio_ctx: the encoder covers the first audio_ctx
+    positions only, the decoder attends over that many keys).  The independent statement of that semantics: an HF model whose `max_source_positions`
+    IS audio_ctx -- the first audio_ctx rows of the positional embedding, 2 audio_ctx mel frames as `input_features` (the convolution's zero padding
+    then sits right behind frame 2 audio_ctx - 1, as in whisper.cpp's truncated conv input).  Stored per case: encoder rows (the last rows included:
+    they are the ones a wrong cut would change), top-16 logits of a teacher-forced sequence, and HF `generate`'s first-window ids / segment times."""
+    from dataclasses import replace
+    from transformers import GenerationConfig
+    from oracle import binding as orc
+    out = {}
+    tmp = tempfile.mkdtemp()
+    for ci, (name, seed, aseed, actx) in enumerate(AUDIO_CTX_CASES):
+        path = os.path.join(tmp, f"{name}-{seed}.bin")
+        ggml_io.write_model(path, name, seed=seed, **ggml_io.NATURAL)
+        hp, filt, vocab, tensors = ggml_io.read_model(path)
+        hp_s = ggml_io.HParams(*(hp.astuple()[:1] + (actx,) + hp.astuple()[2:]))
+        assert hp_s.n_audio_ctx == actx and hp_s.n_audio_state == hp.n_audio_state
+        t_s = dict(tensors)
+        t_s["encoder.positional_embedding"] = tensors["encoder.positional_embedding"][:actx].copy()
+        model = hf_model_tanh(hp_s, t_s)
+        om = orc.OracleModel(path)
+        pcm = synth.speech_like(aseed)
+        mel = om.log_mel(pcm)[:, :2 * actx].astype(np.float32)
+        multilingual = hp.n_vocab >= 51865
+        eot, sot, beg = om.eot, om.sot, om.beg
+        n_lang = hp.n_vocab - 51765 - (1 if multilingual else 0)
+        prompt = [sot, sot + 1, om.transcribe] if multilingual else [sot]
+        toks = prompt + [beg + 1, 4321, 707, 30999, 24, beg + 33, beg + 33, 11, 2600]
+        rows = sorted({0, 1, 17, actx // 2, actx - 3, actx - 2, actx - 1})
+        with torch.no_grad():
+            enc = model.model.encoder(torch.from_numpy(mel)[None]).last_hidden_state[0].numpy()
+            logits = model(encoder_outputs=(torch.from_numpy(enc)[None],), decoder_input_ids=torch.tensor([toks])).logits[0].numpy()
+        topk = np.argsort(-logits, axis=1)[:, :16].astype(np.int32)
+        suppress = [sot, om.nosp, om.solm, om.translate, om.transcribe, om.prev] + [sot + 1 + i for i in range(n_lang)]
+        gc = GenerationConfig(eos_token_id=eot, pad_token_id=eot, bos_token_id=eot, decoder_start_token_id=sot, no_timestamps_token_id=om.not_,
+                              max_initial_timestamp_index=50, suppress_tokens=suppress, begin_suppress_tokens=[220, eot], max_length=448,
+                              is_multilingual=multilingual, return_timestamps=True, do_sample=False, num_beams=1)
+        if multilingual:
+            gc.lang_to_id = {"<|en|>": sot + 1}
+            gc.task_to_id = {"transcribe": om.transcribe, "translate": om.translate}
+        model.generation_config = gc
+        with torch.no_grad():
+            res = model.generate(input_features=torch.from_numpy(mel)[None], decoder_input_ids=torch.tensor([prompt]), return_timestamps=True,
+                                 do_sample=False, num_beams=1, max_new_tokens=224, return_segments=True)
+        segs = res["segments"][0]
+        first = segs[0]["result"]
+        raw = first["sequences"] if isinstance(first, dict) else first
+        raw = [int(t) for t in (raw[0] if raw.dim() == 2 else raw)]
+        if raw[:len(prompt)] == prompt:
+            raw = raw[len(prompt):]
+        w0 = [sg for sg in segs if sg["result"] is segs[0]["result"]]
+        n0 = window0_len(raw, beg, eot)
+        k = f"c{ci}"
+        out[f"{k}_preset"], out[f"{k}_seed"], out[f"{k}_audio"], out[f"{k}_audio_ctx"] = name, seed, aseed, actx
+        out[f"{k}_rows"], out[f"{k}_enc"] = np.array(rows, np.int32), enc[rows].astype(np.float32)
+        out[f"{k}_enc_absmax"] = np.float32(np.abs(enc).max())
+        out[f"{k}_tokens"], out[f"{k}_n_prompt"] = np.array(toks, np.int32), len(prompt)
+        out[f"{k}_topk"], out[f"{k}_topv"] = topk, np.take_along_axis(logits, topk, axis=1).astype(np.float32)
+        out[f"{k}_logit_std"] = np.float32(logits.std())
+        out[f"{k}_ids"], out[f"{k}_n_window0"] = np.array(raw, np.int32), n0
+        out[f"{k}_seg_t0"] = np.array([round(100 * float(sg["start"])) for sg in w0], np.int64)
+        out[f"{k}_seg_t1"] = np.array([round(100 * float(sg["end"])) for sg in w0], np.int64)
+        # what the CPU test will check
+        e_or = om.encode(om.log_mel(pcm), 0, orc.MODE_F32, audio_ctx=actx)
+        ref = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES).full(pcm, orc.default_params(language="en", temperature_inc=0.0, audio_ctx=actx, duration_ms=30000))
+        tr = [int(t) for t in ref["trace"]]
+        print(name, seed, aseed, "audio_ctx", actx, "encoder max|oracle - HF| / absmax", float(np.abs(e_or - enc).max() / np.abs(enc).max()), "HF window 0:", len(raw), "ids,",
+              n0, "sampled by whisper.cpp's loop; oracle equal prefix", tr[:n0] == raw[:n0], "segments", [(s_["t0"], s_["t1"]) for s_ in ref["segments"]][:len(w0)],
+              list(zip(out[f"{k}_seg_t0"].tolist(), out[f"{k}_seg_t1"].tolist())))
+        om.close()
+    out["n_cases"] = len(AUDIO_CTX_CASES)
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_audio_ctx_golden.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
 def large_v3_fixture():
     """hf_large_v3_golden.npz: the FULL-DEPTH shape (32 + 32 layers, d = 1280, 20 heads, 128 mels, 51 866 tokens) -- the seeded synthetic large-v3 model
     bench.py and tests/test_gpu_large_v3.py use (`write_model("large-v3", seed=0)`), loaded into HF with the tanh GELU: encoder rows, per-step top-16
@@ -567,9 +647,11 @@ def generate_long_fixture():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["toy", "shapes", "rules", "tanh", "generate", "generate_long"]
+    which = sys.argv[1:] or ["toy", "shapes", "rules", "tanh", "generate", "generate_long", "audio_ctx"]
     if "generate_long" in which:
         generate_long_fixture()
+    if "audio_ctx" in which:
+        audio_ctx_fixture()
     if "large_v3" in which:      # not part of the default list: ~3 minutes
         large_v3_fixture()
     if "generate_large_v3" in which:      # not part of the default list: ~15 minutes (two oracle windows at full depth in exact f32)

@@ -1,0 +1,159 @@
+"""GPU: `audio_ctx` below the model's n_audio_ctx on the HIP engine (round 5; refused with -9 before).  The encoder pass covers the first audio_ctx
+positions in buffers laid out for that context, the cross-KV cache keeps the model's geometry and a shortened window fills the first audio_ctx key rows
+of its slot, every decoder row carries its window's key count (RowCtl.n_keys).  Held to HF `generate` on models whose max_source_positions is the
+shortened context (tests/golden/hf_audio_ctx_golden.npz), to the oracle under the reference's real parameters, and to itself: chunks of different
+contexts sharing one engine and one decoder pass give their single-chunk results."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from speaksense_amd import synth
+from conftest import report
+from test_oracle_audio_ctx import audio_ctx_case_model, audio_ctx_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("which", ["f16", "bf16"])
+@pytest.mark.parametrize("ci", range(3))
+def test_engine_shortened_context_matches_hf_generate(ci, which, model_dir):
+    from speaksense_amd import binding
+    from oracle import binding as orc
+    from test_gpu_parity import GAP_TOL_BF16, GAP_TOL_F16, check_against_oracle
+    c = audio_ctx_cases()[ci]
+    path = audio_ctx_case_model(c, model_dir)
+    dtype, omode, gap_tol = (binding.DTYPE_F16, orc.MODE_GGML_F16, GAP_TOL_F16) if which == "f16" else (binding.DTYPE_BF16, orc.MODE_BF16, GAP_TOL_BF16)
+    eng = binding.Engine(path, dtype=dtype, max_batch=2, compat=binding.COMPAT_OPENAI_TS_RULES)
+    pcm = synth.speech_like(c["audio"])
+    kw = dict(language="en", temperature_inc=0.0, audio_ctx=c["audio_ctx"], duration_ms=30000)
+    got = eng.new_session().transcribe(pcm, binding.default_params(**kw))
+    tr = [int(t) for t in got["trace"]]
+    n0 = c["n0"]
+    same = tr[:n0] == c["ids"][:n0]
+    worst = 0.0
+    if same:
+        assert [(s["t0"], s["t1"]) for s in got["segments"]][:len(c["seg"])] == c["seg"]
+    else:
+        om = orc.OracleModel(path)
+        _, worst = check_against_oracle(got, om, orc, omode, pcm, orc.default_params(**kw), f"audio_ctx {c['audio_ctx']} case {ci} ({which})", gap_tol, replay_only=True,
+                                        compat=orc.COMPAT_OPENAI_TS_RULES)
+        om.close()
+    if which == "f16":
+        assert same or ci != 0
+    report(f"HIP engine ({which}) vs HF generate with max_source_positions = audio_ctx = {c['audio_ctx']} ({c['preset']}, {n0} ids): "
+           + ("ids and segment times identical" if same else f"near-tie flip(s) proven by forced replay, largest margin {worst:.4f}"))
+    eng.close()
+
+
+def test_engine_audio_ctx_matches_oracle_with_the_ladder(model_dir):
+    """The reference's real parameters (best_of 5, temperature ladder) with shortened contexts, 70 s of audio (several windows: the seek still advances by
+    the timestamps, whatever the encoder saw): every sampled id of every attempt replayed on the oracle."""
+    from speaksense_amd import binding
+    from oracle import binding as orc
+    from test_gpu_parity import GAP_TOL_F16, check_trace_against_oracle
+    c = audio_ctx_cases()[0]
+    path = audio_ctx_case_model(c, model_dir)
+    eng = binding.Engine(path, dtype=binding.DTYPE_F16, max_batch=2)
+    om = orc.OracleModel(path)
+    pcm = np.concatenate([synth.speech_like(31), synth.speech_like(32), synth.speech_like(33)])[:16000 * 70]
+    worst = 0.0
+    for A in (752, 256):
+        got = eng.new_session().transcribe(pcm, binding.default_params(language="en", audio_ctx=A))
+        assert got["n_windows"] >= 2
+        fg, fs, wg, ws = check_trace_against_oracle(got, om, orc, orc.MODE_GGML_F16, pcm, orc.default_params(language="en", audio_ctx=A), f"audio_ctx {A}", GAP_TOL_F16)
+        worst = max(worst, wg)
+    report(f"audio_ctx 752 / 256 with the ladder (f16, {c['preset']}): every sampled id replayed on the oracle, largest greedy margin {worst:.4f}")
+    om.close(); eng.close()
+
+
+def test_fp8_engine_audio_ctx_forced_replay(model_dir):
+    """The e4m3 engine (wide2: d = 1280) with shortened contexts, greedy: every pick is the FP8-mode oracle's argmax or within the margin this model shows
+    at EVERY context, the full one included (profiles/r05_z_fp8_audio_ctx_margins.txt: 3 % of the picks differ, margins up to 0.45 at 1500, 0.56 at
+    1024, 0.60 at 512 -- the natural-EOT wide2 weights are harder on e4m3 than the default ones; f16 differs nowhere)."""
+    from speaksense_amd import binding
+    from oracle import binding as orc
+    from test_gpu_parity import check_against_oracle
+    c = audio_ctx_cases()[2]
+    path = audio_ctx_case_model(c, model_dir)
+    eng = binding.Engine(path, dtype=binding.DTYPE_FP8, max_batch=2)
+    om = orc.OracleModel(path)
+    worst, n_same = 0.0, 0
+    for A, seed in ((1000, 31), (752, 32), (500, 33)):
+        pcm = synth.speech_like(seed)
+        kw = dict(language="en", temperature_inc=0.0, audio_ctx=A)
+        got = eng.new_session().transcribe(pcm, binding.default_params(**kw))
+        same, w = check_against_oracle(got, om, orc, orc.MODE_FP8, pcm, orc.default_params(**kw), f"fp8 audio_ctx {A}", 0.8)
+        n_same += same; worst = max(worst, w)
+    report(f"fp8 engine, audio_ctx 1000 / 752 / 500 (wide2): {n_same}/3 chunks identical to the FP8-mode oracle, the rest proven by forced replay, largest margin {worst:.4f}")
+    om.close(); eng.close()
+
+
+def test_mixed_contexts_share_an_engine(model_dir):
+    """Chunks with audio_ctx 0 / 752 / 256 / 1000 submitted together (their windows ride in the same decoder passes, their encoder passes alternate
+    contexts): each equals its single-chunk run bit for bit, and the full-context chunk equals a run on an engine that never saw a shortened one."""
+    from speaksense_amd import binding
+    c = audio_ctx_cases()[0]
+    path = audio_ctx_case_model(c, model_dir)
+    ctxs = [0, 752, 256, 1000, 0, 256, 752, 0]
+    pcms = [synth.speech_like(40 + i) for i in range(len(ctxs))]
+    fresh = binding.Engine(path, dtype=binding.DTYPE_F16, max_batch=2)
+    want_full = [list(fresh.new_session().transcribe(pcms[i], binding.default_params(language="en"))["trace"]) for i in (0, 4, 7)]
+    fresh.close()
+    eng = binding.Engine(path, dtype=binding.DTYPE_F16, max_batch=8, batch_wait_us=300000)
+    ses = [eng.new_session() for _ in ctxs]
+    tickets = [s.submit(p, binding.default_params(language="en", audio_ctx=a)) for s, p, a in zip(ses, pcms, ctxs)]
+    res = [s.wait(t) for s, t in zip(ses, tickets)]
+    singles = [eng.new_session().transcribe(p, binding.default_params(language="en", audio_ctx=a)) for p, a in zip(pcms, ctxs)]
+    for i, (r, s1) in enumerate(zip(res, singles)):
+        assert list(r["trace"]) == list(s1["trace"]), f"chunk {i} (audio_ctx {ctxs[i]}) differs from its single run"
+        assert [(s["t0"], s["t1"], s["text"]) for s in r["segments"]] == [(s["t0"], s["t1"], s["text"]) for s in s1["segments"]]
+    assert [list(res[i]["trace"]) for i in (0, 4, 7)] == want_full
+    # the same audio under two contexts is two different transcriptions (the context is not ignored)
+    a = eng.new_session().transcribe(pcms[0], binding.default_params(language="en", audio_ctx=256))
+    assert list(a["trace"]) != list(res[0]["trace"])
+    report(f"mixed audio_ctx {ctxs} in one engine: 8/8 chunks equal their single-chunk runs; full-context chunks equal an engine that never shortened")
+    eng.close()
+
+
+def test_audio_ctx_refusals_and_shim(model_dir, monkeypatch):
+    from speaksense_amd import binding
+    from test_gpu_variants import WCtxParams, WFullParams
+    c = audio_ctx_cases()[1]          # toy256: multilingual
+    path = audio_ctx_case_model(c, model_dir)
+    eng = binding.Engine(path, dtype=binding.DTYPE_F16, max_batch=2)
+    pcm = synth.speech_like(5)[:16000 * 10]
+    for kw, code in ((dict(audio_ctx=750), -9), (dict(audio_ctx=1504), -5), (dict(audio_ctx=-4), -9), (dict(audio_ctx=500, language="auto"), -9),
+                     (dict(audio_ctx=500, detect_language=1), -9)):
+        with pytest.raises(binding.SpeakSenseError) as e:
+            eng.new_session().transcribe(pcm, binding.default_params(**dict(dict(language="en"), **kw)))
+        assert e.value.code == code, (kw, e.value.code)
+    want = eng.new_session().transcribe(pcm, binding.default_params(language="en", audio_ctx=500, temperature_inc=0.0))
+    monkeypatch.setenv("SS_DTYPE", "f16")
+    monkeypatch.setenv("SS_MAX_BATCH", "2")
+    L = C.CDLL(binding.LIB_PATH)
+    L.whisper_context_default_params.restype = WCtxParams
+    L.whisper_init_from_file_with_params_no_state.restype = C.c_void_p
+    L.whisper_init_from_file_with_params_no_state.argtypes = [C.c_char_p, WCtxParams]
+    L.whisper_init_state.restype = C.c_void_p
+    L.whisper_init_state.argtypes = [C.c_void_p]
+    L.whisper_full_default_params.restype = WFullParams
+    L.whisper_full_default_params.argtypes = [C.c_int]
+    L.whisper_full_with_state.argtypes = [C.c_void_p, C.c_void_p, WFullParams, C.c_void_p, C.c_int]
+    L.whisper_full_n_segments_from_state.argtypes = [C.c_void_p]
+    L.whisper_full_get_segment_text_from_state.restype = C.c_char_p
+    L.whisper_full_get_segment_text_from_state.argtypes = [C.c_void_p, C.c_int]
+    L.whisper_free_state.argtypes = [C.c_void_p]
+    L.whisper_free.argtypes = [C.c_void_p]
+    ctx = L.whisper_init_from_file_with_params_no_state(path.encode(), L.whisper_context_default_params())
+    st = L.whisper_init_state(ctx)
+    p = L.whisper_full_default_params(0)
+    p.language = b"en"; p.audio_ctx = 500; p.temperature_inc = 0.0; p.no_context = True; p.token_timestamps = True
+    assert L.whisper_full_with_state(ctx, st, p, pcm.ctypes.data_as(C.c_void_p), len(pcm)) == 0
+    assert L.whisper_full_n_segments_from_state(st) == len(want["segments"])
+    for i, s in enumerate(want["segments"]):
+        assert L.whisper_full_get_segment_text_from_state(st, i) == s["text"]
+    p.audio_ctx = 1504
+    assert L.whisper_full_with_state(ctx, st, p, pcm.ctypes.data_as(C.c_void_p), len(pcm)) == -5
+    L.whisper_free_state(st); L.whisper_free(ctx)
+    eng.close()
