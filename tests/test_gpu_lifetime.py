@@ -200,6 +200,10 @@ def test_soak_random_interleavings(toy_ml_path):
             "greedy": dict(), "fixed": dict(fixed_steps=16), "no_ts": dict(no_timestamps=1), "single": dict(single_segment=1), "maxtok": dict(max_tokens=12),
             "ladder": dict(temperature_inc=0.2), "offset": dict(offset_ms=1500), "bad_lang": dict(language="xx"), "bad_ctx": dict(audio_ctx=3000),
             "bad_best": dict(best_of=9, temperature_inc=0.2), "detect": dict(language="auto"),
+            # round 5: shortened encoder contexts (encoder passes alternate buffer geometries, rows of different key counts share decoder passes), a refused
+            # one, segment wrapping and the non-speech mask
+            "ctx752": dict(audio_ctx=752), "ctx256": dict(audio_ctx=256, temperature_inc=0.2), "bad_ctx4": dict(audio_ctx=750), "wrap": dict(max_len=12, split_on_word=1),
+            "nonspeech": dict(suppress_non_speech_tokens=1),
         }
 
         def params(v):
