@@ -10,8 +10,10 @@
 // whisper.cpp routine it restates (marked "wcpp:"; unverifiable offline).  Pinned to the one independent
 // implementation the container has, HF transformers' Whisper on seeded weights (tests/golden/make_golden.py, tests/test_oracle_golden.py):
 // stages on seven shapes (erf and tanh GELU), OpenAI's decoding rules bit for bit under COMPAT_OPENAI_TS_RULES, whole first windows of HF
-// generate() (ids and segment times, 8 cases) and 2 - 3 consecutive windows of 95 s calls under COMPAT_OPENAI_HISTORY as well (seek advance,
-// [prev] + history prompts, absolute times).  HF is not the reference: the header stays "parity unpinned".
+// generate() (ids and segment times, 10 cases + two at the full depth of large-v3) and 2 - 3 consecutive windows of 95 s calls under
+// COMPAT_OPENAI_HISTORY as well (seek advance, [prev] + history prompts, absolute times); shortened contexts (whisper_full_params.audio_ctx)
+// against HF models whose max_source_positions is the shortened context.  No HF counterpart, restated from memory alone: the token-level
+// timestamps, whisper_wrap_segment (max_len / split_on_word), the non-speech symbol list.  HF is not the reference: the header stays "parity unpinned".
 //
 // Numerics modes (orc_opts.mode):
 //   0  F32      : f32 everywhere, exact tanh-GELU / expf (clean mathematical restatement)
