@@ -458,6 +458,18 @@ def audio_ctx_fixture():
     print("wrote", dst, os.path.getsize(dst), "bytes")
 
 
+def non_speech_fixture():
+    """hf_non_speech_ids.npz: transformers' NON_SPEECH_TOKENS / NON_SPEECH_TOKENS_MULTI (configuration_whisper.py: the default `suppress_tokens` of the
+    English and multilingual checkpoints = openai/whisper tokenizer.py non_speech_tokens, as ids of the REAL vocabularies).  The vocabularies are not in
+    the container, but the first 94 ids of every GPT-2 byte-level vocabulary are the printable ASCII characters '!' .. '~' in order (bytes_to_unicode), so
+    the ids below 94 say which single ASCII characters are on the list -- the part of whisper.cpp's symbol table the tests can hold to an independent source."""
+    import transformers.models.whisper.configuration_whisper as c
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_non_speech_ids.npz")
+    np.savez_compressed(dst, en=np.array(c.NON_SPEECH_TOKENS, np.int32), multi=np.array(c.NON_SPEECH_TOKENS_MULTI, np.int32))
+    print("wrote", dst, len(c.NON_SPEECH_TOKENS), len(c.NON_SPEECH_TOKENS_MULTI), "ids; single ASCII characters:",
+          "".join(chr(33 + i) for i in c.NON_SPEECH_TOKENS if i < 94))
+
+
 def large_v3_fixture():
     """hf_large_v3_golden.npz: the FULL-DEPTH shape (32 + 32 layers, d = 1280, 20 heads, 128 mels, 51 866 tokens) -- the seeded synthetic large-v3 model
     bench.py and tests/test_gpu_large_v3.py use (`write_model("large-v3", seed=0)`), loaded into HF with the tanh GELU: encoder rows, per-step top-16
@@ -647,11 +659,13 @@ def generate_long_fixture():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["toy", "shapes", "rules", "tanh", "generate", "generate_long", "audio_ctx"]
+    which = sys.argv[1:] or ["toy", "shapes", "rules", "tanh", "generate", "generate_long", "audio_ctx", "non_speech"]
     if "generate_long" in which:
         generate_long_fixture()
     if "audio_ctx" in which:
         audio_ctx_fixture()
+    if "non_speech" in which:
+        non_speech_fixture()
     if "large_v3" in which:      # not part of the default list: ~3 minutes
         large_v3_fixture()
     if "generate_large_v3" in which:      # not part of the default list: ~15 minutes (two oracle windows at full depth in exact f32)

@@ -132,3 +132,23 @@ def test_whisper_h_shim_honours_max_len_and_non_speech(planted, eng, monkeypatch
         assert L.whisper_full_n_tokens_from_state(st, i) == len(s["token_times"]["ids"])
     L.whisper_free_state(st)
     L.whisper_free(ctx)
+
+
+def test_rules_kernel_single_character_symbols_match_hf_list(model_dir):
+    """The device's non-speech bitmask against transformers' NON_SPEECH_TOKENS on the head of a GPT-2 byte-level vocabulary (ids 0 .. 93 = '!' .. '~'):
+    the ids the flag masks below 94 are exactly HF's (tests/test_oracle_wrap.py holds the oracle to the same list)."""
+    import os
+    from speaksense_amd import binding
+    from test_oracle_wrap import ascii_vocab_model
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hf_non_speech_ids.npz"))
+    want = sorted(int(i) for i in g["en"] if i < 94)
+    e = binding.Engine(ascii_vocab_model(model_dir), dtype=binding.DTYPE_F16, max_batch=2)
+    raw = np.zeros(e.n_vocab, np.float32)
+    beg = e.beg
+    raw[beg:] = -30.0
+    off = e.process_logits(raw, [beg + 3, 700], True, 0, binding.default_params(language="en"), want_row=True)["logprobs"]
+    on = e.process_logits(raw, [beg + 3, 700], True, 0, binding.default_params(language="en", suppress_non_speech_tokens=1), want_row=True)["logprobs"]
+    got = sorted(int(i) for i in np.nonzero(np.isneginf(on[:94]) & ~np.isneginf(off[:94]))[0])
+    assert got == want
+    report(f"non-speech bitmask on the device: the {len(got)} single ASCII characters it masks are transformers' NON_SPEECH_TOKENS below id 94")
+    e.close()

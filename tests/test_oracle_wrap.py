@@ -161,3 +161,31 @@ def test_oracle_suppress_non_speech_tokens_changes_a_transcription(model_dir):
     assert flagged[:first] == plain[:first] and flagged[first] != plain[first]
     assert not (set(flagged) & banned)
     om.close()
+
+
+def ascii_vocab_model(model_dir):
+    """toy.en with ids 0 .. 93 = the printable ASCII characters '!' .. '~' in order: the head of every GPT-2 byte-level vocabulary (the real ones are not here)."""
+    path = os.path.join(model_dir, "toy.en-ascii-head.bin")
+    if not os.path.exists(path):
+        ggml_io.write_model(path, "toy.en", seed=9, vocab_overrides={i: bytes([33 + i]) for i in range(94)})
+    return path
+
+
+def test_non_speech_single_characters_match_hf_list(model_dir):
+    """The single-ASCII-character part of the symbol table against an independent source: transformers' NON_SPEECH_TOKENS (the default suppress_tokens
+    of the real checkpoints, tests/golden/hf_non_speech_ids.npz) lists, below id 94, exactly the characters this restatement masks -- and neither '-'
+    nor the apostrophe."""
+    from oracle import binding as orc
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hf_non_speech_ids.npz"))
+    want = sorted(int(i) for i in g["en"] if i < 94)
+    assert want == sorted(int(i) for i in g["multi"] if i < 94) and len(want) == 23
+    om = orc.OracleModel(ascii_vocab_model(model_dir))
+    st = om.new_state(orc.MODE_F32)
+    raw = np.zeros(om.n_vocab, np.float32)
+    raw[om.beg:] = -30.0          # keep the "timestamp mass beats every text token" rule out of the way: it would mask all text by itself
+    _, off, _ = st.process_logits(raw, [om.beg + 3, 700], True, 0, orc.default_params(language="en"))
+    _, on, _ = st.process_logits(raw, [om.beg + 3, 700], True, 0, orc.default_params(language="en", suppress_non_speech_tokens=1))
+    got = sorted(int(i) for i in np.nonzero(np.isneginf(on[:94]) & ~np.isneginf(off[:94]))[0])
+    assert got == want, "".join(chr(33 + i) for i in sorted(set(got) ^ set(want)))
+    assert ord("-") - 33 not in got and ord("'") - 33 not in got
+    om.close()
