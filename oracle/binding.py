@@ -82,6 +82,7 @@ def lib():
         L.orc_e8m0_exponent.argtypes = [C.c_float]
         L.orc_quantize_rows_f8.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_lang_id.argtypes = [C.c_void_p]
+        L.orc_lang_code_to_id.argtypes = [C.c_char_p]
         L.orc_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
         L.orc_sampled.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_n_segments.argtypes = [C.c_void_p]

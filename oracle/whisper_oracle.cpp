@@ -1446,6 +1446,7 @@ int orc_full_trace(void* sp, const float* pcm, int n, const FullParams* P, const
     return rc;
 }
 int orc_lang_id(void* sp) { return ((State*)sp)->lang_id; }
+int orc_lang_code_to_id(const char* code) { return lang_id(code); }   // wcpp: g_lang (the table whisper_lang_id reads); -1 = unknown
 int orc_tokenize(void* mp, const char* text, int32_t* ids, int n_max) {
     const std::vector<int> t = tokenize(((Model*)mp)->vocab, text);
     if ((int)t.size() > n_max) return -(int)t.size();

@@ -470,6 +470,17 @@ def non_speech_fixture():
           "".join(chr(33 + i) for i in c.NON_SPEECH_TOKENS if i < 94))
 
 
+def languages_fixture():
+    """hf_languages.txt: transformers' LANGUAGES (tokenization_whisper.py = openai/whisper tokenizer.py), one "code name" per line in id order: the
+    language token of id i is sot + 1 + i, so the ORDER is part of the path (prompt_init, language detection)."""
+    from transformers.models.whisper.tokenization_whisper import LANGUAGES
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_languages.txt")
+    with open(dst, "w") as f:
+        for code, name in LANGUAGES.items():
+            f.write(f"{code} {name}\n")
+    print("wrote", dst, len(LANGUAGES), "languages")
+
+
 def large_v3_fixture():
     """hf_large_v3_golden.npz: the FULL-DEPTH shape (32 + 32 layers, d = 1280, 20 heads, 128 mels, 51 866 tokens) -- the seeded synthetic large-v3 model
     bench.py and tests/test_gpu_large_v3.py use (`write_model("large-v3", seed=0)`), loaded into HF with the tanh GELU: encoder rows, per-step top-16
@@ -659,13 +670,15 @@ def generate_long_fixture():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["toy", "shapes", "rules", "tanh", "generate", "generate_long", "audio_ctx", "non_speech"]
+    which = sys.argv[1:] or ["toy", "shapes", "rules", "tanh", "generate", "generate_long", "audio_ctx", "non_speech", "languages"]
     if "generate_long" in which:
         generate_long_fixture()
     if "audio_ctx" in which:
         audio_ctx_fixture()
     if "non_speech" in which:
         non_speech_fixture()
+    if "languages" in which:
+        languages_fixture()
     if "large_v3" in which:      # not part of the default list: ~3 minutes
         large_v3_fixture()
     if "generate_large_v3" in which:      # not part of the default list: ~15 minutes (two oracle windows at full depth in exact f32)

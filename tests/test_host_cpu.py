@@ -365,3 +365,28 @@ def test_session_wait_withholds_results_while_another_ticket_is_outstanding():
     s._pending = 2                       # two tickets submitted
     assert s.wait(object()) is None      # the other one is still outstanding
     assert s.wait(object()) == {"tokens": [1, 2, 3]}
+
+
+def test_language_table_matches_hf_order():
+    """Language i's token is sot + 1 + i: the ORDER of the table is part of the path.  tests/golden/hf_languages.txt is transformers' LANGUAGES (= openai/whisper
+    tokenizer.py) in id order; the product's table (whisper_lang_id / whisper_lang_str / whisper_lang_str_full of the whisper.h shim, the Python binding's
+    copy) and the oracle's must be that list, full names included (whisper_lang_id accepts them)."""
+    import ctypes as C
+    import os
+    from speaksense_amd import binding
+    from oracle import binding as orc
+    here = os.path.dirname(os.path.abspath(__file__))
+    langs = [l.split(" ", 1) for l in open(os.path.join(here, "golden", "hf_languages.txt")).read().strip().splitlines()]
+    assert len(langs) == 100 and langs[0] == ["en", "english"] and langs[99] == ["yue", "cantonese"]
+    L = C.CDLL(binding.LIB_PATH)
+    L.whisper_lang_id.argtypes = [C.c_char_p]
+    L.whisper_lang_str.restype = C.c_char_p
+    L.whisper_lang_str_full.restype = C.c_char_p
+    assert L.whisper_lang_max_id() == 99
+    for i, (code, name) in enumerate(langs):
+        assert L.whisper_lang_id(code.encode()) == i, code
+        assert L.whisper_lang_id(name.encode()) == i, name
+        assert L.whisper_lang_str(i) == code.encode() and L.whisper_lang_str_full(i) == name.encode()
+        assert binding.lang_code(i) == code
+        assert orc.lib().orc_lang_code_to_id(code.encode()) == i
+    assert orc.lib().orc_lang_code_to_id(b"xx") == -1
