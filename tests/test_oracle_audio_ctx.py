@@ -43,8 +43,9 @@ def test_oracle_shortened_context_matches_hf(ci, model_dir):
     assert enc.shape == (A, om.n_audio_state)
     err = np.abs(enc[c["rows"]] - c["enc"]).max() / c["enc_absmax"]
     assert err < 2e-4, err                                   # f32 against f32: summation order only (measured 5 - 8e-5)
-    full = om.encode(om.log_mel(pcm), 0, orc.MODE_F32)
-    assert np.abs(full[A - 1] - enc[A - 1]).max() / c["enc_absmax"] > 1e-2      # the cut is visible: the last rows are not a slice of the full pass
+    if ci != 2:      # (the d = 1280 case skips the two full-context comparisons: CPU time)
+        full = om.encode(om.log_mel(pcm), 0, orc.MODE_F32)
+        assert np.abs(full[A - 1] - enc[A - 1]).max() / c["enc_absmax"] > 1e-2      # the cut is visible: the last rows are not a slice of the full pass
     st = om.new_state(orc.MODE_F32)
     st.set_encoder(enc)
     worst = 0.0
@@ -61,8 +62,9 @@ def test_oracle_shortened_context_matches_hf(ci, model_dir):
     assert tr[:c["n0"]] == c["ids"][:c["n0"]]
     assert [(s["t0"], s["t1"]) for s in ref["segments"]][:len(c["seg"])] == c["seg"]
     # and the context matters: the full-context run of the same audio picks differently somewhere in the window
-    other = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES).full(pcm, orc.default_params(language="en", temperature_inc=0.0, duration_ms=30000))
-    assert [int(t) for t in other["trace"]][:c["n0"]] != c["ids"][:c["n0"]] or ci == 1
+    if ci == 0:
+        other = om.new_state(orc.MODE_F32, compat=orc.COMPAT_OPENAI_TS_RULES).full(pcm, orc.default_params(language="en", temperature_inc=0.0, duration_ms=30000))
+        assert [int(t) for t in other["trace"]][:c["n0"]] != c["ids"][:c["n0"]]
     om.close()
 
 

@@ -73,6 +73,9 @@ def py_wrap(seg, strs, eot, max_len, split_on_word):
         ids, tt0 = ids[cut:], tt0[cut:]
 
 
+_PLAIN = {}      # the unwrapped run of the one (model, audio) the wrap tests share
+
+
 def unwrapped_segments(res):
     return [dict(t0=s["t0"], t1=s["t1"], ids=[int(x) for x in s["token_times"]["ids"]], tok_t0=[int(x) for x in s["token_times"]["t0"]]) for s in res["segments"]]
 
@@ -83,7 +86,9 @@ def test_oracle_wrap_segment(wrap_model, max_len, split_on_word):
     om = orc.OracleModel(wrap_model)
     _, _, strs, _ = ggml_io.read_model(wrap_model)
     pcm = synth.speech_like(11)
-    plain = om.new_state(orc.MODE_F32).full(pcm, orc.default_params(language="en"))
+    if "plain" not in _PLAIN:
+        _PLAIN["plain"] = om.new_state(orc.MODE_F32).full(pcm, orc.default_params(language="en"))
+    plain = _PLAIN["plain"]
     got = om.new_state(orc.MODE_F32).full(pcm, orc.default_params(language="en", max_len=max_len, split_on_word=split_on_word))
     assert list(got["tokens"]) == list(plain["tokens"]) and got["n_encode"] == plain["n_encode"]        # wrapping never feeds back into decoding
     want = [p for seg in unwrapped_segments(plain) for p in py_wrap(seg, strs, om.eot, max_len, split_on_word)]
