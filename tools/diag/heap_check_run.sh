@@ -6,5 +6,5 @@
 # in every order.
 cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
 OUT=gpurun_out/${TAG:-r05_q}_malloc_check.txt
-( MALLOC_CHECK_=3 MALLOC_PERTURB_=165 SS_CRASH_BACKTRACE=1 SS_SOAK_SECONDS=45 timeout 1500 python -m pytest tests/test_gpu_lifetime.py tests/test_gpu_variants.py tests/test_gpu_features.py tests/test_gpu_multi.py -q -m gpu -x -p no:cacheprovider 2>&1 | tail -12 ) > $OUT 2>&1
+( MALLOC_CHECK_=3 MALLOC_PERTURB_=165 SS_CRASH_BACKTRACE=1 SS_SOAK_SECONDS=45 timeout 1500 python -m pytest tests/test_gpu_lifetime.py tests/test_gpu_variants.py tests/test_gpu_features.py tests/test_gpu_multi.py tests/test_gpu_audio_ctx.py tests/test_gpu_wrap.py -q -m gpu -x -p no:cacheprovider 2>&1 | tail -12 ) > $OUT 2>&1
 cat $OUT | cut -c1-250
