@@ -415,6 +415,7 @@ struct EngineT : EngineBase {
         { const char* gv = getenv("SS_DECODE_GRAPH"); use_graph = !(gv && gv[0] == '0'); }     // 0: launch the step kernel by kernel instead of replaying its hipGraph
         { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }   // 0: wait for every step's samples before enqueuing the next step
         if (const char* sm = getenv("SS_CB_START_MIN")) cb_start_min = std::max(1, atoi(sm));
+        if (const char* vg = getenv("SS_VT_GEMM")) vt_gemm = atoi(vg) != 0;
         { const char* lf = getenv("SS_LN_FUSE"); ln_fuse = !(lf && lf[0] == '0'); }
         if (const char* lr = getenv("SS_LN_FUSE_ROWS")) ln_fuse_rows = std::min(16, std::max(1, atoi(lr)));
         compat = donor ? donor->compat : resolve_compat(o.compat);
@@ -587,7 +588,7 @@ struct EngineT : EngineBase {
     // configuration that cannot fit fails here with the numbers, not as a hipMalloc error somewhere inside the fourth lane's workspaces.
     size_t lane_bytes() const {
         const size_t M = (size_t)B * n_ctx, R = kPartRows;
-        size_t enc_ws = ((size_t)B * (2 * n_ctx + 2) * (n_mel + da)) * 2 + M * da * (4 + 2 + 4 + 2 + 2 + 2 + 4) + (size_t)B * Ha * 64 * Tpad * 2 + M * 4 * da * (fp8_enc ? 1 : 2);
+        size_t enc_ws = ((size_t)B * (2 * n_ctx + 2) * (n_mel + da)) * 2 + M * da * (4 + 2 + 6 + 2 + 2 + 2 + 4) + (size_t)B * Ha * 64 * Tpad * 2 + M * 4 * da * (fp8_enc ? 1 : 2);
         if (fp8_enc) enc_ws += 2 * M * da + (M + 255) * (6 * da / 64);
         const size_t cross_b = (size_t)L * B * 2 * H * n_ctx * (fp8_enc ? 65 : 128);
         const size_t self_b = (size_t)2 * L * S * n_tctx * d * 2;
@@ -614,7 +615,7 @@ struct EngineT : EngineBase {
         const size_t M = (size_t)B * n_ctx;
         x0.alloc(((size_t)B * (2 * n_ctx + 2) * n_mel + 256) * 2);
         h1.alloc(((size_t)B * (2 * n_ctx + 2) * da + 256) * 2);
-        x.alloc(M * da * 4); ln.alloc(M * da * 2); qk.alloc(M * 2 * da * 2);
+        x.alloc(M * da * 4); ln.alloc(M * da * 2); qk.alloc(M * 3 * da * 2);     // Q | K | V rows (round 5: V is projected with Q and K, then transposed)
         vT.alloc((size_t)B * Ha * 64 * Tpad * 2);
         att.alloc(M * da * 2); encT.alloc(M * da * 2); encF.alloc(M * da * 4);
         if (fp8_enc) {   // the quantised activations replace the T copy of the MLP hidden state; exponent bytes: one per (row, 64 columns), rows padded to 256
@@ -691,12 +692,16 @@ struct EngineT : EngineBase {
         for (int il = 0; il < La; il++) {
             const EncL& e = enc[il];
             launch_layernorm<T>(x.as<float>(), e.ln1w, e.ln1b, ln.as<T>(), M, da, nullptr, st);
-            launch_gemm<T>(gd(ln.p, da, e.wqkv, M, 2 * da, da, EPI_STORE_T, e.bqkv, qk.p, 2 * da), st);
-            {
+            const int ldq = vt_gemm ? 2 * da : 3 * da;
+            if (vt_gemm) {   // default: the V projection as its own GEMM with the transposing epilogue
+                launch_gemm<T>(gd(ln.p, da, e.wqkv, M, 2 * da, da, EPI_STORE_T, e.bqkv, qk.p, 2 * da), st);
                 GemmDesc g = gd(ln.p, da, e.wqkv + (size_t)2 * da * da, M, da, da, EPI_VT, e.bqkv + 2 * da, vT.p, 0);
                 launch_gemm<T>(g, st);
+            } else {         // SS_VT_GEMM=0 (measured slower): one GEMM for Q | K | V as plain rows, then V -> V^T through LDS tiles; the same bits
+                launch_gemm<T>(gd(ln.p, da, e.wqkv, M, 3 * da, da, EPI_STORE_T, e.bqkv, qk.p, 3 * da), st);
+                launch_v_transpose<T>(qk.as<T>() + 2 * da, 3 * da, vT.as<T>(), Tp, Wn, Ha, nc, st);
             }
-            launch_enc_attention<T>(qk.as<T>(), qk.as<T>() + da, 2 * da, vT.as<T>(), Tp, att.as<T>(), da, Wn, Ha, nc, st);
+            launch_enc_attention<T>(qk.as<T>(), qk.as<T>() + da, ldq, vT.as<T>(), Tp, att.as<T>(), da, Wn, Ha, nc, st);
             {
                 GemmDesc g = gd(att.p, da, e.wo, M, da, da, EPI_RES_F32, e.bo, x.p, da);
                 g.res = x.as<float>();
@@ -733,9 +738,15 @@ struct EngineT : EngineBase {
                 SS_HIP(hipMemcpyAsync(tap8_codes, ln8.p, (size_t)n_ctx * da, hipMemcpyDeviceToHost, st));
                 SS_HIP(hipMemcpyAsync(tap8_sc, ln_sc.p, (size_t)(da / 64) * Mpad, hipMemcpyDeviceToHost, st));
             }
-            launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8, e.sqkv, M, 2 * da, da, F8_STORE_T, e.bqkv, qk.p, 2 * da), st);
-            launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8 + (size_t)2 * da * da, e.sqkv + 2 * da, M, da, da, F8_VT, e.bqkv + 2 * da, vT.p, 0), st);
-            launch_enc_attention_f8<T>(qk.as<T>(), qk.as<T>() + da, 2 * da, vT.as<T>(), Tp, att8.as<unsigned char>(), da, att_sc.as<unsigned char>(), Mpad, Wn, Ha, nc, st);
+            const int ldq = vt_gemm ? 2 * da : 3 * da;
+            if (vt_gemm) {
+                launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8, e.sqkv, M, 2 * da, da, F8_STORE_T, e.bqkv, qk.p, 2 * da), st);
+                launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8 + (size_t)2 * da * da, e.sqkv + 2 * da, M, da, da, F8_VT, e.bqkv + 2 * da, vT.p, 0), st);
+            } else {
+                launch_gemm_f8<T>(gd8(ln8.p, ln_sc.p, da, e.wqkv8, e.sqkv, M, 3 * da, da, F8_STORE_T, e.bqkv, qk.p, 3 * da), st);
+                launch_v_transpose<T>(qk.as<T>() + 2 * da, 3 * da, vT.as<T>(), Tp, Wn, Ha, nc, st);
+            }
+            launch_enc_attention_f8<T>(qk.as<T>(), qk.as<T>() + da, ldq, vT.as<T>(), Tp, att8.as<unsigned char>(), da, att_sc.as<unsigned char>(), Mpad, Wn, Ha, nc, st);
             {
                 GemmF8Desc g = gd8(att8.p, att_sc.p, da, e.wo8, e.so, M, da, da, F8_RES_F32, e.bo, x.p, da);
                 g.res = x.as<float>();
@@ -1008,6 +1019,9 @@ struct EngineT : EngineBase {
     bool use_graph = true, chain_steps = true;
     int ln_fuse_rows = kLnFuseRows;   // (dev: SS_LN_FUSE_ROWS, <= 16, to re-measure where the fusion stops paying)
     bool ln_fuse = true;      // SS_LN_FUSE=0: A/B switch of the LayerNorm-prologue launches for <= kLnFuseRows rows
+    bool vt_gemm = true;      // the V projection as its own GEMM with the transposing epilogue.  SS_VT_GEMM=0 (A/B, round 5): Q | K | V in one GEMM as plain rows +
+                              // a V -> V^T pass through LDS tiles -- same bits, the V third at 0.41 instead of 0.25 of the MFMA pipe, and 1.4 % SLOWER end to end
+                              // (profiles/r05_ah_vt_gemm_ab.txt): the extra 61 MB pass and launch per layer cost more than the epilogue did
     int cb_start_min = 4;     // SS_CB_START_MIN: windows that must be waiting before a running group pauses its decoders for their encoder pass
     static constexpr int direct_pairs = 320;   // (rows x heads) from which the cross-attention runs as one workgroup per (row, head) (large-v3: 16 rows; +2.3 % at 32-row passes, -12 % at 8; same bits either way)
 

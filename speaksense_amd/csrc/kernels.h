@@ -185,6 +185,9 @@ void launch_dec_cross_attention_q(const float* qpart, int n_qpart, const float* 
 // Encoder self-attention, non-causal.  q,k: T [B*Tn][ld] (head h at column h*64); vT: T [B][H][64][Tpad]; out T [B*Tn][ldo]
 template <typename T>
 void launch_enc_attention(const T* q, const T* k, long ld, const T* vT, int Tpad, T* out, long ldo, int B, int H, int Tn, hipStream_t st);
+// V rows [B*Tn][ld] (head h at column h*64) -> V^T [B][H][64][Tpad] for the kernel above (zeros in the key columns >= Tn of the last 64-key tile)
+template <typename T>
+void launch_v_transpose(const T* v, long ld, T* vT, int Tpad, int B, int H, int Tn, hipStream_t st);
 // fp8 engine: the same attention with its output rounded to T and then quantised in the epilogue: e4m3 [B*Tn][ldo] + one exponent byte per (row, head)
 template <typename T>
 void launch_enc_attention_f8(const T* q, const T* k, long ld, const T* vT, int Tpad, unsigned char* out8, long ldo, unsigned char* out_scale, long ldsc, int B, int H, int Tn, hipStream_t st);

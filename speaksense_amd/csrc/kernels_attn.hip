@@ -234,6 +234,43 @@ static void launch_enc_attention_lds(const T* q, const T* k, long ld, const T* v
     enc_attn_lds_kernel<T, QT><<<grid, 256, 3 * 16384, st>>>(q, k, ld, vT, Tpad, out, ldo, H, Tn); SS_LAUNCH_CHECK();
 }
 
+// V [B*Tn][ld] (head h at column h*64) -> V^T [B][H][64][Tpad], 64 x 64 tiles through LDS; key columns t >= Tn of the last tile are written as zeros.
+// Round 5 experiment behind SS_VT_GEMM=0 (not the default): the V projection rides in the Q/K GEMM as plain rows and is transposed here -- the
+// transposing GEMM epilogue stores 8-byte pieces into 16 different rows per instruction and runs at 0.25 of the MFMA pipe against 0.41 for the plain
+// store (profiles/r05_ag_pmc_compute_encoder_kernels.txt).  Same bits; 1.4 % slower end to end (profiles/r05_ah_vt_gemm_ab.txt).
+template <typename T>
+__global__ __launch_bounds__(256) void v_transpose_kernel(const T* __restrict__ v, long ld, T* __restrict__ vT, int Tpad, int H, int Tn) {
+    typedef typename MfmaA<T>::V8 V8;
+    __shared__ T tile[64][64 + 8];          // +8 elements: rows 144 B apart, the column gather below walks 16-B slots without a common bank
+    const int t0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int r = (tid >> 3) + i * 32, c = tid & 7;          // row = key, 8 chunks of 8 elements
+        const int t = t0 + r;
+        V8 x;
+        if (t < Tn) x = *(const V8*)(v + ((long)b * Tn + t) * ld + h * 64 + c * 8);
+        else { for (int e = 0; e < 8; e++) x[e] = (T)0.0f; }
+        *(V8*)&tile[r][c * 8] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int j = (tid >> 3) + i * 32, c = tid & 7;          // row = head column j, chunk of 8 consecutive keys
+        V8 y;
+#pragma unroll
+        for (int e = 0; e < 8; e++) y[e] = tile[c * 8 + e][j];
+        *(V8*)(vT + ((long)(b * H + h) * 64 + j) * Tpad + t0 + c * 8) = y;
+    }
+}
+template <typename T>
+void launch_v_transpose(const T* v, long ld, T* vT, int Tpad, int B, int H, int Tn, hipStream_t st) {
+    if (Tpad < (Tn + 63) / 64 * 64 || Tpad % 8 || ld % 8) throw Error(-1, "v_transpose: V^T rows must be padded to a multiple of 64 keys");
+    v_transpose_kernel<T><<<dim3((Tn + 63) / 64, H, B), 256, 0, st>>>(v, ld, vT, Tpad, H, Tn); SS_LAUNCH_CHECK();
+}
+template void launch_v_transpose<bf16>(const bf16*, long, bf16*, int, int, int, int, hipStream_t);
+template void launch_v_transpose<f16>(const f16*, long, f16*, int, int, int, int, hipStream_t);
+
 template <typename T>
 void launch_enc_attention(const T* q, const T* k, long ld, const T* vT, int Tpad, T* out, long ldo, int B, int H, int Tn, hipStream_t st) {
     launch_enc_attention_lds<T, 4>(q, k, ld, vT, Tpad, out, ldo, B, H, Tn, st);   // 4 query tiles per wave; 2 and 3 measured the same (VALU-bound)

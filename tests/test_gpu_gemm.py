@@ -93,3 +93,34 @@ print("ok")
     env = dict(os.environ, SS_GEMM_K64="0", SS_F8_K128="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("dtype", ["f16", "fp8"])
+def test_fused_qkv_projection_switch_gives_the_same_bits(wide2_path, dtype):
+    """`SS_VT_GEMM=0` (round-5 experiment, measured 1.4 % slower, profiles/r05_ah_vt_gemm_ab.txt): Q | K | V in one GEMM as plain rows and a V -> V^T pass
+    through LDS tiles instead of the transposing GEMM epilogue.  The switch is read at engine creation, so each form gets a process of its own; the encoder
+    output of one window must be identical bit for bit (the projection's summation order per element does not depend on the tiling of N), also with a
+    shortened context (the transpose writes the zero key columns of the last 64-key tile itself)."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = f"""
+import sys, hashlib
+import numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from speaksense_amd import binding, synth
+e = binding.Engine({wide2_path!r}, dtype=binding.DTYPE_{dtype.upper()}, max_batch=2)
+pcm = synth.speech_like(3)
+mel = e.log_mel(pcm)
+h = hashlib.sha256(e.encode(mel, 0).tobytes()).hexdigest()
+r = e.new_session().transcribe(pcm, binding.default_params(language="en", temperature_inc=0.0, audio_ctx=500))
+print(h, hashlib.sha256(np.asarray(r["trace"], np.int32).tobytes()).hexdigest(), len(r["trace"]))
+e.close()
+"""
+    outs = []
+    for v in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SS_VT_GEMM=v), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1], outs
