@@ -615,7 +615,7 @@ struct EngineT : EngineBase {
         const size_t M = (size_t)B * n_ctx;
         x0.alloc(((size_t)B * (2 * n_ctx + 2) * n_mel + 256) * 2);
         h1.alloc(((size_t)B * (2 * n_ctx + 2) * da + 256) * 2);
-        x.alloc(M * da * 4); ln.alloc(M * da * 2); qk.alloc(M * 3 * da * 2);     // Q | K | V rows (round 5: V is projected with Q and K, then transposed)
+        x.alloc(M * da * 4); ln.alloc(M * da * 2); qk.alloc(M * 3 * da * 2);     // Q | K rows [M][2 da]; sized for Q | K | V [M][3 da], the layout of the SS_VT_GEMM=0 form
         vT.alloc((size_t)B * Ha * 64 * Tpad * 2);
         att.alloc(M * da * 2); encT.alloc(M * da * 2); encF.alloc(M * da * 4);
         if (fp8_enc) {   // the quantised activations replace the T copy of the MLP hidden state; exponent bytes: one per (row, 64 columns), rows padded to 256
