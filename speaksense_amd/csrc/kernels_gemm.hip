@@ -777,7 +777,11 @@ template <typename T, int KIND>
 static void launch_gemm_kind(const GemmDesc& g, hipStream_t st) {
     static std::atomic<uint64_t> attr128{0};
     once_per_device(attr128, [] { SS_HIP(hipFuncSetAttribute((const void*)gemm_kernel<T, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, kGemmLds)); });
-    if (g.N % TN == 0 && g.K % TK == 0 && g.K >= 4 * TK && g.M >= 1024) {
+    // Which kernel runs must not depend on M: M = windows x positions, and a window's bits may not depend on how many others share its encoder pass
+    // (the two kernels sum over K in different groupings).  Until round 5 the 256 x 256 form required M >= 1024 -- harmless while every window had
+    // 1500 positions, wrong with whisper_full_params.audio_ctx: one 752-position window took the 128 x 128 kernel, two together the 256 x 256 one, and a
+    // sampled (t > 0) decode told them apart (found by the 600 s soak, profiles/r05_ak_soak_600s_finding.txt).  Rows past M are clamped, any M works.
+    if (g.N % TN == 0 && g.K % TK == 0 && g.K >= 4 * TK) {
         // 256 x 256 tiles, one persistent workgroup per CU (a multiple of 8 so the XCD of the remap is preserved).  Measured and archived under
         // tools/experiments/r02_variants/: two 128 x 256 workgroups per CU (-15..20 %), a start-time stagger of the workgroups (no change, r03_i: worse); static wave priorities (s_setprio 1 for waves 4-7: -5 %, for the staging waves 0-3: no change, r03_r); an 8-phase main loop (tools/experiments/r03_gemm_8phase/: correct, 860-890 against 1090 TF/s at 4096^3).
         int n_cu = device_cu_count() / 8 * 8;

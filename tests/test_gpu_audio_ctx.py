@@ -4,6 +4,7 @@ of its slot, every decoder row carries its window's key count (RowCtl.n_keys).  
 shortened context (tests/golden/hf_audio_ctx_golden.npz), to the oracle under the reference's real parameters, and to itself: chunks of different
 contexts sharing one engine and one decoder pass give their single-chunk results."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -157,3 +158,33 @@ def test_audio_ctx_refusals_and_shim(model_dir, monkeypatch):
     assert L.whisper_full_with_state(ctx, st, p, pcm.ctypes.data_as(C.c_void_p), len(pcm)) == -5
     L.whisper_free_state(st); L.whisper_free(ctx)
     eng.close()
+
+
+@pytest.mark.parametrize("which", ["f16", "bf16", "fp8"])
+def test_shared_encoder_pass_does_not_change_a_short_context_window(which, wide2_path, toy_ml_path):
+    """Found by a 600 s soak in round 5 (1 of 102 688 results): the f16 / bf16 GEMM launcher picked its kernel by M = windows x positions, so ONE 752-position
+    window (M < 1024) ran the 128 x 128 kernel and two together the 256 x 256 one -- different summation grouping, different low bits, and a decode with
+    forced temperature fallbacks (sampled tokens) told them apart.  A window's result may not depend on what shares its encoder pass: chunks decoded with
+    forced fallbacks, alone and as 2 / 3 copies in one pass, at contexts on both sides of every tile boundary."""
+    from speaksense_amd import binding
+    dtype = {"f16": binding.DTYPE_F16, "bf16": binding.DTYPE_BF16, "fp8": binding.DTYPE_FP8}[which]
+    n_checked = 0
+    for path, ctxs in ((toy_ml_path, (256, 700, 752, 768, 1000, 0)), (wide2_path, (500, 752))):
+        if which == "fp8" and path == toy_ml_path:
+            continue                                   # the e4m3 engine needs n_audio_state % 256 == 0
+        eng = binding.Engine(path, dtype=dtype, max_batch=8, n_lanes=1, batch_wait_us=200000)
+        for A in ctxs:
+            for seed in (1, 3):
+                X = synth.speech_like(seed, 16000 * 3)
+                P = binding.default_params(language="en", audio_ctx=A, temperature_inc=0.2, logprob_thold=0.0)
+                alone = [int(t) for t in eng.new_session().transcribe(X, P)["trace"]]
+                for n in (2, 3):
+                    ss = [eng.new_session() for _ in range(n)]
+                    ts = [s.submit(X, P) for s in ss]
+                    for s, t in zip(ss, ts):
+                        r = s.wait(t)
+                        assert r["n_fail"] >= 1
+                        assert [int(x) for x in r["trace"]] == alone, f"{os.path.basename(path)} audio_ctx {A} seed {seed}: {n} copies in one encoder pass differ from the single run"
+                        n_checked += 1
+        eng.close()
+    report(f"shared encoder passes at shortened contexts ({which}): {n_checked} chunks with forced fallbacks equal their single runs")
