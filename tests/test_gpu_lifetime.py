@@ -204,6 +204,8 @@ def test_soak_random_interleavings(toy_ml_path):
             # one, segment wrapping and the non-speech mask
             "ctx752": dict(audio_ctx=752), "ctx256": dict(audio_ctx=256, temperature_inc=0.2), "bad_ctx4": dict(audio_ctx=750), "wrap": dict(max_len=12, split_on_word=1),
             "nonspeech": dict(suppress_non_speech_tokens=1),
+            # sampled decodes at a shortened context: the combination that exposed the M-dependent GEMM kernel choice (profiles/r05_ak_soak_600s_finding.txt)
+            "ctx752_forced_ladder": dict(audio_ctx=752, temperature_inc=0.2, logprob_thold=0.0),
         }
 
         def params(v):
