@@ -6,9 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from speaksense_amd import binding, ggml_io, synth
 
 seconds = float(os.environ.get("SECONDS_", "240"))
-path = os.path.join(tempfile.mkdtemp(), "toy.bin")
-ggml_io.write_model(path, "toy", seed=1)
-eng = binding.Engine(path, max_batch=8, n_lanes=3)
+model = os.environ.get("MODEL_", "toy")          # MODEL_=wide2 DTYPE_=fp8: the e4m3 engine (needs d % 256 == 0)
+dtype = {"f16": binding.DTYPE_F16, "bf16": binding.DTYPE_BF16, "fp8": binding.DTYPE_FP8}[os.environ.get("DTYPE_", "f16")]
+path = os.path.join(tempfile.mkdtemp(), model + ".bin")
+ggml_io.write_model(path, model, seed=1)
+eng = binding.Engine(path, dtype=dtype, max_batch=8, n_lanes=3)
+print("model", model, "dtype", os.environ.get("DTYPE_", "f16"), flush=True)
 variants = {
     "ctx256_ladder": dict(audio_ctx=256, temperature_inc=0.2),
     "ladder_forced": dict(temperature_inc=0.2, logprob_thold=0.0),
