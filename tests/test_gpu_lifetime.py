@@ -192,7 +192,14 @@ def test_soak_random_interleavings(toy_ml_path):
     serial result of the same (audio, parameters) on a fresh session."""
     from speaksense_amd import binding
     seconds = float(os.environ.get("SS_SOAK_SECONDS", "45"))
-    eng = binding.Engine(toy_ml_path, max_batch=8, n_lanes=3)
+    model_path = toy_ml_path
+    if os.environ.get("SS_SOAK_MODEL"):      # e.g. wide2: d = 1280 -- the 256 x 256 GEMM, the one-workgroup cross-attention, (SS_DTYPE=fp8) the e4m3 engine
+        from speaksense_amd import ggml_io
+        model_path = os.path.join(os.path.dirname(toy_ml_path), "soak-" + os.environ["SS_SOAK_MODEL"] + ".bin")
+        if not os.path.exists(model_path):
+            ggml_io.write_model(model_path, os.environ["SS_SOAK_MODEL"], seed=1)
+    dtype = {"f16": binding.DTYPE_F16, "bf16": binding.DTYPE_BF16, "fp8": binding.DTYPE_FP8}[os.environ.get("SS_SOAK_DTYPE", "f16")]
+    eng = binding.Engine(model_path, dtype=dtype, max_batch=8, n_lanes=3)
     try:     # the engine is closed HERE whatever happens: an engine left to the garbage collector after a failed assertion is freed at an arbitrary later point
         lengths = [0.5, 1.0, 3.0, 7.5, 12.0, 29.9, 30.1, 44.0, 65.0]
         audio = {(sd, ln): synth.speech_like(sd, int(16000 * ln)) for sd in (1, 2, 3) for ln in lengths}
