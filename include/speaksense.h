@@ -251,6 +251,9 @@ int ss_log_mel(ss_engine* e, const float* pcm, int32_t n_samples, float* mel_out
 int ss_signal_energy(ss_engine* e, const float* pcm, int32_t n_samples, float* energy_out /* [n_samples] */);
 int ss_encode(ss_engine* e, const float* mel /* [n_mel][n_len] */, int32_t n_len, int32_t seek,
               float* enc_out /* [n_audio_ctx][n_audio_state] */);
+/* the same over a shortened context (ss_params.audio_ctx: a positive multiple of 4 <= n_audio_ctx): the first audio_ctx positions only */
+int ss_encode_ctx(ss_engine* e, const float* mel /* [n_mel][n_len] */, int32_t n_len, int32_t seek, int32_t audio_ctx,
+                  float* enc_out /* [audio_ctx][n_audio_state] */);
 /* Decoder hook on a session: set encoder output (computes cross-KV), then decode tokens at n_past with the
  * session's self-KV; logits_out: [n_vocab] of the LAST token, before any rule. */
 int ss_session_set_encoder(ss_session* s, const float* enc /* [n_audio_ctx][n_audio_state] */);

@@ -106,6 +106,7 @@ def lib():
         L.ss_log_mel.argtypes = [vp, f32p, i32, f32p, i32]
         L.ss_signal_energy.argtypes = [vp, f32p, i32, f32p]
         L.ss_encode.argtypes = [vp, f32p, i32, i32, f32p]
+        L.ss_encode_ctx.argtypes = [vp, f32p, i32, i32, i32, f32p]
         L.ss_session_set_encoder.argtypes = [vp, f32p]
         L.ss_session_decode.argtypes = [vp, vp, i32, i32, f32p]
         L.ss_engine_set_encoder_window.argtypes = [vp, i32, f32p]
@@ -259,8 +260,13 @@ class Engine:
         _check(self.L.ss_log_mel(self.h, _p(pcm), len(pcm), _p(out), n_len))
         return out
 
-    def encode(self, mel: np.ndarray, seek: int = 0) -> np.ndarray:
+    def encode(self, mel: np.ndarray, seek: int = 0, audio_ctx: int = 0) -> np.ndarray:
+        """audio_ctx > 0 (Params.audio_ctx): the first audio_ctx positions only, [audio_ctx][n_audio_state]."""
         mel = np.ascontiguousarray(mel, np.float32)
+        if audio_ctx:
+            out = np.empty((audio_ctx, self.n_audio_state), np.float32)
+            _check(self.L.ss_encode_ctx(self.h, _p(mel), mel.shape[1], seek, int(audio_ctx), _p(out)))
+            return out
         out = np.empty((self.n_audio_ctx, self.n_audio_state), np.float32)
         _check(self.L.ss_encode(self.h, _p(mel), mel.shape[1], seek, _p(out)))
         return out

@@ -374,6 +374,10 @@ int ss_encode(ss_engine* e, const float* mel, int32_t n_len, int32_t seek, float
     if (!e || !mel || !enc_out || n_len <= 0 || seek < 0) return fail(SS_ERR_ARG, "ss_encode: bad argument");
     SS_TRY e->e->encode_host(mel, n_len, seek, enc_out); return SS_OK; SS_CATCH
 }
+int ss_encode_ctx(ss_engine* e, const float* mel, int32_t n_len, int32_t seek, int32_t audio_ctx, float* enc_out) {
+    if (!e || !mel || !enc_out || n_len <= 0 || seek < 0) return fail(SS_ERR_ARG, "ss_encode_ctx: bad argument");
+    SS_TRY e->e->encode_host(mel, n_len, seek, enc_out, audio_ctx); return SS_OK; SS_CATCH
+}
 int ss_session_set_encoder(ss_session* s, const float* enc) {
     if (!s || !enc) return fail(SS_ERR_ARG, "ss_session_set_encoder: bad argument");
     SS_TRY s->s.eng->set_encoder_host(enc); return SS_OK; SS_CATCH

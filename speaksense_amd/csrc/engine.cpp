@@ -1733,16 +1733,18 @@ struct EngineT : EngineBase {
         SS_HIP(hipStreamSynchronize(st));
         memcpy(out, energy_h[0].p, (size_t)n * 4);
     }
-    void encode_host(const float* mel, int n_len, int seek, float* enc_out) override {
+    void encode_host(const float* mel, int n_len, int seek, float* enc_out, int audio_ctx = 0) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
-        set_context(n_ctx);   // stage hooks always run the full context
+        if (audio_ctx > n_ctx) throw Error(SS_ERR_AUDIO_CTX, "encode: audio_ctx larger than the model's n_audio_ctx");
+        if (audio_ctx < 0 || audio_ctx % 4) throw Error(SS_ERR_UNSUPPORTED, "encode: audio_ctx must be a positive multiple of 4 (or 0 = the model's n_audio_ctx)");
+        set_context(audio_ctx > 0 ? audio_ctx : n_ctx);   // stage hooks run the full context unless told otherwise
         mel_d[0].ensure((size_t)n_mel * n_len * 4);
         SS_HIP(hipMemcpyAsync(mel_d[0].p, mel, (size_t)n_mel * n_len * 4, hipMemcpyHostToDevice, st));
-        launch_mel_window<T>(mel_d[0].as<float>(), n_mel, n_len, seek, 2 * n_ctx, x0.as<T>(), st);
+        launch_mel_window<T>(mel_d[0].as<float>(), n_mel, n_len, seek, 2 * nc, x0.as<T>(), st);
         encoder_pass(1, true);
-        SS_HIP(hipMemcpyAsync(enc_out, encF.p, (size_t)n_ctx * da * 4, hipMemcpyDeviceToHost, st));
+        SS_HIP(hipMemcpyAsync(enc_out, encF.p, (size_t)nc * da * 4, hipMemcpyDeviceToHost, st));
         SS_HIP(hipStreamSynchronize(st));
     }
     void fp8_first_quant_host(const float* mel, int n_len, int seek, uint8_t* codes, uint8_t* exps) override {

@@ -83,7 +83,7 @@ struct EngineBase {
     virtual void run_jobs_locked(std::vector<Job*>& jobs) = 0;   // caller holds `mu`
     virtual void log_mel_host(const float* pcm, int n, float* out, int n_len) = 0;
     virtual void signal_energy_host(const float* pcm, int n, float* out) = 0;
-    virtual void encode_host(const float* mel, int n_len, int seek, float* enc_out) = 0;
+    virtual void encode_host(const float* mel, int n_len, int seek, float* enc_out, int audio_ctx = 0) = 0;   // audio_ctx: 0 = n_audio_ctx
     virtual void set_encoder_host(const float* enc) = 0;
     virtual void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out) = 0;
     virtual void set_encoder_window_host(const float* enc, int window) = 0;

@@ -188,3 +188,29 @@ def test_shared_encoder_pass_does_not_change_a_short_context_window(which, wide2
                         n_checked += 1
         eng.close()
     report(f"shared encoder passes at shortened contexts ({which}): {n_checked} chunks with forced fallbacks equal their single runs")
+
+
+@pytest.mark.parametrize("which", ["f16", "bf16"])
+@pytest.mark.parametrize("ci", range(3))
+def test_engine_shortened_encoder_rows_match_hf(ci, which, model_dir):
+    """Stage level, no oracle in between: `ss_encode_ctx` against the encoder rows of the HF model whose max_source_positions is the shortened context --
+    the LAST rows included (the ones a wrong cut or a stale padding row would change) -- at the tolerances of the full-context stage tests
+    (tests/test_gpu_golden.py); and the last row is far from the full-context pass's row at the same position."""
+    from speaksense_amd import binding
+    from test_gpu_golden import ENC_TOL_BF16, ENC_TOL_F16
+    c = audio_ctx_cases()[ci]
+    path = audio_ctx_case_model(c, model_dir)
+    eng = binding.Engine(path, dtype=binding.DTYPE_F16 if which == "f16" else binding.DTYPE_BF16, max_batch=2)
+    pcm = synth.speech_like(c["audio"])
+    mel = eng.log_mel(pcm)
+    A = c["audio_ctx"]
+    full = eng.encode(mel, 0)
+    enc = eng.encode(mel, 0, audio_ctx=A)
+    again = eng.encode(mel, 0)
+    assert enc.shape == (A, eng.n_audio_state) and np.array_equal(full, again)          # the context switch leaves the full-context pass bit-identical
+    err = np.abs(enc[c["rows"]] - c["enc"]).max() / c["enc_absmax"]
+    tol = ENC_TOL_F16 if which == "f16" else ENC_TOL_BF16
+    assert err < tol, err
+    assert np.abs(full[A - 1] - enc[A - 1]).max() / c["enc_absmax"] > 0.1          # (measured 0.27 - 0.29: another computation, not noise)
+    report(f"ss_encode_ctx ({which}) vs HF at max_source_positions = {A} ({c['preset']}): encoder rows {err:.2e} of absmax (tol {tol})")
+    eng.close()
