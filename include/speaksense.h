@@ -257,6 +257,8 @@ int ss_encode_ctx(ss_engine* e, const float* mel /* [n_mel][n_len] */, int32_t n
 /* Decoder hook on a session: set encoder output (computes cross-KV), then decode tokens at n_past with the
  * session's self-KV; logits_out: [n_vocab] of the LAST token, before any rule. */
 int ss_session_set_encoder(ss_session* s, const float* enc /* [n_audio_ctx][n_audio_state] */);
+/* the same for the output of a shortened context ([audio_ctx][n_audio_state], ss_encode_ctx): ss_session_decode then attends over audio_ctx keys */
+int ss_session_set_encoder_ctx(ss_session* s, const float* enc, int32_t audio_ctx);
 int ss_session_decode(ss_session* s, const int32_t* tokens, int32_t n_tokens, int32_t n_past, float* logits_out);
 /* The decoder PASS the batched engine runs, as a stage hook: cross-KV cache slot `window` (< max_batch, lane 0) is filled from an encoder
  * output, then ONE launch carries n_rows (1..128) token rows -- row i = token[i] at position pos[i] of self-KV slot slot[i]

@@ -108,6 +108,7 @@ def lib():
         L.ss_encode.argtypes = [vp, f32p, i32, i32, f32p]
         L.ss_encode_ctx.argtypes = [vp, f32p, i32, i32, i32, f32p]
         L.ss_session_set_encoder.argtypes = [vp, f32p]
+        L.ss_session_set_encoder_ctx.argtypes = [vp, f32p, i32]
         L.ss_session_decode.argtypes = [vp, vp, i32, i32, f32p]
         L.ss_engine_set_encoder_window.argtypes = [vp, i32, f32p]
         L.ss_engine_fp8_first_quant.argtypes = [vp, f32p, i32, i32, C.c_void_p, C.c_void_p]
@@ -493,7 +494,11 @@ class Session:
         _check(self.L.ss_session_rng_discard(self.h, int(n)))
 
     def set_encoder(self, enc: np.ndarray):
+        """enc: [n_audio_ctx][n_audio_state], or fewer rows = the output of a shortened context (Engine.encode(audio_ctx=...))."""
         enc = np.ascontiguousarray(enc, np.float32)
+        if enc.shape[0] < self.eng.n_audio_ctx:
+            _check(self.L.ss_session_set_encoder_ctx(self.h, _p(enc), int(enc.shape[0])))
+            return
         _check(self.L.ss_session_set_encoder(self.h, _p(enc)))
 
     def decode(self, tokens, n_past: int) -> np.ndarray:

@@ -382,6 +382,10 @@ int ss_session_set_encoder(ss_session* s, const float* enc) {
     if (!s || !enc) return fail(SS_ERR_ARG, "ss_session_set_encoder: bad argument");
     SS_TRY s->s.eng->set_encoder_host(enc); return SS_OK; SS_CATCH
 }
+int ss_session_set_encoder_ctx(ss_session* s, const float* enc, int32_t audio_ctx) {
+    if (!s || !enc) return fail(SS_ERR_ARG, "ss_session_set_encoder_ctx: bad argument");
+    SS_TRY s->s.eng->set_encoder_host(enc, audio_ctx); return SS_OK; SS_CATCH
+}
 int ss_engine_set_encoder_window(ss_engine* e, int32_t window, const float* enc) {
     if (!e || !enc) return fail(SS_ERR_ARG, "ss_engine_set_encoder_window: bad argument");
     SS_TRY e->e->set_encoder_window_host(enc, window); return SS_OK; SS_CATCH

@@ -1766,14 +1766,18 @@ struct EngineT : EngineBase {
         for (int m = 0; m < n_ctx; m++)        // exponent bytes out of the GEMM's tile-aware order into [row][64-column block]
             for (int b = 0; b < da / 64; b++) exps[(size_t)m * (da / 64) + b] = sc[f8_scale_index(m, b, Mpad)];
     }
-    void set_encoder_host(const float* encv) override {
+    int hook_n_keys = 0;      // stage hooks: key count of the encoder output last given to set_encoder_host (RowCtl.n_keys of decode_host's rows; 0 = n_ctx)
+    void set_encoder_host(const float* encv, int audio_ctx = 0) override {
         std::lock_guard<std::mutex> lk(mu);
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
-        set_context(n_ctx);   // stage hooks always run the full context
-        SS_HIP(hipMemcpyAsync(encF.p, encv, (size_t)n_ctx * da * 4, hipMemcpyHostToDevice, st));
-        launch_f32_to_T<T>(encF.as<float>(), encT.as<T>(), (size_t)n_ctx * da, st);
-        if (fp8_enc) launch_quantize_f8<T>(encT.as<T>(), da, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, n_ctx, da, st);
+        if (audio_ctx > n_ctx) throw Error(SS_ERR_AUDIO_CTX, "set_encoder: audio_ctx larger than the model's n_audio_ctx");
+        if (audio_ctx < 0 || audio_ctx % 4) throw Error(SS_ERR_UNSUPPORTED, "set_encoder: audio_ctx must be a positive multiple of 4 (or 0 = the model's n_audio_ctx)");
+        set_context(audio_ctx > 0 ? audio_ctx : n_ctx);
+        hook_n_keys = nc == n_ctx ? 0 : nc;
+        SS_HIP(hipMemcpyAsync(encF.p, encv, (size_t)nc * da * 4, hipMemcpyHostToDevice, st));
+        launch_f32_to_T<T>(encF.as<float>(), encT.as<T>(), (size_t)nc * da, st);
+        if (fp8_enc) launch_quantize_f8<T>(encT.as<T>(), da, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, nc, da, st);
         cross_kv_pass(1);
         SS_HIP(hipStreamSynchronize(st));
     }
@@ -1785,7 +1789,7 @@ struct EngineT : EngineBase {
         const RuleConsts rc = rule_consts(P);
         for (int i = 0; i < n; i++) {
             RowCtl c{};
-            c.token = tokens[i]; c.pos = n_past + i; c.slot = 0; c.cross = 0; c.n_hist = 1;
+            c.token = tokens[i]; c.pos = n_past + i; c.slot = 0; c.cross = 0; c.n_hist = 1; c.n_keys = hook_n_keys;
             stage_acquire();
             ctl_h[0] = c; ctl_h[kPartRows] = c;
             std::vector<int> sr;

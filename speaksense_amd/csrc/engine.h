@@ -84,7 +84,7 @@ struct EngineBase {
     virtual void log_mel_host(const float* pcm, int n, float* out, int n_len) = 0;
     virtual void signal_energy_host(const float* pcm, int n, float* out) = 0;
     virtual void encode_host(const float* mel, int n_len, int seek, float* enc_out, int audio_ctx = 0) = 0;   // audio_ctx: 0 = n_audio_ctx
-    virtual void set_encoder_host(const float* enc) = 0;
+    virtual void set_encoder_host(const float* enc, int audio_ctx = 0) = 0;   // audio_ctx: rows of `enc` (0 = n_audio_ctx); decode_host then attends over that many keys
     virtual void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out) = 0;
     virtual void set_encoder_window_host(const float* enc, int window) = 0;
     virtual void fp8_first_quant_host(const float* mel, int n_len, int seek, uint8_t* codes, uint8_t* exps) = 0;

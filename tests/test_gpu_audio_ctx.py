@@ -214,3 +214,32 @@ def test_engine_shortened_encoder_rows_match_hf(ci, which, model_dir):
     assert np.abs(full[A - 1] - enc[A - 1]).max() / c["enc_absmax"] > 0.1          # (measured 0.27 - 0.29: another computation, not noise)
     report(f"ss_encode_ctx ({which}) vs HF at max_source_positions = {A} ({c['preset']}): encoder rows {err:.2e} of absmax (tol {tol})")
     eng.close()
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_engine_shortened_decoder_logits_match_hf(ci, model_dir):
+    """Stage level for the decoder: the HF model's encoder rows are not stored whole, so the engine's own short-context encoder output (held to HF's rows
+    above) goes into `ss_session_set_encoder_ctx`, and the top-16 logits of a prompt pass + 8 KV-cached steps over audio_ctx keys are compared with HF's
+    at the full-context tolerance (tests/test_gpu_golden.py LOGIT_TOL_F16, in units of the logits' standard deviation)."""
+    from speaksense_amd import binding
+    from test_gpu_golden import LOGIT_TOL_F16
+    c = audio_ctx_cases()[ci]
+    eng = binding.Engine(audio_ctx_case_model(c, model_dir), dtype=binding.DTYPE_F16, max_batch=2)
+    pcm = synth.speech_like(c["audio"])
+    enc = eng.encode(eng.log_mel(pcm), 0, audio_ctx=c["audio_ctx"])
+    ses = eng.new_session()
+    ses.set_encoder(enc)
+    n_p, worst = c["n_prompt"], 0.0
+    for pos in range(n_p - 1, len(c["tokens"])):
+        lg = ses.decode(c["tokens"][:n_p], 0) if pos == n_p - 1 else ses.decode(c["tokens"][pos:pos + 1], pos)
+        e = np.abs(lg[c["topk"][pos]] - c["topv"][pos]).max() / c["logit_std"]
+        worst = max(worst, e)
+        assert e < LOGIT_TOL_F16, (pos, e)
+    # the same session back on a full-context encoder output attends over all 1500 keys again
+    full = eng.encode(eng.log_mel(pcm), 0)
+    ses.set_encoder(full)
+    a = ses.decode(c["tokens"][:n_p], 0)
+    ses2 = eng.new_session(); ses2.set_encoder(full)
+    assert np.array_equal(a, ses2.decode(c["tokens"][:n_p], 0))
+    report(f"ss_session_set_encoder_ctx + decode (f16) vs HF over {c['audio_ctx']} keys ({c['preset']}): top-16 logits of {len(c['tokens']) - n_p + 1} steps within {worst:.2e} sigma (tol {LOGIT_TOL_F16})")
+    eng.close()
