@@ -254,8 +254,10 @@ int ss_encode(ss_engine* e, const float* mel /* [n_mel][n_len] */, int32_t n_len
 /* the same over a shortened context (ss_params.audio_ctx: a positive multiple of 4 <= n_audio_ctx): the first audio_ctx positions only */
 int ss_encode_ctx(ss_engine* e, const float* mel /* [n_mel][n_len] */, int32_t n_len, int32_t seek, int32_t audio_ctx,
                   float* enc_out /* [audio_ctx][n_audio_state] */);
-/* Decoder hook on a session: set encoder output (computes cross-KV), then decode tokens at n_past with the
- * session's self-KV; logits_out: [n_vocab] of the LAST token, before any rule. */
+/* Decoder hook on a session: set encoder output (computes cross-KV), then decode tokens at n_past; logits_out: [n_vocab] of the LAST token,
+ * before any rule.  The hook's cross-K/V and self-KV live in ONE slot per engine (lane 0, slot 0), owned by the session that last called
+ * ss_session_set_encoder*: ss_session_decode from any other session, after a transcription ran on lane 0, or with n_past beyond the positions
+ * decoded since that call, fails with SS_ERR_ARG instead of answering from someone else's audio. */
 int ss_session_set_encoder(ss_session* s, const float* enc /* [n_audio_ctx][n_audio_state] */);
 /* the same for the output of a shortened context ([audio_ctx][n_audio_state], ss_encode_ctx): ss_session_decode then attends over audio_ctx keys */
 int ss_session_set_encoder_ctx(ss_session* s, const float* enc, int32_t audio_ctx);

@@ -192,7 +192,11 @@ int whisper_set_mel_with_state(struct whisper_context* ctx, struct whisper_state
  * cross-K/V of every decoder layer: the device kernels of the batch path, one window (ss_encode + ss_session_set_encoder).  0 = ok */
 int whisper_encode(struct whisper_context* ctx, int offset, int n_threads);
 int whisper_encode_with_state(struct whisper_context* ctx, struct whisper_state* state, int offset, int n_threads);
-/* n_tokens tokens at positions n_past .. of the state's self-KV cache, attending to the last whisper_encode* (ss_session_decode).  0 = ok */
+/* n_tokens tokens at positions n_past .., attending to this state's last whisper_encode* (ss_session_decode).  0 = ok.
+ * Deviation from whisper.cpp: the decoder context behind these two calls (one cross-K/V + one self-KV slot) exists ONCE per context, not once
+ * per state.  A state keeps it from its whisper_encode* until another state's whisper_encode* or a whisper_full* that runs on the same lane; after
+ * that its whisper_decode* returns -1 (never another state's audio) until it calls whisper_encode* again and decodes from n_past = 0.  n_past
+ * beyond the positions decoded since the last whisper_encode* is also -1.  An `offset` at or beyond the spectrogram encodes a window of zeros. */
 int whisper_decode(struct whisper_context* ctx, const whisper_token* tokens, int n_tokens, int n_past, int n_threads);
 int whisper_decode_with_state(struct whisper_context* ctx, struct whisper_state* state, const whisper_token* tokens, int n_tokens, int n_past, int n_threads);
 /* raw logits [n_vocab] of the LAST token of the last whisper_decode* (whisper.cpp v1.5.x computes that row only); owned by the state, valid until

@@ -380,11 +380,11 @@ int ss_encode_ctx(ss_engine* e, const float* mel, int32_t n_len, int32_t seek, i
 }
 int ss_session_set_encoder(ss_session* s, const float* enc) {
     if (!s || !enc) return fail(SS_ERR_ARG, "ss_session_set_encoder: bad argument");
-    SS_TRY s->s.eng->set_encoder_host(enc); return SS_OK; SS_CATCH
+    SS_TRY s->s.eng->set_encoder_host(enc, 0, &s->s); return SS_OK; SS_CATCH
 }
 int ss_session_set_encoder_ctx(ss_session* s, const float* enc, int32_t audio_ctx) {
     if (!s || !enc) return fail(SS_ERR_ARG, "ss_session_set_encoder_ctx: bad argument");
-    SS_TRY s->s.eng->set_encoder_host(enc, audio_ctx); return SS_OK; SS_CATCH
+    SS_TRY s->s.eng->set_encoder_host(enc, audio_ctx, &s->s); return SS_OK; SS_CATCH
 }
 int ss_engine_set_encoder_window(ss_engine* e, int32_t window, const float* enc) {
     if (!e || !enc) return fail(SS_ERR_ARG, "ss_engine_set_encoder_window: bad argument");
@@ -402,7 +402,7 @@ int ss_engine_decode_rows(ss_engine* e, const int32_t* token, const int32_t* pos
 int ss_session_decode(ss_session* s, const int32_t* tokens, int32_t n, int32_t n_past, float* logits_out) {
     if (!s || !tokens || !logits_out || n <= 0 || n_past < 0 || n_past + n > s->s.eng->hm.hp.n_text_ctx) return fail(SS_ERR_ARG, "ss_session_decode: bad argument");
     for (int i = 0; i < n; i++) if (tokens[i] < 0 || tokens[i] >= s->s.eng->hm.hp.n_vocab) return fail(SS_ERR_ARG, "ss_session_decode: token out of range");
-    SS_TRY s->s.eng->decode_host(tokens, n, n_past, logits_out); return SS_OK; SS_CATCH
+    SS_TRY s->s.eng->decode_host(tokens, n, n_past, logits_out, &s->s); return SS_OK; SS_CATCH
 }
 int ss_process_logits(ss_engine* e, const float* raw, const int32_t* hist, int32_t n_hist, int32_t has_ts, int32_t seek_delta, const ss_params* params,
                       float out6[6]) {

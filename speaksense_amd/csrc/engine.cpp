@@ -395,6 +395,7 @@ struct EngineT : EngineBase {
         if (fp8_enc && (da % 256 || d % 64)) throw Error(SS_ERR_UNSUPPORTED, "fp8: n_audio_state must be a multiple of 256 (k-step groups of the e4m3 GEMM)");
         if (d % 128 || da % 128) throw Error(SS_ERR_MODEL, "model: state size must be a multiple of 128");
         if (n_ctx % 4 || n_tctx > 448) throw Error(SS_ERR_MODEL, "model: unsupported context sizes");
+        if (const char* vg = getenv("SS_VT_GEMM")) vt_gemm = atoi(vg) != 0;   // before the workspaces are sized: only the =0 form needs the Q | K | V buffer
         if (!donor) check_memory_fits(n_lanes_total);
         SS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         AllocStreamScope alloc_scope(st);
@@ -415,7 +416,6 @@ struct EngineT : EngineBase {
         { const char* gv = getenv("SS_DECODE_GRAPH"); use_graph = !(gv && gv[0] == '0'); }     // 0: launch the step kernel by kernel instead of replaying its hipGraph
         { const char* cv = getenv("SS_DECODE_CHAIN"); chain_steps = !(cv && cv[0] == '0'); }   // 0: wait for every step's samples before enqueuing the next step
         if (const char* sm = getenv("SS_CB_START_MIN")) cb_start_min = std::max(1, atoi(sm));
-        if (const char* vg = getenv("SS_VT_GEMM")) vt_gemm = atoi(vg) != 0;
         { const char* lf = getenv("SS_LN_FUSE"); ln_fuse = !(lf && lf[0] == '0'); }
         if (const char* lr = getenv("SS_LN_FUSE_ROWS")) ln_fuse_rows = std::min(16, std::max(1, atoi(lr)));
         compat = donor ? donor->compat : resolve_compat(o.compat);
@@ -588,7 +588,7 @@ struct EngineT : EngineBase {
     // configuration that cannot fit fails here with the numbers, not as a hipMalloc error somewhere inside the fourth lane's workspaces.
     size_t lane_bytes() const {
         const size_t M = (size_t)B * n_ctx, R = kPartRows;
-        size_t enc_ws = ((size_t)B * (2 * n_ctx + 2) * (n_mel + da)) * 2 + M * da * (4 + 2 + 6 + 2 + 2 + 2 + 4) + (size_t)B * Ha * 64 * Tpad * 2 + M * 4 * da * (fp8_enc ? 1 : 2);
+        size_t enc_ws = ((size_t)B * (2 * n_ctx + 2) * (n_mel + da)) * 2 + M * da * (4 + 2 + (vt_gemm ? 4 : 6) + 2 + 2 + 2 + 4) + (size_t)B * Ha * 64 * Tpad * 2 + M * 4 * da * (fp8_enc ? 1 : 2);
         if (fp8_enc) enc_ws += 2 * M * da + (M + 255) * (6 * da / 64);
         const size_t cross_b = (size_t)L * B * 2 * H * n_ctx * (fp8_enc ? 65 : 128);
         const size_t self_b = (size_t)2 * L * S * n_tctx * d * 2;
@@ -598,14 +598,18 @@ struct EngineT : EngineBase {
     }
     void check_memory_fits(int n_lanes_total) {
         size_t free_b = 0, total_b = 0;
+        // The estimate is a courtesy (a readable refusal instead of an out-of-memory error half-way through the allocations), not a gate a
+        // deployment can get stuck behind: SS_SKIP_MEM_CHECK=1 turns it off, and it leaves 2 % slack for what it cannot see (allocator rounding).
+        if (const char* sk = getenv("SS_SKIP_MEM_CHECK")) if (sk[0] == '1') return;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
-        if (const char* t = getenv("SS_TEST_FREE_MEM_MIB")) free_b = (size_t)atol(t) << 20;   // test hook (tests/test_gpu_lifetime.py)
+        // test hook (tests/test_gpu_lifetime.py), honoured only when SS_TEST_HOOKS=1 is set beside it: a production engine never reads it by accident
+        if (const char* th = getenv("SS_TEST_HOOKS")) if (th[0] == '1') if (const char* t = getenv("SS_TEST_FREE_MEM_MIB")) free_b = (size_t)atol(t) << 20;
         const HParams& hp = hm.hp;
         const size_t enc_w = (size_t)La * 12 * da * da + (size_t)da * 3 * n_mel + (size_t)3 * da * da;
         const size_t dec_w = (size_t)L * 16 * d * d + (size_t)hp.n_vocab * d;
         const size_t weights = (enc_w + dec_w) * 2 + (fp8_enc ? (size_t)La * 12 * da * da + (size_t)L * 2 * d * d : 0);
         const size_t need = weights + (size_t)n_lanes_total * lane_bytes();
-        if (need > free_b)
+        if (need > free_b + free_b / 50)
             throw Error(SS_ERR_ARG, "ss_engine_create: max_batch " + std::to_string(B) + " x max_decoders " + std::to_string(ND) + " on " + std::to_string(n_lanes_total) +
                         " lanes needs ~" + std::to_string(need >> 20) + " MiB of device memory (" + std::to_string(lane_bytes() >> 20) + " MiB per lane + " +
                         std::to_string(weights >> 20) + " MiB of weights), the device has " + std::to_string(free_b >> 20) + " MiB free");
@@ -615,7 +619,7 @@ struct EngineT : EngineBase {
         const size_t M = (size_t)B * n_ctx;
         x0.alloc(((size_t)B * (2 * n_ctx + 2) * n_mel + 256) * 2);
         h1.alloc(((size_t)B * (2 * n_ctx + 2) * da + 256) * 2);
-        x.alloc(M * da * 4); ln.alloc(M * da * 2); qk.alloc(M * 3 * da * 2);     // Q | K rows [M][2 da]; sized for Q | K | V [M][3 da], the layout of the SS_VT_GEMM=0 form
+        x.alloc(M * da * 4); ln.alloc(M * da * 2); qk.alloc(M * (vt_gemm ? 2 : 3) * da * 2);     // Q | K rows [M][2 da]; Q | K | V [M][3 da] only in the SS_VT_GEMM=0 form
         vT.alloc((size_t)B * Ha * 64 * Tpad * 2);
         att.alloc(M * da * 2); encT.alloc(M * da * 2); encF.alloc(M * da * 4);
         if (fp8_enc) {   // the quantised activations replace the T copy of the MLP hidden state; exponent bytes: one per (row, 64 columns), rows padded to 256
@@ -1174,6 +1178,7 @@ struct EngineT : EngineBase {
     }
 
     void run_group(std::vector<Job*>& grp) {
+        hook_owner = nullptr;      // this lane's cache slots now belong to the group (the stage hooks' context lived in slot 0)
         const Vocab& vocab = hm.vocab;
         std::vector<JobState> js;
         SS_HIP(hipEventRecord(ev[0], st));
@@ -1255,15 +1260,20 @@ struct EngineT : EngineBase {
             if (!need.empty() && (active.empty() || (int)need.size() >= std::min(cb_start_min, std::max(1, (n_jobs_alive() + 1) / 2))) && !free_cross.empty()) {
                 spec.valid = false;
                 const bool others_running = !active.empty();
+                auto ctx_of = [&](const JobState& q) { const int a = q.job->P.audio_ctx; return a > 0 && a < n_ctx ? a : n_ctx; };
+                // One context (whisper_full_params.audio_ctx) per encoder pass.  Chunks that ask for another get THEIR pass right behind this one, in
+                // the same round, while cross slots last (re-applying the start threshold let a minority context be passed over again and
+                // again under load; every skipped pass still paused the running decoders).
+                std::vector<JobState*> waiting = need;
+                while (!waiting.empty() && !free_cross.empty()) {
                 std::vector<Window*> fresh;
                 std::vector<int> cmap;
-                auto ctx_of = [&](const JobState& q) { const int a = q.job->P.audio_ctx; return a > 0 && a < n_ctx ? a : n_ctx; };
-                const int pass_ctx = ctx_of(*need.front());      // one context per encoder pass; chunks that ask for another wait for the next pass
+                std::vector<JobState*> rest;
+                const int pass_ctx = ctx_of(*waiting.front());
                 set_context(pass_ctx);
-                for (JobState* qp : need) {
-                    if (free_cross.empty()) break;
+                for (JobState* qp : waiting) {
                     JobState& q = *qp;
-                    if (ctx_of(q) != pass_ctx) continue;
+                    if (free_cross.empty() || ctx_of(q) != pass_ctx) { rest.push_back(qp); continue; }
                     active.emplace_back();
                     Window& w = active.back();
                     w.job = q.job; w.cross = free_cross.back(); free_cross.pop_back();
@@ -1296,6 +1306,8 @@ struct EngineT : EngineBase {
                     if (w->skip) { w->done = true; continue; }
                     w->it = 0;
                     start_attempt(*w, js, free_dec);
+                }
+                waiting.swap(rest);
                 }
             }
             // (2) one round of every active decoder
@@ -1767,8 +1779,11 @@ struct EngineT : EngineBase {
             for (int b = 0; b < da / 64; b++) exps[(size_t)m * (da / 64) + b] = sc[f8_scale_index(m, b, Mpad)];
     }
     int hook_n_keys = 0;      // stage hooks: key count of the encoder output last given to set_encoder_host (RowCtl.n_keys of decode_host's rows; 0 = n_ctx)
-    void set_encoder_host(const float* encv, int audio_ctx = 0) override {
+    const void* hook_owner = nullptr;   // the session whose set_encoder_host filled cross slot 0 (engine.h); nullptr once anything else touched lane 0's slot 0
+    int hook_kv_len = 0;                // positions of self-KV slot 0 that hold hook_owner's history
+    void set_encoder_host(const float* encv, int audio_ctx = 0, const void* owner = nullptr) override {
         std::lock_guard<std::mutex> lk(mu);
+        hook_owner = nullptr; hook_kv_len = 0;
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
         if (audio_ctx > n_ctx) throw Error(SS_ERR_AUDIO_CTX, "set_encoder: audio_ctx larger than the model's n_audio_ctx");
@@ -1780,9 +1795,15 @@ struct EngineT : EngineBase {
         if (fp8_enc) launch_quantize_f8<T>(encT.as<T>(), da, ln8.as<unsigned char>(), ln_sc.as<unsigned char>(), Mpad, nc, da, st);
         cross_kv_pass(1);
         SS_HIP(hipStreamSynchronize(st));
+        hook_owner = owner;
     }
-    void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out) override {
+    void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out, const void* owner = nullptr) override {
         std::lock_guard<std::mutex> lk(mu);
+        if (owner != hook_owner || !hook_owner)
+            throw Error(SS_ERR_ARG, "decode: this session's encoder output is no longer on the device (another session's set_encoder / transcription took the "
+                                    "stage-hook slot): call set_encoder (whisper_encode) again and decode from n_past = 0");
+        if (n_past > hook_kv_len)
+            throw Error(SS_ERR_ARG, "decode: n_past " + std::to_string(n_past) + " is beyond the " + std::to_string(hook_kv_len) + " positions decoded since the last set_encoder");
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
         ss_params P; ss_default_params(&P);
@@ -1800,10 +1821,12 @@ struct EngineT : EngineBase {
         }
         SS_HIP(hipMemcpyAsync(logits_out, logits.p, (size_t)n_vocab * 4, hipMemcpyDeviceToHost, st));
         SS_HIP(hipStreamSynchronize(st));
+        hook_kv_len = n_past + n;
     }
     // stage hook: cross-KV of one window from a given encoder output (cache slot `window` of lane 0)
     void set_encoder_window_host(const float* encv, int window) override {
         std::lock_guard<std::mutex> lk(mu);
+        hook_owner = nullptr;
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
         set_context(n_ctx);   // stage hooks always run the full context
@@ -1820,6 +1843,7 @@ struct EngineT : EngineBase {
     void decode_rows_host(const int32_t* token, const int32_t* pos, const int32_t* slot, const int32_t* crossw, int n, const int32_t* samp_rows, int n_samp,
                           float* logits_out) override {
         std::lock_guard<std::mutex> lk(mu);
+        hook_owner = nullptr;
         SS_HIP(hipSetDevice(opts.device));
         AllocStreamScope alloc_scope(st);
         if (n < 1 || n > kPartRows || n_samp < 1 || n_samp > n) throw Error(SS_ERR_ARG, "decode_rows: 1..128 rows, 1..n sampling rows");

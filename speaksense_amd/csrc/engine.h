@@ -84,8 +84,11 @@ struct EngineBase {
     virtual void log_mel_host(const float* pcm, int n, float* out, int n_len) = 0;
     virtual void signal_energy_host(const float* pcm, int n, float* out) = 0;
     virtual void encode_host(const float* mel, int n_len, int seek, float* enc_out, int audio_ctx = 0) = 0;   // audio_ctx: 0 = n_audio_ctx
-    virtual void set_encoder_host(const float* enc, int audio_ctx = 0) = 0;   // audio_ctx: rows of `enc` (0 = n_audio_ctx); decode_host then attends over that many keys
-    virtual void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out) = 0;
+    // The stage hooks' decoder context (cross-K/V slot 0 + self-KV slot 0 of lane 0) is ONE per engine, not one per session: `owner` (the calling
+    // session) takes it in set_encoder_host, any device group / other hook on lane 0 drops it, and decode_host refuses a caller that does not hold it
+    // or asks for history (n_past) beyond what it has decoded since -- two whisper_states on one context can therefore never read each other's audio.
+    virtual void set_encoder_host(const float* enc, int audio_ctx = 0, const void* owner = nullptr) = 0;   // audio_ctx: rows of `enc` (0 = n_audio_ctx); decode_host then attends over that many keys
+    virtual void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out, const void* owner = nullptr) = 0;
     virtual void set_encoder_window_host(const float* enc, int window) = 0;
     virtual void fp8_first_quant_host(const float* mel, int n_len, int seek, uint8_t* codes, uint8_t* exps) = 0;
     virtual void decode_rows_host(const int32_t* token, const int32_t* pos, const int32_t* slot, const int32_t* cross, int n, const int32_t* samp_rows, int n_samp,

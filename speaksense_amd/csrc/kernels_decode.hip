@@ -13,6 +13,7 @@
 // order by the consumer, so results are run-to-run identical (no float atomics).
 // Variants measured slower and archived (tools/experiments/r02_variants/r02_variants.diff): LayerNorm / flash-decoding-combine prologues inside the
 // GEMV, narrow output tiles without split-K, a residual-update epilogue, non-temporal weight loads (-1.2 %).
+#include <cstdlib>
 #include "kernels.h"
 #include "wave_ops.h"
 
@@ -23,6 +24,14 @@
 // 3091 / 3095x -> 3133 / 3138x, pass 6.70 -> 6.57 ms; one lane alone: no change.  (The cross-attention one level above the encoder GEMMs, s_setprio 1:
 // 3127 - 3137x against 3134 - 3149x, no gain, profiles/r04_m_cross_prio_ab.txt.)
 #define SS_CHAIN_PRIO_STMT __builtin_amdgcn_s_setprio(3);
+// The cross-K/V stream (rows x 245.8 MB per pass, every byte used once) can be marked non-temporal (`global_load ... nt`): its lines then leave L2
+// first instead of evicting the chain kernels' weights / activations and the encoder GEMMs' operand tiles of the other lanes.  Same bytes, same
+// arithmetic.  A/B/A/B on one box (profiles/r06_a_nt_zsplit_yardstick.txt): 3 lanes x 32 rows 3392 / 3400x -> 3461 / 3496x, pass 5.96 / 5.89 -> 5.74 / 5.66 ms;
+// one lane x 8 rows: no change (nothing to evict).  On by default; SS_CROSS_NT=0 restores plain loads.
+template <bool NT, typename V> __device__ __forceinline__ V ld_stream(const V* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
 
 
 namespace ss {
@@ -192,7 +201,8 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
         V8 xf[CB][NFR];
 #pragma unroll
         for (int ct = 0; ct < CB; ct++) {
-            const int mt = (c0 + ct) * 16 < g.M ? c0 + ct : 0;          // a column tile wholly beyond M reads tile 0: its MFMA columns are never stored
+            const int tz = blockIdx.z * CT + c0 + ct;                   // blockIdx.z: which group of CT column tiles (passes of more than 32 rows, launch_dg)
+            const int mt = tz * 16 < g.M ? tz : 0;                      // a column tile wholly beyond M reads tile 0: its MFMA columns are never stored
             const T* xg = (const T*)g.Xt + (((long)mt * (g.ldx >> 5) + (kbeg >> 5)) * 64 + lane) * 8;
 #pragma unroll
             for (int f = 0; f < NFR; f++) xf[ct][f] = *(const V8*)(xg + f * 512);
@@ -213,10 +223,10 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     __syncthreads();
     // ---- epilogue: (CT * 16) m x 16 n outputs ----
     for (int idx = tid; idx < CT * 256; idx += blockDim.x) {
-        const int m = idx >> 4, nn = idx & 15, n = n0 + nn;
+        const int ml = idx >> 4, nn = idx & 15, n = n0 + nn, m = blockIdx.z * (CT * 16) + ml;
         if (m < g.M && n < g.N) {
             float v = 0.f;
-            for (int w = 0; w < NW; w++) v += red[((w * CT + (m >> 4)) * 16 + (m & 15)) * 17 + nn];
+            for (int w = 0; w < NW; w++) v += red[((w * CT + (ml >> 4)) * 16 + (ml & 15)) * 17 + nn];
             dec_epilogue<T, EPI>(g, s, m, n, v);
         }
     }
@@ -294,7 +304,7 @@ static void launch_dgl(const DecGemvDesc& g, int NW, hipStream_t st) {
 template <typename T, int EPI, int CT, int NFR>
 static void launch_dg4(const DecGemvDesc& g, int NW, hipStream_t st) {
     const size_t lds = (size_t)NW * CT * 16 * 17 * 4;
-    dim3 grid(g.N / 16, g.S);
+    dim3 grid(g.N / 16, g.S, (g.M + CT * 16 - 1) / (CT * 16));
     dec_gemv_kernel<T, EPI, CT, NFR><<<grid, NW * 64, lds, st>>>(g); SS_LAUNCH_CHECK();
 }
 template <typename T, int EPI, int CT>
@@ -313,10 +323,17 @@ static void launch_dg3(const DecGemvDesc& g, int NW, hipStream_t st) {
         default: throw Error(-1, "dec_gemv: k per wave must be 32..320");
     }
 }
+// Passes of more than 32 rows.  Rounds 4-5 gave ONE workgroup all the rows (CT = 4 / 8 column tiles, two at a time): the weight tile crosses HBM once,
+// but the workgroup walks 2 - 4 dependent rounds of activation loads from L2 and a 128-row projection took 21 - 37 us against 7 - 10 us at 32 rows
+// (profiles/r05_j_kernel_stats_f16.md).  Round 6: grid.z = groups of 32 rows, every workgroup is the 32-row kernel; the groups of one weight tile
+// are gridDim.x * gridDim.y (a multiple of 8) apart in dispatch order, i.e. on the same XCD, so the tile comes from HBM once and from that XCD's L2 for
+// the other groups.  MFMA columns are independent: a row's bits do not depend on the form.  SS_GEMV_ZSPLIT=0 keeps the old form (A/B).
+static int g_gemv_zsplit = -1;
 template <typename T, int EPI>
 static void launch_dg(const DecGemvDesc& g, int NW, hipStream_t st) {
+    if (g_gemv_zsplit < 0) { const char* e = getenv("SS_GEMV_ZSPLIT"); g_gemv_zsplit = e ? atoi(e) != 0 : 1; }
     if (g.M <= 16) launch_dg3<T, EPI, 1>(g, NW, st);
-    else if (g.M <= 32) launch_dg3<T, EPI, 2>(g, NW, st);
+    else if (g.M <= 32 || g_gemv_zsplit) launch_dg3<T, EPI, 2>(g, NW, st);
     else if (g.M <= 64) launch_dg3<T, EPI, 4>(g, NW, st);
     else launch_dg3<T, EPI, 8>(g, NW, st);     // 65..128 rows (round 4): the weight fragments still cross HBM once per pass
 }
@@ -396,6 +413,11 @@ template void launch_dec_gemv<f16>(const DecGemvDesc&, int, hipStream_t);
 // pass -- what state.full() guarantees per (state, audio) (/root/reference/src/asr/whisper.rs:75).  Rounds 2-4 ran the NR = 4 case as ONE
 // range (one max over 1500 keys): a different rounding of every p, i.e. results that depended on the batch.
 // ---------------------------------------------------------------------------------------------
+static int g_cross_nt = -1;
+static bool cross_nt() {
+    if (g_cross_nt < 0) { const char* e = getenv("SS_CROSS_NT"); g_cross_nt = e ? atoi(e) != 0 : 1; }
+    return g_cross_nt != 0;
+}
 constexpr int kCrossRangeMax = 512;   // keys per range the LDS score buffer holds (n_audio_ctx <= 2048)
 
 __device__ __forceinline__ float cross_combine(const float mxs[kCrossSplitD], const float sums[kCrossSplitD], const float os[kCrossSplitD]) {
@@ -412,7 +434,7 @@ __device__ __forceinline__ float cross_combine(const float mxs[kCrossSplitD], co
     return num / den;
 }
 
-template <typename T, int NR>
+template <typename T, int NR, bool NT>
 __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __restrict__ qpart, int n_qpart, const float* __restrict__ qbias, float qscale,
                                                                const T* __restrict__ kc, const T* __restrict__ vc, long b_stride, int d, int H, int Tn,
                                                                const RowCtl* __restrict__ ctl, float* __restrict__ scratch, T* __restrict__ out_direct) {
@@ -456,7 +478,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 ii[u] = (it + u) * 32 + wave * 8 + r;
-                kv[u] = SS_LDW((const V8*)(K + (long)(k_beg + (ii[u] < nk ? ii[u] : 0)) * 64 + c * 8));
+                kv[u] = ld_stream<NT>((const V8*)(K + (long)(k_beg + (ii[u] < nk ? ii[u] : 0)) * 64 + c * 8));
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -507,7 +529,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q_kernel(const float* __re
             for (int u = 0; u < 4; u++) {
                 const int i = (it + u) * 32 + wave * 8 + r;
                 const bool okk = i < nk;
-                vv[u] = SS_LDW((const V8*)(V + (long)(k_beg + (okk ? i : 0)) * 64 + c * 8));
+                vv[u] = ld_stream<NT>((const V8*)(V + (long)(k_beg + (okk ? i : 0)) * 64 + c * 8));
                 pw[u] = okk ? sc[i] : 0.f;
             }
 #pragma unroll
@@ -564,7 +586,9 @@ void launch_dec_cross_attention_direct(const float* qpart, int n_qpart, const fl
                                        int H, int Tn, const RowCtl* ctl, int M, T* out, hipStream_t st) {
     if ((Tn + kCrossSplitD - 1) / kCrossSplitD > kCrossRangeMax) throw Error(-1, "cross attention: n_audio_ctx too large");
     dim3 grid(1, H, M);
-    dec_cross_attn_q_kernel<T, kCrossSplitD><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, nullptr, out); SS_LAUNCH_CHECK();
+    if (cross_nt()) dec_cross_attn_q_kernel<T, kCrossSplitD, true><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, nullptr, out);
+    else dec_cross_attn_q_kernel<T, kCrossSplitD, false><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, nullptr, out);
+    SS_LAUNCH_CHECK();
 }
 template void launch_dec_cross_attention_direct<bf16>(const float*, int, const float*, float, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int,
                                                       bf16*, hipStream_t);
@@ -576,7 +600,9 @@ void launch_dec_cross_attention_q(const float* qpart, int n_qpart, const float* 
                                   int Tn, const RowCtl* ctl, int M, float* scratch, hipStream_t st) {
     if ((Tn + kCrossSplitD - 1) / kCrossSplitD > kCrossRangeMax) throw Error(-1, "cross attention: n_audio_ctx too large");
     dim3 grid(kCrossSplitD, H, M);
-    dec_cross_attn_q_kernel<T, 1><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch, nullptr); SS_LAUNCH_CHECK();
+    if (cross_nt()) dec_cross_attn_q_kernel<T, 1, true><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch, nullptr);
+    else dec_cross_attn_q_kernel<T, 1, false><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, vc, b_stride, d, H, Tn, ctl, scratch, nullptr);
+    SS_LAUNCH_CHECK();
 }
 template void launch_dec_cross_attention_q<bf16>(const float*, int, const float*, float, const bf16*, const bf16*, long, int, int, int, const RowCtl*, int,
                                                  float*, hipStream_t);
@@ -589,7 +615,7 @@ template void launch_dec_cross_attention_q<f16>(const float*, int, const float*,
 // the exponent of a K row scales its score, the exponent of a V row is folded into its probability.  Arithmetic as the f16 kernel: q rounded
 // to T, scores and P.V accumulated in f32, p rounded to T.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int NR>   // NR as in dec_cross_attn_q_kernel: the same four key ranges and the same combine whichever form runs
+template <typename T, int NR, bool NT>   // NR as in dec_cross_attn_q_kernel: the same four key ranges and the same combine whichever form runs
 __global__ __launch_bounds__(256) void dec_cross_attn_q8_kernel(const float* __restrict__ qpart, int n_qpart, const float* __restrict__ qbias, float qscale,
                                                                 const unsigned char* __restrict__ kc, const unsigned char* __restrict__ ksc, long b_stride,
                                                                 long sc_stride, int d, int H, int Tn, const RowCtl* __restrict__ ctl,
@@ -650,7 +676,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q8_kernel(const float* __r
             for (int u = 0; u < 4; u++) {
                 ii[u] = (it + u) * 64 + wave * 16 + r;
                 const int kk = k_beg + (ii[u] < nk ? ii[u] : 0);
-                kw[u] = SS_LDW((const u32x4*)(K + (long)kk * 64 + c * 16));
+                kw[u] = ld_stream<NT>((const u32x4*)(K + (long)kk * 64 + c * 16));
                 eb[u] = KS[kk];
             }
 #pragma unroll
@@ -705,7 +731,7 @@ __global__ __launch_bounds__(256) void dec_cross_attn_q8_kernel(const float* __r
                 const int i = (it + u) * 64 + wave * 16 + r;
                 const bool okk = i < nk;
                 const int kk = k_beg + (okk ? i : 0);
-                vw[u] = SS_LDW((const u32x4*)(V + (long)kk * 64 + c * 16));
+                vw[u] = ld_stream<NT>((const u32x4*)(V + (long)kk * 64 + c * 16));
                 pw[u] = okk ? sc[i] * __builtin_bit_cast(float, (unsigned)VS[kk] << 23) : 0.f;
             }
 #pragma unroll
@@ -754,10 +780,12 @@ void launch_dec_cross_attention_f8(const float* qpart, int n_qpart, const float*
     if ((Tn + kCrossSplitD - 1) / kCrossSplitD > kCrossRangeMax) throw Error(-1, "cross attention: n_audio_ctx too large");
     if (scratch) {
         dim3 grid(kCrossSplitD, H, M);
-        dec_cross_attn_q8_kernel<T, 1><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, scratch, nullptr);
+        if (cross_nt()) dec_cross_attn_q8_kernel<T, 1, true><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, scratch, nullptr);
+        else dec_cross_attn_q8_kernel<T, 1, false><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, scratch, nullptr);
     } else {
         dim3 grid(1, H, M);
-        dec_cross_attn_q8_kernel<T, kCrossSplitD><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, nullptr, out);
+        if (cross_nt()) dec_cross_attn_q8_kernel<T, kCrossSplitD, true><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, nullptr, out);
+        else dec_cross_attn_q8_kernel<T, kCrossSplitD, false><<<grid, 256, 0, st>>>(qpart, n_qpart, qbias, qscale, kc, ksc, b_stride, sc_stride, d, H, Tn, ctl, nullptr, out);
     }
     SS_LAUNCH_CHECK();
 }

@@ -208,7 +208,7 @@ int whisper_set_mel(struct whisper_context* ctx, const float* data, int n_len, i
 int whisper_encode_with_state(struct whisper_context* ctx, struct whisper_state* state, int offset, int) {
     if (!ctx || !state) return -1;
     if (state->mel.empty() || state->n_len <= 0) { wlog("whisper_encode: no spectrogram (call whisper_pcm_to_mel or whisper_set_mel first)\n"); return -1; }
-    if (offset < 0 || offset >= state->n_len) { wlog("whisper_encode: offset %d outside the spectrogram (%d frames)\n", offset, state->n_len); return -1; }
+    if (offset < 0) { wlog("whisper_encode: negative offset %d\n", offset); return -1; }     // offset >= n_len: a window of zeros, as whisper.cpp pads it (mel_window_kernel zero-fills)
     state->enc.resize((size_t)hp(ctx, 1) * hp(ctx, 2));
     state->encoded = false;
     if (ss_encode(ctx->eng, state->mel.data(), state->n_len, offset, state->enc.data()) != SS_OK ||

@@ -124,13 +124,18 @@ def test_engine_create_refuses_a_configuration_that_cannot_fit(toy_ml_path, wide
         with pytest.raises(binding.SpeakSenseError) as ei:
             binding.Engine(wide2_path, max_batch=128, max_decoders=8, n_lanes=8)
         assert ei.value.code == -1 and "MiB" in str(ei.value), str(ei.value)
-    os.environ["SS_TEST_FREE_MEM_MIB"] = "4096"                    # (test hook: pretend the device has 4 GiB free)
+    os.environ["SS_TEST_FREE_MEM_MIB"] = "4096"                    # (test hook: pretend the device has 4 GiB free) ...
+    binding.Engine(wide2_path, max_batch=32, max_decoders=5, n_lanes=3).close()      # ... ignored unless SS_TEST_HOOKS=1 stands beside it
+    os.environ["SS_TEST_HOOKS"] = "1"
     try:
         with pytest.raises(binding.SpeakSenseError) as ei:
             binding.Engine(wide2_path, max_batch=32, max_decoders=5, n_lanes=3)
         assert ei.value.code == -1 and "lanes needs" in str(ei.value), str(ei.value)
+        os.environ["SS_SKIP_MEM_CHECK"] = "1"                      # the estimate is a courtesy: a deployment can switch it off
+        binding.Engine(wide2_path, max_batch=32, max_decoders=5, n_lanes=3).close()
     finally:
-        del os.environ["SS_TEST_FREE_MEM_MIB"]
+        del os.environ["SS_TEST_FREE_MEM_MIB"], os.environ["SS_TEST_HOOKS"]
+        os.environ.pop("SS_SKIP_MEM_CHECK", None)
     binding.Engine(wide2_path, max_batch=32, max_decoders=5, n_lanes=3).close()
 
 

@@ -482,16 +482,39 @@ def test_whisper_h_full_surface(toy_ml_path, eng, monkeypatch):
     assert not L.whisper_get_logits_from_state(st)                                    # nothing decoded yet
     toks = np.array([eng.sot, eng.sot + 1, eng.transcribe, 1234, 4321], np.int32)
     assert L.whisper_decode_with_state(ctx, st, toks.ctypes.data_as(vp), 3, 0, 4) == -1      # no whisper_encode yet (whisper_full reset the state's window)
-    assert L.whisper_encode_with_state(ctx, st, 100000, 4) == -1                      # offset outside the spectrogram
+    assert L.whisper_encode_with_state(ctx, st, -1, 4) == -1
+    assert L.whisper_encode_with_state(ctx, st, 100000, 4) == 0                       # offset beyond the spectrogram: a zero-padded window, as whisper.cpp
     assert L.whisper_encode_with_state(ctx, st, 200, 4) == 0
-    ses = eng.new_session()
-    ses.set_encoder(eng.encode(eng.log_mel(pcm), 200))
     assert L.whisper_decode_with_state(ctx, st, toks.ctypes.data_as(vp), 3, 0, 4) == 0
-    got = np.ctypeslib.as_array(L.whisper_get_logits_from_state(st), (eng.n_vocab,)).copy()
-    assert np.array_equal(got, ses.decode(toks[:3], 0))
+    got1 = np.ctypeslib.as_array(L.whisper_get_logits_from_state(st), (eng.n_vocab,)).copy()
     assert L.whisper_decode_with_state(ctx, st, toks[3:].ctypes.data_as(vp), 1, 3, 4) == 0
-    assert np.array_equal(np.ctypeslib.as_array(L.whisper_get_logits_from_state(st), (eng.n_vocab,)), ses.decode(toks[3:4], 3))
+    got2 = np.ctypeslib.as_array(L.whisper_get_logits_from_state(st), (eng.n_vocab,)).copy()
+    assert L.whisper_decode_with_state(ctx, st, toks[4:].ctypes.data_as(vp), 1, 9, 4) == -1      # history beyond what was decoded since whisper_encode
+    ses = eng.new_session()
+    ses.set_encoder(eng.encode(eng.log_mel(pcm), 200))                                # the native session takes the engine's stage-hook slot ...
+    assert np.array_equal(got1, ses.decode(toks[:3], 0)) and np.array_equal(got2, ses.decode(toks[3:4], 3))
+    assert L.whisper_decode_with_state(ctx, st, toks[3:].ctypes.data_as(vp), 1, 3, 4) == -1      # ... and the state is refused, not answered from another's audio
     ses.close()
+    # two states on ONE context (whisper-rs create_state() twice), interleaved.  The decoder context behind whisper_encode / whisper_decode is
+    # one per engine: a state that lost it to the other's whisper_encode (or to a whisper_full on lane 0) gets -1 until it encodes again -- never the
+    # other state's audio with return code 0.
+    st2 = L.whisper_init_state(ctx)
+    pcm2 = synth.speech_like(77, 16000 * 8)
+    assert L.whisper_pcm_to_mel_with_state(ctx, st2, pcm2.ctypes.data_as(vp), len(pcm2), 4) == 0
+    assert L.whisper_encode_with_state(ctx, st, 200, 4) == 0                          # A encodes
+    assert L.whisper_encode_with_state(ctx, st2, 0, 4) == 0                           # B encodes: the slot is B's
+    assert L.whisper_decode_with_state(ctx, st, toks.ctypes.data_as(vp), 3, 0, 4) == -1      # A must not see B's audio
+    assert L.whisper_decode_with_state(ctx, st2, toks.ctypes.data_as(vp), 3, 0, 4) == 0
+    b1 = np.ctypeslib.as_array(L.whisper_get_logits_from_state(st2), (eng.n_vocab,)).copy()
+    assert not np.array_equal(b1, got1)                                                # other audio, other logits
+    assert L.whisper_encode_with_state(ctx, st, 200, 4) == 0                          # A again
+    assert L.whisper_decode_with_state(ctx, st2, toks[3:].ctypes.data_as(vp), 1, 3, 4) == -1     # now B lost it (and its self-KV history)
+    assert L.whisper_decode_with_state(ctx, st, toks.ctypes.data_as(vp), 3, 0, 4) == 0
+    assert np.array_equal(np.ctypeslib.as_array(L.whisper_get_logits_from_state(st), (eng.n_vocab,)), got1)
+    assert L.whisper_full_with_state(ctx, st2, p, pcm2.ctypes.data_as(vp), len(pcm2)) == 0        # a transcription on the other state (any lane)
+    rc = L.whisper_decode_with_state(ctx, st, toks[3:].ctypes.data_as(vp), 1, 3, 4)
+    assert rc == -1 or (rc == 0 and np.array_equal(np.ctypeslib.as_array(L.whisper_get_logits_from_state(st), (eng.n_vocab,)), got2))
+    L.whisper_free_state(st2)
 
     # whisper_full_parallel: two halves as one device batch, merged on the context's default state with whisper.cpp's offset rule
     long_pcm = synth.speech_like(24, 16000 * 24)
