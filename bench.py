@@ -240,25 +240,25 @@ def cpu_baseline(path: str, hp, n_steps: int, n_prompt: int):
         ncpu = os.cpu_count() or 1
     cores = max(1, min(64, ncpu))
     om = orc.OracleModel(path)
-    # full depth for the encoder and the cross-KV precompute (nothing extrapolated there); the decoder steps are identical in cost up to the
-    # growing self-KV, so 8 timed steps stand for the prompt + n_steps positions
-    n_enc, n_cross, n_dec = hp.n_audio_layer, hp.n_text_layer, 16
+    # full depth everywhere, nothing extrapolated: every encoder layer, every cross-KV layer, and one decode step at EVERY one of the
+    # prompt + n_steps positions (self-KV histories as long as the real run's); ~16 s of CPU work per repeat for large-v3
+    n_enc, n_cross, n_dec = hp.n_audio_layer, hp.n_text_layer, n_steps + n_prompt
     os.environ.setdefault("OMP_PROC_BIND", "close")   # read when the OpenMP runtime starts: threads stay on their cores
     runs, parts = [], []
     for _ in range(2):      # two timed repeats of the same sample, the faster one is reported (the first also pages the 6 GB f32 model in)
         t = om.time_sample(synth.speech_like(0), orc.MODE_GGML_F16, n_enc, n_cross, n_dec, cores)
         runs.append(t["mel_s"] + t["stem_s"] + hp.n_audio_layer * t["enc_layer_s"] + hp.n_text_layer * t["cross_layer_s"] + (n_steps + n_prompt) * t["dec_step_s"])
         parts.append({"mel": round(t["mel_s"], 3), "conv_stem": round(t["stem_s"], 3), "encoder_layers": round(hp.n_audio_layer * t["enc_layer_s"], 3),
-                      "cross_kv": round(hp.n_text_layer * t["cross_layer_s"], 3), "decoder_extrapolated": round((n_steps + n_prompt) * t["dec_step_s"], 3),
-                      "decoder_step_measured": round(t["dec_step_s"], 4)})
+                      "cross_kv": round(hp.n_text_layer * t["cross_layer_s"], 3), "decoder": round((n_steps + n_prompt) * t["dec_step_s"], 3),
+                      "decoder_step_mean": round(t["dec_step_s"], 4)})
     # the reference runs whisper.cpp with n_threads = 16 (/root/reference/src/asr/whisper.rs:143): the same sample once more on 16 threads, reported beside `value`
     t16 = None
     if cores > 16:
         t = om.time_sample(synth.speech_like(0), orc.MODE_GGML_F16, n_enc, n_cross, n_dec, 16)
         t16 = t["mel_s"] + t["stem_s"] + hp.n_audio_layer * t["enc_layer_s"] + hp.n_text_layer * t["cross_layer_s"] + (n_steps + n_prompt) * t["dec_step_s"]
         parts.append({"mel": round(t["mel_s"], 3), "conv_stem": round(t["stem_s"], 3), "encoder_layers": round(hp.n_audio_layer * t["enc_layer_s"], 3),
-                      "cross_kv": round(hp.n_text_layer * t["cross_layer_s"], 3), "decoder_extrapolated": round((n_steps + n_prompt) * t["dec_step_s"], 3),
-                      "decoder_step_measured": round(t["dec_step_s"], 4)})
+                      "cross_kv": round(hp.n_text_layer * t["cross_layer_s"], 3), "decoder": round((n_steps + n_prompt) * t["dec_step_s"], 3),
+                      "decoder_step_mean": round(t["dec_step_s"], 4)})
     om.close()
     chunk_s = min(runs)
     best_cores = cores
@@ -268,7 +268,7 @@ def cpu_baseline(path: str, hp, n_steps: int, n_prompt: int):
     return {"value": round(CHUNK_SEC / chunk_s, 4), "unit": "audio-sec/s", "cores": best_cores, "kind": "port", "breakdown_s": parts[runs.index(chunk_s)],
             "value_at_threads": {str(cores): round(CHUNK_SEC / min(runs[:2]), 4), "16": round(CHUNK_SEC / t16, 4) if t16 else None},
             "sample": f"1 chunk: log-mel + conv stem + {n_enc}/{hp.n_audio_layer} encoder layers + {n_cross}/{hp.n_text_layer} cross-KV layers + "
-                      f"{n_dec} decode steps timed (nothing extrapolated in the encoder; the decoder share is EXTRAPOLATED from those {n_dec} steps to {n_steps + n_prompt} positions) "
+                      f"{n_dec} decode steps timed, one at every position of the prompt + {n_steps} steps (nothing extrapolated) "
                       f"(est. {chunk_s:.1f} s per 30 s chunk; two repeats: {runs[0]:.1f} / {runs[1]:.1f} s, faster one reported); "
                       f"oracle/whisper_oracle.cpp ggml-f16 mode, {best_cores} OpenMP threads (the faster of {cores} and 16 = the reference's n_threads, whisper.rs:143)"}
 
@@ -351,10 +351,11 @@ def main():
                     "its copy to the host and the per-segment host pass); the headline keeps the reference's setting")
     ap.add_argument("--host-pcm", action="store_true", help="headline steps take host f32 PCM (H2D inside the timed region) instead of HBM-resident PCM")
     ap.add_argument("--dry-run", action="store_true", help="CPU test of the sharding/timing plumbing: stub workload, gloo backend")
+    ap.add_argument("--no-affinity", action="store_true", help="multi-rank runs: do not pin each rank to its own slice of the host's cores")
     ap.add_argument("--dist-backend", default=None, help="override (default nccl on GPU); 'gloo' + SS_BENCH_DEVICE=0 lets several ranks share one GPU for testing")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.dry_run:
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # launched bare (`python bench.py --gpus N`): become the launcher -- one rank per GPU, exactly what the driver's torchrun line does
         import socket
         import subprocess
@@ -369,6 +370,22 @@ def main():
         local_rank_dev = int(os.environ["SS_BENCH_DEVICE"])
     else:
         local_rank_dev = local_rank
+    # Host side of an 8-GPU node: every rank is a process with its engine's lane workers, a token-time pass per chunk and this
+    # Python loop.  Each rank gets its own contiguous slice of the cores the launcher may use (worker threads created later inherit it) and an
+    # explicit OMP_NUM_THREADS (only the cpu_baseline leg of rank 0 uses OpenMP; nothing in the product path does).
+    host = {"cores_visible": None, "cores_this_rank": None, "affinity": None}
+    try:
+        avail = sorted(os.sched_getaffinity(0))
+        host["cores_visible"] = len(avail)
+        if world > 1 and not args.no_affinity and len(avail) >= world:
+            per = len(avail) // world
+            mine = avail[local_rank * per:(local_rank + 1) * per]
+            os.sched_setaffinity(0, mine)
+            os.environ["OMP_NUM_THREADS"] = str(max(1, min(16, per)))
+            host["affinity"] = f"cores {mine[0]}-{mine[-1]}"
+        host["cores_this_rank"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
     import torch
     dist = None
     if world > 1:
@@ -460,10 +477,20 @@ def main():
 
     def before():                   # after the warmup has been drained and the ranks have met: device-time / work counters at the start of the timed region
         marks["tot0"] = eng.totals()
+        marks["cpu0"] = time.process_time()     # CPU seconds of every thread of this rank (Python + the engine's lane workers)
         del latencies[:]
 
     dt, per = timed_steps(step, args.steps, args.warmup, dist, torch.cuda.synchronize, drain, before)
+    cpu_s = time.process_time() - marks["cpu0"]
     tot1 = eng.totals()
+    # host cost per chunk: mean and max over the ranks (one all_reduce each, outside the timed region)
+    cpu_per_chunk = cpu_s / max(1, len(my_chunks) * args.steps)
+    cpu_mean = cpu_max = cpu_per_chunk
+    if dist is not None:
+        tdev = "cuda" if (torch.cuda.is_available() and dist.get_backend() == "nccl") else "cpu"
+        t_sum = torch.tensor([cpu_per_chunk], dtype=torch.float64, device=tdev); t_max = t_sum.clone()
+        dist.all_reduce(t_sum, op=dist.ReduceOp.SUM); dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        cpu_mean, cpu_max = float(t_sum.item()) / world, float(t_max.item())
     tot0 = marks["tot0"]
     lat_main = list(latencies)
     audio_sec = n_gpus * args.batch * args.steps * CHUNK_SEC
@@ -565,7 +592,9 @@ def main():
             "value": round(value, 2), "unit": "audio-sec/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"ggml-{args.model} batch={args.batch}x30s chunks per GPU, "
+            "config": {"workload": f"ggml-{args.model} batch={args.batch}x30s chunks per GPU per step, "
+                                   + (f"{inflight * args.batch} chunks in flight ({inflight} steps x {args.batch}), device batches <= {eng.max_batch} chunks x {tot1['n_lanes']} lanes"
+                                      if inflight > 1 else "one step at a time") + "; "
                                    + (f"Mode F: 1 encoder window + {n_prompt}-token prompt + {args.fixed_steps} greedy steps, EOT suppressed (random weights: "
                                       "natural-EOT decoding would walk the fallback ladder on nearly every window)" if args.fixed_steps > 0
                                       else "Mode N: natural EOT, whisper.cpp fallback rules"),
@@ -578,6 +607,11 @@ def main():
                        "chunks_per_step": n_gpus * args.batch, "parallelism": f"dp{n_gpus} (independent chunks, no collective)",
                        "steps_in_flight": inflight, "engine_lanes": tot1["n_lanes"], "engine_max_batch": eng.max_batch,
                        "validated": "every timed step: tokens per chunk == fixed_steps, >= 1 encoder window per chunk, ids identical to the first step"},
+            "host_cost": {"cpu_s_per_chunk_mean_over_ranks": round(cpu_mean, 5), "cpu_s_per_chunk_max_over_ranks": round(cpu_max, 5),
+                          "cores_busy_per_rank_at_this_rate": round(cpu_mean * args.batch * args.steps / dt, 2),
+                          "cores_visible": host["cores_visible"], "cores_this_rank": host["cores_this_rank"], "affinity_rank0": host["affinity"],
+                          "what": "process CPU time (all threads: Python submit/collect loop, the engine's lane workers incl. the host ladder and the token-time pass) "
+                                  "inside the timed region / chunks this rank processed; cores_busy = that x the rank's chunk rate"},
             "timing": "value: barrier + device sync on both sides, all K steps submitted and collected inside the timed region (incl. the pipeline's fill and drain); "
                       "steady_state: the same engine kept full, rate between two completion instants",
             "steady_state": steady,
@@ -623,6 +657,22 @@ def main():
                 "roofline": {"bound": "hbm", "kernel": "decoder pass (as above)", "achieved": round(s_bytes / (s_pass_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(s_bytes / (s_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": s_bytes, "avg_launch_ms": round(s_pass_ms, 5),
                              "rows_per_launch": round(s_rows, 2)}}
+        # The driver's record keeps `roofline`, `config` and `cpu_baseline` whole and files every other key under extra_keys: the
+        # MFMA-bound half of the path and the latency half of the metric therefore also go INTO those objects.
+        pr = out["phase_roofline"]
+        sb = {"bound": "mfma", "kernel": pr["encoder_fc1_gemm"]["kernel"], "achieved": pr["encoder_fc1_gemm"]["achieved"], "peak": mfma_peak, "unit": "TFLOP/s",
+              "frac": pr["encoder_fc1_gemm"]["frac"], "traffic": pr["encoder_fc1_gemm"]["traffic"], "algorithmic_bytes": pr["encoder_fc1_gemm"]["algorithmic_bytes"],
+              "avg_launch_ms": pr["encoder_fc1_gemm"]["avg_launch_ms"],
+              "encoder_phase_in_pipeline": {"tflops": pr["encoder_phase_tflops"], "frac": pr["encoder_phase_frac_mfma"]}}
+        if strict is not None and strict["d"]["encode_ms"] > 0:
+            e_alone = args.batch * work["enc_flops"] * strict["n"] / (strict["d"]["encode_ms"] * 1e-3) / 1e12
+            sb["encoder_phase_alone"] = {"tflops": round(e_alone, 1), "frac": round(e_alone / mfma_peak, 4),
+                                         "what": f"conv stem + encoder blocks + cross-KV of {args.batch} windows with nothing else on the chip (the batch8_strict leg): algorithmic FLOPs / device time of the phase"}
+        out["roofline"]["mfma_bound_half"] = sb
+        out["config"]["latency"] = {"p50_chunk_latency_ms": out["p50_chunk_latency_ms"], "p50_chunk_latency_unloaded_ms": out["p50_chunk_latency_unloaded_ms"],
+                                    "batch8_strict": {k: out["batch8_strict"][k] for k in ("value", "p50_chunk_latency_ms")} if "batch8_strict" in out else None,
+                                    "value_from_host_pcm": out.get("value_from_host_pcm"),
+                                    "note": "`value` is measured with the PCM already in HBM (the measurement contract); value_from_host_pcm includes the H2D copies (SURVEY section 8d's definition)"}
         if n_gpus == 1 and not args.headline_only and not args.no_mode_n and args.fixed_steps > 0 and "synthetic" in path:
             try:
                 out["mode_n"] = mode_n_leg(args, local_rank_dev, {"f16": binding.DTYPE_F16, "bf16": binding.DTYPE_BF16, "fp8": binding.DTYPE_FP8}[args.dtype],

@@ -98,6 +98,14 @@ int ss_engine_create(const char* path, const ss_engine_opts* opts, ss_engine** o
     EngineBase* e = o.dtype == SS_DTYPE_BF16 ? make_engine_bf16(path, o) : make_engine_f16(path, o);
     *out = new ss_engine{e};
     { std::lock_guard<std::mutex> lk(g_live_mu); g_live.insert(e); }
+    if (e->hm.n_quantised > 0) {
+        // VERDICT r05 #7, decided: block-quantised ggml files (script/download-ggml-model.sh:28-51, `-q5_0` / `-q5_1` / `-q8_0`) are DE-QUANTISED at load and
+        // run the f16 / bf16 kernels.  whisper.cpp multiplies the quantised blocks by q8_0-quantised activations (resources/ggml-metal.metal:918-996 is
+        // the Metal analogue): same weights, different arithmetic, so ids can differ on near ties.  Said at every load of such a file, and in INTEGRATION.md.
+        fprintf(stderr, "[speaksense_hip] %s: %d block-quantised tensors were de-quantised to 16-bit weights at load; this engine computes in f16/bf16, "
+                        "NOT in ggml's quantised-weight x q8_0-activation arithmetic, so results may differ from whisper.cpp on this file in near ties\n",
+                path, e->hm.n_quantised);
+    }
     return SS_OK;
     SS_CATCH
 }

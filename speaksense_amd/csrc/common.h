@@ -121,6 +121,7 @@ struct HostModel {
     std::vector<float> filters;  // [n_mel][n_fft]
     Vocab vocab;
     std::map<std::string, HostTensor> t;
+    int n_quantised = 0;         // tensors that came as ggml block-quantised data (q4_0 .. q8_0) and were de-quantised at load
     const HostTensor& get(const std::string& name) const;
 };
 void load_ggml_model(const char* path, HostModel& m, bool vocab_only = false);  // throws ss::Error(-2,...)

@@ -6,7 +6,7 @@
 //   dec_reduce_ln_kernel   residual add + bias of the previous projection + deterministic reduction of its split-K partials (+ token/positional
 //                          embedding for layer 0) -> LayerNorm -> f16/bf16 rows                                           (one wave per row)
 //   dec_gemv_kernel        weight fragments AND activation fragments go straight from HBM/L2 into VGPRs, all loads issued before the first
-//                          16x16x32 MFMA (16-row weight tile = A operand, 1 / 2 / 4 column tiles of 16 token rows = B operands fed by ONE fetch
+//                          16x16x32 MFMA (16-row weight tile = A operand, 1 or 2 column tiles of 16 token rows = B operands fed by ONE fetch
 //                          of the weight fragments); epilogues: q/k/v scaling + KV-cache append, GELU, logits, or raw split-K partials
 //   dec_cross_attn_q(8)_kernel   cross-attention over the 1500 encoder positions with the q projection's reduction in its prologue
 // Split-K goes across workgroups (grid = N/16 x S) so that N = d projections still launch >= 256 workgroups; partials are summed in a fixed
@@ -17,7 +17,11 @@
 #include "kernels.h"
 #include "wave_ops.h"
 
-#define SS_LDW(p) (*(p))   // streamed-once operands (decoder weights, cross K/V): plain loads
+#ifdef SS_WEIGHTS_NT           // dev A/B (tools/build_variant.sh kernels_decode.hip -DSS_WEIGHTS_NT): decoder weight fragments as non-temporal loads
+#define SS_LDW(p) __builtin_nontemporal_load(p)
+#else
+#define SS_LDW(p) (*(p))   // decoder weight fragments: plain loads
+#endif
 // The latency-bound chain kernels (GEMVs, reduce + LayerNorm, self-attention) raise their waves' issue priority: with several lanes in flight their
 // waves share SIMDs with another lane's streaming cross-attention (or encoder GEMM) waves, which have plenty of independent work to issue; the
 // chain wave's handful of instructions are on some lane's critical path.  A/B/A/B on one box (profiles/r04_l_chain_prio_ab.txt): 3 lanes x 32 rows
@@ -177,7 +181,7 @@ __device__ __forceinline__ void dec_epilogue(const DecGemvDesc& g, int s, int m,
 // NFR = 32-k fragments per wave (k per wave = 32 NFR <= 320), a template parameter: with a run-time count the loads sat behind branches and
 // hipcc put `s_waitcnt vmcnt(0)` between the weight loads, the activation loads of the first column tile and those of the second -- three
 // dependent memory round trips per GEMV (r03: 10.9 us per 32-row projection in the pipeline).  Now every load of the workgroup -- NFR weight
-// fragments from HBM, CT x NFR activation fragments from L2 -- is issued before the first MFMA.  CT = column tiles of 16 token rows (1, 2, 4).
+// fragments from HBM, CT x NFR activation fragments from L2 -- is issued before the first MFMA.  CT = column tiles of 16 token rows (1, 2); grid.z = groups of CT tiles.
 template <typename T, int EPI, int CT, int NFR>
 __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
     SS_CHAIN_PRIO_STMT
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void dec_gemv_kernel(DecGemvDesc g) {
 #pragma unroll
     for (int f = 0; f < NFR; f++) wf[f] = SS_LDW((const V8*)(wp + f * 512));
     // activations: B fragments straight from L2 into VGPRs (no LDS staging, no barrier before the MFMAs), fragment-major like the weights:
-    // one contiguous kilobyte per load.  Token rows >= M hold stale finite values: MFMA columns are independent and never stored.  Two column tiles' loads are in flight at a time (CT = 4: 2 + 2, to stay under 168 VGPRs).
+    // one contiguous kilobyte per load.  Token rows >= M hold stale finite values: MFMA columns are independent and never stored.
     f32x4 acc[CT];
 #pragma unroll
     for (int c0 = 0; c0 < CT; c0 += 2) {
@@ -323,19 +327,15 @@ static void launch_dg3(const DecGemvDesc& g, int NW, hipStream_t st) {
         default: throw Error(-1, "dec_gemv: k per wave must be 32..320");
     }
 }
-// Passes of more than 32 rows.  Rounds 4-5 gave ONE workgroup all the rows (CT = 4 / 8 column tiles, two at a time): the weight tile crosses HBM once,
-// but the workgroup walks 2 - 4 dependent rounds of activation loads from L2 and a 128-row projection took 21 - 37 us against 7 - 10 us at 32 rows
-// (profiles/r05_j_kernel_stats_f16.md).  Round 6: grid.z = groups of 32 rows, every workgroup is the 32-row kernel; the groups of one weight tile
-// are gridDim.x * gridDim.y (a multiple of 8) apart in dispatch order, i.e. on the same XCD, so the tile comes from HBM once and from that XCD's L2 for
-// the other groups.  MFMA columns are independent: a row's bits do not depend on the form.  SS_GEMV_ZSPLIT=0 keeps the old form (A/B).
-static int g_gemv_zsplit = -1;
+// Passes of more than 32 rows: grid.z = groups of 32 rows, every workgroup IS the 32-row kernel.  The groups of one weight tile are
+// gridDim.x * gridDim.y (a multiple of 8) apart in dispatch order, i.e. on the same XCD: the tile comes from HBM once and from that XCD's L2 for the
+// other groups.  MFMA columns are independent, so a row's bits do not depend on the form (tests/test_gpu_batch_invariance.py).  Rounds 4-5 gave ONE
+// workgroup all the rows (4 / 8 column tiles, two at a time): 2 - 4 dependent rounds of activation loads, 21 - 37 us per 128-row projection against
+// 7 - 10 us at 32 rows; A/B on one box (profiles/r06_a_nt_zsplit_yardstick.txt): 1 lane x 128 rows 3156 -> 3283x, 2 lanes x 64 rows 3337 -> 3390x.
 template <typename T, int EPI>
 static void launch_dg(const DecGemvDesc& g, int NW, hipStream_t st) {
-    if (g_gemv_zsplit < 0) { const char* e = getenv("SS_GEMV_ZSPLIT"); g_gemv_zsplit = e ? atoi(e) != 0 : 1; }
     if (g.M <= 16) launch_dg3<T, EPI, 1>(g, NW, st);
-    else if (g.M <= 32 || g_gemv_zsplit) launch_dg3<T, EPI, 2>(g, NW, st);
-    else if (g.M <= 64) launch_dg3<T, EPI, 4>(g, NW, st);
-    else launch_dg3<T, EPI, 8>(g, NW, st);     // 65..128 rows (round 4): the weight fragments still cross HBM once per pass
+    else launch_dg3<T, EPI, 2>(g, NW, st);
 }
 
 // choose split-K so the grid has >= ~256 workgroups; per-wave k must be a multiple of 32 and <= 320

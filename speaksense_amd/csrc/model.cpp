@@ -256,6 +256,7 @@ void load_ggml_model(const char* path, HostModel& m, bool vocab_only) {
             std::vector<uint8_t> raw(n / 32 * bb);
             if (!F.rd(raw.data(), raw.size())) throw Error(-2, "model: truncated tensor " + name);
             for (size_t b = 0; b < n / 32; b++) dequant_block(tt, raw.data() + b * bb, T.f32.data() + b * 32, half_to_float);
+            m.n_quantised++;
         } else {
             throw Error(-2, "model: unsupported tensor type " + std::to_string(tt) + " for " + name);
         }

@@ -38,13 +38,39 @@ def test_bench_two_ranks_with_the_hip_engine():
     assert j["config"]["parallelism"].startswith("dp2") and "cpu_baseline" not in j
 
 
-def test_pool_of_four_engines_64_concurrent_streams(toy_ml_path):
+def test_bench_eight_ranks_one_gpu_64_chunks_per_step():
+    """BASELINE configs[3] / [4]'s node shape made boring before the hardware exists: the driver's `--gpus 8` launch line with the real
+    engine in all EIGHT ranks (pinned to GPU 0, gloo for the barrier / MAX reduction): 64 chunks per step, one JSON line, whole-job aggregate, every
+    rank on its own slice of the host's cores, host CPU seconds per chunk reported (what an 8 x 3-lane node needs from its CPUs)."""
+    env = dict(os.environ, SS_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--model", "base.en", "--steps", "3", "--warmup", "1", "--inflight", "2", "--lanes", "2",
+           "--device-batch", "16", "--dist-backend", "gloo", "--no-cpu-baseline", "--no-steady", "--headline-only"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["chunks_per_step"] == 64 and j["scaling"] == "weak" and j["steps"] == 3
+    assert j["value"] > 0 and abs(j["value"] - 64 * 3 * 30.0 / (j["ms_per_step"] * 3e-3)) < 1e-2 * j["value"]
+    assert j["config"]["parallelism"].startswith("dp8")
+    hc = j["host_cost"]
+    assert 0.0 < hc["cpu_s_per_chunk_mean_over_ranks"] <= hc["cpu_s_per_chunk_max_over_ranks"] < 5.0
+    if hc["cores_visible"] and hc["cores_visible"] >= 8:
+        assert hc["cores_this_rank"] == hc["cores_visible"] // 8 and hc["affinity_rank0"].startswith("cores ")
+    from conftest import report
+    report(f"bench.py --gpus 8 on ONE GPU (base.en, gloo): {j['value']:.0f} xRT aggregate, host CPU {hc['cpu_s_per_chunk_mean_over_ranks'] * 1e3:.1f} ms per chunk "
+           f"(max over ranks {hc['cpu_s_per_chunk_max_over_ranks'] * 1e3:.1f} ms), {hc['cores_this_rank']} of {hc['cores_visible']} cores per rank")
+
+
+@pytest.mark.parametrize("n_eng", [4, 8])
+def test_pool_of_engines_64_concurrent_streams(toy_ml_path, n_eng):
     """ss_pool_* as the in-library form of "chunks sharded round-robin across the GPUs" at configs[3]'s concurrency: 64 sessions submit at once
-    to a pool of four engines; every engine ends up with 16 chunks, every result equals the single-engine result."""
+    to a pool of four / eight engines ([0] * 8 stands for the eight GPUs of the node); every engine gets its share, every result equals the
+    single-engine result."""
     from speaksense_amd import binding
     single = binding.Engine(toy_ml_path, max_batch=8)
-    pool = binding.Pool(toy_ml_path, [0, 0, 0, 0], max_batch=8)
-    assert pool.n_engines == 4
+    pool = binding.Pool(toy_ml_path, [0] * n_eng, max_batch=8)
+    assert pool.n_engines == n_eng
     P = binding.default_params(language="en", temperature_inc=0.0)
     pcms = [synth.speech_like(300 + k % 16, 16000 * 5) for k in range(64)]
     want = {}
@@ -64,8 +90,8 @@ def test_pool_of_four_engines_64_concurrent_streams(toy_ml_path):
         assert list(out[i]["tokens"]) == list(want[i % 16]["tokens"]) and len(out[i]["tokens"]) > 0, i
         assert [s["text"] for s in out[i]["segments"]] == [s["text"] for s in want[i % 16]["segments"]]
     used = [s.last_engine() for s in ses]
-    assert sorted(set(used)) == [0, 1, 2, 3]
-    assert max(used.count(e) for e in range(4)) - min(used.count(e) for e in range(4)) <= 8     # least-loaded routing keeps the engines level
+    assert sorted(set(used)) == list(range(n_eng))
+    assert max(used.count(e) for e in range(n_eng)) - min(used.count(e) for e in range(n_eng)) <= 8     # least-loaded routing keeps the engines level
     pool.close(); single.close()
 
 

@@ -604,7 +604,7 @@ def test_whisper_h_post_1_5_4_library(toy_ml_path, eng, monkeypatch):
 
 
 @pytest.mark.parametrize("ft", ["q5_0", "q5_1", "q8_0", "q4_0"])
-def test_quantised_ggml_models(tmp_path, ft):
+def test_quantised_ggml_models(tmp_path, ft, capfd):
     """Block-quantised ggml files (script/download-ggml-model.sh:28-51 lists the -q5_0 / -q5_1 variants): dequantised at load into the engine's
     f16 operands; ids, segments and timestamps identical to the oracle reading the same file, stages within the f16 tolerances."""
     from oracle import binding as orc
@@ -612,7 +612,10 @@ def test_quantised_ggml_models(tmp_path, ft):
     path = str(tmp_path / f"toy-{ft}.bin")
     ggml_io.write_model(path, "toy", seed=1, ftype=ft)
     om = orc.OracleModel(path)
+    capfd.readouterr()
     e = binding.Engine(path, dtype=binding.DTYPE_F16, max_batch=2)
+    # the library says at load that such a file runs de-quantised 16-bit arithmetic, not ggml's quantised x q8_0 one
+    assert "block-quantised tensors were de-quantised" in capfd.readouterr().err
     assert e.ftype == 2000 + ggml_io.FTYPE_BY_NAME[ft]
     pcm = synth.speech_like(5, 16000 * 20)
     mel = om.log_mel(pcm)

@@ -31,6 +31,20 @@ def test_two_rank_dry_run_gloo():
     assert 0 < j["value"] < 2 * 4 * 30 / 0.04 * 1.01   # 8 chunks per 40 ms step at most
 
 
+def test_eight_rank_dry_run_gloo_self_launched():
+    """`python bench.py --gpus 8` launched bare becomes its own torchrun launcher (the line the driver would use on an 8-GPU node): eight gloo
+    ranks on this CPU box, 64 chunks per step sharded round-robin, one JSON line from rank 0, every rank pinned to its own slice of the cores
+    when there are at least eight."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["steps"] == 2 and j["chunks_rank0"] == [0, 8, 16, 24, 32, 40, 48, 56]
+    assert 0 < j["value"] < 64 * 30 / 0.08 * 1.01      # 64 chunks per 80 ms step at most
+
+
 def test_two_ranks_transcribe_disjoint_shards_gloo(toy_ml_path, tmp_path):
     """The data path across ranks with a real transcriber in place of the GPU engine (the CPU oracle; tests/shard_worker.py): two ranks, 7 chunks
     (ragged), every chunk transcribed exactly once, results gathered in chunk order and identical to a single-process run."""
