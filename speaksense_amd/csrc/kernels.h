@@ -51,6 +51,7 @@ struct GemmDesc {
     int use_batch_map;        // EPI_CROSS_KV: window b of this launch writes cache slot batch_map[b] instead of b
     unsigned char batch_map[128];
     int cache_rows;           // EPI_CROSS_KV: key rows per (slot, head) of the CACHE (n_audio_ctx); 0 = rows_per_batch.  Differs when whisper_full_params.audio_ctx shortens the pass
+    int nt_out;               // set by launch_gemm: 16-bit outputs of more than kNtOutBytes leave as non-temporal stores (kernels_gemm.hip st16_out)
     long long* trace;         // dev tool (tools/gemm_bench.cpp): per workgroup and tile {start, loop start, loop end, stores issued} s_memtime stamps; null in the product
 };
 template <typename T> void launch_gemm(const GemmDesc& g, hipStream_t st);

@@ -176,6 +176,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmDesc g) {
 // The epilogue of a 256 x 256 tile whose accumulators are laid out as in gemm256_kernel: wave (wm, wn) owns rows [m0 + 128 wm, +128) x columns
 // [n0 + 64 wn, +64), acc[ni][mi] = the 16 x 16 fragment at (column group ni, row group mi); a lane holds 4 consecutive columns of row frow
 // (SWAP: 4 consecutive rows of column frow).  A function of its own so that other main loops can share it (tools/experiments/r03_gemm_8phase/).
+// 16-byte output stores of the f16 / bf16 epilogues, non-temporal where the output cannot be cache-resident for its consumer anyway (round 6;
+// A/B/A/B in profiles/r06_f_gemm_nt_stores_ab.txt).  The cross-K/V cache (245.8 MB per window, read by the decoder milliseconds later) always; the other
+// outputs when the launch writes more than kNtOutBytes -- FC1 of a 32-window pass writes 491 MB, more than L2 + MALL hold, and as ordinary
+// write-back lines those stores push the operand tiles the other workgroups are about to re-read out of L2: FC1 + GELU at M = 48 000
+// 1005 - 1021 -> 1063 - 1068 TF/s, QK projection 934 - 952 -> 987 - 995, plain FC1 958 - 964 -> 1005 - 1009; at M = 12 000 (outputs of 61 - 123 MB that the
+// next kernel reads back from the MALL) nt LOSES 4 % on the QK projection, hence the threshold.  Same bytes, same bits.
+constexpr long kNtOutBytes = 160L << 20;
+template <typename V> __device__ __forceinline__ void st16_out(V* p, const V& v, bool nt) {
+    if (nt) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+#ifndef SS_RES_AHEAD
+#define SS_RES_AHEAD 1     // operand row groups in flight in the f32-residual epilogue; 2 / 3 / 4 measured in round 6 (see there): no gain
+#endif
 template <typename T, int KIND, bool ST16>
 __device__ __forceinline__ void epilogue256(const GemmDesc& g, f32x4 (&acc)[4][8], const f32x4 (&bias_v)[4], int m0, int n0, int wm, int wn, int frow, int fg) {
     typedef typename Mfma<T>::V8 V8;
@@ -199,17 +213,25 @@ __device__ __forceinline__ void epilogue256(const GemmDesc& g, f32x4 (&acc)[4][8
             if constexpr (KIND == EPI_RES_F32) return resp + row_off(m, g.o_rows_per_batch, g.o_batch_stride, g.ldo) + n;
             else return posp + (long)(m % g.rows_per_batch) * g.N + n;
         };
-        f32x4 nxt[4];
+        // kResAhead row groups of operand loads in flight.  Round 6 asked whether one group ahead (64 B per lane, 32 KB per CU outstanding) is what
+        // holds this epilogue at 12 - 14 B/clk per CU: 2 / 3 / 4 groups ahead (3: 248 VGPRs, 4: 13 spills) changed nothing (Ox4 571 -> 578 / 578 / 542 TF/s,
+        // FC2x4 1010 -> 1004 / 1014 / 985, A/B/A in profiles/r06_c_res_ahead_and_vendor_kernel.txt).  The limit is not a wave's latency: every CU's epilogue
+        // starts at the same time (persistent workgroups, equal tiles), 256 x 512 KB = 134 MB hit the fabric at once and drain at the CHIP's
+        // ~5.7 TB/s (13.5 B/clk x 256 CUs x 1.65 GHz) while the MFMA pipes idle; the store-only epilogue (9 000 cycles for 128 KB) sits on the same line.
+        constexpr int kResAhead = SS_RES_AHEAD;
+        f32x4 buf[kResAhead][4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ni++) nxt[ni] = *(const f32x4*)src_of(0, ni);
+        for (int p = 0; p < kResAhead; p++)
+#pragma unroll
+            for (int ni = 0; ni < 4; ni++) buf[p][ni] = *(const f32x4*)src_of(p, ni);
 #pragma unroll
         for (int mi = 0; mi < 8; mi++) {
             f32x4 cur[4];
 #pragma unroll
-            for (int ni = 0; ni < 4; ni++) cur[ni] = nxt[ni];
-            if (mi + 1 < 8) {
+            for (int ni = 0; ni < 4; ni++) cur[ni] = buf[mi % kResAhead][ni];
+            if (mi + kResAhead < 8) {
 #pragma unroll
-                for (int ni = 0; ni < 4; ni++) nxt[ni] = *(const f32x4*)src_of(mi + 1, ni);
+                for (int ni = 0; ni < 4; ni++) buf[mi % kResAhead][ni] = *(const f32x4*)src_of(mi + kResAhead, ni);
             }
             const long m = m0 + wm * 128 + mi * 16 + frow;
             if (m >= g.M) continue;
@@ -267,9 +289,9 @@ __device__ __forceinline__ void epilogue256(const GemmDesc& g, f32x4 (&acc)[4][8
                     const int t = (int)(m % g.rows_per_batch);
                     if (g.use_batch_map) b = g.batch_map[b];
                     const long off = ((((long)(l * g.n_batch + b) * 2 + kv) * H + h) * g.cache_rows + t) * 64 + j;
-                    *(u32x4*)((T*)g.out + off) = o16;
+                    __builtin_nontemporal_store(o16, (u32x4*)((T*)g.out + off));
                 } else {
-                    *(u32x4*)((T*)g.out + orow + n) = o16;
+                    st16_out((u32x4*)((T*)g.out + orow + n), o16, g.nt_out != 0);
                 }
             }
         }
@@ -811,6 +833,7 @@ template <typename T>
 void launch_gemm(const GemmDesc& g_in, hipStream_t st) {
     GemmDesc g = g_in;
     if (g.cache_rows <= 0) g.cache_rows = g.rows_per_batch;
+    g.nt_out = (g.kind == EPI_STORE_T || g.kind == EPI_GELU_T) && (long)g.M * g.N * (long)sizeof(T) > kNtOutBytes;
     if (g.N % BN || g.K % BK || g.M <= 0) throw Error(-1, "gemm: N must be a multiple of 128 and K of 64");
     switch (g.kind) {
         case EPI_STORE_T: launch_gemm_kind<T, EPI_STORE_T>(g, st); break;

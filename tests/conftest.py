@@ -55,6 +55,36 @@ def wide2_path(model_dir):
     return _model(model_dir, "wide2")
 
 
+# The driver runs `pytest -m gpu` under a 1200 s limit (779 s in round 5).  Every test keeps running by default, a few on a shortened list of
+# cases; SS_RUN_SLOW=1 restores the full lists (tools/r06/gpu_slow.sh runs them; the report is committed under profiles/).
+SLOW = os.environ.get("SS_RUN_SLOW") == "1"
+
+_ORACLE_MODELS = {}
+
+
+def shared_oracle_model(path: str):
+    """ONE oracle copy of a model file per test session: the 32-layer files take ~5 s to load (3 GB of f16 -> 6 GB of f32) and thirteen tests want
+    one.  The returned object's close() is a no-op; pytest_sessionfinish frees them."""
+    from oracle import binding as orc
+    key = (path, os.path.getmtime(path), os.path.getsize(path))
+    om = _ORACLE_MODELS.get(key)
+    if om is None:
+        om = orc.OracleModel(path)
+        om._real_close = om.close
+        om.close = lambda: None
+        _ORACLE_MODELS[key] = om
+    return om
+
+
+def pytest_sessionfinish(session, exitstatus):
+    for om in _ORACLE_MODELS.values():
+        try:
+            om._real_close()
+        except Exception:
+            pass
+    _ORACLE_MODELS.clear()
+
+
 def report(msg: str):
     """Parity numbers worth keeping (margins, flip counts, stage errors): printed and, on the GPU box, appended to gpurun_out/parity_report.txt."""
     print(msg)

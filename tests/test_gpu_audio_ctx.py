@@ -243,3 +243,73 @@ def test_engine_shortened_decoder_logits_match_hf(ci, model_dir):
     assert np.array_equal(a, ses2.decode(c["tokens"][:n_p], 0))
     report(f"ss_session_set_encoder_ctx + decode (f16) vs HF over {c['audio_ctx']} keys ({c['preset']}): top-16 logits of {len(c['tokens']) - n_p + 1} steps within {worst:.2e} sigma (tol {LOGIT_TOL_F16})")
     eng.close()
+
+
+
+@pytest.mark.parametrize("which", ["f16", "bf16", "fp8"])
+def test_tiny_contexts_through_encoder_attention_and_v_transpose(which, wide2_path, toy_ml_path):
+    """audio_ctx 4, 8 and 64 -- less than one 64-key chunk of enc_attn_lds_kernel, less than one 256-row GEMM tile, a V^T row of mostly padding,
+    cross-attention key ranges of one or two keys -- stage by stage against the oracle run over the same shortened context, at the tolerances of the
+    full-context stage tests: the encoder rows, then the decoder's logits (prompt pass + 3 KV-cached steps) over those few keys; and at 64 keys a whole
+    chunk with ids equal to the oracle's or proven near ties."""
+    from speaksense_amd import binding
+    from oracle import binding as orc
+    from test_gpu_parity import GAP_TOL_BF16, GAP_TOL_F16, check_against_oracle
+    dtype, omode, tol, ltol, gap = {"f16": (binding.DTYPE_F16, orc.MODE_GGML_F16, 6e-3, 6e-3, GAP_TOL_F16), "bf16": (binding.DTYPE_BF16, orc.MODE_BF16, 5e-2, 5e-2, GAP_TOL_BF16),
+                                    "fp8": (binding.DTYPE_FP8, orc.MODE_FP8, 8e-2, 8e-2, 0.8)}[which]
+    worst, worst_l = {}, {}
+    for path in ([wide2_path] if which == "fp8" else [toy_ml_path, wide2_path]):        # the e4m3 engine needs n_audio_state % 256 == 0
+        eng = binding.Engine(path, dtype=dtype, max_batch=2)
+        om = orc.OracleModel(path)
+        pcm = synth.speech_like(61, 16000 * 4)
+        mel = om.log_mel(pcm)
+        toks = [om.sot, om.sot + 1, om.transcribe, om.beg + 3, 1234, 777]
+        for A in (4, 8, 64):
+            ref = om.encode(mel, 0, omode, audio_ctx=A)
+            got = eng.encode(mel, 0, audio_ctx=A)
+            assert got.shape == ref.shape == (A, eng.n_audio_state) and np.isfinite(got).all()
+            err = float(np.abs(got - ref).max() / np.abs(ref).max())
+            worst[A] = max(worst.get(A, 0.0), err)
+            assert err < tol, f"{os.path.basename(path)} {which} audio_ctx {A}: encoder rows {err:.2e} from the oracle"
+            ost = om.new_state(omode); ost.set_encoder(ref)                 # both sides from the SAME encoder rows: the decoder over A keys alone
+            ses = eng.new_session(); ses.set_encoder(ref)
+            r, g = ost.decode(toks[:3], 0), ses.decode(toks[:3], 0)
+            sd = float(r.std())
+            e = float(np.abs(g - r).max()) / sd
+            for i in range(3, len(toks)):
+                r, g = ost.decode(toks[i:i + 1], i), ses.decode(toks[i:i + 1], i)
+                e = max(e, float(np.abs(g - r).max()) / sd)
+            worst_l[A] = max(worst_l.get(A, 0.0), e)
+            assert e < ltol, f"{os.path.basename(path)} {which} audio_ctx {A}: decoder logits {e:.2e} sigma from the oracle"
+            ses.close()
+        kw = dict(language="en", temperature_inc=0.0, audio_ctx=64)
+        res = eng.new_session().transcribe(pcm, binding.default_params(**kw))
+        check_against_oracle(res, om, orc, omode, pcm, orc.default_params(**kw), f"{os.path.basename(path)} {which} audio_ctx 64", gap)
+        om.close(); eng.close()
+    report(f"tiny contexts ({which}): encoder rows vs oracle max|diff|/max " + ", ".join(f"audio_ctx {a}: {e:.1e}" for a, e in sorted(worst.items()))
+           + "; decoder logits over those keys (sigma) " + ", ".join(f"{a}: {e:.1e}" for a, e in sorted(worst_l.items())) + "; a whole chunk at 64 keys equals the oracle or is a proven near tie")
+
+
+@pytest.mark.parametrize("which", ["f16", "fp8"])
+def test_mixed_context_batch_wide2(which, wide2_path):
+    """a mixed-context group on the d = 1280 shape, f16 and e4m3: chunks asking for 0 / 64 / 752 / 8 / 1000 keys submitted together (one encoder pass per
+    waiting context in the same round, the windows then share decoder passes) equal their single-chunk runs, forced fallbacks included."""
+    from speaksense_amd import binding
+    dtype = binding.DTYPE_F16 if which == "f16" else binding.DTYPE_FP8
+    eng = binding.Engine(wide2_path, dtype=dtype, max_batch=8, n_lanes=1, batch_wait_us=300000)
+    ctxs = [0, 64, 752, 8, 1000, 64, 0, 752]
+    pcms = [synth.speech_like(70 + i, 16000 * 4) for i in range(len(ctxs))]
+    Ps = [binding.default_params(language="en", audio_ctx=a, temperature_inc=0.2, logprob_thold=0.0) for a in ctxs]
+    singles = [eng.new_session().transcribe(p, P) for p, P in zip(pcms, Ps)]
+    t0 = eng.totals()
+    ses = [eng.new_session() for _ in ctxs]
+    tickets = [s.submit(p, P) for s, p, P in zip(ses, pcms, Ps)]
+    res = [s.wait(t) for s, t in zip(ses, tickets)]
+    t1 = eng.totals()
+    for i, (r, s1) in enumerate(zip(res, singles)):
+        assert [int(x) for x in r["trace"]] == [int(x) for x in s1["trace"]], f"{which}: chunk {i} (audio_ctx {ctxs[i] or 1500}) differs from its single run"
+        assert np.array_equal(np.asarray(r["plog"]), np.asarray(s1["plog"]))
+    rows = (t1["decoder_rows"] - t0["decoder_rows"]) / max(1, t1["decoder_passes"] - t0["decoder_passes"])
+    assert rows > 2.0, "the mixed-context chunks never shared a decoder pass"
+    report(f"mixed contexts on wide2 ({which}): 8 chunks (audio_ctx 0 / 64 / 752 / 8 / 1000) in one group equal their single runs; {rows:.1f} rows per decoder pass")
+    eng.close()

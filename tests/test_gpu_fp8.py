@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from speaksense_amd import synth
-from conftest import report
+from conftest import SLOW, report, shared_oracle_model
 from test_gpu_parity import check_against_oracle
 
 pytestmark = pytest.mark.gpu
@@ -223,7 +223,7 @@ def test_fp8_large_v3_full_depth(orc):
         ncpu = os.cpu_count() or 1
     orc.set_thread_cap(min(64, ncpu))
     try:
-        om = orc.OracleModel(path)
+        om = shared_oracle_model(path)
         eng = binding.Engine(path, dtype=binding.DTYPE_FP8, max_batch=8)
         pcm = synth.speech_like(1)
         mel = om.log_mel(pcm)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from speaksense_amd import synth
-from conftest import report
+from conftest import SLOW, report, shared_oracle_model
 
 pytestmark = pytest.mark.gpu
 
@@ -49,7 +49,7 @@ def test_large_v3_full_depth_stages_vs_oracle(large_v3_path, eng8):
         ncpu = os.cpu_count() or 1
     orc.set_thread_cap(min(64, ncpu))
     try:
-        om = orc.OracleModel(large_v3_path)
+        om = shared_oracle_model(large_v3_path)
         assert (om.n_audio_layer, om.n_text_layer, om.n_audio_state, om.n_mels, om.n_vocab) == (32, 32, 1280, 128, 51866)
         pcm = synth.speech_like(0)
         mel = om.log_mel(pcm)
@@ -120,7 +120,7 @@ def test_large_v3_decode_vs_oracle_forced_replay(large_v3_path, eng8):
         ncpu = os.cpu_count() or 1
     orc.set_thread_cap(min(64, ncpu))
     try:
-        om = orc.OracleModel(large_v3_path)
+        om = shared_oracle_model(large_v3_path)
         pcm = synth.speech_like(1)
         got = eng8.new_session().transcribe(pcm, binding.default_params(language="en", fixed_steps=32))
         assert len(got["tokens"]) == 32
@@ -143,7 +143,7 @@ def test_large_v3_bf16_forced_replay(large_v3_path):
         ncpu = os.cpu_count() or 1
     orc.set_thread_cap(min(64, ncpu))
     try:
-        om = orc.OracleModel(large_v3_path)
+        om = shared_oracle_model(large_v3_path)
         eng = binding.Engine(large_v3_path, dtype=binding.DTYPE_BF16, max_batch=2)
         pcm = synth.speech_like(2)
         got = eng.new_session().transcribe(pcm, binding.default_params(language="en", fixed_steps=32))

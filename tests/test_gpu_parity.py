@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from speaksense_amd import synth
-from conftest import report
+from conftest import SLOW, report
 
 pytestmark = pytest.mark.gpu
 
@@ -306,6 +306,8 @@ def test_full_path_default_ladder_f16(toy_en_path, toy_ml_path, orc, which, topo
     eng = _eng(path, binding.DTYPE_F16, max_batch=4, compat=compat)
     n_fb = n_fb_same = n_exact = n_calls = n_sflip = 0
     cases = [(s, 30) for s in (3, 4, 5, 6, 7, 8)] + ([(43, 9), (49, 9)] if which == "toy.en" else [])
+    if topo == "rng_state" and not SLOW:       # the <= v1.4.x generator topology (a compat flag) on half the list; per_decoder (the default) keeps all of it
+        cases = cases[:3] + cases[6:]
     for seed, seconds in cases:
         pcm = synth.speech_like(seed, 16000 * seconds)
         ref = om.new_state(orc.MODE_GGML_F16, compat=compat).full(pcm, orc.default_params(language="en"))
@@ -342,8 +344,11 @@ def test_full_path_openai_ts_rules_variant(toy_en_path, toy_ml_path, orc, which)
     om = orc.OracleModel(path)
     eng = _eng(path, binding.DTYPE_F16, max_batch=4, compat=binding.COMPAT_OPENAI_TS_RULES)
     n_diff = n_same = 0
-    for seed in (3, 4, 5):
-        pcm = synth.speech_like(seed, 16000 * 5)     # (forcing a timestamp at every window start makes the toy models advance in tiny steps: ~15 windows per second of audio)
+    # (forcing a timestamp at every window start makes the toy models advance in tiny steps: ~15 windows per second of audio, each an encoder pass of
+    # the CPU oracle.  Default: 2 x 3 s, 45 windows per chunk; SS_RUN_SLOW=1: 4 x 7 s, the round-4 list)
+    seeds, seconds = ((3, 4, 5, 6), 7) if SLOW else ((3, 4), 3)
+    for seed in seeds:
+        pcm = synth.speech_like(seed, 16000 * seconds)
         P = dict(language="en", temperature_inc=0.0)
         got = eng.new_session().transcribe(pcm, binding.default_params(**P))
         # identical, or every pick a proven near tie on the oracle's variant (the toy models' timestamp logits are nearly flat: forcing a
@@ -354,7 +359,7 @@ def test_full_path_openai_ts_rules_variant(toy_en_path, toy_ml_path, orc, which)
         base = om.new_state(orc.MODE_GGML_F16).full(pcm, orc.default_params(**P))
         n_diff += list(base["tokens"]) != list(got["tokens"])
         assert len(got["tokens"]) == 0 or got["tokens"][0] >= om.beg, "first token of the first window is not a timestamp under the OpenAI rule"
-    report(f"{which}: SS_COMPAT_OPENAI_TS_RULES: {n_same}/3 chunks identical to the oracle's variant, the rest proven near ties; {n_diff}/3 differ from the v1.5.x rules")
+    report(f"{which}: SS_COMPAT_OPENAI_TS_RULES: {n_same}/{len(seeds)} chunks ({seconds} s) identical to the oracle's variant, the rest proven near ties; {n_diff}/{len(seeds)} differ from the v1.5.x rules")
     assert n_diff >= 1 and n_same >= 1
     eng.close(); om.close()
 

@@ -491,10 +491,13 @@ def test_whisper_h_full_surface(toy_ml_path, eng, monkeypatch):
     got2 = np.ctypeslib.as_array(L.whisper_get_logits_from_state(st), (eng.n_vocab,)).copy()
     assert L.whisper_decode_with_state(ctx, st, toks[4:].ctypes.data_as(vp), 1, 9, 4) == -1      # history beyond what was decoded since whisper_encode
     ses = eng.new_session()
-    ses.set_encoder(eng.encode(eng.log_mel(pcm), 200))                                # the native session takes the engine's stage-hook slot ...
+    ses.set_encoder(eng.encode(eng.log_mel(pcm), 200))                                # a native session of ANOTHER engine (`eng` is not the context's): same bits
     assert np.array_equal(got1, ses.decode(toks[:3], 0)) and np.array_equal(got2, ses.decode(toks[3:4], 3))
-    assert L.whisper_decode_with_state(ctx, st, toks[3:].ctypes.data_as(vp), 1, 3, 4) == -1      # ... and the state is refused, not answered from another's audio
-    ses.close()
+    ses2 = eng.new_session()
+    ses2.set_encoder(eng.encode(eng.log_mel(pcm), 0))                                 # ... and on one engine a second session takes the stage-hook slot:
+    with pytest.raises(binding.SpeakSenseError):                                      # the first is refused, not answered from the other's audio
+        ses.decode(toks[3:4], 3)
+    ses.close(); ses2.close()
     # two states on ONE context (whisper-rs create_state() twice), interleaved.  The decoder context behind whisper_encode / whisper_decode is
     # one per engine: a state that lost it to the other's whisper_encode (or to a whisper_full on lane 0) gets -1 until it encodes again -- never the
     # other state's audio with return code 0.

@@ -1,6 +1,7 @@
 """Dev tool (not product): what the vendor library (hipBLASLt through torch.matmul) reaches on the encoder GEMM shapes, as a yardstick for
 gemm256k64_kernel.  Operands drawn like tools/gemm_bench.cpp draws them (A uniform [-1, 1), W uniform [-0.05, 0.05)): the chip's clock under an
 MFMA loop depends on the bits that toggle, so a yardstick on other data measures another power point."""
+import os
 import torch
 torch.backends.cuda.matmul.allow_fp16_reduced_precision_reduction = False
 dev = "cuda"
@@ -12,7 +13,7 @@ for (M, N, K, name) in [(12000, 5120, 1280, "FC1"), (12000, 1280, 5120, "FC2"), 
         c = a @ w.t()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
+    reps = int(os.environ.get("SS_YARD_REPS", "20"))
     e0.record()
     for _ in range(reps):
         c = a @ w.t()

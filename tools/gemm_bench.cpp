@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
             g.out = out; g.ldo = s.N; g.o_rows_per_batch = 0; g.res = (float*)out; g.scale = 1.0f; g.rows_per_batch = 1500; g.gelu_f16_in = 1;   // as the f16 engine runs it
             launch_gemm<f16>(g, st);
             hipEventRecord(e0, st);
-            const int reps = 10;
+            const int reps = getenv("SS_GEMM_REPS") ? atoi(getenv("SS_GEMM_REPS")) : 10;   // more repetitions = longer sustained load (the chip's power management reacts within milliseconds)
             for (int i = 0; i < reps; i++) launch_gemm<f16>(g, st);
             hipEventRecord(e1, st); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
