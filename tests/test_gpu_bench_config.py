@@ -208,10 +208,11 @@ def test_natural_preset_32_chunks_distinct_streams_vs_oracle(large_v3_natural_pa
     assert len(streams) >= 24, f"only {len(streams)} distinct token streams among 32 chunks"
     assert n_fail <= 0.1 * n_win, f"{n_fail} fallbacks over {n_win} windows"
     assert max(lens) - min(lens) >= 30 and min(lens) >= 2, lens
-    singles = [eng.new_session().transcribe(p, P) for p in pcms]
-    differing = [i for i in range(32) if list(singles[i]["tokens"]) != list(res[i]["tokens"])]
-    n_same = 32 - len(differing)
-    assert n_same == 32, f"only {n_same}/32 chunks equal their single-chunk run: {differing}"        # batch invariance (round 5)
+    check = list(range(32)) if SLOW else list(range(0, 32, 3)) + [31]       # every chunk with SS_RUN_SLOW=1; 12 of the 32 (~0.4 s each, one at a time) under the driver
+    singles = {i: eng.new_session().transcribe(pcms[i], P) for i in check}
+    differing = [i for i in check if list(singles[i]["tokens"]) != list(res[i]["tokens"])]
+    n_same = len(check) - len(differing)
+    assert not differing, f"only {n_same}/{len(check)} chunks equal their single-chunk run: {differing}"        # batch invariance (round 5)
     om = shared_oracle_model(large_v3_natural_path)
     order = sorted(range(32), key=lambda i: (res[i]["n_windows"], lens[i]))
     # the cheapest non-trivial chunks for the CPU oracle (~25 s per window on 64 threads): one by default, three with SS_RUN_SLOW=1 (the round-4 count).
@@ -223,7 +224,7 @@ def test_natural_preset_32_chunks_distinct_streams_vs_oracle(large_v3_natural_pa
                                                     f"large-v3 natural preset, chunk {i}", GAP_TOL_F16)
         worst = max(worst, wg)
     report(f"large-v3 natural preset, 32 chunks async on Engine(32, 3 lanes): {len(streams)} distinct streams, {n_win} windows, {n_fail} fallbacks, tokens per chunk "
-           f"{min(lens)}..{max(lens)} (median {int(np.median(lens))}), {n_same}/32 equal their single-chunk runs; chunks {picked} replayed call by call on the oracle, "
+           f"{min(lens)}..{max(lens)} (median {int(np.median(lens))}), {n_same}/{len(check)} equal their single-chunk runs; chunks {picked} replayed call by call on the oracle, "
            f"largest greedy margin {worst:.4f}")
     om.close(); eng.close()
 
