@@ -26,7 +26,7 @@ for name, v in per.items():
         n_pass = n
     if any(k in name for k in ("dec_", "logits_rules", "logits_probs", "sample_draw", "skinny", "embed_kernel")) or ("layernorm" in name and n > 400):
         dec_bytes += b
-    is_fc1 = ("gemm_f8_kernel" in name and "Li1E" in name) if dtype == "fp8" else ("gemm256_kernel" in name and "Li1E" in name)
+    is_fc1 = (("gemm_f8" in name and "Li1E" in name) if dtype == "fp8" else ("gemm256" in name and "Li1E" in name)) and "selftest" not in name     # gemm256_kernel / gemm256k64_kernel (round 4 on) / gemm_f8k128_kernel
     if is_fc1:      # EPI_GELU_T / F8_GELU_F8: FC1 (+ conv1 in the f16 engines): the launch with the most traffic is an FC1
         fc1 = (2.0 * f[2] + w[2]) * 1024.0
 rows.sort(reverse=True)
