@@ -10,14 +10,14 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     struct Shape { int N, K; const char* name; int epi; };
     Shape shapes[] = {{3840, 1280, "QKV", DEPI_PART}, {5120, 1280, "FC1", DEPI_GELU_T}, {1280, 5120, "FC2", DEPI_PART}, {1280, 1280, "O", DEPI_PART}, {51904, 1280, "logits", DEPI_LOGITS}};
-    const int M = 8;
+    const int M = getenv("SS_GEMV_M") ? atoi(getenv("SS_GEMV_M")) : 8;     // token rows per launch (8 = batch8_strict, 32 = the headline's passes)
     // many distinct weight copies so every launch streams cold weights from HBM like a real step (32 layers)
     const int NCOPY = getenv("NCOPY") ? atoi(getenv("NCOPY")) : 24;
     for (auto& s : shapes) {
         f16* W; hipMalloc(&W, (size_t)NCOPY * s.N * s.K * 2); hipMemset(W, 0, (size_t)NCOPY * s.N * s.K * 2);
-        f16* X; hipMalloc(&X, (size_t)16 * s.K * 2); hipMemset(X, 0, 16 * s.K * 2);
-        float* part; hipMalloc(&part, (size_t)4 * 16 * s.N * 4);
-        void* out; hipMalloc(&out, (size_t)16 * s.N * 4);
+        f16* X; hipMalloc(&X, (size_t)128 * s.K * 2); hipMemset(X, 0, (size_t)128 * s.K * 2);
+        float* part; hipMalloc(&part, (size_t)4 * 128 * s.N * 4);
+        void* out; hipMalloc(&out, (size_t)128 * s.N * 4);
         float* bias; hipMalloc(&bias, s.N * 4); hipMemset(bias, 0, s.N * 4);
         for (int S = 1; S <= 4; S *= 2) for (int NW = 1; NW <= 4; NW *= 2) {
             if (s.K % S || (s.K / S) % NW) continue;
