@@ -216,7 +216,7 @@ __device__ __forceinline__ void epilogue256(const GemmDesc& g, f32x4 (&acc)[4][8
         // kResAhead row groups of operand loads in flight.  Round 6 asked whether one group ahead (64 B per lane, 32 KB per CU outstanding) is what
         // holds this epilogue at 12 - 14 B/clk per CU: 2 / 3 / 4 groups ahead (3: 248 VGPRs, 4: 13 spills) changed nothing (Ox4 571 -> 578 / 578 / 542 TF/s,
         // FC2x4 1010 -> 1004 / 1014 / 985, A/B/A in profiles/r06_c_res_ahead_and_vendor_kernel.txt).  Nor is it a chip-wide burst (all CUs storing at once):
-        // starting half of the workgroups half a tile late changed nothing either (tools/experiments/r06_gemm_stagger/).  A CU moves this pattern --
+        // starting half of the workgroups half a tile late changed nothing either (FC1 x 4 with this epilogue 758 / 735 -> 755 / 737 TF/s, tools/experiments/r06_gemm_stagger/).  A CU moves this pattern --
         // per wave instruction 16 row segments of 64 B, one output row pitch apart -- at ~13 B/clk whatever else happens; the store-only
         // epilogue (9 000 cycles for 128 KB) sits on the same line.
         constexpr int kResAhead = SS_RES_AHEAD;
