@@ -215,10 +215,11 @@ __device__ __forceinline__ void epilogue256(const GemmDesc& g, f32x4 (&acc)[4][8
         };
         // kResAhead row groups of operand loads in flight.  Round 6 asked whether one group ahead (64 B per lane, 32 KB per CU outstanding) is what
         // holds this epilogue at 12 - 14 B/clk per CU: 2 / 3 / 4 groups ahead (3: 248 VGPRs, 4: 13 spills) changed nothing (Ox4 571 -> 578 / 578 / 542 TF/s,
-        // FC2x4 1010 -> 1004 / 1014 / 985, A/B/A in profiles/r06_c_res_ahead_and_vendor_kernel.txt).  Nor is it a chip-wide burst (all CUs storing at once):
-        // starting half of the workgroups half a tile late changed nothing either (FC1 x 4 with this epilogue 758 / 735 -> 755 / 737 TF/s, tools/experiments/r06_gemm_stagger/).  A CU moves this pattern --
-        // per wave instruction 16 row segments of 64 B, one output row pitch apart -- at ~13 B/clk whatever else happens; the store-only
-        // epilogue (9 000 cycles for 128 KB) sits on the same line.
+        // FC2x4 1010 -> 1004 / 1014 / 985, A/B/A in profiles/r06_c_res_ahead_and_vendor_kernel.txt).  What the rate IS (tools/diag/store_rate_bench.cpp,
+        // profiles/r06_m_store_rate_bench.txt): persistent workgroups with equal tiles all reach their epilogue together, and 256 CUs storing at once share the
+        // chip's ~6.8 TB/s of store bandwidth = 26.6 GB/s per CU, whatever the request shape -- 128 KB in 9 000 cycles at 1.62 GHz is 23.6 GB/s, this epilogue's
+        // 512 KB in 39 000 is 21.8; 32 CUs storing alone reach 82 GB/s each.  De-phasing half of every XCD (tools/experiments/r06_gemm_stagger/) gave nothing:
+        // it splits the operand-sharing patch of an XCD, and any start offset is paid back as a tail of the same length (tiles are quantised).
         constexpr int kResAhead = SS_RES_AHEAD;
         f32x4 buf[kResAhead][4];
 #pragma unroll

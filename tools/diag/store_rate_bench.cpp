@@ -39,14 +39,15 @@ __global__ __launch_bounds__(512) void store_tiles(unsigned char* out, long pitc
 int main() {
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    const long rows = 48000;
+    const int kMaxCus = 256, kTiles = 8;
     long long* cyc; CK(hipMalloc(&cyc, 256 * 8));
     printf("%-28s %6s %8s | %10s %10s %12s\n", "request shape", "CUs", "pitch B", "us/launch", "GB/s chip", "B/clk per CU");
     for (long pitch : {10240L, 5120L, 2560L}) {
-        unsigned char* out; CK(hipMalloc(&out, (size_t)rows * pitch)); CK(hipMemset(out, 0, (size_t)rows * pitch));
         const int n_col_tiles = (int)(pitch / 512);
+        const long rows = ((long)kMaxCus * kTiles / n_col_tiles + 2) * 256;        // every (workgroup, tile) writes a tile of its own
+        unsigned char* out; CK(hipMalloc(&out, (size_t)rows * pitch)); CK(hipMemset(out, 0, (size_t)rows * pitch));
         for (int cus : {256, 128, 32}) {
-            const int tiles = 8;
+            const int tiles = kTiles;
             auto run = [&](auto kern, const char* name) {
                 CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                 kern<<<cus, 512, 96 * 1024, st>>>(out, pitch, tiles, n_col_tiles, cyc);
