@@ -174,6 +174,10 @@ void ss_session_free(ss_session* s) {
         // else: the engine is being (or has been) freed -- teardown completes every chunk before it returns; spin on the counter, never touch `e`
         else { live.unlock(); while (s->s.in_flight.load() > 0) std::this_thread::yield(); }
     }
+    {   // the stage hooks' decoder context may still name this session: a later session allocated at the same address must not inherit it
+        std::lock_guard<std::mutex> live(g_live_mu);
+        if (g_live.count(s->s.eng)) { const void* me = &s->s; s->s.eng->hook_owner.compare_exchange_strong(me, nullptr); }
+    }
     delete s;
 }
 

@@ -1779,7 +1779,7 @@ struct EngineT : EngineBase {
             for (int b = 0; b < da / 64; b++) exps[(size_t)m * (da / 64) + b] = sc[f8_scale_index(m, b, Mpad)];
     }
     int hook_n_keys = 0;      // stage hooks: key count of the encoder output last given to set_encoder_host (RowCtl.n_keys of decode_host's rows; 0 = n_ctx)
-    const void* hook_owner = nullptr;   // the session whose set_encoder_host filled cross slot 0 (engine.h); nullptr once anything else touched lane 0's slot 0
+    // hook_owner (engine.h): the session whose set_encoder_host filled cross slot 0; nullptr once anything else touched lane 0's slot 0
     int hook_kv_len = 0;                // positions of self-KV slot 0 that hold hook_owner's history
     void set_encoder_host(const float* encv, int audio_ctx = 0, const void* owner = nullptr) override {
         std::lock_guard<std::mutex> lk(mu);
@@ -1799,7 +1799,7 @@ struct EngineT : EngineBase {
     }
     void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out, const void* owner = nullptr) override {
         std::lock_guard<std::mutex> lk(mu);
-        if (owner != hook_owner || !hook_owner)
+        if (!owner || owner != hook_owner.load())
             throw Error(SS_ERR_ARG, "decode: this session's encoder output is no longer on the device (another session's set_encoder / transcription took the "
                                     "stage-hook slot): call set_encoder (whisper_encode) again and decode from n_past = 0");
         if (n_past > hook_kv_len)

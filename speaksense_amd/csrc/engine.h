@@ -87,6 +87,7 @@ struct EngineBase {
     // The stage hooks' decoder context (cross-K/V slot 0 + self-KV slot 0 of lane 0) is ONE per engine, not one per session: `owner` (the calling
     // session) takes it in set_encoder_host, any device group / other hook on lane 0 drops it, and decode_host refuses a caller that does not hold it
     // or asks for history (n_past) beyond what it has decoded since -- two whisper_states on one context can therefore never read each other's audio.
+    std::atomic<const void*> hook_owner{nullptr};   // the session that holds the stage hooks' decoder context; ss_session_free drops it (a later session at the same address must not inherit it)
     virtual void set_encoder_host(const float* enc, int audio_ctx = 0, const void* owner = nullptr) = 0;   // audio_ctx: rows of `enc` (0 = n_audio_ctx); decode_host then attends over that many keys
     virtual void decode_host(const int32_t* tokens, int n, int n_past, float* logits_out, const void* owner = nullptr) = 0;
     virtual void set_encoder_window_host(const float* enc, int window) = 0;

@@ -498,6 +498,10 @@ def test_whisper_h_full_surface(toy_ml_path, eng, monkeypatch):
     with pytest.raises(binding.SpeakSenseError):                                      # the first is refused, not answered from the other's audio
         ses.decode(toks[3:4], 3)
     ses.close(); ses2.close()
+    ses3 = eng.new_session()                                                          # the owner was freed: whoever comes next (possibly at its address) must encode first
+    with pytest.raises(binding.SpeakSenseError):
+        ses3.decode(toks[:3], 0)
+    ses3.close()
     # two states on ONE context (whisper-rs create_state() twice), interleaved.  The decoder context behind whisper_encode / whisper_decode is
     # one per engine: a state that lost it to the other's whisper_encode (or to a whisper_full on lane 0) gets -1 until it encodes again -- never the
     # other state's audio with return code 0.
